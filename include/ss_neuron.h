@@ -1,0 +1,132 @@
+/*
+ * ss_neuron.h — C-ABI of the MI355X-native StereoSpike neuron engine (libss_neuron.so).
+ *
+ * This is the drop-in boundary for the one hot path BASELINE.json names: the post-conv point-wise
+ * chain of every spiking stage of the reference network, fused over the T-step loop
+ *
+ *      MultiplyBy            /root/reference/network/blocks.py:106-107      y = x * scale
+ *      IF/LIF/PLIF charge    spikingjelly.clock_driven.neuron (un-vendored; call sites
+ *                            /root/reference/network/SNN_models.py:78..128,266..316, blocks.py:150,157)
+ *      Heaviside fire        surrogate.ATan / surrogate.Sigmoid forward (train.py:118, blocks.py:142)
+ *      hard reset            BaseNode.neuronal_reset, detach_reset=True at every call site
+ *      skip / SEW add        SNN_models.py:171,176,181,186 (out_deconvK + out_conv(K-1)); blocks.py:171 (out += identity)
+ *      firing-rate counts    SNN_models.py:219-242 (count_nonzero / numel)
+ *      I-neuron read-out     SNN_models.py:150,172-188 (IFNode(v_threshold=inf) used as an accumulator)
+ *
+ * and the surrogate-gradient backward of the same chain (what torch autograd does op by op in the
+ * reference).  The reference has no FFI for this path (it is 100 % Python); the Python
+ * binding a maintainer would add is shown in INTEGRATION.md and shipped in stereospike_amd/_lib.py.
+ *
+ * Conventions
+ *  - plain pointers and sizes; no allocation, no hidden global state; the caller owns every buffer.
+ *  - every pointer is DEVICE memory (HBM) visible to the HIP device that `stream` belongs to.
+ *  - sequences are laid out [T][N] contiguous, N = B*C*H*W of one layer (NCHW flattened), fp32.
+ *  - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *  - return 0 on success, a negative errno-style code otherwise (never throws across the ABI).
+ *  - deterministic: integer atomics for the counters, fixed-order two-pass reduction for g_k.
+ *  - thread-safe for disjoint buffers.
+ *  - rounding: every binary fp32 op rounds separately (no FMA contraction), in the order the eager
+ *    PyTorch reference evaluates them, so spikes / h / v are bit-identical to the CPU reference.
+ */
+#ifndef SS_NEURON_H
+#define SS_NEURON_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_OK        0
+#define SS_EINVAL  (-22)   /* bad argument (null pointer, T<=0, unknown kind, misaligned buffer ...) */
+#define SS_ELAUNCH  (-5)   /* the HIP runtime refused the launch (hipGetLastError != hipSuccess) */
+
+/* neuron kind — which charge equation */
+#define SS_KIND_IF    0    /* h = v + xs                                  neuron.IFNode            */
+#define SS_KIND_LIF   1    /* h = v + (xs - (v - v_reset)) / tau          neuron.LIFNode (true division) */
+#define SS_KIND_PLIF  2    /* h = v + (xs - (v - v_reset)) * k, k=sigmoid(w)   neuron.ParametricLIFNode */
+
+/* surrogate gradient used by the backward */
+#define SS_SG_ATAN     0   /* g * (1 / (1 + (pi/2*alpha*x)^2)) * (alpha/2)      surrogate.ATan    */
+#define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
+
+/* ABI version of this header; ss_abi_version() of the loaded library must match. */
+#define SS_ABI_VERSION 1
+int ss_abi_version(void);
+
+/* Number of floats the caller must provide as `g_k_ws` to ss_neuron_bwd_f32 when g_k != NULL. */
+long long ss_neuron_gk_ws_floats(void);
+
+/*
+ * Fused forward over T steps.  For n in [0,N), with v = v_init ? v_init[n] : v_reset:
+ *   for t in 0..T-1:
+ *      xs  = x_seq[t][n] * scale
+ *      h   = charge(kind, v, xs)                      (see SS_KIND_*)
+ *      z   = ((h - v_th) >= 0) ? 1.f : 0.f            (1 at exactly 0; v_th = +inf never fires)
+ *      v   = (1.f - z) * h + z * v_reset              (hard reset, evaluated literally)
+ *      out_seq[t][n] = skip_seq ? z + skip_seq[t][n] : z
+ *      if (h_seq) h_seq[t][n] = h
+ *   v_last[n] = v
+ *   if (nnz) { nnz[0] += #{(t,n): z != 0};  nnz[1] += #{(t,n): out != 0} }      (64-bit integer atomics)
+ *
+ * x_seq is the conv output BEFORE MultiplyBy.  h_seq == NULL selects the inference variant (8 B/update
+ * instead of 12).  `k` is a DEVICE pointer to one float, sigmoid(w), read only when kind == SS_KIND_PLIF
+ * (so the learnable w never has to be synchronised to the host); `tau` is read only for SS_KIND_LIF.
+ * out_seq may not alias x_seq; h_seq MAY alias x_seq (in-place h over the dead conv output).
+ * Replaces: the Sequential(conv, MultiplyBy, Node) tails and the adds cited at the top of this file.
+ */
+int ss_neuron_fwd_f32(const float* x_seq, const float* v_init, const float* skip_seq,
+                      float* out_seq, float* h_seq, float* v_last, unsigned long long* nnz,
+                      int T, long long N,
+                      float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset,
+                      void* stream);
+
+/*
+ * Surrogate-gradient backward of ss_neuron_fwd_f32 (reverse-t loop; what autograd does through
+ * surrogate.*.backward, neuronal_reset, neuronal_charge and MultiplyBy in the reference).
+ * With g_v = g_v_last ? g_v_last[n] : 0, for t = T-1..0:
+ *      xh  = h_seq[t][n] - v_th;  z = (xh >= 0)
+ *      g_s = g_out_seq[t][n]                       (+ g_v*v_reset - g_v*h  when detach_reset == 0)
+ *      g_h = sg'(xh) * g_s + g_v * (1.f - z)
+ *      IF  : g_x = g_h;        g_v = g_h
+ *      LIF : g_x = g_h / tau;  g_v = g_h - g_x
+ *      PLIF: g_x = g_h * k;    g_v = g_h - g_x;   acc_k += g_h * ((h - v_prev) / k)
+ *      g_x_seq[t][n] = g_x * scale
+ *   g_v_init[n] = g_v   (if non-NULL)
+ * dL/d skip_seq is g_out_seq itself (identity) and is therefore not written.
+ * g_k (PLIF, may be NULL): *g_k = sum over all (t,n) of acc_k, reduced in a fixed order (per-lane ->
+ * wavefront -> workgroup -> second pass over workgroup partials held in g_k_ws) so repeated runs are
+ * bit-identical.  v_init (the same pointer given to fwd, NULL => v_reset) is read only to form v_prev at t=0.
+ */
+int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
+                      float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                      int T, long long N,
+                      float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset,
+                      void* stream);
+
+/*
+ * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing
+ * IF membrane that the K predict_depth heads charge in the order K-1..0 of the reference's forward
+ * (predict_depth4 first), every time step.  pd_seq element (t,k,m) is at pd_seq[t*stride_t + k*stride_k + m],
+ * k = 0 is the head charged FIRST.  With v = v_init ? v_init[m] : v_reset:
+ *   for t: for k:  h = v + pd(t,k,m) * scale;  v = (1.f - 0.f) * h + 0.f * v_reset;  depth_seq[t][k][m] = v
+ * depth_seq is [T][K][M] contiguous; depth_seq[T-1][K-1] is the pool's final membrane.
+ * The additions happen in exactly this (t outer, k inner) order — it is part of fp32 parity.
+ */
+int ss_ipool_fwd_f32(const float* pd_seq, long long stride_t, long long stride_k, const float* v_init,
+                     float* depth_seq, int T, int K, long long M,
+                     float scale, float v_reset, void* stream);
+
+/*
+ * Backward of the pool: g_pd(t,k,m) = scale * sum of g_depth_seq over every (t',k') at or after (t,k)
+ * in charge order (+ g_v_last), accumulated from the last charge backwards; g_v_init[m] = the full sum.
+ * g_pd_seq uses the same strides as pd_seq.
+ */
+int ss_ipool_bwd_f32(const float* g_depth_seq, const float* g_v_last,
+                     float* g_pd_seq, long long stride_t, long long stride_k, float* g_v_init,
+                     int T, int K, long long M, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS_NEURON_H */
