@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of BASELINE.json: train frames/sec of StereoSpike (binocular, T = 5,
+260x346 voxels) on N MI355X, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training iteration on one batch of synthetic input per GPU: reset_net -> T-step forward
+(convs on PyTorch-ROCm, every neuron layer one fused HIP launch) -> Total_Loss -> backward (fused surrogate
+backward; with N > 1 the RCCL gradient all-reduce overlapped) -> Adam step -> detach.  Inputs are resident in HBM
+when the timed region starts.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  roofline     — the fused neuron forward kernel (dominant hand-written kernel): algorithmic bytes / HIP-event time
+                 over the launches inside the timed region, vs the 8 TB/s HBM3E peak;
+  cpu_baseline — the oracle's unfused eager-PyTorch port of the same training step on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='samples per GPU (config 3: 16)')
+    ap.add_argument('--T', type=int, default=5)
+    ap.add_argument('--model', default='StereoSpike', choices=['StereoSpike', 'PLIFNet'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
+    ap.add_argument('--channels-last', type=int, default=0)
+    ap.add_argument('--bucket-mb', type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build_net(model, device):
+    from stereospike_amd.clock_driven import surrogate
+    from stereospike_amd.network import SNN_models as S
+    torch.manual_seed(2021)                                   # train.py:53
+    if model == 'StereoSpike':
+        net = S.StereoSpike(surrogate_function=surrogate.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
+                            multiply_factor=10.)              # gain 10 so neurons fire
+    else:
+        net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., v_threshold=1.0, v_reset=0.0,
+                                                                             use_plif=True, multiply_factor=10.)
+    return net.to(device)
+
+
+def cpu_baseline(model, T, budget_s):
+    """The oracle's eager port (oracle/ref_network.py on oracle/sj_clock_driven.py — the reference's op sequence)
+    running the same training step on the host cores: B = 1, T = 5, 1 warm-up + >= 2 timed iterations within
+    ~budget_s seconds.  Reported, not a target."""
+    from oracle import ref_network as rn, sj_clock_driven as sj
+    from stereospike_amd.engine import synthetic_batch
+    torch.manual_seed(2021)
+    if model == 'StereoSpike':
+        net = rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan())
+    else:
+        net = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=10.)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    B = 1
+    x, gt = synthetic_batch(B, T, seed=2021)
+
+    def step():
+        out = rn.run_sequence(net, x)
+        loss = rn.total_loss(out[0], gt, out[1])
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        net.detach()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if (n >= 2 and el >= budget_s) or n >= 20 or el > 3 * budget_s:
+            break
+    return dict(value=B * n / el, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{model} binocular T={T} 260x346 fp32, B=1, {n} timed training iterations after 1 warm-up, '
+                       f'eager unfused oracle port, torch {torch.__version__} CPU, {torch.get_num_threads()} threads '
+                       f'of {os.cpu_count()} logical CPUs')
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU fallback for the product path'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+
+    from stereospike_amd import _lib
+    from stereospike_amd.dp import GradientAllReducer
+    from stereospike_amd.engine import Trainer, synthetic_batch
+    from stereospike_amd.fused import TIMER
+    _lib.lib()                                                # fail loudly here if the HIP library is missing
+
+    net = build_net(a.model, dev)
+    if a.channels_last:
+        net = net.to(memory_format=torch.channels_last)
+    reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20))) if world > 1 else None
+    trainer = Trainer(net, reducer=reducer)
+    x, gt = synthetic_batch(a.batch, a.T, seed=2021 + rank, device=dev)     # resident in HBM before timing
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(x, gt)
+    sync()
+    TIMER.enabled = True
+    TIMER.clear()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, pred = trainer.step(x, gt)
+    sync()
+    elapsed = time.perf_counter() - t0
+    TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    summ = TIMER.summary()
+
+    if rank == 0:
+        frames = a.batch * world * a.steps
+        fwd = summ.get('neuron_fwd_train', dict(launches=0, bytes=0, ms=0.0, updates=0))
+        bwd = summ.get('neuron_bwd', dict(launches=0, bytes=0, ms=0.0, updates=0))
+
+        def roof(d):
+            ach = (d['bytes'] / 1e9) / (d['ms'] / 1e3) if d['ms'] > 0 else 0.0
+            return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(),
+                        launches=d['launches'], avg_launch_us=round(1e3 * d['ms'] / max(1, d['launches']), 2),
+                        bytes_per_launch=int(d['bytes'] / max(1, d['launches'])))
+        from stereospike_amd.network.metrics import MeanDepthError
+        out = {
+            'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(1e3 * elapsed / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
+                                   f'(reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd',
+                       'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
+                       'parallelism': f'dp{world}', 'weights': 'default init, seed 2021, multiply_factor 10',
+                       'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
+            'roofline': dict(kernel='neuron_fwd_kernel (fused gain+charge+fire+reset+skip over T, fp32, 12-16 B/update)',
+                             **roof(fwd)),
+            'roofline_bwd': dict(kernel='neuron_bwd_kernel (fused surrogate backward over T, fp32, 12 B/update)',
+                                 **roof(bwd)),
+            'neuron_share_of_step': round((fwd['ms'] + bwd['ms']) / (1e3 * elapsed), 4),
+            'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.model, a.T, a.cpu_seconds)
+            out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the forward kernel from the rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
+    by profiles/collect_pmc.sh with the guide's gfx950 correction: FETCH_SIZE doubled); None if not collected."""
+    p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get('neuron_fwd_train_bytes_per_launch')
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == '__main__':
+    main()

@@ -80,8 +80,16 @@ class RefNet(nn.Module):
                  'out_deconv4', 'out_add4', 'out_deconv3', 'out_add3', 'out_deconv2', 'out_add2',
                  'out_deconv1', 'out_add1']
 
-    def __init__(self, in_ch, tail, bottleneck_block, head_gain, ineuron, returns_spikes, conv_bias):
+    def __init__(self, in_ch, tail, bottleneck_block, head_gain, ineuron, returns_spikes, conv_bias,
+                 input_size=(260, 346)):
         super().__init__()
+        # The reference hard-wires 260x346 (SNN_models.py:111-146).  `input_size` generalises the same arithmetic
+        # (k5 s2 p2 pyramid) so tests can run the identical graph on small frames; the default is the reference.
+        sizes = [tuple(input_size)]
+        for _ in range(4):
+            sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
+        dec = [(ci, co, sizes[3 - j]) for j, (ci, co, _) in enumerate(DEC)]
+        assert tuple(input_size) != (260, 346) or [d[2] for d in dec] == [d[2] for d in DEC]
         self.max_test_accuracy = float('inf')
         self.epoch = 0
         self.returns_spikes = returns_spikes
@@ -89,10 +97,10 @@ class RefNet(nn.Module):
         for i, (ci, co) in enumerate(ENC, 1):
             setattr(self, f'conv{i}', nn.Sequential(nn.Conv2d(ci, co, 5, 2, 2, bias=conv_bias), *tail(co)))
         self.bottleneck = nn.Sequential(bottleneck_block(), bottleneck_block())
-        for lvl, (ci, co, size) in zip((4, 3, 2, 1), DEC):
+        for lvl, (ci, co, size) in zip((4, 3, 2, 1), dec):
             setattr(self, f'deconv{lvl}', nn.Sequential(UpConv(ci, co, 5, size), *tail(co)))
         for lvl, c in zip((4, 3, 2, 1), (256, 128, 64, 32)):
-            head = [UpConv(c, 1, 3, (260, 346), bias=True)] + ([Gain(head_gain)] if head_gain is not None else [])
+            head = [UpConv(c, 1, 3, sizes[0], bias=True)] + ([Gain(head_gain)] if head_gain is not None else [])
             setattr(self, f'predict_depth{lvl}', nn.Sequential(*head))
         self.Ineurons = ineuron
 
@@ -137,7 +145,7 @@ class RefNet(nn.Module):
 
 
 def build(name, multiply_factor=1., surrogate_function=None, tau=10., v_threshold=1.0, v_reset=0.0, use_plif=False,
-          activation_function=None, sigmoid_alpha=4.0):
+          activation_function=None, sigmoid_alpha=4.0, input_size=(260, 346)):
     """name in {'StereoSpike', 'PLIFNet', 'PLIFNetMono', 'ANN'}; kwargs as the reference constructors."""
     if name == 'StereoSpike':
         # SNN_models.py:71-72: v_threshold / v_reset arguments are swallowed (always 1.0 / 0.0); the bottleneck
@@ -147,7 +155,7 @@ def build(name, multiply_factor=1., surrogate_function=None, tau=10., v_threshol
         bn_node = lambda: sj.IFNode(1.0, 0.0, sj.Sigmoid(sigmoid_alpha), True)
         tail = lambda c: [Gain(multiply_factor), node()]
         return RefNet(4, tail, lambda: SEWBlock(512, bn_node, multiply_factor), multiply_factor,
-                      sj.IFNode(float('inf'), 0.0, sg), True, False)
+                      sj.IFNode(float('inf'), 0.0, sg), True, False, input_size)
     if name in ('PLIFNet', 'PLIFNetMono'):
         if use_plif:   # library-default surrogate (Sigmoid)
             node = lambda: sj.ParametricLIFNode(tau, v_threshold, v_reset, sj.Sigmoid(sigmoid_alpha), True)
@@ -156,12 +164,13 @@ def build(name, multiply_factor=1., surrogate_function=None, tau=10., v_threshol
         bn_node = lambda: sj.ParametricLIFNode(tau, v_threshold, v_reset, sj.Sigmoid(sigmoid_alpha), True)  # :293-294
         tail = lambda c: [Gain(multiply_factor), node()]
         return RefNet(4 if name == 'PLIFNet' else 2, tail, lambda: SEWBlock(512, bn_node, multiply_factor),
-                      multiply_factor, sj.IFNode(float('inf'), v_reset, sj.ATan()), name == 'PLIFNet', False)
+                      multiply_factor, sj.IFNode(float('inf'), v_reset, sj.ATan()), name == 'PLIFNet', False, input_size)
     if name == 'ANN':
         act = activation_function if activation_function is not None else nn.Sigmoid()
         tail = lambda c: [act, nn.BatchNorm2d(c)]
         # ANN_models.py:41-66 encoder convs have bias, :75-94 the decoder up-convs keep bias=False, :98-109 no gain
-        return RefNet(4, tail, lambda: AnnResBlock(512, act), None, sj.IFNode(float('inf'), 0., sj.ATan()), False, True)
+        return RefNet(4, tail, lambda: AnnResBlock(512, act), None, sj.IFNode(float('inf'), 0., sj.ATan()), False, True,
+                      input_size)
     raise ValueError(name)
 
 

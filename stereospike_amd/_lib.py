@@ -1,0 +1,135 @@
+"""ctypes binding of libss_neuron.so (include/ss_neuron.h) — the only way the product reaches its kernels.
+
+There is NO fallback: if the library is missing, or a tensor is not a contiguous fp32 HIP tensor, the call
+raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to the runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
+ABI_VERSION = 1
+
+KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
+SG_ATAN, SG_SIGMOID = 0, 1
+
+_lib = None
+
+
+class SSNeuronError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SSNeuronError(
+            f'{LIB_PATH} not found: the HIP extension is not built.  Run `python -c "import __graft_entry__ as g; '
+            f'g.build()"` or `make -C stereospike_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+    L.ss_abi_version.restype = i32
+    L.ss_neuron_gk_ws_floats.restype = i64
+    L.ss_neuron_fwd_f32.argtypes = [p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, p]
+    L.ss_neuron_bwd_f32.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
+    L.ss_ipool_fwd_f32.argtypes = [p, i64, i64, p, p, i32, i32, i64, f32, f32, p]
+    L.ss_ipool_bwd_f32.argtypes = [p, p, p, i64, i64, p, i32, i32, i64, f32, p]
+    for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32):
+        f.restype = i32
+    if L.ss_abi_version() != ABI_VERSION:
+        raise SSNeuronError(f'libss_neuron.so ABI {L.ss_abi_version()} != expected {ABI_VERSION}; rebuild')
+    _lib = L
+    return _lib
+
+
+EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
+           'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32')
+
+
+def _ptr(t, name, numel=None):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise SSNeuronError(f'{name}: expected a torch.Tensor, got {type(t)}')
+    if not t.is_cuda:
+        raise SSNeuronError(f'{name}: tensor is on {t.device}; the StereoSpike neuron engine runs on the MI355X only '
+                            f'(no CPU fallback — use oracle/ for CPU checking)')
+    if not t.is_contiguous():
+        raise SSNeuronError(f'{name}: tensor must be contiguous')
+    if numel is not None and t.numel() != numel:
+        raise SSNeuronError(f'{name}: expected {numel} elements, got {t.numel()}')
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t, name, numel=None):
+    if t is not None and t.dtype != torch.float32:
+        raise SSNeuronError(f'{name}: expected float32, got {t.dtype}')
+    return _ptr(t, name, numel)
+
+
+def _stream(ref):
+    return C.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+
+def _check(rc, fn):
+    if rc != 0:
+        raise SSNeuronError(f'{fn} failed with code {rc} (-22 = invalid argument, -5 = HIP launch error)')
+
+
+def _require_hip(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        where = t.device if isinstance(t, torch.Tensor) else type(t)
+        raise SSNeuronError(f'{name} is on {where}: the StereoSpike neuron engine runs on the MI355X only — there is '
+                            f'no CPU fallback (oracle/ holds the CPU checker used by the tests)')
+
+
+def neuron_fwd(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, scale, kind, tau, k, v_th, v_reset):
+    _require_hip(x_seq, 'x_seq')
+    if nnz is not None and (nnz.dtype != torch.int64 or nnz.numel() != 2):
+        raise SSNeuronError('nnz must be an int64 tensor of 2 elements')
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_fwd_f32(_f32(x_seq, 'x_seq', T * N), _f32(v_init, 'v_init', N),
+                                     _f32(skip_seq, 'skip_seq', T * N), _f32(out_seq, 'out_seq', T * N),
+                                     _f32(h_seq, 'h_seq', T * N), _f32(v_last, 'v_last', N), _ptr(nnz, 'nnz'),
+                                     T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, _stream(x_seq))
+    _check(rc, 'ss_neuron_fwd_f32')
+
+
+def neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+               v_th, v_reset, surrogate, alpha, detach_reset):
+    _require_hip(h_seq, 'h_seq')
+    with torch.cuda.device(h_seq.device):
+        rc = lib().ss_neuron_bwd_f32(_f32(g_out_seq, 'g_out_seq', T * N), _f32(g_v_last, 'g_v_last', N),
+                                     _f32(h_seq, 'h_seq', T * N), _f32(v_init, 'v_init', N),
+                                     _f32(g_x_seq, 'g_x_seq', T * N), _f32(g_v_init, 'g_v_init', N),
+                                     _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'),
+                                     T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
+                                     int(bool(detach_reset)), _stream(h_seq))
+    _check(rc, 'ss_neuron_bwd_f32')
+
+
+def ipool_fwd(pd_seq, stride_t, stride_k, v_init, depth_seq, T, K, M, scale, v_reset):
+    _require_hip(pd_seq, 'pd_seq')
+    with torch.cuda.device(pd_seq.device):
+        rc = lib().ss_ipool_fwd_f32(_f32(pd_seq, 'pd_seq'), stride_t, stride_k, _f32(v_init, 'v_init', M),
+                                    _f32(depth_seq, 'depth_seq', T * K * M), T, K, M, scale, v_reset, _stream(pd_seq))
+    _check(rc, 'ss_ipool_fwd_f32')
+
+
+def ipool_bwd(g_depth_seq, g_v_last, g_pd_seq, stride_t, stride_k, g_v_init, T, K, M, scale):
+    _require_hip(g_depth_seq, 'g_depth_seq')
+    with torch.cuda.device(g_depth_seq.device):
+        rc = lib().ss_ipool_bwd_f32(_f32(g_depth_seq, 'g_depth_seq', T * K * M), _f32(g_v_last, 'g_v_last', M),
+                                    _f32(g_pd_seq, 'g_pd_seq'), stride_t, stride_k, _f32(g_v_init, 'g_v_init', M),
+                                    T, K, M, scale, _stream(g_depth_seq))
+    _check(rc, 'ss_ipool_bwd_f32')
+
+
+def gk_ws_floats():
+    return int(lib().ss_neuron_gk_ws_floats())

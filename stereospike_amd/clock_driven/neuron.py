@@ -1,0 +1,132 @@
+"""`neuron.BaseNode / IFNode / LIFNode / ParametricLIFNode` with the constructor signatures the reference uses
+(SNN_models.py:78...150, 266...338, 451...523; blocks.py:150,157; ANN_models.py:111) and the protocol its helpers
+rely on (SNN_models.py:22-48: `isinstance(m, neuron.BaseNode)`, `m.v`, `m.v.detach_()`, `hasattr(m, 'reset')`,
+`isinstance(m, neuron.IFNode)`).
+
+Every step — single (`node(x)`, the drop-in call) or a whole `[T, ...]` sequence (`node.forward_sequence`) —
+is one launch of the fused HIP kernel behind include/ss_neuron.h; the membrane `v` is carried between calls
+exactly like upstream's stateful single-step nodes until `reset()`.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..fused import NeuronCfg, fused_neuron
+from . import surrogate as _sg
+
+
+class BaseNode(nn.Module):
+    _kind = None
+
+    def __init__(self, v_threshold: float = 1., v_reset: float = 0., surrogate_function=None,
+                 detach_reset: bool = False):
+        super().__init__()
+        assert isinstance(v_threshold, float)
+        assert isinstance(detach_reset, bool)
+        if v_reset is None:
+            raise NotImplementedError('soft reset (v_reset=None) is not used by the reference and not implemented')
+        assert isinstance(v_reset, float)
+        self.v_threshold = v_threshold
+        self.v_reset = v_reset
+        self.detach_reset = detach_reset
+        self.surrogate_function = _sg.Sigmoid() if surrogate_function is None else surrogate_function
+        self.v = v_reset          # python float until the first charge, then a tensor (as upstream)
+
+    # ---- state protocol -------------------------------------------------------------------------
+    def reset(self):
+        self.v = self.v_reset
+
+    def detach(self):
+        if isinstance(self.v, torch.Tensor):
+            self.v.detach_()
+
+    def extra_repr(self):
+        return f'v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}'
+
+    # ---- fused evaluation ---------------------------------------------------------------------------
+    def _tau(self) -> float:
+        return 2.0
+
+    def _k(self) -> Optional[torch.Tensor]:
+        return None
+
+    def _cfg(self, scale: float) -> NeuronCfg:
+        sg = self.surrogate_function
+        sg_id = getattr(sg, 'sg_id', None)
+        if sg_id is None or not getattr(sg, 'spiking', True):
+            raise TypeError(f'{type(self).__name__}: surrogate_function must be a spiking surrogate.ATan or '
+                            f'surrogate.Sigmoid (got {sg!r}); the fused HIP backward implements these two')
+        return NeuronCfg(kind=self._kind, scale=float(scale), tau=float(self._tau()), v_th=float(self.v_threshold),
+                         v_reset=float(self.v_reset), surrogate=sg_id, alpha=float(sg.alpha),
+                         detach_reset=bool(self.detach_reset))
+
+    def _v_init(self, like: torch.Tensor) -> Optional[torch.Tensor]:
+        v = self.v
+        if isinstance(v, torch.Tensor):
+            if v.shape != like.shape:
+                raise _lib.SSNeuronError(f'membrane shape {tuple(v.shape)} != input shape {tuple(like.shape)}; '
+                                         f'call functional.reset_net(net) when the batch shape changes')
+            return v
+        if float(v) == self.v_reset:
+            return None                      # the kernel starts from the v_reset constant
+        return torch.full_like(like, float(v))
+
+    def forward_sequence(self, x_seq: torch.Tensor, scale: float = 1., skip_seq: Optional[torch.Tensor] = None,
+                         nnz: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x_seq [T, ...]: T steps from the current membrane; returns out_seq [T, ...] and carries v forward."""
+        out_seq, v_last = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0]), skip_seq=skip_seq,
+                                       k=self._k(), nnz=nnz)
+        self.v = v_last
+        return out_seq
+
+    def forward_fused(self, x: torch.Tensor, scale: float = 1., skip: Optional[torch.Tensor] = None,
+                      nnz: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One step with the preceding MultiplyBy gain and an optional following add folded in."""
+        return self.forward_sequence(x.unsqueeze(0), scale, None if skip is None else skip.unsqueeze(0), nnz)[0]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward_fused(x)
+
+
+class IFNode(BaseNode):
+    """h = v + x"""
+    _kind = _lib.KIND_IF
+
+
+class LIFNode(BaseNode):
+    """h = v + (x - (v - v_reset)) / tau   (true division)"""
+    _kind = _lib.KIND_LIF
+
+    def __init__(self, tau: float = 2., v_threshold: float = 1., v_reset: float = 0., surrogate_function=None,
+                 detach_reset: bool = False):
+        assert isinstance(tau, float) and tau > 1.
+        super().__init__(v_threshold, v_reset, surrogate_function, detach_reset)
+        self.tau = tau
+
+    def _tau(self):
+        return self.tau
+
+    def extra_repr(self):
+        return super().extra_repr() + f', tau={self.tau}'
+
+
+class ParametricLIFNode(BaseNode):
+    """h = v + (x - (v - v_reset)) * sigmoid(w), w learnable 0-dim, initialised to -log(init_tau - 1)."""
+    _kind = _lib.KIND_PLIF
+
+    def __init__(self, init_tau: float = 2.0, v_threshold: float = 1., v_reset: float = 0., surrogate_function=None,
+                 detach_reset: bool = False):
+        assert isinstance(init_tau, float) and init_tau > 1.
+        super().__init__(v_threshold, v_reset, surrogate_function, detach_reset)
+        self.w = nn.Parameter(torch.as_tensor(-math.log(init_tau - 1.), dtype=torch.float32))
+
+    def _k(self):
+        # stays on the device and in the autograd graph: dL/dw = dL/dk * k * (1 - k) is torch's sigmoid backward
+        return self.w.sigmoid()
+
+    def extra_repr(self):
+        with torch.no_grad():
+            return super().extra_repr() + f', tau={1. / self.w.sigmoid().item():.4g}'

@@ -1,0 +1,493 @@
+// ss_neuron.hip — hand-written CDNA4 (gfx950 / MI355X) kernels + the C-ABI of include/ss_neuron.h.
+//
+// The hot path of the reference: after every conv the
+// reference runs ~10 eager point-wise kernels per time step (MultiplyBy, charge, sub, >=, cast, 1-z, mul,
+// mul, add, skip add — /root/reference/network/blocks.py:106-107,161-171, SNN_models.py:152-192 plus the
+// un-vendored spikingjelly single-step nodes) and autograd mirrors them in backward.  Here the whole chain,
+// over all T steps, is ONE streaming kernel per layer in each direction.
+//
+// Design for MI355X (all HBM-bound, ~12 flops per 12 bytes — no MFMA, no GEMM reshaping):
+//  * flat 1-D over N = B*C*H*W neurons; one lane owns 4 consecutive neurons (16-B dwordx4 accesses, a
+//    wavefront covers 1 KiB contiguous per instruction => perfectly coalesced);
+//  * the membrane v of a lane's 4 neurons lives in VGPRs across the t-loop: the state is private to the
+//    lane, so staging it in LDS would only add a ds_write/ds_read round trip per step;
+//    LDS is used where lanes actually exchange data — the workgroup stage of the firing-rate / dL/dk reductions;
+//  * T is a template parameter for the common values so the T independent dwordx4 loads of a lane are all
+//    issued before the first dependent VALU op (T x 16 B in flight per lane); a runtime-T fallback exists;
+//  * grid = min(needed, 256 CUs x 8 workgroups) with a grid-stride loop, 256-thread workgroups (4 waves);
+//  * firing-rate counters: per-lane integer count -> wavefront butterfly (__shfl_xor over 64 lanes) ->
+//    4 partials in LDS -> one 64-bit integer atomic per counter per workgroup (deterministic);
+//  * dL/dk (PLIF): per-lane fp32 -> wavefront butterfly -> LDS -> one partial per workgroup in the caller's
+//    workspace -> second single-workgroup pass in fixed order (deterministic, no float atomics).
+//
+// Rounding discipline: compiled with -ffp-contract=off; every fp32 op below is written in the order eager
+// PyTorch evaluates the reference (x*scale first, true division by tau, (1-z)*h + z*v_reset literally).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <type_traits>
+
+#include "ss_neuron.h"
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kMaxGrid = 2048;       // 256 CUs x 8 workgroups/CU
+constexpr long long kGkWsFloats = kMaxGrid;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// element-wise pieces (scalar; applied to each of a lane's 4 neurons)
+// ---------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ float charge(float v, float xs, float tau, float k, float v_reset)
+{
+    if (KIND == SS_KIND_IF) return v + xs;
+    float d = xs - (v - v_reset);                 // (v - 0.f) == v bit-for-bit: covers both upstream branches
+    if (KIND == SS_KIND_LIF) return v + d / tau;  // IEEE-correct division (true division in the CPU reference)
+    return v + d * k;
+}
+
+__device__ __forceinline__ float heaviside(float xh) { return (xh >= 0.f) ? 1.f : 0.f; }
+
+template <int SG>
+__device__ __forceinline__ float surrogate_grad(float xh, float alpha, float c_atan, float half_alpha, float g)
+{
+    if (SG == SS_SG_ATAN) {
+        float u = xh * c_atan;
+        float p = u * u;
+        float r = 1.f / (p + 1.f);
+        return (r * half_alpha) * g;
+    }
+    float s = 1.f / (1.f + expf(-(xh * alpha)));
+    return ((g * (1.f - s)) * s) * alpha;
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* x_seq; const float* v_init; const float* skip_seq;
+    float* out_seq; float* h_seq; float* v_last; unsigned long long* nnz;
+    int T; long long N;
+    float scale, tau, v_th, v_reset; const float* k;
+};
+
+// VEC = 4: lane owns one f4 per time step; VEC = 1: scalar tail / unaligned fallback.
+template <int KIND, int TS, bool SKIP, bool SAVE_H, int VEC>
+__global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
+{
+    typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
+    const int T = (TS > 0) ? TS : a.T;
+    const long long NV = a.N / VEC;                       // vectors per time step
+    const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
+    const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset;
+    unsigned c_spk = 0, c_out = 0;
+
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
+        const vec_t* xp = reinterpret_cast<const vec_t*>(a.x_seq) + i;
+        const vec_t* sp = SKIP ? reinterpret_cast<const vec_t*>(a.skip_seq) + i : nullptr;
+        vec_t* op = reinterpret_cast<vec_t*>(a.out_seq) + i;
+        vec_t* hp = SAVE_H ? reinterpret_cast<vec_t*>(a.h_seq) + i : nullptr;
+
+        vec_t vv;
+        if (a.v_init) vv = reinterpret_cast<const vec_t*>(a.v_init)[i];
+        else { if constexpr (VEC == 4) vv = (f4){v_reset, v_reset, v_reset, v_reset}; else vv = v_reset; }
+
+        if constexpr (TS > 0) {
+            // all T loads of this lane are independent of the recurrence: issue them up front
+            vec_t xs[TS];
+            vec_t ss[SKIP ? TS : 1];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                xs[t] = xp[(long long)t * NV];
+                if (SKIP) ss[t] = sp[(long long)t * NV];
+            }
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                vec_t hv, ov;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float x, v, s = 0.f;
+                    if constexpr (VEC == 4) { x = xs[t][e]; v = vv[e]; if (SKIP) s = ss[t][e]; }
+                    else { x = xs[t]; v = vv; if (SKIP) s = ss[t]; }
+                    float h = charge<KIND>(v, x * scale, tau, k, v_reset);
+                    float z = heaviside(h - v_th);
+                    v = (1.f - z) * h + z * v_reset;
+                    float o = SKIP ? z + s : z;
+                    c_spk += (z != 0.f); c_out += (o != 0.f);
+                    if constexpr (VEC == 4) { hv[e] = h; ov[e] = o; vv[e] = v; } else { hv = h; ov = o; vv = v; }
+                }
+                if (SAVE_H) hp[(long long)t * NV] = hv;
+                op[(long long)t * NV] = ov;
+            }
+        } else {
+            // runtime T: one step of look-ahead, latency otherwise hidden by occupancy
+            vec_t xn = xp[0];
+            vec_t sn; if (SKIP) sn = sp[0];
+            for (int t = 0; t < T; ++t) {
+                vec_t xc = xn, sc; if (SKIP) sc = sn;
+                if (t + 1 < T) { xn = xp[(long long)(t + 1) * NV]; if (SKIP) sn = sp[(long long)(t + 1) * NV]; }
+                vec_t hv, ov;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float x, v, s = 0.f;
+                    if constexpr (VEC == 4) { x = xc[e]; v = vv[e]; if (SKIP) s = sc[e]; }
+                    else { x = xc; v = vv; if (SKIP) s = sc; }
+                    float h = charge<KIND>(v, x * scale, tau, k, v_reset);
+                    float z = heaviside(h - v_th);
+                    v = (1.f - z) * h + z * v_reset;
+                    float o = SKIP ? z + s : z;
+                    c_spk += (z != 0.f); c_out += (o != 0.f);
+                    if constexpr (VEC == 4) { hv[e] = h; ov[e] = o; vv[e] = v; } else { hv = h; ov = o; vv = v; }
+                }
+                if (SAVE_H) hp[(long long)t * NV] = hv;
+                op[(long long)t * NV] = ov;
+            }
+        }
+        reinterpret_cast<vec_t*>(a.v_last)[i] = vv;
+    }
+
+    if (a.nnz) {   // wave-uniform
+        __shared__ unsigned s_cnt[2][kBlock / 64];
+        unsigned ws = wave_sum_u32(c_spk), wo = wave_sum_u32(c_out);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_cnt[0][wave] = ws; s_cnt[1][wave] = wo; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long ts = 0, to = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) { ts += s_cnt[0][w]; to += s_cnt[1][w]; }
+            if (ts) atomicAdd(&a.nnz[0], ts);
+            if (to) atomicAdd(&a.nnz[1], to);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float* g_out_seq; const float* g_v_last; const float* h_seq; const float* v_init;
+    float* g_x_seq; float* g_v_init; float* g_k_partials;
+    int T; long long N;
+    float scale, tau, v_th, v_reset, alpha; const float* k; int detach_reset;
+};
+
+template <int KIND, int SG, int TS, int VEC>
+__global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
+{
+    typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
+    const int T = (TS > 0) ? TS : a.T;
+    const long long NV = a.N / VEC;
+    const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
+    const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset, alpha = a.alpha;
+    const float c_atan = (float)(M_PI / 2.0 * (double)alpha);
+    const float half_alpha = (float)((double)alpha / 2.0);
+    const bool detach = a.detach_reset != 0;
+    const bool want_gk = (KIND == SS_KIND_PLIF) && a.g_k_partials != nullptr;
+    float acc_k = 0.f;
+
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
+        const vec_t* gp = reinterpret_cast<const vec_t*>(a.g_out_seq) + i;
+        const vec_t* hp = reinterpret_cast<const vec_t*>(a.h_seq) + i;
+        vec_t* xp = reinterpret_cast<vec_t*>(a.g_x_seq) + i;
+
+        vec_t gv;
+        if (a.g_v_last) gv = reinterpret_cast<const vec_t*>(a.g_v_last)[i];
+        else { if constexpr (VEC == 4) gv = (f4){0.f, 0.f, 0.f, 0.f}; else gv = 0.f; }
+        vec_t v0;   // membrane before step 0 (PLIF dL/dk only)
+        if constexpr (VEC == 4) v0 = (f4){0.f, 0.f, 0.f, 0.f}; else v0 = 0.f;
+        if (want_gk) {
+            if (a.v_init) v0 = reinterpret_cast<const vec_t*>(a.v_init)[i];
+            else { if constexpr (VEC == 4) v0 = (f4){v_reset, v_reset, v_reset, v_reset}; else v0 = v_reset; }
+        }
+
+        auto step = [&](vec_t g, vec_t h, vec_t hprev, bool first) -> vec_t {
+            vec_t gx;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float ge, he, hpe, gve, v0e;
+                if constexpr (VEC == 4) { ge = g[e]; he = h[e]; hpe = hprev[e]; gve = gv[e]; v0e = v0[e]; }
+                else { ge = g; he = h; hpe = hprev; gve = gv; v0e = v0; }
+                float xh = he - v_th;
+                float z = heaviside(xh);
+                float g_s = ge;
+                if (!detach) g_s = g_s + (gve * v_reset - gve * he);
+                float g_h = surrogate_grad<SG>(xh, alpha, c_atan, half_alpha, g_s) + gve * (1.f - z);
+                float g_x;
+                if (KIND == SS_KIND_IF) { g_x = g_h; gve = g_h; }
+                else if (KIND == SS_KIND_LIF) { g_x = g_h / tau; gve = g_h - g_x; }
+                else {
+                    g_x = g_h * k; gve = g_h - g_x;
+                    if (want_gk) {
+                        float v_prev;
+                        if (first) v_prev = v0e;
+                        else { float zp = heaviside(hpe - v_th); v_prev = (1.f - zp) * hpe + zp * v_reset; }
+                        acc_k += g_h * ((he - v_prev) / k);
+                    }
+                }
+                if constexpr (VEC == 4) { gx[e] = g_x * scale; gv[e] = gve; } else { gx = g_x * scale; gv = gve; }
+            }
+            return gx;
+        };
+
+        if constexpr (TS > 0) {
+            vec_t gs[TS], hs[TS];
+#pragma unroll
+            for (int t = TS - 1; t >= 0; --t) { gs[t] = gp[(long long)t * NV]; hs[t] = hp[(long long)t * NV]; }
+#pragma unroll
+            for (int t = TS - 1; t >= 0; --t)
+                xp[(long long)t * NV] = step(gs[t], hs[t], hs[t > 0 ? t - 1 : 0], t == 0);
+        } else {
+            vec_t gn = gp[(long long)(T - 1) * NV], hn = hp[(long long)(T - 1) * NV];
+            for (int t = T - 1; t >= 0; --t) {
+                vec_t gc = gn, hc = hn;
+                if (t > 0) { gn = gp[(long long)(t - 1) * NV]; hn = hp[(long long)(t - 1) * NV]; }
+                xp[(long long)t * NV] = step(gc, hc, hn, t == 0);
+            }
+        }
+        if (a.g_v_init) reinterpret_cast<vec_t*>(a.g_v_init)[i] = gv;
+    }
+
+    if (want_gk) {   // wave-uniform
+        __shared__ float s_k[kBlock / 64];
+        float w = wave_sum_f32(acc_k);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) s_k[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < kBlock / 64; ++q) s += s_k[q];
+            a.g_k_partials[blockIdx.x] = s;
+        }
+    }
+}
+
+// second pass of the dL/dk reduction: fixed order -> bit-reproducible.  tail = scalar-tail kernel's partial.
+__global__ __launch_bounds__(kBlock) void gk_finish_kernel(const float* partials, int n, float* g_k)
+{
+    __shared__ float s[kBlock];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += kBlock) acc += partials[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = kBlock / 2; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *g_k = s[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// I-neuron read-out pool
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ipool_fwd_kernel(const float* pd, long long st, long long sk, const float* v_init,
+                                                           float* depth, int T, int K, long long M, float scale, float v_reset)
+{
+    for (long long m = (long long)blockIdx.x * kBlock + threadIdx.x; m < M; m += (long long)gridDim.x * kBlock) {
+        float v = v_init ? v_init[m] : v_reset;
+        for (int t = 0; t < T; ++t)
+            for (int k = 0; k < K; ++k) {
+                float h = v + pd[(long long)t * st + (long long)k * sk + m] * scale;
+                v = (1.f - 0.f) * h + 0.f * v_reset;
+                depth[((long long)t * K + k) * M + m] = v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ipool_bwd_kernel(const float* g_depth, const float* g_v_last, float* g_pd,
+                                                           long long st, long long sk, float* g_v_init,
+                                                           int T, int K, long long M, float scale)
+{
+    for (long long m = (long long)blockIdx.x * kBlock + threadIdx.x; m < M; m += (long long)gridDim.x * kBlock) {
+        float g_v = g_v_last ? g_v_last[m] : 0.f;
+        for (int t = T - 1; t >= 0; --t)
+            for (int k = K - 1; k >= 0; --k) {
+                g_v = g_depth[((long long)t * K + k) * M + m] + g_v;
+                g_pd[(long long)t * st + (long long)k * sk + m] = g_v * scale;
+            }
+        if (g_v_init) g_v_init[m] = g_v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------------
+inline int grid_for(long long work_items)
+{
+    long long g = (work_items + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int KIND, int TS, bool SKIP, bool SAVE_H>
+int launch_fwd(const FwdArgs& a, hipStream_t s)
+{
+    const bool vec = (a.N % 4 == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
+                     (!a.v_init || aligned16(a.v_init)) && (!SKIP || aligned16(a.skip_seq)) &&
+                     (!SAVE_H || aligned16(a.h_seq));
+    if (a.N == 0) return SS_OK;
+    if (vec) hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, SAVE_H, 4>), dim3(grid_for(a.N / 4)), dim3(kBlock), 0, s, a);
+    else     hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, SAVE_H, 1>), dim3(grid_for(a.N)), dim3(kBlock), 0, s, a);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+template <int KIND, int TS>
+int dispatch_fwd_flags(const FwdArgs& a, hipStream_t s)
+{
+    const bool skip = a.skip_seq != nullptr, save_h = a.h_seq != nullptr;
+    if (skip) return save_h ? launch_fwd<KIND, TS, true, true>(a, s) : launch_fwd<KIND, TS, true, false>(a, s);
+    return save_h ? launch_fwd<KIND, TS, false, true>(a, s) : launch_fwd<KIND, TS, false, false>(a, s);
+}
+
+template <int KIND>
+int dispatch_fwd_T(const FwdArgs& a, hipStream_t s)
+{
+    switch (a.T) {
+        case 1: return dispatch_fwd_flags<KIND, 1>(a, s);
+        case 2: return dispatch_fwd_flags<KIND, 2>(a, s);
+        case 4: return dispatch_fwd_flags<KIND, 4>(a, s);
+        case 5: return dispatch_fwd_flags<KIND, 5>(a, s);
+        case 8: return dispatch_fwd_flags<KIND, 8>(a, s);
+        case 10: return dispatch_fwd_flags<KIND, 10>(a, s);
+        default: return dispatch_fwd_flags<KIND, 0>(a, s);
+    }
+}
+
+template <int KIND, int SG, int TS>
+int launch_bwd(const BwdArgs& a, hipStream_t s, int* grid_out)
+{
+    const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.g_x_seq) &&
+                     (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
+                     (!a.v_init || aligned16(a.v_init));
+    const int grid = vec ? grid_for(a.N / 4) : grid_for(a.N);
+    *grid_out = grid;
+    if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4>), dim3(grid), dim3(kBlock), 0, s, a);
+    else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1>), dim3(grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+template <int KIND, int SG>
+int dispatch_bwd_T(const BwdArgs& a, hipStream_t s, int* grid_out)
+{
+    switch (a.T) {
+        case 1: return launch_bwd<KIND, SG, 1>(a, s, grid_out);
+        case 2: return launch_bwd<KIND, SG, 2>(a, s, grid_out);
+        case 4: return launch_bwd<KIND, SG, 4>(a, s, grid_out);
+        case 5: return launch_bwd<KIND, SG, 5>(a, s, grid_out);
+        case 8: return launch_bwd<KIND, SG, 8>(a, s, grid_out);
+        case 10: return launch_bwd<KIND, SG, 10>(a, s, grid_out);
+        default: return launch_bwd<KIND, SG, 0>(a, s, grid_out);
+    }
+}
+
+template <int KIND>
+int dispatch_bwd_sg(const BwdArgs& a, int surrogate, hipStream_t s, int* grid_out)
+{
+    return surrogate == SS_SG_ATAN ? dispatch_bwd_T<KIND, SS_SG_ATAN>(a, s, grid_out)
+                                   : dispatch_bwd_T<KIND, SS_SG_SIGMOID>(a, s, grid_out);
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+long long ss_neuron_gk_ws_floats(void) { return kGkWsFloats; }
+
+int ss_neuron_fwd_f32(const float* x_seq, const float* v_init, const float* skip_seq,
+                      float* out_seq, float* h_seq, float* v_last, unsigned long long* nnz,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, void* stream)
+{
+    if (!x_seq || !out_seq || !v_last || T <= 0 || N < 0) return SS_EINVAL;
+    if (kind < SS_KIND_IF || kind > SS_KIND_PLIF) return SS_EINVAL;
+    if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
+    if (out_seq == x_seq) return SS_EINVAL;
+    FwdArgs a{x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (kind) {
+        case SS_KIND_IF: return dispatch_fwd_T<SS_KIND_IF>(a, s);
+        case SS_KIND_LIF: return dispatch_fwd_T<SS_KIND_LIF>(a, s);
+        default: return dispatch_fwd_T<SS_KIND_PLIF>(a, s);
+    }
+}
+
+int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
+                      float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+{
+    if (!g_out_seq || !h_seq || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
+    if (kind < SS_KIND_IF || kind > SS_KIND_PLIF) return SS_EINVAL;
+    if (surrogate != SS_SG_ATAN && surrogate != SS_SG_SIGMOID) return SS_EINVAL;
+    if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
+    const bool want_gk = (kind == SS_KIND_PLIF) && g_k != nullptr;
+    if (want_gk && !g_k_ws) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        if (want_gk && hipMemsetAsync(g_k, 0, sizeof(float), s) != hipSuccess) return SS_ELAUNCH;
+        return SS_OK;
+    }
+    BwdArgs a{g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, want_gk ? g_k_ws : nullptr,
+              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset};
+    int grid = 0, rc;
+    switch (kind) {
+        case SS_KIND_IF: rc = dispatch_bwd_sg<SS_KIND_IF>(a, surrogate, s, &grid); break;
+        case SS_KIND_LIF: rc = dispatch_bwd_sg<SS_KIND_LIF>(a, surrogate, s, &grid); break;
+        default: rc = dispatch_bwd_sg<SS_KIND_PLIF>(a, surrogate, s, &grid); break;
+    }
+    if (rc != SS_OK) return rc;
+    if (want_gk) {
+        hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(kBlock), 0, s, g_k_ws, grid, g_k);
+        if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    }
+    return SS_OK;
+}
+
+int ss_ipool_fwd_f32(const float* pd_seq, long long stride_t, long long stride_k, const float* v_init,
+                     float* depth_seq, int T, int K, long long M, float scale, float v_reset, void* stream)
+{
+    if (!pd_seq || !depth_seq || T <= 0 || K <= 0 || M < 0) return SS_EINVAL;
+    if (M == 0) return SS_OK;
+    hipLaunchKernelGGL(ipool_fwd_kernel, dim3(grid_for(M)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       pd_seq, stride_t, stride_k, v_init, depth_seq, T, K, M, scale, v_reset);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_ipool_bwd_f32(const float* g_depth_seq, const float* g_v_last, float* g_pd_seq,
+                     long long stride_t, long long stride_k, float* g_v_init,
+                     int T, int K, long long M, float scale, void* stream)
+{
+    if (!g_depth_seq || !g_pd_seq || T <= 0 || K <= 0 || M < 0) return SS_EINVAL;
+    if (M == 0) return SS_OK;
+    hipLaunchKernelGGL(ipool_bwd_kernel, dim3(grid_for(M)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       g_depth_seq, g_v_last, g_pd_seq, stride_t, stride_k, g_v_init, T, K, M, scale);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+}  // extern "C"

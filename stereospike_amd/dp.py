@@ -1,0 +1,89 @@
+"""Data-parallel training of the hot path across the GPUs of one node: one process per GPU,
+`torch.distributed` with backend "nccl" (= RCCL over xGMI on ROCm); gloo on CPU for the tests.
+
+The reference has no distributed code at all; this is the build-side addition BASELINE.json asks for.  The
+model shards along the batch only (no BatchNorm in the SNNs, nothing to shard along T — a strict recurrence).
+One collective per step: a SUM all-reduce of the 18.15 M-element fp32 gradient (72.6 MB), pre-divided by the
+world size.  Sizing for xGMI rather than NVSwitch: a ring all-reduce over 8 GPUs moves 2*(7/8)*72.6 MB = 127 MB per
+GPU at ~153 GB/s per link => ~1 ms against a >= 100 ms step, so a handful of large buckets (default 4 x ~18 MB,
+big enough to run at link bandwidth, few enough to keep launch count low) issued as soon as their gradients
+are final hides the whole exchange under the remaining backward (the decoder's gradients are ready first, the
+encoder's last; layer-by-layer BPTT produces each weight gradient exactly once per step).
+
+Gradients live directly in the flat bucket buffers (p.grad is a view), so there is no pack/unpack copy.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradientAllReducer:
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 20 << 20, process_group=None,
+                 broadcast_from: Optional[int] = 0):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        if self.world > 1 and broadcast_from is not None:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=broadcast_from, group=process_group)
+        # backward visits parameters roughly in reverse registration order: fill buckets in that order
+        self.buckets: List[dict] = []
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= bucket_bytes:
+                self._close(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._close(cur)
+        self._slot = {}
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b['params']):
+                self._slot[id(p)] = (bi, pi)
+                p.register_post_accumulate_grad_hook(self._hook)
+        self.zero_grad()
+
+    def _close(self, params):
+        p0 = params[0]
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=p0.dtype, device=p0.device)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.buckets.append(dict(params=params, flat=flat, views=views, pending=len(params), work=None))
+
+    def zero_grad(self):
+        """Zero the buckets and (re)attach p.grad as views into them — use instead of optimizer.zero_grad()."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'] = len(b['params'])
+            b['work'] = None
+            for p, v in zip(b['params'], b['views']):
+                p.grad = v
+
+    def _hook(self, p):
+        bi, pi = self._slot[id(p)]
+        b = self.buckets[bi]
+        v = b['views'][pi]
+        if p.grad.data_ptr() != v.data_ptr():
+            # autograd replaced the view (grad was None): copy into the bucket and re-attach
+            v.copy_(p.grad)
+            p.grad = v
+        b['pending'] -= 1
+        if b['pending'] == 0 and self.world > 1:
+            b['flat'].div_(self.world)
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for the in-flight all-reduces (call after loss.backward(), before optimizer.step())."""
+        for b in self.buckets:
+            if b['work'] is not None:
+                b['work'].wait()
+                b['work'] = None
+            elif self.world > 1 and b['pending'] != 0:
+                # a parameter received no gradient this step: reduce what there is so ranks stay consistent
+                b['flat'].div_(self.world)
+                dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
+            b['pending'] = len(b['params'])

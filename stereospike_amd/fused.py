@@ -1,0 +1,167 @@
+"""torch.autograd front-end of the C-ABI (include/ss_neuron.h).
+
+`fused_neuron(x_seq, ...)` replaces, for one layer and all T steps at once, what the reference spreads over
+MultiplyBy.forward (/root/reference/network/blocks.py:106-107), the spikingjelly single-step node
+(call sites SNN_models.py:78...128, 266...316, blocks.py:150,157), the skip / SEW adds (SNN_models.py:171-186,
+blocks.py:171) and, in backward, the autograd chain through surrogate.ATan / surrogate.Sigmoid.
+
+`ipool(pd_seq, ...)` replaces the shared I-neuron read-out (SNN_models.py:150,172-188).
+
+Everything here needs the HIP library and HIP tensors; there is no eager fallback.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class NeuronCfg:
+    kind: int                    # _lib.KIND_*
+    scale: float = 1.0           # MultiplyBy gain folded into the kernel
+    tau: float = 2.0             # LIF only
+    v_th: float = 1.0
+    v_reset: float = 0.0
+    surrogate: int = _lib.SG_SIGMOID
+    alpha: float = 4.0
+    detach_reset: bool = True
+
+
+class KernelTimer:
+    """Optional HIP-event timing of every fused launch (bench.py's roofline leg).  Events are recorded on the
+    stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []        # (tag, algorithmic_bytes, updates, start_event, end_event)
+
+    def start(self):
+        if not self.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, tag, nbytes, updates):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((tag, nbytes, updates, e0, e1))
+
+    def summary(self):
+        """{tag: dict(launches, bytes, updates, ms)} — call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, nbytes, updates, e0, e1 in self.records:
+            d = out.setdefault(tag, dict(launches=0, bytes=0, updates=0, ms=0.0))
+            d['launches'] += 1
+            d['bytes'] += nbytes
+            d['updates'] += updates
+            d['ms'] += e0.elapsed_time(e1)
+        return out
+
+    def clear(self):
+        self.records = []
+
+
+TIMER = KernelTimer()
+
+
+class _FusedNeuron(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz):
+        T = x_seq.shape[0]
+        N = x_seq.numel() // T
+        x_seq = x_seq.contiguous()
+        if skip_seq is not None:
+            skip_seq = skip_seq.contiguous()
+        if v_init is not None:
+            v_init = v_init.contiguous()
+        need_grad = any(ctx.needs_input_grad[:4])
+        out_seq = torch.empty_like(x_seq)
+        h_seq = torch.empty_like(x_seq) if need_grad else None
+        v_last = torch.empty(x_seq.shape[1:], dtype=x_seq.dtype, device=x_seq.device)
+        e0 = TIMER.start()
+        _lib.neuron_fwd(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, cfg.scale, cfg.kind, cfg.tau, k,
+                        cfg.v_th, cfg.v_reset)
+        per = 4 * (2 + (1 if need_grad else 0) + (1 if skip_seq is not None else 0))
+        TIMER.stop(e0, 'neuron_fwd_train' if need_grad else 'neuron_fwd_infer', per * T * N, T * N)
+        ctx.cfg = cfg
+        ctx.T, ctx.N = T, N
+        ctx.has_vinit = v_init is not None
+        ctx.has_skip = skip_seq is not None
+        ctx.set_materialize_grads(False)
+        if need_grad:
+            # h_seq is all the backward needs (z_t, v_{t-1} are recomputed from it); the OUTPUT is not saved because
+            # the reference mutates it in place (blocks.py:171).  v_init only feeds the PLIF dL/dk term at t = 0.
+            keep_v = v_init if (cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]) else None
+            ctx.save_for_backward(h_seq, keep_v, k)
+        return out_seq, v_last
+
+    @staticmethod
+    def backward(ctx, g_out_seq, g_v_last):
+        h_seq, v_init, k = ctx.saved_tensors
+        cfg, T, N = ctx.cfg, ctx.T, ctx.N
+        if g_out_seq is None:
+            g_out_seq = torch.zeros_like(h_seq)
+        g_out_seq = g_out_seq.contiguous()
+        if g_v_last is not None:
+            g_v_last = g_v_last.contiguous()
+        g_x_seq = torch.empty_like(h_seq)
+        want_gv = ctx.has_vinit and ctx.needs_input_grad[1]
+        g_v_init = torch.empty(h_seq.shape[1:], dtype=h_seq.dtype, device=h_seq.device) if want_gv else None
+        want_gk = cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]
+        g_k = g_k_ws = None
+        if want_gk:
+            g_k = torch.empty((), dtype=h_seq.dtype, device=h_seq.device)
+            g_k_ws = torch.empty(_lib.gk_ws_floats(), dtype=h_seq.dtype, device=h_seq.device)
+        e0 = TIMER.start()
+        _lib.neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, cfg.scale, cfg.kind,
+                        cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
+        TIMER.stop(e0, 'neuron_bwd', 12 * T * N, T * N)
+        g_skip = g_out_seq if (ctx.has_skip and ctx.needs_input_grad[2]) else None   # identity
+        return g_x_seq, g_v_init, g_skip, g_k, None, None
+
+
+def fused_neuron(x_seq: torch.Tensor, cfg: NeuronCfg, v_init: Optional[torch.Tensor] = None,
+                 skip_seq: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None,
+                 nnz: Optional[torch.Tensor] = None):
+    """x_seq: [T, ...] conv output (before the gain).  Returns (out_seq [T, ...], v_last [...])."""
+    if cfg.kind == _lib.KIND_PLIF and k is None:
+        raise _lib.SSNeuronError('PLIF needs k = sigmoid(w) as a 0-dim HIP tensor')
+    return _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz)
+
+
+class _IPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pd_seq, v_init, scale, v_reset):
+        # pd_seq: [K, T, M...] (k = 0 is the head charged first) — i.e. torch.stack of the K head outputs
+        pd_seq = pd_seq.contiguous()
+        K, T = pd_seq.shape[0], pd_seq.shape[1]
+        M = pd_seq.numel() // (K * T)
+        if v_init is not None:
+            v_init = v_init.contiguous()
+        depth_seq = torch.empty((T, K) + tuple(pd_seq.shape[2:]), dtype=pd_seq.dtype, device=pd_seq.device)
+        _lib.ipool_fwd(pd_seq, M, T * M, v_init, depth_seq, T, K, M, scale, v_reset)
+        ctx.dims = (T, K, M)
+        ctx.scale = scale
+        ctx.shape = pd_seq.shape
+        ctx.has_vinit = v_init is not None
+        return depth_seq
+
+    @staticmethod
+    def backward(ctx, g_depth_seq):
+        T, K, M = ctx.dims
+        g_depth_seq = g_depth_seq.contiguous()
+        g_pd = torch.empty(ctx.shape, dtype=g_depth_seq.dtype, device=g_depth_seq.device)
+        want_gv = ctx.has_vinit and ctx.needs_input_grad[1]
+        g_v_init = torch.empty(ctx.shape[2:], dtype=g_depth_seq.dtype, device=g_depth_seq.device) if want_gv else None
+        _lib.ipool_bwd(g_depth_seq, None, g_pd, M, T * M, g_v_init, T, K, M, ctx.scale)
+        return g_pd, g_v_init, None, None
+
+
+def ipool(pd_seq: torch.Tensor, scale: float, v_reset: float, v_init: Optional[torch.Tensor] = None):
+    """pd_seq [K, T, ...] -> depth_seq [T, K, ...]: membrane snapshots after every charge (t outer, k inner)."""
+    return _IPool.apply(pd_seq, v_init, float(scale), float(v_reset))

@@ -1,0 +1,243 @@
+"""The spiking encoder-decoder models of the reference, same class names / constructor signatures / forward I/O /
+state_dict keys (/root/reference/network/SNN_models.py):
+
+    NeuromorphicNet                                                    :11-60
+    StereoSpike                                                        :63-248
+    fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike        :251-435
+    fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike   :438-622
+
+Execution is layer-by-layer over a [T, B, C, H, W] sequence: each conv runs once on the [T*B] batch
+(PyTorch-ROCm), each neuron layer is one fused HIP launch that walks the T steps with the membrane in registers,
+the decoder skip add / SEW add are kernel epilogues, and the four predict_depth heads charge the shared I-neuron
+pool in one launch that keeps the reference's (t outer, head 4->1 inner) fp32 summation order.  Because the
+network is purely feed-forward this is mathematically the reference's step-by-step evaluation
+(`reset_net(net); for t: net(x[:, t:t+1])`).
+
+`net(x)` is the reference's single-step call (consumes x[:, 0], membranes carried across calls until
+functional.reset_net).  `net.forward_sequence(x)` consumes all T frames of x [B, T, C, H, W] in one pass and
+returns what the last of T successive `net(...)` calls would return.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ..clock_driven import layer, neuron, surrogate
+from ..fused import ipool
+from .blocks import MultiplyBy, NNConvUpsampling, SEWResBlock, SpikingStage
+
+_RATE_KEYS = ('out_bottom', 'out_conv1', 'out_conv2', 'out_conv3', 'out_conv4', 'out_rconv', 'out_combined',
+              'out_deconv4', 'out_add4', 'out_deconv3', 'out_add3', 'out_deconv2', 'out_add2', 'out_deconv1',
+              'out_add1')
+
+
+def _pyramid(input_size):
+    """Spatial sizes after bottom, conv1..conv4 (k5 s2 p2): (260,346) -> (130,173),(65,87),(33,44),(17,22)."""
+    sizes = [tuple(input_size)]
+    for _ in range(4):
+        h, w = sizes[-1]
+        sizes.append(((h + 4 - 5) // 2 + 1, (w + 4 - 5) // 2 + 1))
+    return sizes
+
+
+class NeuromorphicNet(nn.Module):
+    def __init__(self, surrogate_function=None, detach_reset=True, v_threshold=1.0, v_reset=0.0):
+        super().__init__()
+        self.surrogate_fct = surrogate.Sigmoid() if surrogate_function is None else surrogate_function
+        self.detach_rst = detach_reset
+        self.v_th = v_threshold
+        self.v_rst = v_reset
+        self.max_test_accuracy = float('inf')
+        self.epoch = 0
+
+    # -- state utilities (SNN_models.py:22-48) ------------------------------------------------------
+    def detach(self):
+        for m in self.modules():
+            if isinstance(m, neuron.BaseNode):
+                m.detach()
+            elif isinstance(m, layer.Dropout) and m.mask is not None:
+                m.mask.detach_()
+
+    def get_network_state(self):
+        return [m.v for m in self.modules() if hasattr(m, 'reset') and hasattr(m, 'v')]
+
+    def change_network_state(self, new_state):
+        it = iter(new_state)
+        for m in self.modules():
+            if hasattr(m, 'reset') and hasattr(m, 'v'):
+                m.v = next(it)
+
+    def set_output_potentials(self, new_pots):
+        it = iter(new_pots)
+        for m in self.modules():
+            if isinstance(m, neuron.IFNode):
+                m.v = next(it)
+
+    def increment_epoch(self):
+        self.epoch += 1
+
+    def get_max_accuracy(self):
+        return self.max_test_accuracy
+
+    def update_max_accuracy(self, new_acc):
+        self.max_test_accuracy = new_acc
+
+    def count_trainable_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+class _SpikingEncoderDecoder(NeuromorphicNet):
+    """Topology shared by the three models; subclasses only choose the neuron factory and the input channels."""
+    _returns_spikes = True
+
+    def _build(self, in_channels, make_node, make_resblock, multiply_factor, ineurons, input_size=(260, 346)):
+        sz = _pyramid(input_size)
+        self.input_size = tuple(input_size)
+
+        def stage(synapse):
+            return SpikingStage(synapse, MultiplyBy(multiply_factor), make_node())
+
+        self.bottom = stage(nn.Conv2d(in_channels, 32, kernel_size=5, stride=1, padding=2, bias=False))
+        chans = (32, 64, 128, 256, 512)
+        for i in range(1, 5):
+            setattr(self, f'conv{i}', stage(nn.Conv2d(chans[i - 1], chans[i], kernel_size=5, stride=2, padding=2,
+                                                      bias=False)))
+        self.bottleneck = nn.Sequential(make_resblock(), make_resblock())
+        for lvl in (4, 3, 2, 1):
+            setattr(self, f'deconv{lvl}', stage(NNConvUpsampling(chans[lvl], chans[lvl - 1], kernel_size=5,
+                                                                  up_size=sz[lvl - 1])))
+        for lvl in (4, 3, 2, 1):
+            setattr(self, f'predict_depth{lvl}', nn.Sequential(
+                NNConvUpsampling(chans[lvl - 1], 1, kernel_size=3, up_size=sz[0], bias=True),
+                MultiplyBy(multiply_factor)))
+        self.Ineurons = ineurons
+
+    # -- the engine --------------------------------------------------------------------------------------
+    def _run(self, x_seq: torch.Tensor, count: bool = False):
+        """x_seq [T, B, C, H, W] -> (depth_seq [T, 4, B, 1, H, W], last-step spike tensors, counters)."""
+        T, B = x_seq.shape[:2]
+        cnt = {}
+
+        def nnz(name):
+            if not count:
+                return None
+            cnt[name] = torch.zeros(2, dtype=torch.int64, device=x_seq.device)
+            return cnt[name]
+
+        enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]
+        for i in range(1, 5):
+            enc.append(getattr(self, f'conv{i}').forward_sequence(enc[-1], None, nnz(f'conv{i}')))
+        cur = self.bottleneck[0].forward_sequence(enc[4])
+        cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
+        spikes, heads = [cur], []
+        for lvl in (4, 3, 2, 1):
+            cur = getattr(self, f'deconv{lvl}').forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
+            spikes.append(cur)
+            head = getattr(self, f'predict_depth{lvl}')
+            heads.append(head[0](cur.flatten(0, 1)).view(T, B, 1, *self.input_size))
+        # shared I-neuron pool: v += gain * head, heads charged in the order 4,3,2,1 every step (:172-188)
+        gains = [h[1].scale_value for h in (self.predict_depth4, self.predict_depth3, self.predict_depth2,
+                                            self.predict_depth1)]
+        if any(isinstance(g, torch.Tensor) for g in gains) or len({float(g) for g in gains}) != 1:
+            heads = [torch.mul(p, g) for p, g in zip(heads, gains)]
+            gain = 1.0
+        else:
+            gain = float(gains[0])
+        pool = self.Ineurons
+        depth_seq = ipool(torch.stack(heads), gain, pool.v_reset, pool._v_init(heads[0][0]))
+        pool.v = depth_seq[T - 1, 3]
+        return depth_seq, [s[T - 1] for s in spikes], cnt, (T, B)
+
+    def forward_sequence(self, x: torch.Tensor):
+        """x [B, T, C, H, W]: all T frames in one pass, membranes carried from their current state."""
+        depth_seq, spikes, _, (T, _) = self._run(x.transpose(0, 1).contiguous())
+        depths = [depth_seq[T - 1, k] for k in (3, 2, 1, 0)]          # [depth1, depth2, depth3, depth4]
+        return (depths, spikes) if self._returns_spikes else depths
+
+    def forward(self, x: torch.Tensor):
+        # x must be of shape [batch_size, num_frames_per_depth_map, C, H, W]; like the reference only frame 0 is read
+        return self.forward_sequence(x[:, 0:1])
+
+    def calculate_firing_rates(self, x: torch.Tensor):
+        """Density count_nonzero / numel of the 14 named tensors, from the counters the fused kernels accumulate
+        (wavefront reductions + integer atomics) instead of a second pass over every tensor."""
+        _, _, cnt, (T, B) = self._run(x[:, 0:1].transpose(0, 1).contiguous(), count=True)
+        rates = {k: 0. for k in _RATE_KEYS}
+
+        def numel(stage_name):
+            node_v = (self.bottleneck[1].sn2 if stage_name == 'rconv' else getattr(self, stage_name)[2]).v
+            return T * node_v.numel()
+
+        for name in ('bottom', 'conv1', 'conv2', 'conv3', 'conv4'):
+            rates[f'out_{name}'] = cnt[name][0].float() / numel(name)
+        rates['out_rconv'] = cnt['rconv'][1].float() / numel('rconv')
+        for lvl in (4, 3, 2, 1):
+            rates[f'out_deconv{lvl}'] = cnt[f'deconv{lvl}'][0].float() / numel(f'deconv{lvl}')
+            rates[f'out_add{lvl}'] = cnt[f'deconv{lvl}'][1].float() / numel(f'deconv{lvl}')
+        return rates
+
+    def set_init_depths_potentials(self, depth_prior):
+        self.Ineurons.v = depth_prior
+
+
+class StereoSpike(_SpikingEncoderDecoder):
+    """Baseline binocular model: IF neurons everywhere, all potentials reset before every prediction.
+
+    As in the reference (SNN_models.py:71-72, :105-106) the `v_threshold` / `v_reset` arguments are accepted but
+    not forwarded (1.0 / 0.0 are always used) and the bottleneck keeps SEWResBlock's default Sigmoid surrogate
+    whatever `surrogate_function` is — quirks kept on purpose, they are part of numerical parity."""
+
+    def __init__(self, surrogate_function=None, detach_reset=True, v_threshold=1.0, v_reset=0.0, multiply_factor=1.,
+                 input_size=(260, 346)):
+        super().__init__(surrogate_function=surrogate_function, detach_reset=detach_reset)
+
+        def node():
+            return neuron.IFNode(v_threshold=self.v_th, v_reset=self.v_rst, surrogate_function=self.surrogate_fct,
+                                 detach_reset=True)
+
+        def resblock():
+            return SEWResBlock(512, v_threshold=self.v_th, v_reset=self.v_rst, connect_function='ADD',
+                               multiply_factor=multiply_factor)
+
+        self._build(4, node, resblock, multiply_factor,
+                    neuron.IFNode(v_threshold=float('inf'), v_reset=0.0, surrogate_function=self.surrogate_fct),
+                    input_size)
+
+
+class fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(_SpikingEncoderDecoder):
+    """LIF (ATan surrogate) or PLIF (library-default Sigmoid surrogate) variant; the bottleneck is always PLIF.
+    The paper's setting: tau=3.0, multiply_factor=10.0, use_plif=True (train.py:120)."""
+    _in_channels = 4
+
+    def __init__(self, use_plif=False, detach_reset=True, tau=10., v_threshold=1.0, v_reset=0.0, multiply_factor=1.,
+                 input_size=(260, 346)):
+        super().__init__(detach_reset=detach_reset)
+        self.is_cext_model = False
+
+        def node():
+            if use_plif:
+                return neuron.ParametricLIFNode(init_tau=tau, v_threshold=v_threshold, v_reset=v_reset,
+                                                detach_reset=True)
+            return neuron.LIFNode(tau=tau, v_threshold=v_threshold, v_reset=v_reset,
+                                  surrogate_function=surrogate.ATan(), detach_reset=True)
+
+        def resblock():
+            return SEWResBlock(512, v_threshold=v_threshold, v_reset=v_reset, connect_function='ADD',
+                               multiply_factor=multiply_factor, use_plif=True, tau=tau)
+
+        self._build(self._in_channels, node, resblock, multiply_factor,
+                    neuron.IFNode(v_threshold=float('inf'), v_reset=v_reset, surrogate_function=surrogate.ATan()),
+                    input_size)
+
+
+class fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike(
+        fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike):
+    """One camera only (2 input channels); returns the depth list alone (SNN_models.py:566)."""
+    _in_channels = 2
+    _returns_spikes = False
+
+    def __init__(self, use_plif=False, detach_reset=True, tau=10., v_threshold=1.0, v_reset=0.0,
+                 final_activation=nn.Identity, multiply_factor=1., input_size=(260, 346)):
+        super().__init__(use_plif=use_plif, detach_reset=detach_reset, tau=tau, v_threshold=v_threshold,
+                         v_reset=v_reset, multiply_factor=multiply_factor, input_size=input_size)
+        self.final_activation = final_activation

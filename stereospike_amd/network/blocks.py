@@ -1,0 +1,157 @@
+"""Building blocks with the reference's names, signatures and state_dict layout
+(/root/reference/network/blocks.py): MultiplyBy (:90-107), NNConvUpsampling (:110-132), SEWResBlock (:135-181),
+plus BilinConvUpsampling (:15-37) and ResBlock (:40-83) for the ANN twin.
+
+What is different is *how* they run on the MI355X: wherever the reference chains
+conv -> MultiplyBy -> neuron (-> add), the conv stays a PyTorch-ROCm op and everything after it is one fused
+HIP launch (stereospike_amd/csrc/ss_neuron.hip), for a single step or for a whole [T, B, C, H, W] sequence.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ..clock_driven import neuron, surrogate
+
+
+class MultiplyBy(nn.Module):
+    """y = x * scale_value (a python float, or a 1-element Parameter when learnable).  In a SpikingStage /
+    SEWResBlock a non-learnable gain is folded into the neuron kernel's prologue instead of costing a pass."""
+
+    def __init__(self, scale_value: float = 5., learnable: bool = False) -> None:
+        super().__init__()
+        self.scale_value = nn.Parameter(torch.tensor([float(scale_value)])) if learnable else scale_value
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return torch.mul(input, self.scale_value)
+
+    def extra_repr(self):
+        return f'scale_value={float(self.scale_value)}'
+
+
+def _fold_gain(mul: MultiplyBy, y: torch.Tensor):
+    """(tensor, scale) such that the neuron kernel computes (tensor * scale): fold a constant gain, apply a
+    learnable one with torch so autograd reaches its Parameter."""
+    if isinstance(mul.scale_value, torch.Tensor):
+        return mul(y), 1.0
+    return y, float(mul.scale_value)
+
+
+class _UpConv(nn.Module):
+    """resize to (up_size + k - 1) then a valid k x k conv => output is exactly up_size; `.up[1]` is the Conv2d."""
+    _mode = None
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, up_size: tuple, bias: bool = False):
+        super().__init__()
+        size = (up_size[0] + (kernel_size - 1), up_size[1] + (kernel_size - 1))
+        resize = nn.UpsamplingNearest2d(size=size) if self._mode == 'nearest' else nn.UpsamplingBilinear2d(size=size)
+        self.up = nn.Sequential(
+            resize,
+            nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1, padding=0, bias=bias),
+        )
+
+    def forward(self, x):
+        return self.up(x)
+
+
+class NNConvUpsampling(_UpConv):
+    """Nearest-neighbour resize + conv (checkerboard-free 'deconvolution'; integer spike counts stay integer)."""
+    _mode = 'nearest'
+
+
+class BilinConvUpsampling(_UpConv):
+    _mode = 'bilinear'
+
+
+class SpikingStage(nn.Sequential):
+    """Sequential(conv | NNConvUpsampling, MultiplyBy, Node) — the layout of every spiking stage of the reference
+    (SNN_models.py:75-129), so parameters keep their names ('bottom.0.weight', 'deconv4.0.up.1.weight',
+    'bottom.2.w').  Calling it runs the conv in PyTorch-ROCm and gain + charge + fire + reset (+ skip add,
+    + firing-rate counters) as one fused launch."""
+
+    def forward(self, x: torch.Tensor, skip: Optional[torch.Tensor] = None, nnz=None) -> torch.Tensor:
+        y, scale = _fold_gain(self[1], self[0](x))
+        return self[2].forward_fused(y, scale, skip, nnz)
+
+    def forward_sequence(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None):
+        """x_seq [T, B, C, H, W] -> [T, B, C', H', W']: the conv sees one [T*B] batch (time steps are independent
+        for a feed-forward synapse), the neuron kernel then walks t = 0..T-1 with v in registers."""
+        T, B = x_seq.shape[:2]
+        y = self[0](x_seq.flatten(0, 1))
+        y, scale = _fold_gain(self[1], y)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
+
+
+class ResBlock(nn.Module):
+    """Residual block of the ANN twin (conv -> activation -> BatchNorm, twice, then the connect function)."""
+
+    def __init__(self, in_channels: int, connect_function='ADD', kernel_size: int = 3, bias: bool = False,
+                 activation_function: nn.Module = nn.Tanh()):
+        super().__init__()
+        pad = (kernel_size - 1) // 2
+        for name in ('conv1', 'conv2'):
+            setattr(self, name, nn.Sequential(
+                nn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=1, padding=pad, bias=bias),
+                activation_function,
+                nn.BatchNorm2d(in_channels)))
+        self.connect_function = connect_function
+
+    def forward(self, x):
+        return _connect(self.connect_function, self.conv2(self.conv1(x)), x, spiking=False)
+
+
+def _connect(fn: str, out: torch.Tensor, identity: torch.Tensor, spiking: bool):
+    if fn == 'ADD':
+        out += identity
+        return out
+    if fn in ('MUL', 'AND'):
+        out *= identity
+        return out
+    if fn == 'NMUL':
+        return identity * (1. - out)
+    if fn == 'OR' and spiking:
+        return surrogate.ATan(spiking=True)(out + identity)
+    raise NotImplementedError(fn)
+
+
+class SEWResBlock(nn.Module):
+    """Spike-Element-Wise residual block (arXiv:2102.04159): conv-gain-neuron twice, then g(out, identity).
+    With 'ADD' (the only connect function the reference uses, SNN_models.py:105-106) the residual add is the
+    epilogue of the second neuron kernel; the other connect functions run unfused."""
+
+    def __init__(self, in_channels: int, connect_function='ADD', v_threshold=1., v_reset=0.,
+                 surrogate_function=None, use_plif=False, tau=2., multiply_factor=1.):
+        super().__init__()
+        if surrogate_function is None:
+            surrogate_function = surrogate.Sigmoid()
+
+        def node():
+            if use_plif:
+                return neuron.ParametricLIFNode(init_tau=tau, v_threshold=v_threshold, v_reset=v_reset,
+                                                surrogate_function=surrogate_function, detach_reset=True)
+            return neuron.IFNode(v_threshold=v_threshold, v_reset=v_reset, surrogate_function=surrogate_function,
+                                 detach_reset=True)
+
+        def conv():
+            return nn.Sequential(nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1, bias=False),
+                                 MultiplyBy(multiply_factor))
+
+        self.conv1, self.sn1 = conv(), node()
+        self.conv2, self.sn2 = conv(), node()
+        self.connect_function = connect_function
+
+    def forward_sequence(self, x_seq: torch.Tensor, nnz=None) -> torch.Tensor:
+        T, B = x_seq.shape[:2]
+
+        def half(conv, sn, inp, skip, cnt):
+            y, scale = _fold_gain(conv[1], conv[0](inp.flatten(0, 1)))
+            return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt)
+
+        out = half(self.conv1, self.sn1, x_seq, None, None)
+        if self.connect_function == 'ADD':
+            return half(self.conv2, self.sn2, out, x_seq, nnz)
+        out = half(self.conv2, self.sn2, out, None, nnz)
+        return _connect(self.connect_function, out, x_seq, spiking=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward_sequence(x.unsqueeze(0))[0]

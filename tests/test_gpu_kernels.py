@@ -1,0 +1,218 @@
+"""GPU parity tests proper: the HIP kernels, called through the C-ABI (stereospike_amd._lib -> libss_neuron.so),
+against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): spikes / h / v BIT-EXACT; gradients bit-exact with the ATan surrogate and
+within 1e-6 relative (stated here) with the Sigmoid surrogate (device expf vs libm/torch); dL/dk within 1e-5
+relative (fp32 tree reduction vs the oracle's double accumulation), run-to-run bit-reproducible.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import c_oracle, kat_cases, bit_equal, rel_err
+
+pytestmark = pytest.mark.gpu
+
+KIND = {'IF': 0, 'LIF': 1, 'PLIF': 2}
+SG = {'ATan': 0, 'Sigmoid': 1}
+DEV = 'cuda:0'
+
+
+def _dev(a):
+    return None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def hip_fwd(x, *, kind, scale, tau, k, v_th, v_reset, v_init=None, skip=None, save_h=True, count=False):
+    from stereospike_amd import _lib
+    T, N = x.shape
+    xd, vd, sd = _dev(x), _dev(v_init), _dev(skip)
+    out = torch.empty_like(xd)
+    h = torch.empty_like(xd) if save_h else None
+    v_last = torch.empty(N, device=DEV)
+    nnz = torch.zeros(2, dtype=torch.int64, device=DEV) if count else None
+    kd = None if k is None else torch.tensor([k], dtype=torch.float32, device=DEV)
+    _lib.neuron_fwd(xd, vd, sd, out, h, v_last, nnz, T, N, scale, KIND[kind], tau, kd, v_th, v_reset)
+    torch.cuda.synchronize()
+    return dict(out=out.cpu().numpy(), h=None if h is None else h.cpu().numpy(), v_last=v_last.cpu().numpy(),
+                nnz=None if nnz is None else nnz.cpu().numpy())
+
+
+def hip_bwd(g_out, h, *, kind, scale, tau, k, v_th, v_reset, surrogate, alpha, v_init=None, g_v_last=None,
+            detach_reset=True):
+    from stereospike_amd import _lib
+    T, N = h.shape
+    gd, hd, vd, gvd = _dev(g_out), _dev(h), _dev(v_init), _dev(g_v_last)
+    g_x = torch.empty_like(hd)
+    g_v_init = torch.empty(N, device=DEV)
+    plif = kind == 'PLIF'
+    g_k = torch.zeros(1, device=DEV) if plif else None
+    ws = torch.empty(_lib.gk_ws_floats(), device=DEV) if plif else None
+    kd = None if k is None else torch.tensor([k], dtype=torch.float32, device=DEV)
+    _lib.neuron_bwd(gd, gvd, hd, vd, g_x, g_v_init, g_k, ws, T, N, scale, KIND[kind], tau, kd, v_th, v_reset,
+                    SG[surrogate], alpha, detach_reset)
+    torch.cuda.synchronize()
+    return dict(g_x=g_x.cpu().numpy(), g_v_init=g_v_init.cpu().numpy(), g_k=None if g_k is None else float(g_k.item()))
+
+
+def test_library_is_the_hip_one():
+    from stereospike_amd import _lib
+    assert _lib.lib().ss_abi_version() == _lib.ABI_VERSION
+    assert _lib.LIB_PATH.endswith('stereospike_amd/lib/libss_neuron.so')
+
+
+def test_kat_fixtures_bit_exact():
+    """Every committed known-answer vector: spikes, h, v_last bit-exact; g_x per the stated tolerance."""
+    n = 0
+    for i, cfg, c in kat_cases():
+        kw = dict(kind=cfg['kind'], scale=cfg['scale'], tau=cfg['tau'], k=cfg['k'], v_th=cfg['v_th'],
+                  v_reset=cfg['v_reset'])
+        skip = c['skip'].astype(np.float32) if 'skip' in c else None
+        f = hip_fwd(c['x'], v_init=c.get('v_init'), skip=skip, count=True, **kw)
+        assert np.array_equal(f['out'], c['out'].astype(np.float32)), f'case {i} {cfg}: spike mask differs'
+        assert bit_equal(f['h'], c['h']), f'case {i} {cfg}: h differs'
+        assert bit_equal(f['v_last'], c['v_last']), f'case {i} {cfg}: v_last differs'
+        z = (c['h'] - np.float32(cfg['v_th'])) >= 0
+        assert int(f['nnz'][0]) == int(z.sum()) and int(f['nnz'][1]) == int((c['out'] != 0).sum())
+        b = hip_bwd(c['g_out'], c['h'], v_init=c.get('v_init'), g_v_last=c['g_v_last'], surrogate=cfg['surrogate'],
+                    alpha=cfg['alpha'], **kw)
+        if cfg['surrogate'] == 'ATan':
+            assert bit_equal(b['g_x'], c['g_x']), f'case {i} {cfg}: g_x not bit-exact (rel {rel_err(b["g_x"], c["g_x"])})'
+        else:
+            assert rel_err(b['g_x'], c['g_x']) < 1e-6, f'case {i} {cfg}'
+        if 'g_v_init' in c:
+            assert rel_err(b['g_v_init'], c['g_v_init']) < 1e-6
+        if cfg['kind'] == 'PLIF':
+            k = cfg['k']
+            g_w = b['g_k'] * k * (1 - k)
+            assert abs(g_w - float(c['g_w'])) <= 2e-5 * max(1.0, abs(float(c['g_w']))) + 1e-4, (i, g_w, float(c['g_w']))
+        n += 1
+    assert n >= 60
+
+
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+@pytest.mark.parametrize('T', [1, 3, 5, 7, 10])
+@pytest.mark.parametrize('N', [4, 1000, 4099, 262144 + 4])
+def test_random_vs_c_oracle(kind, T, N):
+    """Seeded random inputs, ragged sizes (N % 4 != 0 -> scalar path; templated and runtime-T paths)."""
+    rng = np.random.default_rng(T * 1000003 + N)
+    x = (rng.standard_normal((T, N)) * 0.2).astype(np.float32)
+    v_init = (rng.standard_normal(N) * 0.5).astype(np.float32) if N % 2 == 0 else None
+    skip = rng.integers(0, 3, (T, N)).astype(np.float32) if T % 2 == 1 else None
+    kw = dict(kind=kind, scale=10.0, tau=3.0, k=0.3333333 if kind == 'PLIF' else None, v_th=1.0, v_reset=0.0)
+    ref = c_oracle.neuron_fwd(x, v_init=v_init, skip_seq=skip, count=True, **kw)
+    got = hip_fwd(x, v_init=v_init, skip=skip, count=True, **kw)
+    assert np.array_equal(ref['out'], got['out'])
+    assert bit_equal(ref['h'], got['h']) and bit_equal(ref['v_last'], got['v_last'])
+    assert np.array_equal(ref['nnz'].astype(np.int64), got['nnz'])
+    inf = hip_fwd(x, v_init=v_init, skip=skip, save_h=False, **kw)       # inference variant (no h)
+    assert np.array_equal(inf['out'], got['out']) and bit_equal(inf['v_last'], got['v_last'])
+    g = rng.standard_normal((T, N)).astype(np.float32)
+    gv = rng.standard_normal(N).astype(np.float32)
+    for sg, alpha in (('ATan', 2.0), ('Sigmoid', 4.0)):
+        rb = c_oracle.neuron_bwd(g, ref['h'], v_init=v_init, g_v_last=gv, surrogate=sg, alpha=alpha, **kw)
+        gb = hip_bwd(g, ref['h'], v_init=v_init, g_v_last=gv, surrogate=sg, alpha=alpha, **kw)
+        if sg == 'ATan':
+            assert bit_equal(rb['g_x'], gb['g_x']) and bit_equal(rb['g_v_init'], gb['g_v_init'])
+        else:
+            assert rel_err(gb['g_x'], rb['g_x']) < 1e-6 and rel_err(gb['g_v_init'], rb['g_v_init']) < 1e-6
+        if kind == 'PLIF':
+            assert abs(gb['g_k'] - rb['g_k']) <= 1e-5 * abs(rb['g_k']) + 2e-7 * T * N
+            again = hip_bwd(g, ref['h'], v_init=v_init, g_v_last=gv, surrogate=sg, alpha=alpha, **kw)
+            assert again['g_k'] == gb['g_k'], 'dL/dk must be bit-reproducible run to run'
+
+
+def test_edge_cases():
+    """Exact threshold, +-1 ulp, infinite threshold (I-neuron use), non-detached reset, v_reset != 0."""
+    one = np.float32(1.0)
+    x = np.array([[one, np.nextafter(one, np.float32(2)), np.nextafter(one, np.float32(0)), 0.0, -0.0, 5.0, -5.0, 1e-38]],
+                 np.float32)
+    kw = dict(kind='IF', scale=1.0, tau=2.0, k=None, v_th=1.0, v_reset=0.0)
+    ref, got = c_oracle.neuron_fwd(x, **kw), hip_fwd(x, **kw)
+    assert np.array_equal(got['out'][0], [1, 1, 0, 0, 0, 1, 0, 0])
+    assert bit_equal(ref['v_last'], got['v_last']) and bit_equal(ref['h'], got['h'])
+    kw_inf = dict(kw, v_th=float('inf'))
+    x5 = np.tile(x, (5, 1))
+    ref, got = c_oracle.neuron_fwd(x5, **kw_inf), hip_fwd(x5, **kw_inf)
+    assert not got['out'].any() and bit_equal(ref['v_last'], got['v_last'])
+    g = np.ones_like(x5)
+    for sg, alpha in (('ATan', 2.0), ('Sigmoid', 4.0)):
+        rb = c_oracle.neuron_bwd(g, ref['h'], surrogate=sg, alpha=alpha, g_v_last=np.ones(8, np.float32), **kw_inf)
+        gb = hip_bwd(g, ref['h'], surrogate=sg, alpha=alpha, g_v_last=np.ones(8, np.float32), **kw_inf)
+        assert np.array_equal(rb['g_x'], gb['g_x'])          # surrogate derivative is exactly 0 at -inf
+    rng = np.random.default_rng(5)
+    xr = rng.standard_normal((5, 4096)).astype(np.float32)
+    kw2 = dict(kind='LIF', scale=2.0, tau=10.0, k=None, v_th=1.0, v_reset=0.1)
+    ref, got = c_oracle.neuron_fwd(xr, **kw2), hip_fwd(xr, **kw2)
+    assert bit_equal(ref['h'], got['h'])
+    rb = c_oracle.neuron_bwd(xr, ref['h'], surrogate='ATan', alpha=2.0, detach_reset=False, **kw2)
+    gb = hip_bwd(xr, ref['h'], surrogate='ATan', alpha=2.0, detach_reset=False, **kw2)
+    assert bit_equal(rb['g_x'], gb['g_x'])
+
+
+def test_empty_and_invalid():
+    from stereospike_amd import _lib
+    x = torch.zeros(0, device=DEV)
+    out, v = torch.zeros(0, device=DEV), torch.zeros(0, device=DEV)
+    L = _lib.lib()
+    import ctypes as C
+    p = lambda t: C.c_void_p(t.data_ptr())
+    one = torch.zeros(4, device=DEV)
+    assert L.ss_neuron_fwd_f32(p(one), None, None, p(one.clone()), None, p(one.clone()), None, 1, 0, 1.0, 0, 2.0, None, 1.0, 0.0, None) == 0
+    assert L.ss_neuron_fwd_f32(None, None, None, p(one), None, p(one), None, 1, 4, 1.0, 0, 2.0, None, 1.0, 0.0, None) == -22
+    assert L.ss_neuron_fwd_f32(p(one), None, None, p(one.clone()), None, p(one.clone()), None, 0, 4, 1.0, 0, 2.0, None, 1.0, 0.0, None) == -22
+    assert L.ss_neuron_fwd_f32(p(one), None, None, p(one.clone()), None, p(one.clone()), None, 1, 4, 1.0, 7, 2.0, None, 1.0, 0.0, None) == -22
+    assert L.ss_neuron_fwd_f32(p(one), None, None, p(one.clone()), None, p(one.clone()), None, 1, 4, 1.0, 2, 2.0, None, 1.0, 0.0, None) == -22  # PLIF without k
+    with pytest.raises(_lib.SSNeuronError):
+        _lib.neuron_fwd(torch.zeros(4), None, None, torch.zeros(4), None, torch.zeros(4), None, 1, 4, 1.0, 0, 2.0, None, 1.0, 0.0)
+
+
+def test_ipool_vs_oracle():
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(9)
+    for T, K, M in ((1, 4, 89960), (5, 4, 4100), (3, 2, 7)):
+        pd = rng.standard_normal((T, K, M)).astype(np.float32)
+        v0 = rng.standard_normal(M).astype(np.float32)
+        ref = c_oracle.ipool_fwd(pd, scale=10.0, v_reset=0.0, v_init=v0)
+        pdd = _dev(np.ascontiguousarray(pd.transpose(1, 0, 2)))       # [K, T, M] as torch.stack gives
+        depth = torch.empty(T, K, M, device=DEV)
+        _lib.ipool_fwd(pdd, M, T * M, _dev(v0), depth, T, K, M, 10.0, 0.0)
+        assert bit_equal(depth, ref)
+        g = rng.standard_normal((T, K, M)).astype(np.float32)
+        rb = c_oracle.ipool_bwd(g, scale=10.0)
+        g_pd = torch.empty(K, T, M, device=DEV)
+        g_v0 = torch.empty(M, device=DEV)
+        _lib.ipool_bwd(_dev(g), None, g_pd, M, T * M, g_v0, T, K, M, 10.0)
+        assert bit_equal(g_pd.permute(1, 0, 2).contiguous(), rb['g_pd']) and bit_equal(g_v0, rb['g_v_init'])
+
+
+def test_full_size_properties():
+    """Config-3 sized layer (B16 x T5 x 32x260x346 = 2.3e8 updates): size-independent checks only.
+    (a) linearity of the backward in g_out, (b) counters == count_nonzero of the outputs, (c) sub-range equals
+    the small-N result bit for bit (no cross-lane leakage), (d) T-split equivalence: running T=5 equals T=2 then T=3
+    from the carried membrane."""
+    from stereospike_amd import _lib
+    T, N = 5, 16 * 32 * 260 * 346
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(T, N, device=DEV, generator=g) * 0.15
+    out, h, v = torch.empty_like(x), torch.empty_like(x), torch.empty(N, device=DEV)
+    nnz = torch.zeros(2, dtype=torch.int64, device=DEV)
+    _lib.neuron_fwd(x, None, None, out, h, v, nnz, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+    assert int(nnz[0]) == int(out.count_nonzero()) == int(nnz[1])
+    assert set(out.unique().tolist()) <= {0.0, 1.0}
+    # (c)
+    n = 4096
+    sub = c_oracle.neuron_fwd(x[:, 12345 * 4:12345 * 4 + n].cpu().numpy(), kind='IF', scale=10.0, v_th=1.0, v_reset=0.0)
+    assert bit_equal(h[:, 12345 * 4:12345 * 4 + n], sub['h'])
+    # (d)
+    o1, h1, v1 = torch.empty(2, N, device=DEV), torch.empty(2, N, device=DEV), torch.empty(N, device=DEV)
+    _lib.neuron_fwd(x[:2].contiguous(), None, None, o1, h1, v1, None, 2, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+    o2, h2, v2 = torch.empty(3, N, device=DEV), torch.empty(3, N, device=DEV), torch.empty(N, device=DEV)
+    _lib.neuron_fwd(x[2:].contiguous(), v1, None, o2, h2, v2, None, 3, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+    assert torch.equal(torch.cat([o1, o2]), out) and torch.equal(v2, v) and torch.equal(torch.cat([h1, h2]), h)
+    del o1, o2, h1, h2
+    # (a)
+    ga = torch.randn(T, N, device=DEV, generator=g)
+    gx1, gx2 = torch.empty_like(x), torch.empty_like(x)
+    _lib.neuron_bwd(ga, None, h, None, gx1, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+    _lib.neuron_bwd(ga * 2, None, h, None, gx2, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+    assert torch.equal(gx1 * 2, gx2)        # scaling by 2 is exact in fp32
