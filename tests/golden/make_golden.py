@@ -271,7 +271,8 @@ def gen_model(ref, tag, make_ref, make_oracle, C, T, returns_spikes, seed=2021):
     torch.manual_seed(seed)
     orc = make_oracle()
     assert list(net.state_dict().keys()) == list(orc.state_dict().keys())
-    assert state_sha(net) == state_sha(orc), 'same seed must give same default init'
+    sha0 = state_sha(net)          # before any forward: BatchNorm running stats (ANN) change afterwards
+    assert sha0 == state_sha(orc), 'same seed must give same default init'
     x = synth_input(1, T, C, seed + 1)
     gt = synth_label(1, seed + 2)
 
@@ -294,7 +295,7 @@ def gen_model(ref, tag, make_ref, make_oracle, C, T, returns_spikes, seed=2021):
     for (k, p), (_, q) in zip(net.named_parameters(), orc.named_parameters()):
         assert torch.equal(p.grad, q.grad), f'oracle grad {k} != reference'
     out = dict(x=x.numpy().astype(np.uint8), gt=gt.numpy(), loss=L.detach().numpy(), mde=mde.numpy(),
-               state_sha=np.array(state_sha(net)), seed=np.array(seed), T=np.array(T), C=np.array(C))
+               state_sha=np.array(sha0), seed=np.array(seed), T=np.array(T), C=np.array(C))
     for i, t in enumerate(d):
         out[f'depth{i + 1}'] = t.detach().numpy()
     for name, t in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), s):

@@ -1,0 +1,83 @@
+"""CPU suite, part 2: the C-ABI library loads without a GPU and exports every symbol include/ss_neuron.h declares;
+the product path never touches the oracle and fails loudly off-GPU.  (No compute calls here.)"""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'ss_neuron.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(?:int|long long)\s+(ss_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert _declared() == sorted(['ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
+                                  'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32'])
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from stereospike_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'stereospike_amd', 'csrc'), 'all'])
+    L = _lib.lib()
+    for name in _declared():
+        assert hasattr(L, name), name
+    assert sorted(_lib.EXPORTS) == _declared()
+    assert L.ss_abi_version() == 1
+    assert L.ss_neuron_gk_ws_floats() >= 2048
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if ' T ' in l}
+    assert set(_declared()) <= exported
+    # a gfx950 code object is embedded
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob
+
+
+def test_argument_validation_without_a_gpu():
+    """NULL / bad-size arguments are rejected before any HIP call (returns -22, never crashes)."""
+    from stereospike_amd import _lib
+    L = _lib.lib()
+    assert L.ss_neuron_fwd_f32(None, None, None, None, None, None, None, 1, 4, 1.0, 0, 2.0, None, 1.0, 0.0, None) == -22
+    assert L.ss_neuron_bwd_f32(None, None, None, None, None, None, None, None, 1, 4, 1.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, 1,
+                               None) == -22
+    assert L.ss_ipool_fwd_f32(None, 0, 0, None, None, 1, 4, 4, 1.0, 0.0, None) == -22
+    assert L.ss_ipool_bwd_f32(None, None, None, 0, 0, None, 1, 4, 4, 1.0, None) == -22
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from stereospike_amd import _lib
+    from stereospike_amd.clock_driven import neuron, surrogate
+    from stereospike_amd.network.SNN_models import StereoSpike
+    node = neuron.IFNode(surrogate_function=surrogate.ATan())
+    with pytest.raises(_lib.SSNeuronError, match='no CPU fallback'):
+        node(torch.zeros(2, 3))
+    net = StereoSpike(multiply_factor=10., input_size=(32, 40))
+    with pytest.raises(_lib.SSNeuronError):
+        net(torch.zeros(1, 1, 4, 32, 40))
+
+
+def test_product_fails_loudly_without_the_library(monkeypatch):
+    from stereospike_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libss_neuron.so')
+    with pytest.raises(_lib.SSNeuronError, match='not built'):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'stereospike_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), os.path.join(d, f)
+                assert 'ss_ref_' not in src and 'libss_oracle' not in src, os.path.join(d, f)
+    out = subprocess.check_output(['ldd', os.path.join(pkg, 'lib', 'libss_neuron.so')]).decode()
+    assert 'oracle' not in out

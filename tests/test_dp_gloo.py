@@ -1,0 +1,103 @@
+"""CPU suite, part 4: the N > 1 path on CPU — world_size 2, gloo, one process per "device".
+
+DP semantics under test: the reference's loss couples the samples of a batch, so DP is defined as
+"reference loss on each rank's local shard, gradients averaged"; the single-process equivalent evaluates the loss
+shard by shard and averages the shard gradients.  The model is the oracle's eager CPU network (tests may use the
+oracle; the product network needs the MI355X), driven by the product's GradientAllReducer (bucketed, overlapped,
+gradients living in the flat buckets)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from _util import ref_network as rn, sj, synth_input, synth_label
+
+H, W = 32, 40
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make_net():
+    torch.manual_seed(2021)
+    return rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=10., input_size=(H, W))
+
+
+def _shard_grads(net, x, gt):
+    out = rn.run_sequence(net, x)
+    loss = rn.total_loss(out[0], gt, out[1])
+    loss.backward()
+    return loss.detach()
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from stereospike_amd.dp import GradientAllReducer
+    net = _make_net()
+    if rank == 1:                      # ranks start from different weights: the reducer must broadcast rank 0's
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.01)
+    red = GradientAllReducer(net, bucket_bytes=bucket_bytes)
+    x = synth_input(4, 2, 4, 11, H, W, lam=0.1)
+    gt = synth_label(4, 12, H, W)
+    sl = slice(2 * rank, 2 * rank + 2)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    for it in range(2):                # two steps: bucket views must survive zero_grad
+        _shard_grads(net, x[sl], gt[sl])
+        red.finish()
+        if it == 0:
+            g0 = [p.grad.clone() for p in net.parameters()]
+        opt.step()
+        red.zero_grad()
+    q.put((rank, [g.numpy() for g in g0], [p.detach().numpy() for p in net.parameters()], len(red.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_bytes', [1 << 20, 64 << 20])
+def test_two_rank_gradients_equal_shardwise_single_process(bucket_bytes):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single process, shard-by-shard accumulation, mean of shard gradients, two SGD steps
+    torch.set_num_threads(4)
+    net = _make_net()
+    x = synth_input(4, 2, 4, 11, H, W, lam=0.1)
+    gt = synth_label(4, 12, H, W)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    g0 = None
+    for it in range(2):
+        for r in range(2):
+            _shard_grads(net, x[2 * r:2 * r + 2], gt[2 * r:2 * r + 2])
+        for p in net.parameters():
+            p.grad.div_(2)
+        if it == 0:
+            g0 = [p.grad.clone().numpy() for p in net.parameters()]
+        opt.step()
+        opt.zero_grad()
+    for (rank, grads, params, nb) in res:
+        assert (nb == 2) if bucket_bytes == (64 << 20) else (nb > 4)      # 72.6 MB of fp32 parameters
+        for a, b in zip(grads, g0):
+            assert np.allclose(a, b, rtol=1e-4, atol=1e-6 * (np.abs(b).max() + 1e-12)), rank
+        for a, p in zip(params, net.parameters()):
+            assert np.allclose(a, p.detach().numpy(), rtol=1e-3, atol=1e-5)
+    # both ranks hold identical parameters after the steps
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)

@@ -1,0 +1,179 @@
+"""CPU suite, part 1: pin the oracle.
+
+  * oracle/ss_neuron_ref.c (fused recurrence) == oracle/sj_clock_driven.py run through torch autograd, on every
+    committed known-answer vector and on fresh seeded inputs: forward bit-exact; backward bit-exact (ATan) /
+    <= 3e-7 relative (Sigmoid: libm expf vs torch's vectorised sigmoid);
+  * oracle/ref_network.py == the committed fixtures that the reference's own network/*.py produced
+    (tests/golden/make_golden.py) — bit-exact on the machine/torch build that generated them (recorded in `meta`),
+    tolerance otherwise;
+  * the I-neuron pool restatement, the loss / MDE restatement against the PURE-reference fixture.
+"""
+import json
+import platform
+
+import numpy as np
+import pytest
+import torch
+
+from _util import bit_equal, c_oracle, kat_cases, load_npz, ref_network as rn, rel_err, sj
+
+
+def test_c_oracle_matches_kat_fixtures():
+    n = 0
+    for i, cfg, c in kat_cases():
+        kw = dict(kind=cfg['kind'], scale=cfg['scale'], tau=cfg['tau'], k=cfg['k'], v_th=cfg['v_th'], v_reset=cfg['v_reset'])
+        skip = c['skip'].astype(np.float32) if 'skip' in c else None
+        f = c_oracle.neuron_fwd(c['x'], v_init=c.get('v_init'), skip_seq=skip, count=True, **kw)
+        assert np.array_equal(f['out'], c['out'].astype(np.float32)), (i, cfg)
+        assert bit_equal(f['h'], c['h']) and bit_equal(f['v_last'], c['v_last']), (i, cfg)
+        assert int(f['nnz'][1]) == int((c['out'] != 0).sum())
+        b = c_oracle.neuron_bwd(c['g_out'], c['h'], v_init=c.get('v_init'), g_v_last=c['g_v_last'],
+                                surrogate=cfg['surrogate'], alpha=cfg['alpha'], **kw)
+        if cfg['surrogate'] == 'ATan':
+            assert bit_equal(b['g_x'], c['g_x']), (i, cfg)
+        else:
+            assert rel_err(b['g_x'], c['g_x']) < 3e-7, (i, cfg)
+        if 'g_v_init' in c:
+            assert rel_err(b['g_v_init'], c['g_v_init']) < 3e-7
+        if cfg['kind'] == 'PLIF':
+            k = cfg['k']
+            assert abs(b['g_k'] * k * (1 - k) - float(c['g_w'])) <= 1e-5 * abs(float(c['g_w'])) + 1e-4
+        n += 1
+    assert n == 60
+
+
+def test_kat_fixtures_contain_threshold_edge_cases():
+    hit = 0
+    for i, cfg, c in kat_cases():
+        if cfg['kind'] == 'IF' and 'v_init' not in c and cfg['v_reset'] == 0.0:
+            h0 = c['h'][0, :96].reshape(32, 3)
+            one = np.float32(1.0)
+            # exactly at threshold fires, +1ulp fires, -1ulp does not
+            ok = (np.abs(h0[:, 0] - one) <= np.spacing(one))
+            z = c['out'][0, :96].reshape(32, 3) - (c['skip'][0, :96].reshape(32, 3) if 'skip' in c else 0)
+            at = h0 == one
+            assert (z[at] == 1).all() and (z[h0 > one] == 1).all() and (z[h0 < one] == 0).all()
+            hit += int(at.sum() > 0)
+    assert hit > 0
+
+
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+@pytest.mark.parametrize('sg,alpha', [('ATan', 2.0), ('Sigmoid', 4.0), ('Sigmoid', 1.0)])
+def test_c_oracle_vs_eager_autograd(kind, sg, alpha):
+    from golden.make_golden import eager_neuron
+    rng = np.random.default_rng(hash((kind, sg, alpha)) % 2 ** 32)
+    for T, N, scale, v_reset in ((1, 257, 1.0, 0.0), (4, 1000, 10.0, 0.1), (7, 333, 3.0, 0.0)):
+        x = (rng.standard_normal((T, N)) * 1.5 / scale).astype(np.float32)
+        g = rng.standard_normal((T, N)).astype(np.float32)
+        gv = rng.standard_normal(N).astype(np.float32)
+        vi = (rng.standard_normal(N) * 0.5).astype(np.float32)
+        skip = rng.integers(0, 3, (T, N)).astype(np.float32)
+        e = eager_neuron(kind, x, scale, 2.5, 1.0, v_reset, sg, alpha, g, gv, skip, vi)
+        kw = dict(kind=kind, scale=scale, tau=2.5, k=e['k'], v_th=1.0, v_reset=v_reset, v_init=vi)
+        f = c_oracle.neuron_fwd(x, skip_seq=skip, **kw)
+        assert np.array_equal(f['out'], e['out']) and bit_equal(f['h'], e['h']) and bit_equal(f['v_last'], e['v_last'])
+        b = c_oracle.neuron_bwd(g, f['h'], g_v_last=gv, surrogate=sg, alpha=alpha, **kw)
+        if sg == 'ATan':
+            assert bit_equal(b['g_x'], e['g_x']) and bit_equal(b['g_v_init'], e['g_v_init'])
+        else:
+            assert rel_err(b['g_x'], e['g_x']) < 3e-7 and rel_err(b['g_v_init'], e['g_v_init']) < 3e-7
+        if kind == 'PLIF':
+            k = e['k']
+            assert abs(b['g_k'] * k * (1 - k) - e['g_w']) <= 1e-5 * abs(e['g_w']) + 1e-4
+
+
+def test_non_detached_reset_matches_autograd():
+    """detach_reset=False (library default; the reference's I-neuron pool) — the adjoint keeps the reset path."""
+    rng = np.random.default_rng(3)
+    T, N = 4, 500
+    x = rng.standard_normal((T, N)).astype(np.float32)
+    g = rng.standard_normal((T, N)).astype(np.float32)
+    xt = torch.tensor(x, requires_grad=True)
+    node = sj.IFNode(1.0, 0.1, sj.ATan(), False)
+    outs = [node(xt[t]) for t in range(T)]
+    (torch.stack(outs) * torch.tensor(g)).sum().backward()
+    f = c_oracle.neuron_fwd(x, kind='IF', v_th=1.0, v_reset=0.1)
+    b = c_oracle.neuron_bwd(g, f['h'], kind='IF', v_th=1.0, v_reset=0.1, surrogate='ATan', alpha=2.0, detach_reset=False)
+    assert rel_err(b['g_x'], xt.grad.numpy()) < 1e-6
+
+
+def test_ipool_oracle_vs_eager_ifnode():
+    """IFNode(v_threshold=inf) charged by K heads per step == ss_ref_ipool (SNN_models.py:150,172-188)."""
+    rng = np.random.default_rng(4)
+    T, K, M = 3, 4, 1000
+    pd = rng.standard_normal((T, K, M)).astype(np.float32)
+    g = rng.standard_normal((T, K, M)).astype(np.float32)
+    pdt = torch.tensor(pd, requires_grad=True)
+    pool = sj.IFNode(float('inf'), 0.0, sj.ATan())
+    snaps = []
+    for t in range(T):
+        for k in range(K):
+            pool(torch.mul(pdt[t, k], 10.0))
+            snaps.append(pool.v)
+    depth = torch.stack(snaps).view(T, K, M)
+    (depth * torch.tensor(g)).sum().backward()
+    ref = c_oracle.ipool_fwd(pd, scale=10.0, v_reset=0.0)
+    assert bit_equal(ref, depth.detach().numpy())
+    rb = c_oracle.ipool_bwd(g, scale=10.0)
+    assert bit_equal(rb['g_pd'], pdt.grad.numpy())
+
+
+def _same_machine(meta):
+    return meta['torch'] == torch.__version__ and meta['threads'] == torch.get_num_threads() and \
+        meta['cpu'] == (platform.processor() or platform.machine())
+
+
+@pytest.mark.parametrize('tag,name,kw,T', [
+    ('stereospike_T1', 'StereoSpike', dict(multiply_factor=10.), 1),
+    ('plif_T5', 'PLIFNet', dict(tau=3., use_plif=True, multiply_factor=10.), 5),
+    ('mono_plif_T1', 'PLIFNetMono', dict(tau=3., use_plif=True, multiply_factor=10.), 1),
+    ('ann_T1', 'ANN', dict(), 1),
+])
+def test_oracle_network_vs_reference_fixture(tag, name, kw, T):
+    """The fixture holds what /root/reference/network/*.py itself computed (spikingjelly stand-in = sj_clock_driven)."""
+    z = load_npz(f'model_{tag}.npz')
+    meta = json.loads(str(z['meta']))
+    torch.manual_seed(int(z['seed']))
+    if name == 'StereoSpike':
+        kw = dict(kw, surrogate_function=sj.ATan())
+    net = rn.build(name, sigmoid_alpha=meta['sigmoid_alpha'], **kw) if name != 'ANN' else rn.build(name)
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in net.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    assert h.hexdigest() == str(z['state_sha']), 'default init under the recorded seed must reproduce the weights'
+    x = torch.tensor(z['x'].astype(np.float32))
+    gt = torch.tensor(z['gt'])
+    res = rn.run_sequence(net, x)
+    depths, spikes = res if isinstance(res, tuple) else (res, [])
+    loss = rn.total_loss(depths, gt, spikes)
+    mde = rn.mean_depth_error(depths[0].detach(), gt)
+    exact = _same_machine(meta)
+    scale = float(np.abs(z['depth1']).max())
+    for i, d in enumerate(depths):
+        if exact:
+            assert bit_equal(d, z[f'depth{i + 1}']), f'depth{i + 1}'
+        else:
+            assert float(np.abs(d.detach().numpy() - z[f'depth{i + 1}']).max()) <= 2e-2 * scale
+    for nm, s in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), spikes):
+        mism = float((s.detach().numpy() != z[nm].astype(np.float32)).mean())
+        assert mism == 0.0 if exact else mism <= 2e-3, (nm, mism)
+    assert abs(float(loss) - float(z['loss'])) <= (0 if exact else 2e-3 * abs(float(z['loss'])))
+    assert abs(float(mde) - float(z['mde'])) <= (0 if exact else 2e-3 * abs(float(z['mde'])))
+    if tag == 'stereospike_T1':      # one backward is enough for the CPU budget
+        loss.backward()
+        l2 = np.array([p.grad.double().norm().item() for p in net.parameters()])
+        assert np.allclose(l2, z['grad_l2'], rtol=1e-12 if exact else 2e-2, atol=0)
+
+
+def test_loss_and_mde_restatement_vs_pure_reference_fixture():
+    z = load_npz('loss_metric.npz')
+    for ci in range(int(z['n_cases'])):
+        preds = [torch.tensor(z[f'l{ci}_pred{i}'], requires_grad=True) for i in range(4)]
+        gt = torch.tensor(z[f'l{ci}_gt'])
+        spikes = [torch.tensor(z[f'l{ci}_spk{i}'].astype(np.float32)) for i in range(5)]
+        for pen in (False, True):
+            L = rn.total_loss(preds, gt, spikes, penalize_spikes=pen, beta=0.5)
+            assert float(L) == float(z[f'l{ci}_{"pen" if pen else "nopen"}_loss'])
+        assert float(rn.mean_depth_error(preds[0].detach(), gt)) == float(z[f'l{ci}_mde'])
