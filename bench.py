@@ -19,11 +19,13 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from stereospike_amd import miopen_cache  # noqa: E402
+miopen_cache.enable()                     # before torch/MIOpen initialise: in-tree kernel cache (see module doc)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
@@ -126,8 +128,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
+        t_w = time.perf_counter()
         trainer.step(x, gt)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f'[bench] warm-up step {i}: {time.perf_counter() - t_w:.2f} s (first steps include MIOpen kernel '
+                  f'compilation when the in-tree cache is cold)', file=sys.stderr, flush=True)
     sync()
     TIMER.enabled = True
     TIMER.clear()

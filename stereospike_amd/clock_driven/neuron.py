@@ -41,7 +41,7 @@ class BaseNode(nn.Module):
 
     def detach(self):
         if isinstance(self.v, torch.Tensor):
-            self.v.detach_()
+            self.v = self.v.detach()      # (not detach_(): the I-pool membrane is a view of the read-out buffer)
 
     def extra_repr(self):
         return f'v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}'

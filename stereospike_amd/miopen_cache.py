@@ -1,0 +1,15 @@
+"""MIOpen start-up cost control.  The PyTorch-ROCm wheel ships no pre-compiled MIOpen kernels for gfx950, so the first
+call of every distinct conv configuration JIT-compiles its kernels (measured: 5 - 140 s each, ~10 min for the whole
+network, profiles/README.md).  MIOpen keeps them in a user cache; pointing that cache at an in-tree, git-ignored
+directory lets it travel with the repo snapshot exactly like the built libss_neuron.so, so later processes (and later
+GPU boxes) start in seconds.  Must be called before the first conv (ideally before `import torch`)."""
+import os
+
+CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'miopen_cache')
+
+
+def enable(path: str = CACHE_DIR):
+    os.makedirs(path, exist_ok=True)
+    os.environ.setdefault('MIOPEN_USER_DB_PATH', path)
+    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', path)
+    return path

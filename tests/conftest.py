@@ -2,11 +2,14 @@ import os
 import sys
 
 import pytest
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+from stereospike_amd import miopen_cache  # noqa: E402
+miopen_cache.enable()          # share the in-tree MIOpen kernel cache with bench.py (cold compiles take minutes)
+
+import torch  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 

@@ -1,0 +1,127 @@
+"""CPU suite, part 5: the host-side graph wiring (SpikingStage / SEWResBlock / model forward_sequence / autograd
+Functions / I-pool ordering / firing-rate bookkeeping) checked WITHOUT a GPU.
+
+The four C-ABI entry points of stereospike_amd._lib are monkeypatched — in this test process only — by the C oracle
+operating on host memory, so that the product's Python layer can run on CPU tensors and be diffed against the oracle
+network (which is pinned to the reference's own network/*.py).  This exercises host logic only; it says nothing about
+the HIP kernels (tests/test_gpu_*.py do) and the product itself contains no such path (tests/test_abi.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from _util import c_oracle, ref_network as rn, sj, synth_input, synth_label
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+@pytest.fixture()
+def host_backend(monkeypatch):
+    from stereospike_amd import _lib
+    L = c_oracle.lib()
+
+    def neuron_fwd(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, scale, kind, tau, k, v_th, v_reset):
+        cnt = None
+        if nnz is not None:
+            cnt = np.zeros(2, np.uint64)
+        rc = L.ss_ref_neuron_fwd_f32(_p(x_seq), _p(v_init), _p(skip_seq), _p(out_seq), _p(h_seq), _p(v_last),
+                                     None if cnt is None else cnt.ctypes.data_as(C.c_void_p), T, N, scale, kind, tau,
+                                     _p(k), v_th, v_reset)
+        assert rc == 0
+        if nnz is not None:
+            nnz += torch.from_numpy(cnt.astype(np.int64))
+
+    def neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                   v_th, v_reset, surrogate, alpha, detach_reset):
+        rc = L.ss_ref_neuron_bwd_f32(_p(g_out_seq), _p(g_v_last), _p(h_seq), _p(v_init), _p(g_x_seq), _p(g_v_init),
+                                     _p(g_k), T, N, scale, kind, tau, _p(k), v_th, v_reset, surrogate, alpha,
+                                     int(detach_reset))
+        assert rc == 0
+
+    def ipool_fwd(pd_seq, st, sk, v_init, depth_seq, T, K, M, scale, v_reset):
+        assert L.ss_ref_ipool_fwd_f32(_p(pd_seq), st, sk, _p(v_init), _p(depth_seq), T, K, M, scale, v_reset) == 0
+
+    def ipool_bwd(g_depth_seq, g_v_last, g_pd_seq, st, sk, g_v_init, T, K, M, scale):
+        assert L.ss_ref_ipool_bwd_f32(_p(g_depth_seq), _p(g_v_last), _p(g_pd_seq), st, sk, _p(g_v_init), T, K, M,
+                                      scale) == 0
+
+    monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
+    monkeypatch.setattr(_lib, 'neuron_bwd', neuron_bwd)
+    monkeypatch.setattr(_lib, 'ipool_fwd', ipool_fwd)
+    monkeypatch.setattr(_lib, 'ipool_bwd', ipool_bwd)
+    monkeypatch.setattr(_lib, 'gk_ws_floats', lambda: 1)
+    yield
+
+
+def _pair(name, H, W):
+    from stereospike_amd.clock_driven import surrogate
+    from stereospike_amd.network import SNN_models as S
+    torch.manual_seed(2021)
+    if name == 'StereoSpike':
+        orc = rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(), input_size=(H, W))
+        net = S.StereoSpike(surrogate_function=surrogate.ATan(), multiply_factor=10., input_size=(H, W))
+    else:
+        orc = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=10., input_size=(H, W))
+        net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., use_plif=True, multiply_factor=10.,
+                                                                             input_size=(H, W))
+    net.load_state_dict(orc.state_dict())
+    return orc, net
+
+
+@pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
+def test_single_step_graph_is_bit_identical_to_the_oracle_network(host_backend, name):
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    H, W = 48, 64
+    orc, net = _pair(name, H, W)
+    x = synth_input(2, 1, 4, 5, H, W, lam=0.1)
+    gt = synth_label(2, 6, H, W)
+    sj.reset_net(orc)
+    d0, s0 = orc(x)
+    functional.reset_net(net)
+    d1, s1 = net(x)
+    for a, b in zip(s0, s1):
+        assert torch.equal(a, b)
+    for a, b in zip(d0, d1):
+        assert torch.equal(a, b)
+    L0 = rn.total_loss(d0, gt, s0)
+    L1 = Total_Loss()(d1, gt, s1)
+    assert abs(float(L0) - float(L1)) <= 2e-6 * abs(float(L0))
+    L0.backward()
+    L1.backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), orc.named_parameters()):
+        a, b = p.grad, q.grad
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, k
+    # stateful second call without reset + firing rates
+    d0b, s0b = orc(x)
+    d1b, s1b = net(x)
+    assert all(torch.equal(a, b) for a, b in zip(s0b, s1b))
+    sj.reset_net(orc)
+    functional.reset_net(net)
+    r0 = orc.calculate_firing_rates(x)
+    r1 = net.calculate_firing_rates(x)
+    assert list(r0.keys()) == list(r1.keys())
+    for k in r0:
+        assert abs(float(r0[k]) - float(r1[k])) < 1e-7, k
+
+
+def test_sequence_path_equals_stepwise_oracle(host_backend):
+    """forward_sequence (convs on the [T*B] batch, one fused launch per layer) vs reset + T single-step oracle calls."""
+    from stereospike_amd.clock_driven import functional
+    H, W = 48, 64
+    orc, net = _pair('PLIFNet', H, W)
+    x = synth_input(2, 4, 4, 7, H, W, lam=0.1)
+    d0, s0 = rn.run_sequence(orc, x)
+    functional.reset_net(net)
+    d1, s1 = net.forward_sequence(x)
+    for a, b in zip(s0, s1):
+        assert float((a != b).float().mean()) <= 1e-4       # oneDNN may pick another kernel for the larger batch
+    for a, b in zip(d0, d1):
+        assert float((a - b).abs().max()) <= 1e-3 * float(a.abs().max())
+    (sum(d.sum() for d in d1)).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    net.detach()
+    assert all(not m.v.requires_grad for m in net.modules() if hasattr(m, 'v') and torch.is_tensor(m.v))
