@@ -40,9 +40,11 @@ def parse():
     ap.add_argument('--model', default='StereoSpike', choices=['StereoSpike', 'PLIFNet'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
+    ap.add_argument('--miopen-find', type=int, default=0, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     ap.add_argument('--channels-last', type=int, default=0)
     ap.add_argument('--bucket-mb', type=float, default=20.0)
+    ap.add_argument('--fuse-upconv', type=int, default=1,
+                    help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
     return ap.parse_args()
 
 
@@ -116,6 +118,8 @@ def main():
     from stereospike_amd.fused import TIMER
     _lib.lib()                                                # fail loudly here if the HIP library is missing
 
+    from stereospike_amd.network import blocks as _blocks
+    _blocks.FUSE_UPCONV = bool(a.fuse_upconv)
     net = build_net(a.model, dev)
     if a.channels_last:
         net = net.to(memory_format=torch.channels_last)
@@ -149,11 +153,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     summ = TIMER.summary()
+    shapes = TIMER.summary(by_shape=True)
 
     if rank == 0:
         frames = a.batch * world * a.steps
-        fwd = summ.get('neuron_fwd_train', dict(launches=0, bytes=0, ms=0.0, updates=0))
-        bwd = summ.get('neuron_bwd', dict(launches=0, bytes=0, ms=0.0, updates=0))
+        zero = dict(launches=0, bytes=0, ms=0.0, updates=0)
+        # the dominant launch shape of the forward kernel: the largest layer (bottom: B x T x 32 x 260 x 346 updates)
+        fwd_shapes = {k: v for k, v in shapes.items() if k[0] == 'neuron_fwd_train'}
+        dom = max(fwd_shapes, key=lambda k: k[1]) if fwd_shapes else None
+        fwd = fwd_shapes.get(dom, zero)
+        bwd_shapes = {k: v for k, v in shapes.items() if k[0] == 'neuron_bwd'}
+        bwd = bwd_shapes.get(max(bwd_shapes, key=lambda k: k[1]), zero) if bwd_shapes else zero
+        fwd_all = [v for k, v in summ.items() if k.startswith('neuron_fwd')]
+        all_ms = sum(v['ms'] for k, v in summ.items() if k.startswith('neuron_'))
+        all_bytes = sum(v['bytes'] for k, v in summ.items() if k.startswith('neuron_'))
 
         def roof(d):
             ach = (d['bytes'] / 1e9) / (d['ms'] / 1e3) if d['ms'] > 0 else 0.0
@@ -170,13 +183,20 @@ def main():
             'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
                                    f'(reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd',
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
-                       'parallelism': f'dp{world}', 'weights': 'default init, seed 2021, multiply_factor 10',
+                       'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'weights': 'default init, seed 2021, multiply_factor 10',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
-            'roofline': dict(kernel='neuron_fwd_kernel (fused gain+charge+fire+reset+skip over T, fp32, 12-16 B/update)',
+            'roofline': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, fp32, '
+                                    f'12 B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
                              **roof(fwd)),
-            'roofline_bwd': dict(kernel='neuron_bwd_kernel (fused surrogate backward over T, fp32, 12 B/update)',
-                                 **roof(bwd)),
-            'neuron_share_of_step': round((fwd['ms'] + bwd['ms']) / (1e3 * elapsed), 4),
+            'roofline_bwd': dict(kernel='neuron_bwd_kernel (fused surrogate backward over T, fp32, 12 B/update), '
+                                        'largest launch shape', **roof(bwd)),
+            'neuron_kernels_all_layers': dict(
+                launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
+                ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
+                achieved_GBps=round(all_bytes / 1e9 / (all_ms / 1e3), 1) if all_ms else 0.0,
+                share_of_step=round(all_ms / (1e3 * elapsed), 4)),
+            'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
+                                                if not k.startswith('neuron_')},
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
         if world == 1 and not a.no_cpu_baseline:

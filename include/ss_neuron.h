@@ -126,6 +126,30 @@ int ss_ipool_bwd_f32(const float* g_depth_seq, const float* g_v_last,
                      float* g_pd_seq, long long stride_t, long long stride_k, float* g_v_init,
                      int T, int K, long long M, float scale, void* stream);
 
+/*
+ * predict_depth head synapse (SNN_models.py:133-148): NNConvUpsampling(C -> 1, k, up_size=(H,W), bias=True), i.e.
+ * UpsamplingNearest2d(size=(H+k-1, W+k-1)) followed by a valid k x k conv to ONE channel (blocks.py:124-128).
+ * Because the output has a single channel, the channel contraction commutes with the resize: with the k*k per-tap
+ * projections of the LOW-RES map  P[nb][tap][iy][ix] = sum_c w[c][tap] * in[nb][c][iy][ix]  (a 1x1 conv, done by the
+ * caller), the head is the gather
+ *      out[nb][y][x] = bias + sum_{ky,kx} P[nb][ky*k+kx][ src_y[y+ky] ][ src_x[x+kx] ]
+ * where src_y / src_x are the nearest-neighbour source indices of the up-sampled rows / columns (int32 tables of
+ * H+k-1 / W+k-1 entries, computed by the caller exactly as torch's UpsamplingNearest2d does).  The (H+k-1)x(W+k-1)xC
+ * up-sampled tensor (93 MB per sample-step for predict_depth4) is never materialised.  bias: device pointer to one
+ * float, or NULL.  Taps are summed in (ky, kx) order, bias last.
+ */
+int ss_upconv1_fwd_f32(const float* P, const int* src_y, const int* src_x, const float* bias, float* out,
+                       long long NB, int k, int h, int w, int H, int W, void* stream);
+
+/*
+ * Adjoint of the gather:  g_P[nb][tap][iy][ix] = sum of g_out[nb][Y-ky][X-kx] over the up-sampled rows Y in
+ * [y_lo[iy], y_hi[iy]) and columns X in [x_lo[ix], x_hi[ix]) that map to (iy, ix), restricted to 0 <= Y-ky < H,
+ * 0 <= X-kx < W.  Each g_P element is produced by exactly one lane in a fixed order (no atomics => deterministic).
+ * y_lo/y_hi: int32 [h]; x_lo/x_hi: int32 [w].  (dL/dbias = sum(g_out) is left to the caller.)
+ */
+int ss_upconv1_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                       float* g_P, long long NB, int k, int h, int w, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

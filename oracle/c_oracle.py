@@ -35,8 +35,10 @@ def lib():
                                                i32, f32, i32]
         _lib.ss_ref_ipool_fwd_f32.argtypes = [fp, i64, i64, fp, fp, i32, i32, i64, f32, f32]
         _lib.ss_ref_ipool_bwd_f32.argtypes = [fp, fp, fp, i64, i64, fp, i32, i32, i64, f32]
+        _lib.ss_ref_upconv1_fwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i32, i32, i32, i32, i32]
+        _lib.ss_ref_upconv1_bwd_f32.argtypes = [fp, fp, fp, fp, fp, fp, i64, i32, i32, i32, i32, i32]
         for f in (_lib.ss_ref_neuron_fwd_f32, _lib.ss_ref_neuron_bwd_f32, _lib.ss_ref_ipool_fwd_f32,
-                  _lib.ss_ref_ipool_bwd_f32):
+                  _lib.ss_ref_ipool_bwd_f32, _lib.ss_ref_upconv1_fwd_f32, _lib.ss_ref_upconv1_bwd_f32):
             f.restype = C.c_int
     return _lib
 
@@ -106,3 +108,29 @@ def ipool_bwd(g_depth_seq, *, scale=1.0, g_v_last=None):
     if rc:
         raise ValueError(f'ss_ref_ipool_bwd_f32 -> {rc}')
     return dict(g_pd=g_pd, g_v_init=g_v_init)
+
+
+def upconv1_fwd(P, src_y, src_x, bias, H, W):
+    """P [NB, k*k, h, w] float32; src_y/src_x int32 tables; returns out [NB, H, W]."""
+    P = _f32(P)
+    NB, kk, h, w = P.shape
+    k = int(round(kk ** 0.5))
+    sy, sx = np.ascontiguousarray(src_y, np.int32), np.ascontiguousarray(src_x, np.int32)
+    b = None if bias is None else np.asarray([bias], np.float32)
+    out = np.empty((NB, H, W), np.float32)
+    rc = lib().ss_ref_upconv1_fwd_f32(_p(P), _p(sy), _p(sx), _p(b), _p(out), NB, k, h, w, H, W)
+    if rc:
+        raise ValueError(f'ss_ref_upconv1_fwd_f32 -> {rc}')
+    return out
+
+
+def upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, k):
+    g_out = _f32(g_out)
+    NB, H, W = g_out.shape
+    t = [np.ascontiguousarray(a, np.int32) for a in (y_lo, y_hi, x_lo, x_hi)]
+    h, w = len(t[0]), len(t[2])
+    g_P = np.empty((NB, k * k, h, w), np.float32)
+    rc = lib().ss_ref_upconv1_bwd_f32(_p(g_out), _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), _p(g_P), NB, k, h, w, H, W)
+    if rc:
+        raise ValueError(f'ss_ref_upconv1_bwd_f32 -> {rc}')
+    return g_P

@@ -168,3 +168,44 @@ int ss_ref_ipool_bwd_f32(const float *g_depth_seq, const float *g_v_last, float 
     }
     return 0;
 }
+
+/* predict_depth head (SNN_models.py:133-148; blocks.py:124-128) as a gather over per-tap projections — see
+ * include/ss_neuron.h ss_upconv1_*.  tests/test_oracle.py pins it against torch's UpsamplingNearest2d + Conv2d. */
+int ss_ref_upconv1_fwd_f32(const float *P, const int *src_y, const int *src_x, const float *bias, float *out,
+                           long long NB, int k, int h, int w, int H, int W)
+{
+    if (!P || !src_y || !src_x || !out || NB < 0 || k <= 0) return -22;
+    const float b = bias ? *bias : 0.f;
+    for (long long nb = 0; nb < NB; ++nb)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float acc = 0.f;
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx)
+                        acc += P[((nb * (k * k) + ky * k + kx) * h + src_y[y + ky]) * (long long)w + src_x[x + kx]];
+                out[(nb * H + y) * (long long)W + x] = acc + b;
+            }
+    return 0;
+}
+
+int ss_ref_upconv1_bwd_f32(const float *g_out, const int *y_lo, const int *y_hi, const int *x_lo, const int *x_hi,
+                           float *g_P, long long NB, int k, int h, int w, int H, int W)
+{
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || k <= 0) return -22;
+    for (long long nb = 0; nb < NB; ++nb)
+        for (int tap = 0; tap < k * k; ++tap)
+            for (int iy = 0; iy < h; ++iy)
+                for (int ix = 0; ix < w; ++ix) {
+                    const int ky = tap / k, kx = tap % k;
+                    int y0 = y_lo[iy] - ky, y1 = y_hi[iy] - ky, x0 = x_lo[ix] - kx, x1 = x_hi[ix] - kx;
+                    if (y0 < 0) y0 = 0;
+                    if (x0 < 0) x0 = 0;
+                    if (y1 > H) y1 = H;
+                    if (x1 > W) x1 = W;
+                    float acc = 0.f;
+                    for (int y = y0; y < y1; ++y)
+                        for (int x = x0; x < x1; ++x) acc += g_out[(nb * H + y) * (long long)W + x];
+                    g_P[((nb * (k * k) + tap) * h + iy) * (long long)w + ix] = acc;
+                }
+    return 0;
+}

@@ -39,7 +39,10 @@ def lib():
     L.ss_neuron_bwd_f32.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
     L.ss_ipool_fwd_f32.argtypes = [p, i64, i64, p, p, i32, i32, i64, f32, f32, p]
     L.ss_ipool_bwd_f32.argtypes = [p, p, p, i64, i64, p, i32, i32, i64, f32, p]
-    for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32):
+    L.ss_upconv1_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_upconv1_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
+              L.ss_upconv1_fwd_f32, L.ss_upconv1_bwd_f32):
         f.restype = i32
     if L.ss_abi_version() != ABI_VERSION:
         raise SSNeuronError(f'libss_neuron.so ABI {L.ss_abi_version()} != expected {ABI_VERSION}; rebuild')
@@ -48,7 +51,7 @@ def lib():
 
 
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
-           'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32')
+           'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -129,6 +132,30 @@ def ipool_bwd(g_depth_seq, g_v_last, g_pd_seq, stride_t, stride_k, g_v_init, T, 
                                     _f32(g_pd_seq, 'g_pd_seq'), stride_t, stride_k, _f32(g_v_init, 'g_v_init', M),
                                     T, K, M, scale, _stream(g_depth_seq))
     _check(rc, 'ss_ipool_bwd_f32')
+
+
+def _i32(t, name, numel):
+    if t.dtype != torch.int32:
+        raise SSNeuronError(f'{name}: expected int32, got {t.dtype}')
+    return _ptr(t, name, numel)
+
+
+def upconv1_fwd(P, src_y, src_x, bias, out, NB, k, h, w, H, W):
+    _require_hip(P, 'P')
+    with torch.cuda.device(P.device):
+        rc = lib().ss_upconv1_fwd_f32(_f32(P, 'P', NB * k * k * h * w), _i32(src_y, 'src_y', H + k - 1),
+                                      _i32(src_x, 'src_x', W + k - 1), _f32(bias, 'bias', 1),
+                                      _f32(out, 'out', NB * H * W), NB, k, h, w, H, W, _stream(P))
+    _check(rc, 'ss_upconv1_fwd_f32')
+
+
+def upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, h, w, H, W):
+    _require_hip(g_out, 'g_out')
+    with torch.cuda.device(g_out.device):
+        rc = lib().ss_upconv1_bwd_f32(_f32(g_out, 'g_out', NB * H * W), _i32(y_lo, 'y_lo', h), _i32(y_hi, 'y_hi', h),
+                                      _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
+                                      _f32(g_P, 'g_P', NB * k * k * h * w), NB, k, h, w, H, W, _stream(g_out))
+    _check(rc, 'ss_upconv1_bwd_f32')
 
 
 def gk_ws_floats():

@@ -328,6 +328,59 @@ __global__ __launch_bounds__(kBlock) void ipool_bwd_kernel(const float* g_depth,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// predict_depth head: nearest-upsample + valid kxk conv to one channel, as a gather over per-tap projections
+// ---------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(kBlock) void upconv1_fwd_kernel(const float* __restrict__ P, const int* __restrict__ src_y,
+                                                             const int* __restrict__ src_x, const float* __restrict__ bias,
+                                                             float* __restrict__ out, long long NB, int h, int w, int H, int W)
+{
+    const long long total = NB * H * W;
+    const float b = bias ? *bias : 0.f;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const long long nb = i / ((long long)W * H);
+        const float* Pn = P + nb * (long long)(K * K) * h * w;
+        int sx[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) sx[kx] = src_x[x + kx];
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int sy = src_y[y + ky];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+                acc += Pn[((long long)(ky * K + kx) * h + sy) * w + sx[kx]];
+        }
+        out[i] = acc + b;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void upconv1_bwd_kernel(const float* __restrict__ g_out, const int* __restrict__ y_lo,
+                                                             const int* __restrict__ y_hi, const int* __restrict__ x_lo,
+                                                             const int* __restrict__ x_hi, float* __restrict__ g_P,
+                                                             long long NB, int h, int w, int H, int W)
+{
+    const long long total = NB * (K * K) * h * w;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int ix = (int)(i % w);
+        const int iy = (int)((i / w) % h);
+        const int tap = (int)((i / ((long long)w * h)) % (K * K));
+        const long long nb = i / ((long long)w * h * K * K);
+        const int ky = tap / K, kx = tap % K;
+        int y0 = y_lo[iy] - ky, y1 = y_hi[iy] - ky, x0 = x_lo[ix] - kx, x1 = x_hi[ix] - kx;
+        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > H ? H : y1; x1 = x1 > W ? W : x1;
+        const float* g = g_out + nb * (long long)H * W;
+        float acc = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) acc += g[(long long)y * W + x];
+        g_P[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------
 inline int grid_for(long long work_items)
@@ -487,6 +540,34 @@ int ss_ipool_bwd_f32(const float* g_depth_seq, const float* g_v_last, float* g_p
     if (M == 0) return SS_OK;
     hipLaunchKernelGGL(ipool_bwd_kernel, dim3(grid_for(M)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        g_depth_seq, g_v_last, g_pd_seq, stride_t, stride_k, g_v_init, T, K, M, scale);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv1_fwd_f32(const float* P, const int* src_y, const int* src_x, const float* bias, float* out,
+                       long long NB, int k, int h, int w, int H, int W, void* stream)
+{
+    if (!P || !src_y || !src_x || !out || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 1 && k != 3 && k != 5) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(NB * H * W);
+    if (k == 1) hipLaunchKernelGGL(upconv1_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, s, P, src_y, src_x, bias, out, NB, h, w, H, W);
+    else if (k == 3) hipLaunchKernelGGL(upconv1_fwd_kernel<3>, dim3(grid), dim3(kBlock), 0, s, P, src_y, src_x, bias, out, NB, h, w, H, W);
+    else hipLaunchKernelGGL(upconv1_fwd_kernel<5>, dim3(grid), dim3(kBlock), 0, s, P, src_y, src_x, bias, out, NB, h, w, H, W);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv1_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                       float* g_P, long long NB, int k, int h, int w, int H, int W, void* stream)
+{
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 1 && k != 3 && k != 5) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = grid_for(NB * (long long)(k * k) * h * w);
+    if (k == 1) hipLaunchKernelGGL(upconv1_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, h, w, H, W);
+    else if (k == 3) hipLaunchKernelGGL(upconv1_bwd_kernel<3>, dim3(grid), dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, h, w, H, W);
+    else hipLaunchKernelGGL(upconv1_bwd_kernel<5>, dim3(grid), dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -23,7 +23,9 @@ class Trainer:
 
     def __init__(self, net, lr=2e-4, weight_decay=0.0, reducer=None, loss_module=None):
         self.net = net
-        self.opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=weight_decay)
+        on_gpu = next(net.parameters()).is_cuda
+        # one fused multi-tensor launch for the 21-34 parameter tensors instead of ~10 kernels per tensor
+        self.opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=weight_decay, fused=on_gpu)
         self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=[8, 42, 60], gamma=0.5)  # train.py:127
         self.loss_module = loss_module or Total_Loss(alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=False)
         self.reducer = reducer

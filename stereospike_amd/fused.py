@@ -51,11 +51,12 @@ class KernelTimer:
         e1.record()
         self.records.append((tag, nbytes, updates, e0, e1))
 
-    def summary(self):
-        """{tag: dict(launches, bytes, updates, ms)} — call after torch.cuda.synchronize()."""
+    def summary(self, by_shape=False):
+        """{tag: dict(launches, bytes, updates, ms)} — call after torch.cuda.synchronize().  by_shape=True keys the
+        groups by (tag, updates per launch) so one launch shape can be priced against the roofline on its own."""
         out = {}
         for tag, nbytes, updates, e0, e1 in self.records:
-            d = out.setdefault(tag, dict(launches=0, bytes=0, updates=0, ms=0.0))
+            d = out.setdefault((tag, updates) if by_shape else tag, dict(launches=0, bytes=0, updates=0, ms=0.0))
             d['launches'] += 1
             d['bytes'] += nbytes
             d['updates'] += updates
@@ -87,7 +88,8 @@ class _FusedNeuron(torch.autograd.Function):
         _lib.neuron_fwd(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, cfg.scale, cfg.kind, cfg.tau, k,
                         cfg.v_th, cfg.v_reset)
         per = 4 * (2 + (1 if need_grad else 0) + (1 if skip_seq is not None else 0))
-        TIMER.stop(e0, 'neuron_fwd_train' if need_grad else 'neuron_fwd_infer', per * T * N, T * N)
+        TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if skip_seq is not None else ''),
+                   per * T * N, T * N)
         ctx.cfg = cfg
         ctx.T, ctx.N = T, N
         ctx.has_vinit = v_init is not None
@@ -165,3 +167,67 @@ class _IPool(torch.autograd.Function):
 def ipool(pd_seq: torch.Tensor, scale: float, v_reset: float, v_init: Optional[torch.Tensor] = None):
     """pd_seq [K, T, ...] -> depth_seq [T, K, ...]: membrane snapshots after every charge (t outer, k inner)."""
     return _IPool.apply(pd_seq, v_init, float(scale), float(v_reset))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# predict_depth head synapse without the materialised up-sampled tensor
+# ----------------------------------------------------------------------------------------------------------
+def nearest_tables(in_size: int, out_size: int):
+    """Source index of every up-sampled position, computed by torch's own UpsamplingNearest2d on the CPU (so it is the
+    reference's mapping bit for bit, including its float rounding), and the inverse ranges [lo, hi) per source index."""
+    src = torch.nn.functional.interpolate(torch.arange(in_size, dtype=torch.float32).view(1, 1, in_size, 1),
+                                          size=(out_size, 1), mode='nearest').view(-1).to(torch.int32)
+    assert bool((src[1:] >= src[:-1]).all())
+    lo = torch.searchsorted(src, torch.arange(in_size, dtype=torch.int32), right=False).to(torch.int32)
+    hi = torch.searchsorted(src, torch.arange(in_size, dtype=torch.int32), right=True).to(torch.int32)
+    return src, lo, hi
+
+
+class _UpConv1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, bias, tables, k, H, W):
+        P = P.contiguous()
+        NB, kk, h, w = P.shape
+        assert kk == k * k
+        src_y, y_lo, y_hi, src_x, x_lo, x_hi = tables
+        out = torch.empty((NB, 1, H, W), dtype=P.dtype, device=P.device)
+        e0 = TIMER.start()
+        _lib.upconv1_fwd(P, src_y, src_x, bias, out, NB, k, h, w, H, W)
+        TIMER.stop(e0, 'upconv1_fwd', 4 * (P.numel() + out.numel()), out.numel())
+        ctx.tables = tables
+        ctx.dims = (NB, k, h, w, H, W)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        NB, k, h, w, H, W = ctx.dims
+        _, y_lo, y_hi, _, x_lo, x_hi = ctx.tables
+        g_out = g_out.contiguous()
+        g_P = torch.empty((NB, k * k, h, w), dtype=g_out.dtype, device=g_out.device)
+        e0 = TIMER.start()
+        _lib.upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, h, w, H, W)
+        TIMER.stop(e0, 'upconv1_bwd', 4 * (g_P.numel() + g_out.numel()), g_out.numel())
+        g_bias = g_out.sum().view(1) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return g_P, g_bias, None, None, None, None
+
+
+def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int):
+    """NNConvUpsampling(C_in -> C_out, k, up_size=(H, W)) applied to x [NB, C_in, h, w] (blocks.py:124-132) WITHOUT the
+    up-sampled tensor.  Nearest-neighbour resize only replicates pixels, so the channel contraction commutes with it:
+      1. per-tap projections at LOW resolution  P[nb][co][tap] = W[co, :, tap] . x[nb]   — one 1x1 conv
+         (C_in -> C_out*k*k, a plain GEMM on PyTorch-ROCm; (h*w)/(H*W) ~ 1/4.3 of the direct conv's MACs for the
+         decoder stages, 1/63 for predict_depth4);
+      2. out[nb][co][y][x] = sum_taps P[nb][co][tap][src_y[y+ky]][src_x[x+kx]]  — the fused gather kernel
+         ss_upconv1_fwd_f32 with (nb, co) as its image index.
+    Same value as the reference's two-op form up to fp32 summation order (channels first, taps second).  weight is the
+    Conv2d weight [C_out, C_in, k, k]; autograd reaches it through the projection."""
+    NB, Cin, h, w = x.shape
+    Cout = weight.shape[0]
+    w_taps = weight.permute(0, 2, 3, 1).reshape(Cout * k * k, Cin, 1, 1)      # rows ordered (co, ky, kx)
+    P = torch.nn.functional.conv2d(x, w_taps)                                   # [NB, Cout*k*k, h, w]
+    one_bias = bias if (bias is not None and Cout == 1) else None
+    out = _UpConv1.apply(P.view(NB * Cout, k * k, h, w), one_bias, tables, k, H, W).view(NB, Cout, H, W)
+    if bias is not None and Cout != 1:
+        out = out + bias.view(1, Cout, 1, 1)
+    return out

@@ -64,7 +64,7 @@ class StereoSpike_equivalentANN(AnalogNet):
         heads = []
         for lvl in (4, 3, 2, 1):
             cur = getattr(self, f'deconv{lvl}')(cur) + enc[lvl - 1]
-            heads.append(getattr(self, f'predict_depth{lvl}')(cur))
+            heads.append(getattr(self, f'predict_depth{lvl}')[0].forward_projected(cur))
         pool = self.Ineurons
         depth = ipool(torch.stack(heads).unsqueeze(1), 1.0, pool.v_reset, pool._v_init(heads[0]))[0]
         pool.v = depth[3]

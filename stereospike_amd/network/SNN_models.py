@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from ..clock_driven import layer, neuron, surrogate
 from ..fused import ipool
+from . import blocks as _blocks
 from .blocks import MultiplyBy, NNConvUpsampling, SEWResBlock, SpikingStage
 
 _RATE_KEYS = ('out_bottom', 'out_conv1', 'out_conv2', 'out_conv3', 'out_conv4', 'out_rconv', 'out_combined',
@@ -134,7 +135,8 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             cur = getattr(self, f'deconv{lvl}').forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
             spikes.append(cur)
             head = getattr(self, f'predict_depth{lvl}')
-            heads.append(head[0](cur.flatten(0, 1)).view(T, B, 1, *self.input_size))
+            synapse = head[0].forward_projected if _blocks.FUSE_UPCONV else head[0]
+            heads.append(synapse(cur.flatten(0, 1)).view(T, B, 1, *self.input_size))
         # shared I-neuron pool: v += gain * head, heads charged in the order 4,3,2,1 every step (:172-188)
         gains = [h[1].scale_value for h in (self.predict_depth4, self.predict_depth3, self.predict_depth2,
                                             self.predict_depth1)]

@@ -216,3 +216,59 @@ def test_full_size_properties():
     _lib.neuron_bwd(ga, None, h, None, gx1, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
     _lib.neuron_bwd(ga * 2, None, h, None, gx2, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
     assert torch.equal(gx1 * 2, gx2)        # scaling by 2 is exact in fp32
+
+
+def test_upconv1_heads_vs_oracle_and_torch():
+    """Fused predict_depth head (nearest-upsample + valid 3x3 conv to one channel) == the oracle's gather (same
+    summation order => bit-exact) and == torch's UpsamplingNearest2d + Conv2d on the CPU within 2e-6."""
+    import torch.nn as nn
+    from stereospike_amd import _lib
+    from stereospike_amd.fused import nearest_tables, upconv_projected
+    torch.manual_seed(0)
+    for (C, h, w, H, W, k) in [(256, 33, 44, 260, 346, 3), (32, 260, 346, 260, 346, 3), (5, 7, 9, 20, 30, 3), (6, 17, 22, 33, 44, 5)]:
+        up = nn.Sequential(nn.UpsamplingNearest2d(size=(H + k - 1, W + k - 1)), nn.Conv2d(C, 1, k, bias=True))
+        x = (torch.rand(3, C, h, w) < 0.4).float().requires_grad_()
+        y = up(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        sy, ylo, yhi = nearest_tables(h, H + k - 1)
+        sx, xlo, xhi = nearest_tables(w, W + k - 1)
+        tables = tuple(t.to(DEV) for t in (sy, ylo, yhi, sx, xlo, xhi))
+        xd = x.detach().to(DEV).requires_grad_()
+        wd = up[1].weight.detach().to(DEV).requires_grad_()
+        bd = up[1].bias.detach().to(DEV).requires_grad_()
+        yd = upconv_projected(xd, wd, bd, tables, k, H, W)
+        yd.backward(g.to(DEV))
+        assert rel_err(yd, y) < 2e-6
+        assert rel_err(xd.grad, x.grad) < 1e-5 and rel_err(wd.grad, up[1].weight.grad) < 1e-5
+        assert rel_err(bd.grad, up[1].bias.grad) < 1e-5
+        # kernel vs C oracle on the same projections: identical order => bit-exact
+        P = torch.nn.functional.conv2d(x.detach(), up[1].weight.detach().view(C, k * k).t().reshape(k * k, C, 1, 1))
+        ref = c_oracle.upconv1_fwd(P.numpy(), sy.numpy(), sx.numpy(), float(up[1].bias), H, W)
+        out = torch.empty(3, 1, H, W, device=DEV)
+        _lib.upconv1_fwd(P.to(DEV), tables[0], tables[3], bd.detach(), out, 3, k, h, w, H, W)
+        assert bit_equal(out[:, 0], ref)
+        gref = c_oracle.upconv1_bwd(g.numpy()[:, 0], ylo.numpy(), yhi.numpy(), xlo.numpy(), xhi.numpy(), k)
+        gP = torch.empty(3, k * k, h, w, device=DEV)
+        _lib.upconv1_bwd(g.to(DEV).contiguous(), tables[1], tables[2], tables[4], tables[5], gP, 3, k, h, w, H, W)
+        assert bit_equal(gP, gref)
+
+
+def test_upconv_projected_multichannel_vs_torch():
+    """Decoder synapse NNConvUpsampling(C_in -> C_out, k=5) through projection + gather == torch's two-op form (CPU)."""
+    import torch.nn as nn
+    from stereospike_amd.fused import nearest_tables, upconv_projected
+    torch.manual_seed(1)
+    for (Cin, Cout, h, w, H, W, k) in [(512, 256, 17, 22, 33, 44, 5), (64, 32, 130, 173, 260, 346, 5), (8, 4, 9, 11, 20, 25, 5)]:
+        up = nn.Sequential(nn.UpsamplingNearest2d(size=(H + k - 1, W + k - 1)), nn.Conv2d(Cin, Cout, k, bias=False))
+        x = (torch.rand(2, Cin, h, w) < 0.4).float().requires_grad_()
+        y = up(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        tables = tuple(t.to(DEV) for t in (nearest_tables(h, H + k - 1) + nearest_tables(w, W + k - 1)))
+        xd = x.detach().to(DEV).requires_grad_()
+        wd = up[1].weight.detach().to(DEV).requires_grad_()
+        yd = upconv_projected(xd, wd, None, tables, k, H, W)
+        yd.backward(g.to(DEV))
+        assert rel_err(yd, y) < 3e-6, (Cin, Cout)
+        assert rel_err(xd.grad, x.grad) < 2e-5 and rel_err(wd.grad, up[1].weight.grad) < 2e-5, (Cin, Cout)

@@ -1,7 +1,7 @@
 """CPU suite, part 5: the host-side graph wiring (SpikingStage / SEWResBlock / model forward_sequence / autograd
-Functions / I-pool ordering / firing-rate bookkeeping) checked WITHOUT a GPU.
+Functions / I-pool ordering / fused predict heads / firing-rate bookkeeping) checked WITHOUT a GPU.
 
-The four C-ABI entry points of stereospike_amd._lib are monkeypatched — in this test process only — by the C oracle
+The compute entry points of stereospike_amd._lib are monkeypatched — in this test process only — by the C oracle
 operating on host memory, so that the product's Python layer can run on CPU tensors and be diffed against the oracle
 network (which is pinned to the reference's own network/*.py).  This exercises host logic only; it says nothing about
 the HIP kernels (tests/test_gpu_*.py do) and the product itself contains no such path (tests/test_abi.py)."""
@@ -48,6 +48,14 @@ def host_backend(monkeypatch):
         assert L.ss_ref_ipool_bwd_f32(_p(g_depth_seq), _p(g_v_last), _p(g_pd_seq), st, sk, _p(g_v_init), T, K, M,
                                       scale) == 0
 
+    def upconv1_fwd(P, src_y, src_x, bias, out, NB, k, h, w, H, W):
+        assert L.ss_ref_upconv1_fwd_f32(_p(P), _p(src_y), _p(src_x), _p(bias), _p(out), NB, k, h, w, H, W) == 0
+
+    def upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, h, w, H, W):
+        assert L.ss_ref_upconv1_bwd_f32(_p(g_out), _p(y_lo), _p(y_hi), _p(x_lo), _p(x_hi), _p(g_P), NB, k, h, w, H, W) == 0
+
+    monkeypatch.setattr(_lib, 'upconv1_fwd', upconv1_fwd)
+    monkeypatch.setattr(_lib, 'upconv1_bwd', upconv1_bwd)
     monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
     monkeypatch.setattr(_lib, 'neuron_bwd', neuron_bwd)
     monkeypatch.setattr(_lib, 'ipool_fwd', ipool_fwd)
@@ -86,10 +94,11 @@ def test_single_step_graph_is_bit_identical_to_the_oracle_network(host_backend, 
     for a, b in zip(s0, s1):
         assert torch.equal(a, b)
     for a, b in zip(d0, d1):
-        assert torch.equal(a, b)
+        # the heads sum channels first, taps second (ss_upconv1): same value, different fp32 summation order
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
     L0 = rn.total_loss(d0, gt, s0)
     L1 = Total_Loss()(d1, gt, s1)
-    assert abs(float(L0) - float(L1)) <= 2e-6 * abs(float(L0))
+    assert abs(float(L0) - float(L1)) <= 1e-5 * abs(float(L0))
     L0.backward()
     L1.backward()
     for (k, p), (_, q) in zip(net.named_parameters(), orc.named_parameters()):

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Target of the rocprofv3 --pmc passes: a few launches of the fused forward (train) and backward kernels at the
+config-3 bottom-layer size (B16 x T5 x 32x260x346 = 2.3e8 updates, 2.76 GB algorithmic per launch)."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stereospike_amd import _lib
+dev = 'cuda:0'
+T, N = 5, 16 * 32 * 260 * 346
+x = torch.randn(T, N, device=dev) * 0.15
+out, h, g, gx = torch.empty_like(x), torch.empty_like(x), torch.randn(T, N, device=dev), torch.empty_like(x)
+v = torch.empty(N, device=dev)
+for _ in range(5):
+    _lib.neuron_fwd(x, None, None, out, h, v, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+    _lib.neuron_bwd(g, None, h, None, gx, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+torch.cuda.synchronize()
+print('algorithmic bytes per launch', 12 * T * N)
