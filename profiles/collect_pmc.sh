@@ -9,6 +9,6 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o pmc -- python "$REPO/tools/pmc_target.py" > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o pmc -- python "$REPO/tools/pmc_target.py" > "$OUT/write.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- python "$REPO/tools/pmc_target.py" > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- python "$REPO/tools/pmc_target.py" > "$OUT/write.log" 2>&1
 python "$REPO/profiles/parse_pmc.py" "$OUT" | tee "$OUT/pmc_traffic.json"

@@ -1,37 +1,53 @@
 #!/usr/bin/env python3
-"""Reduce the rocprofv3 --pmc CSVs to per-launch HBM bytes for the fused kernels (see collect_pmc.sh)."""
+"""Reduce the rocprofv3 --pmc outputs (rocpd sqlite .db and/or counter_collection.csv) to per-launch HBM bytes for the
+fused kernels (see collect_pmc.sh).  gfx950: FETCH_SIZE counts 64 B per 128-B request => doubled (MI355X_MICROARCH.md §HBM);
+FETCH_SIZE / WRITE_SIZE are in KiB."""
 import csv
 import glob
 import json
 import os
+import sqlite3
 import sys
 
 out_dir = sys.argv[1]
+
+
+def key_of(name):
+    return 'neuron_fwd' if 'neuron_fwd_kernel' in name else 'neuron_bwd' if 'neuron_bwd_kernel' in name else None
 
 
 def mean_counter(sub, counter):
     vals = {}
     for path in glob.glob(os.path.join(out_dir, sub, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(path)):
-            if row.get('Counter_Name') != counter:
-                continue
-            name = row.get('Kernel_Name', '')
-            key = 'neuron_fwd' if 'neuron_fwd_kernel' in name else 'neuron_bwd' if 'neuron_bwd_kernel' in name else None
-            if key:
-                vals.setdefault(key, []).append(float(row['Counter_Value']))
+            if row.get('Counter_Name') == counter and key_of(row.get('Kernel_Name', '')):
+                vals.setdefault(key_of(row['Kernel_Name']), []).append(float(row['Counter_Value']))
+    if not vals:
+        for path in glob.glob(os.path.join(out_dir, sub, '**', '*.db'), recursive=True):
+            cur = sqlite3.connect(path).cursor()
+            q = ("select s.kernel_name, e.value from rocpd_pmc_event e join rocpd_info_pmc i on e.pmc_id = i.id "
+                 "join rocpd_kernel_dispatch d on e.event_id = d.event_id "
+                 "join rocpd_info_kernel_symbol s on d.kernel_id = s.id where i.name = ?")
+            for name, value in cur.execute(q, (counter,)):
+                if key_of(name):
+                    vals.setdefault(key_of(name), []).append(float(value))
     return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
 
 
 fetch, nf = mean_counter('fetch', 'FETCH_SIZE')
 write, nw = mean_counter('write', 'WRITE_SIZE')
 T, N = 5, 16 * 32 * 260 * 346
-res = {'workload': 'B16 x T5 x 32x260x346 layer, IF, fp32', 'algorithmic_bytes_per_launch': 12 * T * N,
-       'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported'}
+res = {'workload': 'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, tools/pmc_target.py',
+       'algorithmic_bytes_per_launch_12B_per_update': 12 * T * N,
+       'o_n_terms_bytes': {'neuron_fwd': 4 * N, 'neuron_bwd': 0},
+       'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported; '
+               'separate --pmc passes; the forward also writes v_last (4 B x N, an O(N) term outside the per-update figure)'}
 for k in ('neuron_fwd', 'neuron_bwd'):
     if k in fetch and k in write:
+        hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],
-                  'hbm_bytes_per_launch': int((2 * fetch[k] + write[k]) * 1024),
-                  'ratio_to_algorithmic': round((2 * fetch[k] + write[k]) * 1024 / (12 * T * N), 3)}
+                  'hbm_read_bytes': int(2 * fetch[k] * 1024), 'hbm_write_bytes': int(write[k] * 1024),
+                  'hbm_bytes_per_launch': int(hbm), 'ratio_to_algorithmic': round(hbm / (12 * T * N), 4)}
 if 'neuron_fwd' in res:
     res['neuron_fwd_train_bytes_per_launch'] = res['neuron_fwd']['hbm_bytes_per_launch']
 print(json.dumps(res, indent=1))

@@ -183,7 +183,18 @@ def nearest_tables(in_size: int, out_size: int):
     return src, lo, hi
 
 
+# how the low-res per-tap projection is evaluated
+#   'chunked' : frame-chunked GEMM + gather so the projection tensor P stays resident in the 256 MiB Infinity Cache
+#               between its producer and its consumer (default; see _UpConvProjected)
+#   'conv'    : one MIOpen 1x1 convolution over the whole batch, P materialised in HBM
+#   'matmul'  : one rocBLAS batched GEMM over the whole batch, P materialised in HBM
+PROJECTION_IMPL = 'chunked'
+P_CHUNK_BYTES = 96 << 20          # per-chunk size of P: comfortably inside the 256 MiB MALL next to x / out / g_out
+
+
 class _UpConv1(torch.autograd.Function):
+    """The gather alone (P given): used by the 'conv' / 'matmul' variants, autograd reaches W through P."""
+
     @staticmethod
     def forward(ctx, P, bias, tables, k, H, W):
         P = P.contiguous()
@@ -212,20 +223,86 @@ class _UpConv1(torch.autograd.Function):
         return g_P, g_bias, None, None, None, None
 
 
+class _UpConvProjected(torch.autograd.Function):
+    """Projection GEMM + gather, walked over chunks of frames.  P (C_out*k*k channels at low resolution — 6x the size of
+    the stage's output for deconv1) is produced and consumed chunk by chunk, each chunk <= P_CHUNK_BYTES, so it lives in
+    the Infinity Cache and never makes the round trip to HBM; the same holds for g_P in backward, which feeds the two
+    GEMMs (dgrad, wgrad) right after the gather adjoint writes it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, tables, k, H, W):
+        x = x.contiguous()
+        NB, Cin, h, w = x.shape
+        Cout, kk, hw = weight.shape[0], k * k, h * w
+        W2 = weight.permute(0, 2, 3, 1).reshape(Cout * kk, Cin).contiguous()        # rows ordered (co, ky, kx)
+        src_y, _, _, src_x, _, _ = tables
+        out = torch.empty((NB, Cout, H, W), dtype=x.dtype, device=x.device)
+        n = max(1, min(NB, P_CHUNK_BYTES // (Cout * kk * hw * 4)))
+        one_bias = bias if (bias is not None and Cout == 1) else None
+        e0 = TIMER.start()
+        for c0 in range(0, NB, n):
+            c1 = min(NB, c0 + n)
+            P = torch.matmul(W2, x[c0:c1].view(c1 - c0, Cin, hw))                     # [n, Cout*kk, hw]
+            _lib.upconv1_fwd(P, src_y, src_x, one_bias, out[c0:c1], (c1 - c0) * Cout, k, h, w, H, W)
+        if bias is not None and Cout != 1:
+            out += bias.view(1, Cout, 1, 1)
+        TIMER.stop(e0, 'upconv_projected_fwd', 4 * (x.numel() + out.numel()), out.numel())
+        ctx.save_for_backward(x, W2)
+        ctx.tables, ctx.k, ctx.n = tables, k, n
+        ctx.wshape = weight.shape
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, W2 = ctx.saved_tensors
+        k, n = ctx.k, ctx.n
+        _, y_lo, y_hi, _, x_lo, x_hi = ctx.tables
+        NB, Cin, h, w = x.shape
+        Cout, kk, hw = ctx.wshape[0], k * k, h * w
+        H, W = g_out.shape[-2:]
+        g_out = g_out.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_x = torch.empty_like(x) if need_x else None
+        g_W2 = torch.zeros_like(W2) if need_w else None
+        W2t = W2.t().contiguous()
+        e0 = TIMER.start()
+        for c0 in range(0, NB, n):
+            c1 = min(NB, c0 + n)
+            m = c1 - c0
+            g_P = torch.empty((m, Cout * kk, hw), dtype=x.dtype, device=x.device)
+            _lib.upconv1_bwd(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, m * Cout, k, h, w, H, W)
+            if need_x:
+                torch.matmul(W2t, g_P, out=g_x[c0:c1].view(m, Cin, hw))               # dgrad
+            if need_w:
+                g_W2 += torch.bmm(g_P, x[c0:c1].view(m, Cin, hw).transpose(1, 2)).sum(0)   # wgrad
+        TIMER.stop(e0, 'upconv_projected_bwd', 4 * (x.numel() + g_out.numel()), g_out.numel())
+        g_w = g_W2.view(Cout, k, k, Cin).permute(0, 3, 1, 2).contiguous() if need_w else None
+        g_b = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = g_out.sum((0, 2, 3))
+        return g_x, g_w, g_b, None, None, None, None
+
+
 def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int):
     """NNConvUpsampling(C_in -> C_out, k, up_size=(H, W)) applied to x [NB, C_in, h, w] (blocks.py:124-132) WITHOUT the
     up-sampled tensor.  Nearest-neighbour resize only replicates pixels, so the channel contraction commutes with it:
-      1. per-tap projections at LOW resolution  P[nb][co][tap] = W[co, :, tap] . x[nb]   — one 1x1 conv
-         (C_in -> C_out*k*k, a plain GEMM on PyTorch-ROCm; (h*w)/(H*W) ~ 1/4.3 of the direct conv's MACs for the
-         decoder stages, 1/63 for predict_depth4);
+      1. per-tap projections at LOW resolution  P[nb][co][tap] = W[co, :, tap] . x[nb]   — a plain GEMM
+         (C_in -> C_out*k*k on PyTorch-ROCm; (h*w)/(H*W) ~ 1/4.3 of the direct conv's MACs for the decoder stages,
+         1/63 for predict_depth4);
       2. out[nb][co][y][x] = sum_taps P[nb][co][tap][src_y[y+ky]][src_x[x+kx]]  — the fused gather kernel
          ss_upconv1_fwd_f32 with (nb, co) as its image index.
     Same value as the reference's two-op form up to fp32 summation order (channels first, taps second).  weight is the
-    Conv2d weight [C_out, C_in, k, k]; autograd reaches it through the projection."""
+    Conv2d weight [C_out, C_in, k, k]."""
+    if PROJECTION_IMPL == 'chunked':
+        return _UpConvProjected.apply(x, weight, bias, tables, k, H, W)
     NB, Cin, h, w = x.shape
     Cout = weight.shape[0]
-    w_taps = weight.permute(0, 2, 3, 1).reshape(Cout * k * k, Cin, 1, 1)      # rows ordered (co, ky, kx)
-    P = torch.nn.functional.conv2d(x, w_taps)                                   # [NB, Cout*k*k, h, w]
+    w_taps = weight.permute(0, 2, 3, 1).reshape(Cout * k * k, Cin)              # rows ordered (co, ky, kx)
+    if PROJECTION_IMPL == 'matmul':      # rocBLAS strided-batched GEMM: [Cout*k*k, Cin] x [NB][Cin, h*w]
+        P = torch.matmul(w_taps, x.reshape(NB, Cin, h * w))
+    else:                                # MIOpen 1x1 convolution
+        P = torch.nn.functional.conv2d(x, w_taps.view(Cout * k * k, Cin, 1, 1))
     one_bias = bias if (bias is not None and Cout == 1) else None
     out = _UpConv1.apply(P.view(NB * Cout, k * k, h, w), one_bias, tables, k, H, W).view(NB, Cout, H, W)
     if bias is not None and Cout != 1:

@@ -15,6 +15,9 @@ layers = [('deconv4', 512, 256, 5, (17, 22), (33, 44)), ('deconv3', 256, 128, 5,
           ('pd4', 256, 1, 3, (33, 44), (260, 346)), ('pd3', 128, 1, 3, (65, 87), (260, 346)),
           ('pd2', 64, 1, 3, (130, 173), (260, 346)), ('pd1', 32, 1, 3, (260, 346), (260, 346))]
 which = os.environ.get('WHICH', 'projected,miopen').split(',')
+from stereospike_amd import fused
+fused.PROJECTION_IMPL = os.environ.get('PROJ', 'auto')
+print('PROJECTION_IMPL', fused.PROJECTION_IMPL)
 for name, ci, co, k, insz, up in layers:
     m = NNConvUpsampling(ci, co, k, up, bias=(co == 1)).to(dev)
     x = (torch.rand(NB, ci, *insz, device=dev) < 0.3).float().requires_grad_()
