@@ -150,6 +150,21 @@ int ss_upconv1_fwd_f32(const float* P, const int* src_y, const int* src_x, const
 int ss_upconv1_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                        float* g_P, long long NB, int k, int h, int w, int H, int W, void* stream);
 
+/*
+ * Channels-last variants of the two gather kernels, for C_out > 1 stages kept in NHWC memory end to end:
+ *   P     [NB][h][w][k*k*C]   channel index = tap*C + c   (exactly the row-major result of the single GEMM
+ *                              x[NB*h*w, C_in] @ W[C_in, k*k*C]: no per-image batching, no layout transposes)
+ *   out   [NB][H][W][C]
+ *   out[nb][y][x][c] = (bias ? bias[c] : 0) + sum_{ky,kx} P[nb][src_y[y+ky]][src_x[x+kx]][(ky*k+kx)*C + c]   (taps in (ky,kx) order,
+ *   bias last).  A lane owns 4 consecutive channels of one pixel (16-B accesses, consecutive lanes = consecutive
+ *   channels then consecutive pixels => coalesced reads of P and writes of out).  C % 4 != 0 falls back to one channel per lane.
+ * The adjoint g_P[nb][iy][ix][tap*C + c] = rectangle sum of g_out[nb][.][.][c] (rows first, as ss_upconv1_bwd_f32).
+ */
+int ss_upconv_cl_fwd_f32(const float* P, const int* src_y, const int* src_x, const float* bias, float* out,
+                         long long NB, int k, int C, int h, int w, int H, int W, void* stream);
+int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                         float* g_P, long long NB, int k, int C, int h, int w, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,8 +37,11 @@ def lib():
         _lib.ss_ref_ipool_bwd_f32.argtypes = [fp, fp, fp, i64, i64, fp, i32, i32, i64, f32]
         _lib.ss_ref_upconv1_fwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i32, i32, i32, i32, i32]
         _lib.ss_ref_upconv1_bwd_f32.argtypes = [fp, fp, fp, fp, fp, fp, i64, i32, i32, i32, i32, i32]
+        _lib.ss_ref_upconv_cl_fwd_f32.argtypes = [fp, fp, fp, fp, fp, i64, i32, i32, i32, i32, i32, i32]
+        _lib.ss_ref_upconv_cl_bwd_f32.argtypes = [fp, fp, fp, fp, fp, fp, i64, i32, i32, i32, i32, i32, i32]
         for f in (_lib.ss_ref_neuron_fwd_f32, _lib.ss_ref_neuron_bwd_f32, _lib.ss_ref_ipool_fwd_f32,
-                  _lib.ss_ref_ipool_bwd_f32, _lib.ss_ref_upconv1_fwd_f32, _lib.ss_ref_upconv1_bwd_f32):
+                  _lib.ss_ref_ipool_bwd_f32, _lib.ss_ref_upconv1_fwd_f32, _lib.ss_ref_upconv1_bwd_f32,
+                  _lib.ss_ref_upconv_cl_fwd_f32, _lib.ss_ref_upconv_cl_bwd_f32):
             f.restype = C.c_int
     return _lib
 
@@ -133,4 +136,29 @@ def upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, k):
     rc = lib().ss_ref_upconv1_bwd_f32(_p(g_out), _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), _p(g_P), NB, k, h, w, H, W)
     if rc:
         raise ValueError(f'ss_ref_upconv1_bwd_f32 -> {rc}')
+    return g_P
+
+
+def upconv_cl_fwd(P, src_y, src_x, bias, k, C, H, W):
+    """P [NB, h, w, k*k*C] float32 (channel = tap*C + c); returns out [NB, H, W, C]."""
+    P = _f32(P)
+    NB, h, w, _ = P.shape
+    sy, sx = np.ascontiguousarray(src_y, np.int32), np.ascontiguousarray(src_x, np.int32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    out = np.empty((NB, H, W, C), np.float32)
+    rc = lib().ss_ref_upconv_cl_fwd_f32(_p(P), _p(sy), _p(sx), _p(b), _p(out), NB, k, C, h, w, H, W)
+    if rc:
+        raise ValueError(f'ss_ref_upconv_cl_fwd_f32 -> {rc}')
+    return out
+
+
+def upconv_cl_bwd(g_out, y_lo, y_hi, x_lo, x_hi, k):
+    g_out = _f32(g_out)
+    NB, H, W, C = g_out.shape
+    t = [np.ascontiguousarray(a, np.int32) for a in (y_lo, y_hi, x_lo, x_hi)]
+    h, w = len(t[0]), len(t[2])
+    g_P = np.empty((NB, h, w, k * k * C), np.float32)
+    rc = lib().ss_ref_upconv_cl_bwd_f32(_p(g_out), _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), _p(g_P), NB, k, C, h, w, H, W)
+    if rc:
+        raise ValueError(f'ss_ref_upconv_cl_bwd_f32 -> {rc}')
     return g_P

@@ -202,10 +202,61 @@ int ss_ref_upconv1_bwd_f32(const float *g_out, const int *y_lo, const int *y_hi,
                     if (x0 < 0) x0 = 0;
                     if (y1 > H) y1 = H;
                     if (x1 > W) x1 = W;
+                    /* rectangle sum, row sums first: C[y] = sum_x (x ascending), then sum_y C[y] (y ascending) */
                     float acc = 0.f;
-                    for (int y = y0; y < y1; ++y)
-                        for (int x = x0; x < x1; ++x) acc += g_out[(nb * H + y) * (long long)W + x];
+                    for (int y = y0; y < y1; ++y) {
+                        float cs = 0.f;
+                        for (int x = x0; x < x1; ++x) cs += g_out[(nb * H + y) * (long long)W + x];
+                        acc += cs;
+                    }
                     g_P[((nb * (k * k) + tap) * h + iy) * (long long)w + ix] = acc;
+                }
+    return 0;
+}
+
+/* channels-last variants (include/ss_neuron.h ss_upconv_cl_*): P [NB][h][w][k*k*C] (channel = tap*C + c), out [NB][H][W][C] */
+int ss_ref_upconv_cl_fwd_f32(const float *P, const int *src_y, const int *src_x, const float *bias, float *out,
+                             long long NB, int k, int C, int h, int w, int H, int W)
+{
+    if (!P || !src_y || !src_x || !out || NB < 0 || k <= 0 || C <= 0) return -22;
+    const long long KKC = (long long)k * k * C;
+    for (long long nb = 0; nb < NB; ++nb)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int c = 0; c < C; ++c) {
+                    float acc = 0.f;
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            acc += P[((nb * h + src_y[y + ky]) * (long long)w + src_x[x + kx]) * KKC + (ky * k + kx) * C + c];
+                    out[((nb * H + y) * (long long)W + x) * C + c] = acc + (bias ? bias[c] : 0.f);
+                }
+    return 0;
+}
+
+int ss_ref_upconv_cl_bwd_f32(const float *g_out, const int *y_lo, const int *y_hi, const int *x_lo, const int *x_hi,
+                             float *g_P, long long NB, int k, int C, int h, int w, int H, int W)
+{
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || k <= 0 || C <= 0) return -22;
+    const long long KKC = (long long)k * k * C;
+    for (long long nb = 0; nb < NB; ++nb)
+        for (int iy = 0; iy < h; ++iy)
+            for (int ix = 0; ix < w; ++ix)
+                for (int tap = 0; tap < k * k; ++tap) {
+                    const int ky = tap / k, kx = tap % k;
+                    int y0 = y_lo[iy] - ky, y1 = y_hi[iy] - ky, x0 = x_lo[ix] - kx, x1 = x_hi[ix] - kx;
+                    if (y0 < 0) y0 = 0;
+                    if (x0 < 0) x0 = 0;
+                    if (y1 > H) y1 = H;
+                    if (x1 > W) x1 = W;
+                    for (int c = 0; c < C; ++c) {
+                        float acc = 0.f;
+                        for (int y = y0; y < y1; ++y) {
+                            float cs = 0.f;
+                            for (int x = x0; x < x1; ++x) cs += g_out[((nb * H + y) * (long long)W + x) * C + c];
+                            acc += cs;
+                        }
+                        g_P[((nb * h + iy) * (long long)w + ix) * KKC + tap * C + c] = acc;
+                    }
                 }
     return 0;
 }

@@ -41,8 +41,10 @@ def lib():
     L.ss_ipool_bwd_f32.argtypes = [p, p, p, i64, i64, p, i32, i32, i64, f32, p]
     L.ss_upconv1_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     L.ss_upconv1_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_cl_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_cl_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
-              L.ss_upconv1_fwd_f32, L.ss_upconv1_bwd_f32):
+              L.ss_upconv1_fwd_f32, L.ss_upconv1_bwd_f32, L.ss_upconv_cl_fwd_f32, L.ss_upconv_cl_bwd_f32):
         f.restype = i32
     if L.ss_abi_version() != ABI_VERSION:
         raise SSNeuronError(f'libss_neuron.so ABI {L.ss_abi_version()} != expected {ABI_VERSION}; rebuild')
@@ -51,7 +53,8 @@ def lib():
 
 
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
-           'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32')
+           'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
+           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -156,6 +159,24 @@ def upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, h, w, H, W):
                                       _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
                                       _f32(g_P, 'g_P', NB * k * k * h * w), NB, k, h, w, H, W, _stream(g_out))
     _check(rc, 'ss_upconv1_bwd_f32')
+
+
+def upconv_cl_fwd(P, src_y, src_x, bias, out, NB, k, C, h, w, H, W):
+    _require_hip(P, 'P')
+    with torch.cuda.device(P.device):
+        rc = lib().ss_upconv_cl_fwd_f32(_f32(P, 'P', NB * k * k * C * h * w), _i32(src_y, 'src_y', H + k - 1),
+                                        _i32(src_x, 'src_x', W + k - 1), _f32(bias, 'bias', C),
+                                        _f32(out, 'out', NB * H * W * C), NB, k, C, h, w, H, W, _stream(P))
+    _check(rc, 'ss_upconv_cl_fwd_f32')
+
+
+def upconv_cl_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, C, h, w, H, W):
+    _require_hip(g_out, 'g_out')
+    with torch.cuda.device(g_out.device):
+        rc = lib().ss_upconv_cl_bwd_f32(_f32(g_out, 'g_out', NB * H * W * C), _i32(y_lo, 'y_lo', h), _i32(y_hi, 'y_hi', h),
+                                        _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
+                                        _f32(g_P, 'g_P', NB * k * k * C * h * w), NB, k, C, h, w, H, W, _stream(g_out))
+    _check(rc, 'ss_upconv_cl_bwd_f32')
 
 
 def gk_ws_floats():

@@ -63,8 +63,10 @@ class BaseNode(nn.Module):
                          v_reset=float(self.v_reset), surrogate=sg_id, alpha=float(sg.alpha),
                          detach_reset=bool(self.detach_reset))
 
-    def _v_init(self, like: torch.Tensor) -> Optional[torch.Tensor]:
+    def _v_init(self, like: torch.Tensor, channels_last: bool = False) -> Optional[torch.Tensor]:
         v = self.v
+        if isinstance(v, torch.Tensor) and channels_last:
+            v = v.permute(0, 2, 3, 1)          # logical [B, C, H, W] -> the NHWC array the kernel walks
         if isinstance(v, torch.Tensor):
             if v.shape != like.shape:
                 raise _lib.SSNeuronError(f'membrane shape {tuple(v.shape)} != input shape {tuple(like.shape)}; '
@@ -75,11 +77,14 @@ class BaseNode(nn.Module):
         return torch.full_like(like, float(v))
 
     def forward_sequence(self, x_seq: torch.Tensor, scale: float = 1., skip_seq: Optional[torch.Tensor] = None,
-                         nnz: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x_seq [T, ...]: T steps from the current membrane; returns out_seq [T, ...] and carries v forward."""
-        out_seq, v_last = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0]), skip_seq=skip_seq,
-                                       k=self._k(), nnz=nnz)
-        self.v = v_last
+                         nnz: Optional[torch.Tensor] = None, channels_last: bool = False) -> torch.Tensor:
+        """x_seq [T, ...]: T steps from the current membrane; returns out_seq [T, ...] and carries v forward.
+        The kernel is element-wise, so any memory layout works as long as x, skip and v share it; with
+        channels_last=True x_seq is an NHWC array [T, B, H, W, C] and `self.v` keeps its logical [B, C, H, W] shape
+        (a permuted view of the NHWC membrane)."""
+        out_seq, v_last = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0], channels_last),
+                                       skip_seq=skip_seq, k=self._k(), nnz=nnz)
+        self.v = v_last.permute(0, 3, 1, 2) if channels_last else v_last
         return out_seq
 
     def forward_fused(self, x: torch.Tensor, scale: float = 1., skip: Optional[torch.Tensor] = None,

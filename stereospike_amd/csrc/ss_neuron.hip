@@ -37,6 +37,32 @@ constexpr long long kGkWsFloats = kMaxGrid;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Streaming-access policy of the neuron kernels (A/B-measured with tools/bench_kernels.py, see profiles/):
+//   SS_NT_H  : h_seq is written once and read only by the backward pass, much later => non-temporal store
+//   SS_NT_X  : x_seq (conv output) / g_out are read exactly once                   => non-temporal load
+#ifndef SS_NT_H
+#define SS_NT_H 0
+#endif
+#ifndef SS_NT_X
+#define SS_NT_X 0
+#endif
+template <typename V> __device__ __forceinline__ V load_stream(const V* p)
+{
+#if SS_NT_X
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename V> __device__ __forceinline__ void store_h(V* p, V v)
+{
+#if SS_NT_H
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------
 // element-wise pieces (scalar; applied to each of a lane's 4 neurons)
 // ---------------------------------------------------------------------------------------------------
@@ -115,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
             vec_t ss[SKIP ? TS : 1];
 #pragma unroll
             for (int t = 0; t < TS; ++t) {
-                xs[t] = xp[(long long)t * NV];
+                xs[t] = load_stream(xp + (long long)t * NV);
                 if (SKIP) ss[t] = sp[(long long)t * NV];
             }
 #pragma unroll
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
                     c_spk += (z != 0.f); c_out += (o != 0.f);
                     if constexpr (VEC == 4) { hv[e] = h; ov[e] = o; vv[e] = v; } else { hv = h; ov = o; vv = v; }
                 }
-                if (SAVE_H) hp[(long long)t * NV] = hv;
+                if (SAVE_H) store_h(hp + (long long)t * NV, hv);
                 op[(long long)t * NV] = ov;
             }
         } else {
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
         if constexpr (TS > 0) {
             vec_t gs[TS], hs[TS];
 #pragma unroll
-            for (int t = TS - 1; t >= 0; --t) { gs[t] = gp[(long long)t * NV]; hs[t] = hp[(long long)t * NV]; }
+            for (int t = TS - 1; t >= 0; --t) { gs[t] = load_stream(gp + (long long)t * NV); hs[t] = load_stream(hp + (long long)t * NV); }
 #pragma unroll
             for (int t = TS - 1; t >= 0; --t)
                 xp[(long long)t * NV] = step(gs[t], hs[t], hs[t > 0 ? t - 1 : 0], t == 0);
@@ -330,53 +356,250 @@ __global__ __launch_bounds__(kBlock) void ipool_bwd_kernel(const float* g_depth,
 // ---------------------------------------------------------------------------------------------------
 // predict_depth head: nearest-upsample + valid kxk conv to one channel, as a gather over per-tap projections
 // ---------------------------------------------------------------------------------------------------
+// Index decoding uses 32-bit arithmetic only (one image = blockIdx.y, at most 2^31 elements per image): 64-bit
+// div/mod per element made the first version of these kernels ALU-bound (profiles/r01/kernel_stats_v1.csv).
 template <int K>
 __global__ __launch_bounds__(kBlock) void upconv1_fwd_kernel(const float* __restrict__ P, const int* __restrict__ src_y,
                                                              const int* __restrict__ src_x, const float* __restrict__ bias,
-                                                             float* __restrict__ out, long long NB, int h, int w, int H, int W)
+                                                             float* __restrict__ out, int NB, int h, int w, int H, int W)
 {
-    const long long total = NB * H * W;
+    const unsigned pix = blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= (unsigned)(H * W)) return;
+    const unsigned y = pix / (unsigned)W, x = pix - y * (unsigned)W;
     const float b = bias ? *bias : 0.f;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const int x = (int)(i % W);
-        const int y = (int)((i / W) % H);
-        const long long nb = i / ((long long)W * H);
-        const float* Pn = P + nb * (long long)(K * K) * h * w;
-        int sx[K];
+    int sx[K], sy[K];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) sx[kx] = src_x[x + kx];
+    for (int q = 0; q < K; ++q) { sx[q] = src_x[x + q]; sy[q] = src_y[y + q] * w; }
+    const unsigned hw = (unsigned)(h * w);
+    for (int img = blockIdx.y; img < NB; img += gridDim.y) {
+        const float* Pn = P + (long long)img * (K * K) * hw;
         float acc = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int sy = src_y[y + ky];
+        for (int ky = 0; ky < K; ++ky)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
-                acc += Pn[((long long)(ky * K + kx) * h + sy) * w + sx[kx]];
-        }
-        out[i] = acc + b;
+                acc += Pn[(unsigned)(ky * K + kx) * hw + (unsigned)(sy[ky] + sx[kx])];
+        out[(long long)img * (H * W) + pix] = acc + b;
     }
 }
+
+// Adjoint of the gather.  One workgroup owns a 4 x 64 tile of SOURCE pixels of one image: the g_out window that maps to
+// it ((4*rep + K-1) rows x (64*rep + K-1) columns, rep ~ 2 for the decoder stages) is staged once in LDS with coalesced
+// row reads; every lane then forms its K*K rectangle sums from LDS and writes K*K coalesced planes of g_P.
+// Each rectangle sum is evaluated row-sums-first: C[y] = sum_x g[y][x] (x ascending), then sum_y C[y] (y ascending) —
+// the order oracle/ss_neuron_ref.c restates.  Fast path (block-uniform): when every source pixel of the tile is
+// replicated at most 3 times per axis, a lane reads its (K+2) x (K+2) window once with static indexing and shares the
+// row sums between the K*K taps (49 LDS reads instead of ~106 for K = 5).  Windows that do not fit the LDS tile
+// (large up-sampling ratios, e.g. predict_depth4's 7.9x) read g_out directly.
+constexpr int kBwdTileY = 4, kBwdTileX = 64, kBwdLds = 6144;      // 24 KiB of LDS
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void upconv1_bwd_kernel(const float* __restrict__ g_out, const int* __restrict__ y_lo,
                                                              const int* __restrict__ y_hi, const int* __restrict__ x_lo,
                                                              const int* __restrict__ x_hi, float* __restrict__ g_P,
-                                                             long long NB, int h, int w, int H, int W)
+                                                             int NB, int h, int w, int H, int W)
 {
-    const long long total = NB * (K * K) * h * w;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const int ix = (int)(i % w);
-        const int iy = (int)((i / w) % h);
-        const int tap = (int)((i / ((long long)w * h)) % (K * K));
-        const long long nb = i / ((long long)w * h * K * K);
-        const int ky = tap / K, kx = tap % K;
-        int y0 = y_lo[iy] - ky, y1 = y_hi[iy] - ky, x0 = x_lo[ix] - kx, x1 = x_hi[ix] - kx;
-        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > H ? H : y1; x1 = x1 > W ? W : x1;
-        const float* g = g_out + nb * (long long)H * W;
-        float acc = 0.f;
-        for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) acc += g[(long long)y * W + x];
-        g_P[i] = acc;
+    __shared__ float tile[kBwdLds];
+    __shared__ int s_small;
+    const int tx = threadIdx.x & (kBwdTileX - 1), ty = threadIdx.x >> 6;
+    const int ix0 = blockIdx.x * kBwdTileX, iy0 = blockIdx.y * kBwdTileY;
+    const int ix = ix0 + tx, iy = iy0 + ty;
+    const bool valid = ix < w && iy < h;
+    // window of g_out covered by this source tile (block-uniform)
+    const int iyl = min(iy0 + kBwdTileY, h) - 1, ixl = min(ix0 + kBwdTileX, w) - 1;
+    const int r0 = max(y_lo[iy0] - (K - 1), 0), r1 = min(y_hi[iyl], H);
+    const int c0 = max(x_lo[ix0] - (K - 1), 0), c1 = min(x_hi[ixl], W);
+    const int rh = max(r1 - r0, 0), rw = max(c1 - c0, 0);
+    const bool fits = rh * rw <= kBwdLds;
+    int ylo = 0, yhi = 0, xlo = 0, xhi = 0;
+    if (valid) { ylo = y_lo[iy]; yhi = y_hi[iy]; xlo = x_lo[ix]; xhi = x_hi[ix]; }
+    const int ry = yhi - ylo, rx = xhi - xlo;                         // replication counts of this source pixel
+    if (threadIdx.x == 0) s_small = 1;
+    __syncthreads();
+    if (ry > 3 || rx > 3) s_small = 0;                                // benign race: all writers store 0
+    __syncthreads();
+    const bool small = fits && s_small != 0;
+    const unsigned hw = (unsigned)(h * w);
+    for (int img = blockIdx.z; img < NB; img += gridDim.z) {
+        const float* g = g_out + (long long)img * (H * W);
+        if (fits) {
+            for (int r = ty; r < rh; r += kBlock / kBwdTileX)
+                for (int c = tx; c < rw; c += kBwdTileX) tile[r * rw + c] = g[(r0 + r) * W + (c0 + c)];
+            __syncthreads();
+        }
+        if (valid) {
+            float* gp = g_P + (long long)img * (K * K) * hw + (unsigned)(iy * w + ix);
+            if (small) {
+                // window rows ylo-(K-1) .. ylo+2, cols xlo-(K-1) .. xlo+2 (zero outside the image / beyond the replication)
+                float acc[K][K];
+#pragma unroll
+                for (int r = 0; r < K + 2; ++r) {
+                    const int y = ylo - (K - 1) + r;
+                    const bool yok = y >= 0 && y < H && (y - r0) < rh;
+                    float row[K + 2];
+#pragma unroll
+                    for (int c = 0; c < K + 2; ++c) {
+                        const int x = xlo - (K - 1) + c;
+                        const bool ok = yok && x >= 0 && x < W && (x - c0) < rw;
+                        row[c] = ok ? tile[(y - r0) * rw + (x - c0)] : 0.f;
+                    }
+                    float C[K];                                        // row sums for the K horizontal taps
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int b0 = K - 1 - kx;                     // first column of tap kx inside the window
+                        float cs = 0.f;
+                        if (rx > 0) cs += row[b0];
+                        if (rx > 1) cs += row[b0 + 1];
+                        if (rx > 2) cs += row[b0 + 2];
+                        C[kx] = cs;
+                    }
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky) {
+                        const int a = r - (K - 1) + ky;                // which row of tap ky's rectangle this window row is
+                        if (a == 0) {
+#pragma unroll
+                            for (int kx = 0; kx < K; ++kx) { acc[ky][kx] = 0.f; if (ry > 0) acc[ky][kx] += C[kx]; }
+                        } else if (a == 1 || a == 2) {
+                            if (ry > a) {
+#pragma unroll
+                                for (int kx = 0; kx < K; ++kx) acc[ky][kx] += C[kx];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) gp[(unsigned)(ky * K + kx) * hw] = acc[ky][kx];
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const int y0 = max(ylo - ky, 0), y1 = min(yhi - ky, H);
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int x0 = max(xlo - kx, 0), x1 = min(xhi - kx, W);
+                        float acc = 0.f;
+                        for (int y = y0; y < y1; ++y) {
+                            float cs = 0.f;
+                            if (fits) { for (int x = x0; x < x1; ++x) cs += tile[(y - r0) * rw + (x - c0)]; }
+                            else      { for (int x = x0; x < x1; ++x) cs += g[y * W + x]; }
+                            acc += cs;
+                        }
+                        gp[(unsigned)(ky * K + kx) * hw] = acc;
+                    }
+                }
+            }
+        }
+        if (fits) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// channels-last gather kernels (decoder kept in NHWC: P is the row-major output of ONE GEMM, no transposes)
+// ---------------------------------------------------------------------------------------------------
+template <int K, int VEC>
+__global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __restrict__ P, const int* __restrict__ src_y,
+                                                               const int* __restrict__ src_x, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int NB, int C, int h, int w, int H, int W)
+{
+    typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
+    const unsigned CV = (unsigned)C / VEC;                            // channel vectors per pixel
+    const unsigned idx = blockIdx.x * kBlock + threadIdx.x;           // (pixel, channel vector) of one image
+    if (idx >= (unsigned)(H * W) * CV) return;
+    const unsigned pix = idx / CV, cv = idx - pix * CV;
+    const unsigned y = pix / (unsigned)W, x = pix - y * (unsigned)W;
+    const unsigned KKC = (unsigned)(K * K * C);
+    unsigned off[K][K];                                               // source pixel offsets (in floats) per tap
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const unsigned sy = (unsigned)src_y[y + ky] * (unsigned)w;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+            off[ky][kx] = (sy + (unsigned)src_x[x + kx]) * KKC + (unsigned)((ky * K + kx) * C) + cv * VEC;
+    }
+    vec_t b;
+    if constexpr (VEC == 4) b = bias ? *reinterpret_cast<const f4*>(bias + cv * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+    else b = bias ? bias[cv] : 0.f;
+    for (int img = blockIdx.y; img < NB; img += gridDim.y) {
+        const float* Pn = P + (long long)img * h * w * KKC;
+        vec_t acc;
+        if constexpr (VEC == 4) acc = (f4){0.f, 0.f, 0.f, 0.f}; else acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const vec_t*>(Pn + off[ky][kx]);
+        *reinterpret_cast<vec_t*>(out + ((long long)img * (H * W) + pix) * C + cv * VEC) = acc + b;
+    }
+}
+
+template <int K, int VEC>
+__global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __restrict__ g_out, const int* __restrict__ y_lo,
+                                                               const int* __restrict__ y_hi, const int* __restrict__ x_lo,
+                                                               const int* __restrict__ x_hi, float* __restrict__ g_P,
+                                                               int NB, int C, int h, int w, int H, int W)
+{
+    typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
+    const unsigned CV = (unsigned)C / VEC;
+    const unsigned idx = blockIdx.x * kBlock + threadIdx.x;           // (source pixel, channel vector) of one image
+    if (idx >= (unsigned)(h * w) * CV) return;
+    const unsigned sp = idx / CV, cv = idx - sp * CV;
+    const unsigned iy = sp / (unsigned)w, ix = sp - iy * (unsigned)w;
+    const int ylo = y_lo[iy], yhi = y_hi[iy], xlo = x_lo[ix], xhi = x_hi[ix];
+    const int ry = yhi - ylo, rx = xhi - xlo;
+    const unsigned KKC = (unsigned)(K * K * C);
+    vec_t zero;
+    if constexpr (VEC == 4) zero = (f4){0.f, 0.f, 0.f, 0.f}; else zero = 0.f;
+    for (int img = blockIdx.y; img < NB; img += gridDim.y) {
+        const float* g = g_out + (long long)img * (H * W) * C + cv * VEC;
+        float* gp = g_P + ((long long)img * (h * w) + sp) * KKC + cv * VEC;
+        if (ry <= 3 && rx <= 3) {
+            // per vertical tap: up to 3 rows of a (K+2)-wide window, row sums shared between the K horizontal taps
+            // (rows re-read per ky hit L1; the ky loop is kept rolled so the kernel stays below ~100 VGPRs instead of 255)
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                vec_t acc[K];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[kx] = zero;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int y = ylo - ky + a;
+                    if (a < ry && y >= 0 && y < H) {
+                        vec_t row[K + 2];
+#pragma unroll
+                        for (int c = 0; c < K + 2; ++c) {
+                            const int x = xlo - (K - 1) + c;
+                            const bool ok = x >= 0 && x < W && c < K - 1 + rx;
+                            row[c] = ok ? *reinterpret_cast<const vec_t*>(g + (long long)(y * W + x) * C) : zero;
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) {
+                            const int b0 = K - 1 - kx;
+                            vec_t cs = zero;
+                            if (rx > 0) cs += row[b0];
+                            if (rx > 1) cs += row[b0 + 1];
+                            if (rx > 2) cs += row[b0 + 2];
+                            acc[kx] += cs;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc[kx];
+            }
+        } else {
+            for (int ky = 0; ky < K; ++ky) {
+                const int y0 = max(ylo - ky, 0), y1 = min(yhi - ky, H);
+                for (int kx = 0; kx < K; ++kx) {
+                    const int x0 = max(xlo - kx, 0), x1 = min(xhi - kx, W);
+                    vec_t acc = zero;
+                    for (int y = y0; y < y1; ++y) {
+                        vec_t cs = zero;
+                        for (int x = x0; x < x1; ++x) cs += *reinterpret_cast<const vec_t*>(g + (long long)(y * W + x) * C);
+                        acc += cs;
+                    }
+                    *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc;
+                }
+            }
+        }
     }
 }
 
@@ -459,6 +682,30 @@ int dispatch_bwd_sg(const BwdArgs& a, int surrogate, hipStream_t s, int* grid_ou
 {
     return surrogate == SS_SG_ATAN ? dispatch_bwd_T<KIND, SS_SG_ATAN>(a, s, grid_out)
                                    : dispatch_bwd_T<KIND, SS_SG_SIGMOID>(a, s, grid_out);
+}
+
+template <int K>
+int launch_cl_fwd(const float* P, const int* sy, const int* sx, const float* bias, float* out, int NB, int C, int h, int w,
+                         int H, int W, hipStream_t s)
+{
+    const bool vec = (C % 4 == 0) && aligned16(P) && aligned16(out) && (!bias || aligned16(bias));
+    const long long per_img = (long long)H * W * (vec ? C / 4 : C);
+    const dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
+    if (vec) hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 4>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
+    else     hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 1>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+template <int K>
+int launch_cl_bwd(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi, float* g_P,
+                         int NB, int C, int h, int w, int H, int W, hipStream_t s)
+{
+    const bool vec = (C % 4 == 0) && aligned16(g_out) && aligned16(g_P);
+    const long long per_img = (long long)h * w * (vec ? C / 4 : C);
+    const dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
+    if (vec) hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 4>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
+    else     hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 1>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
 }  // namespace
@@ -549,11 +796,13 @@ int ss_upconv1_fwd_f32(const float* P, const int* src_y, const int* src_x, const
     if (!P || !src_y || !src_x || !out || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
     if (k != 1 && k != 3 && k != 5) return SS_EINVAL;
     if (NB == 0) return SS_OK;
+    if (NB > 0x7fffffffLL || (long long)H * W > 0x7fffffffLL || (long long)k * k * h * w > 0x7fffffffLL) return SS_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(NB * H * W);
-    if (k == 1) hipLaunchKernelGGL(upconv1_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, s, P, src_y, src_x, bias, out, NB, h, w, H, W);
-    else if (k == 3) hipLaunchKernelGGL(upconv1_fwd_kernel<3>, dim3(grid), dim3(kBlock), 0, s, P, src_y, src_x, bias, out, NB, h, w, H, W);
-    else hipLaunchKernelGGL(upconv1_fwd_kernel<5>, dim3(grid), dim3(kBlock), 0, s, P, src_y, src_x, bias, out, NB, h, w, H, W);
+    const dim3 grid((unsigned)((H * W + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
+    const int nb = (int)NB;
+    if (k == 1) hipLaunchKernelGGL(upconv1_fwd_kernel<1>, grid, dim3(kBlock), 0, s, P, src_y, src_x, bias, out, nb, h, w, H, W);
+    else if (k == 3) hipLaunchKernelGGL(upconv1_fwd_kernel<3>, grid, dim3(kBlock), 0, s, P, src_y, src_x, bias, out, nb, h, w, H, W);
+    else hipLaunchKernelGGL(upconv1_fwd_kernel<5>, grid, dim3(kBlock), 0, s, P, src_y, src_x, bias, out, nb, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -563,12 +812,42 @@ int ss_upconv1_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, con
     if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
     if (k != 1 && k != 3 && k != 5) return SS_EINVAL;
     if (NB == 0) return SS_OK;
+    if (NB > 0x7fffffffLL || (long long)H * W > 0x7fffffffLL || (long long)k * k * h * w > 0x7fffffffLL) return SS_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = grid_for(NB * (long long)(k * k) * h * w);
-    if (k == 1) hipLaunchKernelGGL(upconv1_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, h, w, H, W);
-    else if (k == 3) hipLaunchKernelGGL(upconv1_bwd_kernel<3>, dim3(grid), dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, h, w, H, W);
-    else hipLaunchKernelGGL(upconv1_bwd_kernel<5>, dim3(grid), dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, h, w, H, W);
+    const dim3 grid((unsigned)((w + kBwdTileX - 1) / kBwdTileX), (unsigned)((h + kBwdTileY - 1) / kBwdTileY),
+                    (unsigned)(NB < 65535 ? NB : 65535));
+    if (grid.y > 65535u) return SS_EINVAL;
+    const int nb = (int)NB;
+    if (k == 1) hipLaunchKernelGGL(upconv1_bwd_kernel<1>, grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, nb, h, w, H, W);
+    else if (k == 3) hipLaunchKernelGGL(upconv1_bwd_kernel<3>, grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, nb, h, w, H, W);
+    else hipLaunchKernelGGL(upconv1_bwd_kernel<5>, grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, nb, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_cl_fwd_f32(const float* P, const int* src_y, const int* src_x, const float* bias, float* out,
+                         long long NB, int k, int C, int h, int w, int H, int W, void* stream)
+{
+    if (!P || !src_y || !src_x || !out || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 1 && k != 3 && k != 5) return SS_EINVAL;
+    if (NB > 0x7fffffffLL || (long long)H * W * C > 0x7fffffffLL || (long long)k * k * C * h * w > 0x7fffffffLL) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (k == 1) return launch_cl_fwd<1>(P, src_y, src_x, bias, out, (int)NB, C, h, w, H, W, s);
+    if (k == 3) return launch_cl_fwd<3>(P, src_y, src_x, bias, out, (int)NB, C, h, w, H, W, s);
+    return launch_cl_fwd<5>(P, src_y, src_x, bias, out, (int)NB, C, h, w, H, W, s);
+}
+
+int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                         float* g_P, long long NB, int k, int C, int h, int w, int H, int W, void* stream)
+{
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 1 && k != 3 && k != 5) return SS_EINVAL;
+    if (NB > 0x7fffffffLL || (long long)H * W * C > 0x7fffffffLL || (long long)k * k * C * h * w > 0x7fffffffLL) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (k == 1) return launch_cl_bwd<1>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+    if (k == 3) return launch_cl_bwd<3>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+    return launch_cl_bwd<5>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
 }
 
 }  // extern "C"

@@ -188,7 +188,10 @@ def nearest_tables(in_size: int, out_size: int):
 #               between its producer and its consumer (default; see _UpConvProjected)
 #   'conv'    : one MIOpen 1x1 convolution over the whole batch, P materialised in HBM
 #   'matmul'  : one rocBLAS batched GEMM over the whole batch, P materialised in HBM
-PROJECTION_IMPL = 'chunked'
+#   'auto'    : 'chunked' when a chunk holds >= 4 frames (small maps: deconv4, deconv3, the heads — few, large GEMMs),
+#               otherwise 'conv' (deconv2, deconv1: per-frame GEMMs with K = C_in <= 128 are launch/latency-bound;
+#               measured on MI355X, profiles/r01/upconv_variants.log)
+PROJECTION_IMPL = 'auto'
 P_CHUNK_BYTES = 96 << 20          # per-chunk size of P: comfortably inside the 256 MiB MALL next to x / out / g_out
 
 
@@ -294,12 +297,15 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
          ss_upconv1_fwd_f32 with (nb, co) as its image index.
     Same value as the reference's two-op form up to fp32 summation order (channels first, taps second).  weight is the
     Conv2d weight [C_out, C_in, k, k]."""
-    if PROJECTION_IMPL == 'chunked':
-        return _UpConvProjected.apply(x, weight, bias, tables, k, H, W)
     NB, Cin, h, w = x.shape
     Cout = weight.shape[0]
+    impl = PROJECTION_IMPL
+    if impl == 'auto':
+        impl = 'chunked' if P_CHUNK_BYTES // (Cout * k * k * h * w * 4) >= 4 else 'conv'
+    if impl == 'chunked':
+        return _UpConvProjected.apply(x, weight, bias, tables, k, H, W)
     w_taps = weight.permute(0, 2, 3, 1).reshape(Cout * k * k, Cin)              # rows ordered (co, ky, kx)
-    if PROJECTION_IMPL == 'matmul':      # rocBLAS strided-batched GEMM: [Cout*k*k, Cin] x [NB][Cin, h*w]
+    if impl == 'matmul':                 # rocBLAS strided-batched GEMM: [Cout*k*k, Cin] x [NB][Cin, h*w]
         P = torch.matmul(w_taps, x.reshape(NB, Cin, h * w))
     else:                                # MIOpen 1x1 convolution
         P = torch.nn.functional.conv2d(x, w_taps.view(Cout * k * k, Cin, 1, 1))
@@ -308,3 +314,82 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
     if bias is not None and Cout != 1:
         out = out + bias.view(1, Cout, 1, 1)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# channels-last (NHWC) form of the same up-conv: the decoder's fast path
+# ----------------------------------------------------------------------------------------------------------
+WGRAD_SPLIT_ROWS = 16384          # split-K granularity of the weight-gradient GEMM (K = NB*h*w rows)
+
+
+class _UpConvProjectedCL(torch.autograd.Function):
+    """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
+    forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
+              then the channels-last gather kernel (ss_upconv_cl_fwd_f32);
+    backward: g_P = gather adjoint (ss_upconv_cl_bwd_f32); dgrad g_x = g_P @ W^T (one GEMM); wgrad g_W = x^T @ g_P as a
+              split-K batched GEMM (the contraction runs over all NB*h*w rows) summed over the splits.
+    Frames are walked in chunks whose P stays inside the Infinity Cache when a chunk holds >= 4 frames, else in one
+    pass with P in HBM (same policy as the NCHW path)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W):
+        x_cl = x_cl.contiguous()
+        NB, h, w, Cin = x_cl.shape
+        Cout, kk = weight.shape[0], k * k
+        Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()      # column index = tap*C_out + co
+        src_y, _, _, src_x, _, _ = tables
+        out = torch.empty((NB, H, W, Cout), dtype=x_cl.dtype, device=x_cl.device)
+        n = P_CHUNK_BYTES // (Cout * kk * h * w * 4)
+        n = NB if n < 4 else min(NB, n)
+        e0 = TIMER.start()
+        for c0 in range(0, NB, n):
+            c1 = min(NB, c0 + n)
+            P = torch.mm(x_cl[c0:c1].view((c1 - c0) * h * w, Cin), Wt)             # [(n*h*w), kk*Cout]
+            _lib.upconv_cl_fwd(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
+        TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
+        ctx.save_for_backward(x_cl, Wt)
+        ctx.tables, ctx.k, ctx.n = tables, k, n
+        ctx.wshape = weight.shape
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x_cl, Wt = ctx.saved_tensors
+        k, n = ctx.k, ctx.n
+        _, y_lo, y_hi, _, x_lo, x_hi = ctx.tables
+        NB, h, w, Cin = x_cl.shape
+        Cout, kk = ctx.wshape[0], k * k
+        H, W = g_out.shape[1:3]
+        g_out = g_out.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_x = torch.empty_like(x_cl) if need_x else None
+        g_Wt = torch.zeros_like(Wt) if need_w else None
+        W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
+        e0 = TIMER.start()
+        for c0 in range(0, NB, n):
+            c1 = min(NB, c0 + n)
+            rows = (c1 - c0) * h * w
+            g_P = torch.empty((rows, kk * Cout), dtype=x_cl.dtype, device=x_cl.device)
+            _lib.upconv_cl_bwd(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+            if need_x:
+                torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))                 # dgrad
+            if need_w:
+                xs = x_cl[c0:c1].view(rows, Cin)
+                S = max(1, rows // WGRAD_SPLIT_ROWS)
+                L = rows // S
+                if S > 1:
+                    g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout)).sum(0)
+                    if S * L < rows:
+                        g_Wt.addmm_(xs[S * L:].t(), g_P[S * L:])
+                else:
+                    g_Wt.addmm_(xs.t(), g_P)
+        TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
+        g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
+        g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return g_x, g_w, g_b, None, None, None, None
+
+
+def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int):
+    """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out]."""
+    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W)

@@ -131,12 +131,22 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         cur = self.bottleneck[0].forward_sequence(enc[4])
         cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
         spikes, heads = [cur], []
+        cl = _blocks.FUSE_UPCONV and _blocks.DECODER_CHANNELS_LAST
+        if cl:
+            cur = cur.permute(0, 1, 3, 4, 2).contiguous()              # decoder runs on NHWC arrays [T, B, h, w, C]
         for lvl in (4, 3, 2, 1):
-            cur = getattr(self, f'deconv{lvl}').forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
-            spikes.append(cur)
-            head = getattr(self, f'predict_depth{lvl}')
-            synapse = head[0].forward_projected if _blocks.FUSE_UPCONV else head[0]
-            heads.append(synapse(cur.flatten(0, 1)).view(T, B, 1, *self.input_size))
+            stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
+            if cl:
+                skip = enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
+                cur = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'))
+                spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
+                pd = head[0].forward_projected_cl(cur.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW
+            else:
+                cur = stage.forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
+                spikes.append(cur)
+                synapse = head[0].forward_projected if _blocks.FUSE_UPCONV else head[0]
+                pd = synapse(cur.flatten(0, 1))
+            heads.append(pd.view(T, B, 1, *self.input_size))
         # shared I-neuron pool: v += gain * head, heads charged in the order 4,3,2,1 every step (:172-188)
         gains = [h[1].scale_value for h in (self.predict_depth4, self.predict_depth3, self.predict_depth2,
                                             self.predict_depth1)]

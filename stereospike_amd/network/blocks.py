@@ -12,12 +12,16 @@ import torch
 import torch.nn as nn
 
 from ..clock_driven import neuron, surrogate
-from ..fused import nearest_tables, upconv_projected
+from ..fused import nearest_tables, upconv_projected, upconv_projected_cl
 
 
 # The sequence fast path evaluates NNConvUpsampling through forward_projected (no up-sampled tensor).  Set to False to
 # fall back to the reference's two-op form on MIOpen (used by bench.py --no-fuse-upconv for A/B measurements).
 FUSE_UPCONV = True
+# Keep the decoder (deconv4..1, their skip adds, the predict_depth heads) in NHWC memory: the projection is then ONE
+# row-major GEMM per stage and the gather kernels read/write 16-B channel vectors (no MIOpen layout transposes, no
+# per-image batched GEMMs).  The neuron kernels are layout-agnostic.  False = NCHW decoder (bench.py --decoder-nhwc 0).
+DECODER_CHANNELS_LAST = True
 
 
 class MultiplyBy(nn.Module):
@@ -86,6 +90,15 @@ class NNConvUpsampling(_UpConv):
                                 Hu - k + 1, Wu - k + 1)
 
 
+    def forward_projected_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
+        """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array)."""
+        conv = self.up[1]
+        k = conv.kernel_size[0]
+        Hu, Wu = self.up[0].size
+        return upconv_projected_cl(x_cl, conv.weight, conv.bias, self._tables(x_cl.shape[1], x_cl.shape[2], x_cl.device),
+                                   k, Hu - k + 1, Wu - k + 1)
+
+
 class BilinConvUpsampling(_UpConv):
     _mode = 'bilinear'
 
@@ -109,6 +122,15 @@ class SpikingStage(nn.Sequential):
             else syn(x_seq.flatten(0, 1))
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
+
+
+    def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None):
+        """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
+        NNConvUpsampling."""
+        T, B = x_seq.shape[:2]
+        y = self[0].forward_projected_cl(x_seq.flatten(0, 1))
+        y, scale = _fold_gain(self[1], y)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True)
 
 
 class ResBlock(nn.Module):

@@ -272,3 +272,43 @@ def test_upconv_projected_multichannel_vs_torch():
         yd.backward(g.to(DEV))
         assert rel_err(yd, y) < 3e-6, (Cin, Cout)
         assert rel_err(xd.grad, x.grad) < 2e-5 and rel_err(wd.grad, up[1].weight.grad) < 2e-5, (Cin, Cout)
+
+
+def test_upconv_channels_last_vs_oracle_and_torch():
+    """NHWC decoder synapse: one GEMM + channels-last gather == C oracle (bit-exact kernels) == torch two-op (2e-6)."""
+    import torch.nn as nn
+    from stereospike_amd import _lib
+    from stereospike_amd.fused import nearest_tables, upconv_projected_cl
+    torch.manual_seed(2)
+    for (Cin, Cout, h, w, H, W, k, B) in [(512, 256, 17, 22, 33, 44, 5, 3), (64, 32, 130, 173, 260, 346, 5, 2),
+                                           (8, 4, 9, 11, 20, 25, 5, 2), (32, 1, 65, 87, 260, 346, 3, 2), (6, 3, 5, 7, 40, 50, 3, 2)]:
+        up = nn.Sequential(nn.UpsamplingNearest2d(size=(H + k - 1, W + k - 1)), nn.Conv2d(Cin, Cout, k, bias=(Cout == 1)))
+        x = (torch.rand(B, Cin, h, w) < 0.4).float().requires_grad_()
+        y = up(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        tabs = nearest_tables(h, H + k - 1) + nearest_tables(w, W + k - 1)
+        tables = tuple(t.to(DEV) for t in tabs)
+        x_cl = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_()
+        wd = up[1].weight.detach().to(DEV).requires_grad_()
+        bd = up[1].bias.detach().to(DEV).requires_grad_() if Cout == 1 else None
+        y_cl = upconv_projected_cl(x_cl, wd, bd, tables, k, H, W)
+        y_cl.backward(g.permute(0, 2, 3, 1).contiguous().to(DEV))
+        assert rel_err(y_cl.permute(0, 3, 1, 2), y) < 3e-6, (Cin, Cout)
+        assert rel_err(x_cl.grad.permute(0, 3, 1, 2), x.grad) < 2e-5, (Cin, Cout)
+        assert rel_err(wd.grad, up[1].weight.grad) < 2e-5, (Cin, Cout)
+        if bd is not None:
+            assert rel_err(bd.grad, up[1].bias.grad) < 2e-5
+        # kernels vs the C oracle on identical P / g_out: same summation order => bit-exact
+        Wt = up[1].weight.detach().permute(1, 2, 3, 0).reshape(Cin, k * k * Cout)
+        P = (x.detach().permute(0, 2, 3, 1).reshape(-1, Cin) @ Wt).view(B, h, w, k * k * Cout).contiguous()
+        bias_np = None if Cout != 1 else up[1].bias.detach().numpy()
+        ref = c_oracle.upconv_cl_fwd(P.numpy(), tabs[0].numpy(), tabs[3].numpy(), bias_np, k, Cout, H, W)
+        out = torch.empty(B, H, W, Cout, device=DEV)
+        _lib.upconv_cl_fwd(P.to(DEV), tables[0], tables[3], None if bd is None else bd.detach(), out, B, k, Cout, h, w, H, W)
+        assert bit_equal(out, ref), (Cin, Cout)
+        g_cl = g.permute(0, 2, 3, 1).contiguous()
+        gref = c_oracle.upconv_cl_bwd(g_cl.numpy(), tabs[1].numpy(), tabs[2].numpy(), tabs[4].numpy(), tabs[5].numpy(), k)
+        gP = torch.empty(B, h, w, k * k * Cout, device=DEV)
+        _lib.upconv_cl_bwd(g_cl.to(DEV), tables[1], tables[2], tables[4], tables[5], gP, B, k, Cout, h, w, H, W)
+        assert bit_equal(gP, gref), (Cin, Cout)

@@ -54,6 +54,15 @@ def host_backend(monkeypatch):
     def upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, h, w, H, W):
         assert L.ss_ref_upconv1_bwd_f32(_p(g_out), _p(y_lo), _p(y_hi), _p(x_lo), _p(x_hi), _p(g_P), NB, k, h, w, H, W) == 0
 
+    def upconv_cl_fwd(P, src_y, src_x, bias, out, NB, k, C, h, w, H, W):
+        assert L.ss_ref_upconv_cl_fwd_f32(_p(P), _p(src_y), _p(src_x), _p(bias), _p(out), NB, k, C, h, w, H, W) == 0
+
+    def upconv_cl_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, C, h, w, H, W):
+        assert L.ss_ref_upconv_cl_bwd_f32(_p(g_out), _p(y_lo), _p(y_hi), _p(x_lo), _p(x_hi), _p(g_P), NB, k, C, h, w, H,
+                                          W) == 0
+
+    monkeypatch.setattr(_lib, 'upconv_cl_fwd', upconv_cl_fwd)
+    monkeypatch.setattr(_lib, 'upconv_cl_bwd', upconv_cl_bwd)
     monkeypatch.setattr(_lib, 'upconv1_fwd', upconv1_fwd)
     monkeypatch.setattr(_lib, 'upconv1_bwd', upconv1_bwd)
     monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
@@ -79,10 +88,13 @@ def _pair(name, H, W):
     return orc, net
 
 
+@pytest.mark.parametrize('decoder_nhwc', [True, False])
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
-def test_single_step_graph_is_bit_identical_to_the_oracle_network(host_backend, name):
+def test_single_step_graph_is_bit_identical_to_the_oracle_network(host_backend, name, decoder_nhwc, monkeypatch):
     from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network import blocks
     from stereospike_amd.network.loss import Total_Loss
+    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', decoder_nhwc)
     H, W = 48, 64
     orc, net = _pair(name, H, W)
     x = synth_input(2, 1, 4, 5, H, W, lam=0.1)

@@ -24,9 +24,12 @@ for name, ci, co, k, insz, up in layers:
     for mode in which:
         if mode == 'miopen' and name not in os.environ.get('MIOPEN_LAYERS', 'deconv4,pd4').split(','):
             continue
-        fn = m.forward_projected if mode == 'projected' else m.forward
+        fn = m.forward_projected if mode == 'projected' else m.forward_projected_cl if mode == 'cl' else m.forward
+        xin = x
+        if mode == 'cl':
+            xin = x.detach().permute(0, 2, 3, 1).contiguous().requires_grad_()
         def run():
-            y = fn(x)
+            y = fn(xin)
             y.backward(torch.ones_like(y))
         t0 = time.time(); run(); torch.cuda.synchronize(); first = time.time() - t0
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -36,9 +39,9 @@ for name, ci, co, k, insz, up in layers:
         ms = e0.elapsed_time(e1) / 3
         # forward only
         with torch.no_grad():
-            fn(x); torch.cuda.synchronize()
+            fn(xin); torch.cuda.synchronize()
             e0.record()
-            for _ in range(3): fn(x)
+            for _ in range(3): fn(xin)
             e1.record(); torch.cuda.synchronize()
         fms = e0.elapsed_time(e1) / 3
         print(f'{name:8s} {mode:10s} fwd+bwd {ms:8.2f} ms   fwd {fms:7.2f} ms   first call {first:6.1f} s   '
