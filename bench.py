@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--channels-last', type=int, default=0)
     ap.add_argument('--bucket-mb', type=float, default=20.0)
     ap.add_argument('--decoder-nhwc', type=int, default=1, help='1: decoder kept in NHWC memory (one GEMM per stage)')
+    ap.add_argument('--encoder-nhwc', type=int, default=1, help='1: encoder/bottleneck activations in NHWC as well')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
     return ap.parse_args()
@@ -58,7 +59,7 @@ def build_net(model, device):
                             multiply_factor=10.)              # gain 10 so neurons fire
     else:
         net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., v_threshold=1.0, v_reset=0.0,
-                                                                             use_plif=True, multiply_factor=10.)
+                                                                             use_plif=True, multiply_factor=30.)
     return net.to(device)
 
 
@@ -72,7 +73,7 @@ def cpu_baseline(model, T, budget_s):
     if model == 'StereoSpike':
         net = rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan())
     else:
-        net = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=10.)
+        net = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=30.)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
     B = 1
     x, gt = synthetic_batch(B, T, seed=2021)
@@ -122,6 +123,7 @@ def main():
     from stereospike_amd.network import blocks as _blocks
     _blocks.FUSE_UPCONV = bool(a.fuse_upconv)
     _blocks.DECODER_CHANNELS_LAST = bool(a.decoder_nhwc)
+    _blocks.ENCODER_CHANNELS_LAST = bool(a.encoder_nhwc)
     net = build_net(a.model, dev)
     if a.channels_last:
         net = net.to(memory_format=torch.channels_last)
@@ -185,7 +187,7 @@ def main():
             'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
                                    f'(reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd',
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
-                       'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'weights': 'default init, seed 2021, multiply_factor 10',
+                       'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': 'default init, seed 2021, multiply_factor 10',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
             'roofline': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, fp32, '
                                     f'12 B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',

@@ -105,6 +105,25 @@ int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float
                       void* stream);
 
 /*
+ * 16-bit activation I/O variants (BASELINE.json configs 2 and 5: bf16 / fp16 activations, fp32 membrane state).
+ * x_seq, skip_seq, out_seq (and g_out_seq, g_x_seq) hold IEEE fp16 (dtype = SS_DT_F16) or bfloat16 (SS_DT_BF16) values;
+ * every input is widened to fp32 on load, ALL arithmetic and the membrane (v_init, v_last, h_seq, g_v_*) stay fp32 exactly
+ * as in the f32 entry points, results are rounded to nearest-even on store (spikes 0/1/2/3 are exact in both formats).
+ * h_seq stays fp32 so the backward recomputes the very spike mask the forward produced.
+ * Algorithmic bytes per update: 8 B forward-train (2 + 2 + 4), 4 B inference, 8 B backward (2 + 4 + 2).
+ */
+#define SS_DT_F16   1
+#define SS_DT_BF16  2
+int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_seq,
+                      void* out_seq, float* h_seq, float* v_last, unsigned long long* nnz,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int dtype, void* stream);
+int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
+                      void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream);
+
+/*
  * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing
  * IF membrane that the K predict_depth heads charge in the order K-1..0 of the reference's forward
  * (predict_depth4 first), every time step.  pd_seq element (t,k,m) is at pd_seq[t*stride_t + k*stride_k + m],

@@ -41,6 +41,10 @@ def lib():
     L.ss_ipool_bwd_f32.argtypes = [p, p, p, i64, i64, p, i32, i32, i64, f32, p]
     L.ss_upconv1_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     L.ss_upconv1_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_neuron_fwd_x16.argtypes = [p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, p]
+    L.ss_neuron_bwd_x16.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, i32, p]
+    L.ss_neuron_fwd_x16.restype = i32
+    L.ss_neuron_bwd_x16.restype = i32
     L.ss_upconv_cl_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_cl_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
@@ -54,7 +58,7 @@ def lib():
 
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
-           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32')
+           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16')
 
 
 def _ptr(t, name, numel=None):
@@ -118,6 +122,45 @@ def neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_w
                                      T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
                                      int(bool(detach_reset)), _stream(h_seq))
     _check(rc, 'ss_neuron_bwd_f32')
+
+
+DT_CODE = {torch.float16: 1, torch.bfloat16: 2}
+
+
+def _x16(t, name, numel, dtype):
+    if t is not None and t.dtype != dtype:
+        raise SSNeuronError(f'{name}: expected {dtype}, got {t.dtype}')
+    return _ptr(t, name, numel)
+
+
+def neuron_fwd_x16(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, scale, kind, tau, k, v_th, v_reset):
+    """16-bit activation I/O (x / skip / out in fp16 or bf16), fp32 membrane and h."""
+    _require_hip(x_seq, 'x_seq')
+    dt = x_seq.dtype
+    if dt not in DT_CODE:
+        raise SSNeuronError(f'x_seq: expected float16 or bfloat16, got {dt}')
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_fwd_x16(_x16(x_seq, 'x_seq', T * N, dt), _f32(v_init, 'v_init', N),
+                                     _x16(skip_seq, 'skip_seq', T * N, dt), _x16(out_seq, 'out_seq', T * N, dt),
+                                     _f32(h_seq, 'h_seq', T * N), _f32(v_last, 'v_last', N), _ptr(nnz, 'nnz'),
+                                     T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, DT_CODE[dt], _stream(x_seq))
+    _check(rc, 'ss_neuron_fwd_x16')
+
+
+def neuron_bwd_x16(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                   v_th, v_reset, surrogate, alpha, detach_reset):
+    _require_hip(h_seq, 'h_seq')
+    dt = g_out_seq.dtype
+    if dt not in DT_CODE:
+        raise SSNeuronError(f'g_out_seq: expected float16 or bfloat16, got {dt}')
+    with torch.cuda.device(h_seq.device):
+        rc = lib().ss_neuron_bwd_x16(_x16(g_out_seq, 'g_out_seq', T * N, dt), _f32(g_v_last, 'g_v_last', N),
+                                     _f32(h_seq, 'h_seq', T * N), _f32(v_init, 'v_init', N),
+                                     _x16(g_x_seq, 'g_x_seq', T * N, dt), _f32(g_v_init, 'g_v_init', N),
+                                     _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'), T, N, scale, kind, tau,
+                                     _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha, int(bool(detach_reset)),
+                                     DT_CODE[dt], _stream(h_seq))
+    _check(rc, 'ss_neuron_bwd_x16')
 
 
 def ipool_fwd(pd_seq, stride_t, stride_k, v_init, depth_seq, T, K, M, scale, v_reset):

@@ -23,6 +23,8 @@
 // Rounding discipline: compiled with -ffp-contract=off; every fp32 op below is written in the order eager
 // PyTorch evaluates the reference (x*scale first, true division by tau, (1-z)*h + z*v_reset literally).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <math.h>
 #include <type_traits>
@@ -319,6 +321,181 @@ __global__ __launch_bounds__(kBlock) void gk_finish_kernel(const float* partials
         __syncthreads();
     }
     if (threadIdx.x == 0) *g_k = s[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 16-bit activation I/O variants (fp16 / bf16 in HBM, fp32 arithmetic and membrane): a lane owns 8 consecutive
+// neurons = one 16-B load of x, one 16-B store of out and two 16-B stores of h per time step.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+template <int DT> __device__ __forceinline__ float widen(unsigned short b)
+{
+    if (DT == SS_DT_F16) return __half2float(__ushort_as_half(b));
+    return __uint_as_float((unsigned)b << 16);
+}
+template <int DT> __device__ __forceinline__ unsigned short narrow(float f)
+{
+    if (DT == SS_DT_F16) return __half_as_ushort(__float2half_rn(f));
+    unsigned u = __float_as_uint(f);                       // round to nearest even (NaN kept quiet)
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct Fwd16Args {
+    const unsigned short* x_seq; const float* v_init; const unsigned short* skip_seq;
+    unsigned short* out_seq; float* h_seq; float* v_last; unsigned long long* nnz;
+    int T; long long N;
+    float scale, tau, v_th, v_reset; const float* k;
+};
+
+template <int KIND, int DT, bool SKIP, bool SAVE_H, int VEC>
+__global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
+{
+    const long long NV = a.N / VEC;
+    const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
+    const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset;
+    unsigned c_spk = 0, c_out = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = a.v_init ? a.v_init[i * VEC + e] : v_reset;
+        for (int t = 0; t < a.T; ++t) {
+            const long long base = ((long long)t * NV + i) * VEC;
+            unsigned short xb[VEC], sb[VEC], ob[VEC];
+            float h[VEC];
+            if constexpr (VEC == 8) {
+                const u16x8 xv = *reinterpret_cast<const u16x8*>(a.x_seq + base);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[e] = xv[e];
+                if (SKIP) {
+                    const u16x8 sv = *reinterpret_cast<const u16x8*>(a.skip_seq + base);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sb[e] = sv[e];
+                }
+            } else { xb[0] = a.x_seq[base]; if (SKIP) sb[0] = a.skip_seq[base]; }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float hh = charge<KIND>(v[e], widen<DT>(xb[e]) * scale, tau, k, v_reset);
+                const float z = heaviside(hh - v_th);
+                v[e] = (1.f - z) * hh + z * v_reset;
+                const float o = SKIP ? z + widen<DT>(sb[e]) : z;
+                c_spk += (z != 0.f); c_out += (o != 0.f);
+                h[e] = hh; ob[e] = narrow<DT>(o);
+            }
+            if constexpr (VEC == 8) {
+                u16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = ob[e];
+                *reinterpret_cast<u16x8*>(a.out_seq + base) = ov;
+                if (SAVE_H) {
+                    *reinterpret_cast<f4*>(a.h_seq + base) = (f4){h[0], h[1], h[2], h[3]};
+                    *reinterpret_cast<f4*>(a.h_seq + base + 4) = (f4){h[4], h[5], h[6], h[7]};
+                }
+            } else { a.out_seq[base] = ob[0]; if (SAVE_H) a.h_seq[base] = h[0]; }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a.v_last[i * VEC + e] = v[e];
+    }
+    if (a.nnz) {
+        __shared__ unsigned s_cnt[2][kBlock / 64];
+        unsigned ws = wave_sum_u32(c_spk), wo = wave_sum_u32(c_out);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_cnt[0][wave] = ws; s_cnt[1][wave] = wo; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long ts = 0, to = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) { ts += s_cnt[0][w]; to += s_cnt[1][w]; }
+            if (ts) atomicAdd(&a.nnz[0], ts);
+            if (to) atomicAdd(&a.nnz[1], to);
+        }
+    }
+}
+
+struct Bwd16Args {
+    const unsigned short* g_out_seq; const float* g_v_last; const float* h_seq; const float* v_init;
+    unsigned short* g_x_seq; float* g_v_init; float* g_k_partials;
+    int T; long long N;
+    float scale, tau, v_th, v_reset, alpha; const float* k; int detach_reset;
+};
+
+template <int KIND, int SG, int DT, int VEC>
+__global__ __launch_bounds__(kBlock) void neuron_bwd16_kernel(Bwd16Args a)
+{
+    const long long NV = a.N / VEC;
+    const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
+    const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset, alpha = a.alpha;
+    const float c_atan = (float)(M_PI / 2.0 * (double)alpha);
+    const float half_alpha = (float)((double)alpha / 2.0);
+    const bool detach = a.detach_reset != 0;
+    const bool want_gk = (KIND == SS_KIND_PLIF) && a.g_k_partials != nullptr;
+    float acc_k = 0.f;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
+        float gv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gv[e] = a.g_v_last ? a.g_v_last[i * VEC + e] : 0.f;
+        for (int t = a.T - 1; t >= 0; --t) {
+            const long long base = ((long long)t * NV + i) * VEC;
+            unsigned short gb[VEC], xb[VEC];
+            float h[VEC], hp[VEC];
+            if constexpr (VEC == 8) {
+                const u16x8 g8 = *reinterpret_cast<const u16x8*>(a.g_out_seq + base);
+                const f4 h0 = *reinterpret_cast<const f4*>(a.h_seq + base), h1 = *reinterpret_cast<const f4*>(a.h_seq + base + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gb[e] = g8[e]; h[e] = e < 4 ? h0[e & 3] : h1[e & 3]; }
+            } else { gb[0] = a.g_out_seq[base]; h[0] = a.h_seq[base]; }
+            if (want_gk) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    hp[e] = t > 0 ? a.h_seq[base - a.N + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = h[e] - v_th;
+                const float z = heaviside(xh);
+                float g_s = widen<DT>(gb[e]);
+                if (!detach) g_s = g_s + (gv[e] * v_reset - gv[e] * h[e]);
+                const float g_h = surrogate_grad<SG>(xh, alpha, c_atan, half_alpha, g_s) + gv[e] * (1.f - z);
+                float g_x;
+                if (KIND == SS_KIND_IF) { g_x = g_h; gv[e] = g_h; }
+                else if (KIND == SS_KIND_LIF) { g_x = g_h / tau; gv[e] = g_h - g_x; }
+                else {
+                    g_x = g_h * k; gv[e] = g_h - g_x;
+                    if (want_gk) {
+                        float v_prev;
+                        if (t == 0) v_prev = a.v_init ? a.v_init[i * VEC + e] : v_reset;
+                        else { const float zp = heaviside(hp[e] - v_th); v_prev = (1.f - zp) * hp[e] + zp * v_reset; }
+                        acc_k += g_h * ((h[e] - v_prev) / k);
+                    }
+                }
+                xb[e] = narrow<DT>(g_x * scale);
+            }
+            if constexpr (VEC == 8) {
+                u16x8 xv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = xb[e];
+                *reinterpret_cast<u16x8*>(a.g_x_seq + base) = xv;
+            } else a.g_x_seq[base] = xb[0];
+        }
+        if (a.g_v_init) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a.g_v_init[i * VEC + e] = gv[e];
+        }
+    }
+    if (want_gk) {
+        __shared__ float s_k[kBlock / 64];
+        float w = wave_sum_f32(acc_k);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) s_k[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < kBlock / 64; ++q) s += s_k[q];
+            a.g_k_partials[blockIdx.x] = s;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -708,6 +885,34 @@ int launch_cl_bwd(const float* g_out, const int* y_lo, const int* y_hi, const in
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
+template <int KIND, int DT>
+int dispatch_fwd16(const Fwd16Args& a, hipStream_t s)
+{
+    const bool skip = a.skip_seq != nullptr, save_h = a.h_seq != nullptr;
+    const bool vec = (a.N % 8 == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
+                     (!a.v_init || aligned16(a.v_init)) && (!skip || aligned16(a.skip_seq)) && (!save_h || aligned16(a.h_seq));
+    const int grid = vec ? grid_for(a.N / 8) : grid_for(a.N);
+#define SS_L16(SK, SH) do { if (vec) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, SK, SH, 8>), dim3(grid), dim3(kBlock), 0, s, a); \
+                            else hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, SK, SH, 1>), dim3(grid), dim3(kBlock), 0, s, a); } while (0)
+    if (skip) { if (save_h) SS_L16(true, true); else SS_L16(true, false); }
+    else      { if (save_h) SS_L16(false, true); else SS_L16(false, false); }
+#undef SS_L16
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+template <int KIND, int SG, int DT>
+int dispatch_bwd16(const Bwd16Args& a, hipStream_t s, int* grid_out)
+{
+    const bool vec = (a.N % 8 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.g_x_seq) &&
+                     (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
+                     (!a.v_init || aligned16(a.v_init));
+    const int grid = vec ? grid_for(a.N / 8) : grid_for(a.N);
+    *grid_out = grid;
+    if (vec) hipLaunchKernelGGL((neuron_bwd16_kernel<KIND, SG, DT, 8>), dim3(grid), dim3(kBlock), 0, s, a);
+    else     hipLaunchKernelGGL((neuron_bwd16_kernel<KIND, SG, DT, 1>), dim3(grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -761,6 +966,64 @@ int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float
         case SS_KIND_LIF: rc = dispatch_bwd_sg<SS_KIND_LIF>(a, surrogate, s, &grid); break;
         default: rc = dispatch_bwd_sg<SS_KIND_PLIF>(a, surrogate, s, &grid); break;
     }
+    if (rc != SS_OK) return rc;
+    if (want_gk) {
+        hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(kBlock), 0, s, g_k_ws, grid, g_k);
+        if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    }
+    return SS_OK;
+}
+
+int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_seq,
+                      void* out_seq, float* h_seq, float* v_last, unsigned long long* nnz,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int dtype, void* stream)
+{
+    if (!x_seq || !out_seq || !v_last || T <= 0 || N < 0) return SS_EINVAL;
+    if (kind < SS_KIND_IF || kind > SS_KIND_PLIF || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
+    if (out_seq == x_seq) return SS_EINVAL;
+    if (N == 0) return SS_OK;
+    Fwd16Args a{static_cast<const unsigned short*>(x_seq), v_init, static_cast<const unsigned short*>(skip_seq),
+                static_cast<unsigned short*>(out_seq), h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define SS_D16(KK) (dtype == SS_DT_F16 ? dispatch_fwd16<KK, SS_DT_F16>(a, s) : dispatch_fwd16<KK, SS_DT_BF16>(a, s))
+    switch (kind) {
+        case SS_KIND_IF: return SS_D16(SS_KIND_IF);
+        case SS_KIND_LIF: return SS_D16(SS_KIND_LIF);
+        default: return SS_D16(SS_KIND_PLIF);
+    }
+#undef SS_D16
+}
+
+int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
+                      void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+{
+    if (!g_out_seq || !h_seq || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
+    if (kind < SS_KIND_IF || kind > SS_KIND_PLIF || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (surrogate != SS_SG_ATAN && surrogate != SS_SG_SIGMOID) return SS_EINVAL;
+    if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
+    const bool want_gk = (kind == SS_KIND_PLIF) && g_k != nullptr;
+    if (want_gk && !g_k_ws) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N == 0) {
+        if (want_gk && hipMemsetAsync(g_k, 0, sizeof(float), s) != hipSuccess) return SS_ELAUNCH;
+        return SS_OK;
+    }
+    Bwd16Args a{static_cast<const unsigned short*>(g_out_seq), g_v_last, h_seq, v_init, static_cast<unsigned short*>(g_x_seq),
+                g_v_init, want_gk ? g_k_ws : nullptr, T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset};
+    int grid = 0, rc;
+#define SS_B16(KK, SGG) (dtype == SS_DT_F16 ? dispatch_bwd16<KK, SGG, SS_DT_F16>(a, s, &grid) : dispatch_bwd16<KK, SGG, SS_DT_BF16>(a, s, &grid))
+#define SS_B16S(KK) (surrogate == SS_SG_ATAN ? SS_B16(KK, SS_SG_ATAN) : SS_B16(KK, SS_SG_SIGMOID))
+    switch (kind) {
+        case SS_KIND_IF: rc = SS_B16S(SS_KIND_IF); break;
+        case SS_KIND_LIF: rc = SS_B16S(SS_KIND_LIF); break;
+        default: rc = SS_B16S(SS_KIND_PLIF); break;
+    }
+#undef SS_B16S
+#undef SS_B16
     if (rc != SS_OK) return rc;
     if (want_gk) {
         hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(kBlock), 0, s, g_k_ws, grid, g_k);

@@ -20,11 +20,13 @@ import torch.distributed as dist
 
 class GradientAllReducer:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 20 << 20, process_group=None,
-                 broadcast_from: Optional[int] = 0):
+                 broadcast_from: Optional[int] = 0, reduce_single_rank: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # reduce_single_rank=True issues the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self._active = dist.is_initialized() and (self.world > 1 or reduce_single_rank)
         params = [p for p in module.parameters() if p.requires_grad]
-        if self.world > 1 and broadcast_from is not None:
+        if self._active and broadcast_from is not None:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=broadcast_from, group=process_group)
         # backward visits parameters roughly in reverse registration order: fill buckets in that order
@@ -72,7 +74,7 @@ class GradientAllReducer:
             v.copy_(p.grad)
             p.grad = v
         b['pending'] -= 1
-        if b['pending'] == 0 and self.world > 1:
+        if b['pending'] == 0 and self._active:
             b['flat'].div_(self.world)
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -82,7 +84,7 @@ class GradientAllReducer:
             if b['work'] is not None:
                 b['work'].wait()
                 b['work'] = None
-            elif self.world > 1 and b['pending'] != 0:
+            elif self._active and b['pending'] != 0:
                 # a parameter received no gradient this step: reduce what there is so ranks stay consistent
                 b['flat'].div_(self.world)
                 dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)

@@ -81,19 +81,26 @@ class _FusedNeuron(torch.autograd.Function):
         if v_init is not None:
             v_init = v_init.contiguous()
         need_grad = any(ctx.needs_input_grad[:4])
+        half = x_seq.dtype in (torch.float16, torch.bfloat16)       # 16-bit activations, fp32 membrane (configs 2 / 5)
+        if skip_seq is not None and skip_seq.dtype != x_seq.dtype:
+            skip_seq = skip_seq.to(x_seq.dtype)                      # spikes are small integers: exact in every format
         out_seq = torch.empty_like(x_seq)
-        h_seq = torch.empty_like(x_seq) if need_grad else None
-        v_last = torch.empty(x_seq.shape[1:], dtype=x_seq.dtype, device=x_seq.device)
+        h_seq = torch.empty(x_seq.shape, dtype=torch.float32, device=x_seq.device) if need_grad else None
+        v_last = torch.empty(x_seq.shape[1:], dtype=torch.float32, device=x_seq.device)
+        if v_init is not None and v_init.dtype != torch.float32:
+            v_init = v_init.float()
         e0 = TIMER.start()
-        _lib.neuron_fwd(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, cfg.scale, cfg.kind, cfg.tau, k,
-                        cfg.v_th, cfg.v_reset)
-        per = 4 * (2 + (1 if need_grad else 0) + (1 if skip_seq is not None else 0))
+        (_lib.neuron_fwd_x16 if half else _lib.neuron_fwd)(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N,
+                                                          cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
+        es = 2 if half else 4
+        per = es * (2 + (1 if skip_seq is not None else 0)) + (4 if need_grad else 0)
         TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if skip_seq is not None else ''),
                    per * T * N, T * N)
         ctx.cfg = cfg
         ctx.T, ctx.N = T, N
         ctx.has_vinit = v_init is not None
         ctx.has_skip = skip_seq is not None
+        ctx.io_dtype = x_seq.dtype
         ctx.set_materialize_grads(False)
         if need_grad:
             # h_seq is all the backward needs (z_t, v_{t-1} are recomputed from it); the OUTPUT is not saved because
@@ -106,12 +113,13 @@ class _FusedNeuron(torch.autograd.Function):
     def backward(ctx, g_out_seq, g_v_last):
         h_seq, v_init, k = ctx.saved_tensors
         cfg, T, N = ctx.cfg, ctx.T, ctx.N
+        half = ctx.io_dtype in (torch.float16, torch.bfloat16)
         if g_out_seq is None:
-            g_out_seq = torch.zeros_like(h_seq)
-        g_out_seq = g_out_seq.contiguous()
+            g_out_seq = torch.zeros(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
+        g_out_seq = g_out_seq.to(ctx.io_dtype).contiguous()
         if g_v_last is not None:
-            g_v_last = g_v_last.contiguous()
-        g_x_seq = torch.empty_like(h_seq)
+            g_v_last = g_v_last.float().contiguous()
+        g_x_seq = torch.empty(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
         want_gv = ctx.has_vinit and ctx.needs_input_grad[1]
         g_v_init = torch.empty(h_seq.shape[1:], dtype=h_seq.dtype, device=h_seq.device) if want_gv else None
         want_gk = cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]
@@ -120,9 +128,10 @@ class _FusedNeuron(torch.autograd.Function):
             g_k = torch.empty((), dtype=h_seq.dtype, device=h_seq.device)
             g_k_ws = torch.empty(_lib.gk_ws_floats(), dtype=h_seq.dtype, device=h_seq.device)
         e0 = TIMER.start()
-        _lib.neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, cfg.scale, cfg.kind,
-                        cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, 'neuron_bwd', 12 * T * N, T * N)
+        (_lib.neuron_bwd_x16 if half else _lib.neuron_bwd)(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+                                                          T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset,
+                                                          cfg.surrogate, cfg.alpha, cfg.detach_reset)
+        TIMER.stop(e0, 'neuron_bwd', (8 if half else 12) * T * N, T * N)
         g_skip = g_out_seq if (ctx.has_skip and ctx.needs_input_grad[2]) else None   # identity
         return g_x_seq, g_v_init, g_skip, g_k, None, None
 
@@ -138,6 +147,7 @@ def fused_neuron(x_seq: torch.Tensor, cfg: NeuronCfg, v_init: Optional[torch.Ten
 
 class _IPool(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, pd_seq, v_init, scale, v_reset):
         # pd_seq: [K, T, M...] (k = 0 is the head charged first) — i.e. torch.stack of the K head outputs
         pd_seq = pd_seq.contiguous()
@@ -154,9 +164,10 @@ class _IPool(torch.autograd.Function):
         return depth_seq
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g_depth_seq):
         T, K, M = ctx.dims
-        g_depth_seq = g_depth_seq.contiguous()
+        g_depth_seq = g_depth_seq.float().contiguous()
         g_pd = torch.empty(ctx.shape, dtype=g_depth_seq.dtype, device=g_depth_seq.device)
         want_gv = ctx.has_vinit and ctx.needs_input_grad[1]
         g_v_init = torch.empty(ctx.shape[2:], dtype=g_depth_seq.dtype, device=g_depth_seq.device) if want_gv else None
@@ -195,10 +206,15 @@ PROJECTION_IMPL = 'auto'
 P_CHUNK_BYTES = 96 << 20          # per-chunk size of P: comfortably inside the 256 MiB MALL next to x / out / g_out
 
 
+_fwd32 = torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: inputs -> fp32, autocast off inside
+_bwd32 = torch.amp.custom_bwd(device_type='cuda')
+
+
 class _UpConv1(torch.autograd.Function):
     """The gather alone (P given): used by the 'conv' / 'matmul' variants, autograd reaches W through P."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, P, bias, tables, k, H, W):
         P = P.contiguous()
         NB, kk, h, w = P.shape
@@ -214,10 +230,11 @@ class _UpConv1(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd32
     def backward(ctx, g_out):
         NB, k, h, w, H, W = ctx.dims
         _, y_lo, y_hi, _, x_lo, x_hi = ctx.tables
-        g_out = g_out.contiguous()
+        g_out = g_out.float().contiguous()
         g_P = torch.empty((NB, k * k, h, w), dtype=g_out.dtype, device=g_out.device)
         e0 = TIMER.start()
         _lib.upconv1_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, h, w, H, W)
@@ -233,6 +250,7 @@ class _UpConvProjected(torch.autograd.Function):
     GEMMs (dgrad, wgrad) right after the gather adjoint writes it."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, weight, bias, tables, k, H, W):
         x = x.contiguous()
         NB, Cin, h, w = x.shape
@@ -257,6 +275,7 @@ class _UpConvProjected(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd32
     def backward(ctx, g_out):
         x, W2 = ctx.saved_tensors
         k, n = ctx.k, ctx.n
@@ -264,7 +283,7 @@ class _UpConvProjected(torch.autograd.Function):
         NB, Cin, h, w = x.shape
         Cout, kk, hw = ctx.wshape[0], k * k, h * w
         H, W = g_out.shape[-2:]
-        g_out = g_out.contiguous()
+        g_out = g_out.float().contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_x = torch.empty_like(x) if need_x else None
         g_W2 = torch.zeros_like(W2) if need_w else None
@@ -332,6 +351,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
     pass with P in HBM (same policy as the NCHW path)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x_cl, weight, bias, tables, k, H, W):
         x_cl = x_cl.contiguous()
         NB, h, w, Cin = x_cl.shape
@@ -354,6 +374,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd32
     def backward(ctx, g_out):
         x_cl, Wt = ctx.saved_tensors
         k, n = ctx.k, ctx.n
@@ -361,7 +382,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         NB, h, w, Cin = x_cl.shape
         Cout, kk = ctx.wshape[0], k * k
         H, W = g_out.shape[1:3]
-        g_out = g_out.contiguous()
+        g_out = g_out.float().contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_x = torch.empty_like(x_cl) if need_x else None
         g_Wt = torch.zeros_like(Wt) if need_w else None

@@ -125,19 +125,29 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             cnt[name] = torch.zeros(2, dtype=torch.int64, device=x_seq.device)
             return cnt[name]
 
-        enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]
-        for i in range(1, 5):
-            enc.append(getattr(self, f'conv{i}').forward_sequence(enc[-1], None, nnz(f'conv{i}')))
-        cur = self.bottleneck[0].forward_sequence(enc[4])
-        cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
-        spikes, heads = [cur], []
         cl = _blocks.FUSE_UPCONV and _blocks.DECODER_CHANNELS_LAST
-        if cl:
-            cur = cur.permute(0, 1, 3, 4, 2).contiguous()              # decoder runs on NHWC arrays [T, B, h, w, C]
+        enc_cl = cl and _blocks.ENCODER_CHANNELS_LAST and all(
+            getattr(b, 'connect_function', 'ADD') == 'ADD' for b in self.bottleneck)
+        if enc_cl:          # whole network on NHWC arrays [T, B, h, w, C]: no layout copies anywhere
+            enc = [self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'))]
+            for i in range(1, 5):
+                enc.append(getattr(self, f'conv{i}').forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}')))
+            cur = self.bottleneck[0].forward_sequence_cl(enc[4])
+            cur = self.bottleneck[1].forward_sequence_cl(cur, nnz('rconv'))
+            spikes, heads = [cur.permute(0, 1, 4, 2, 3)], []
+        else:
+            enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]
+            for i in range(1, 5):
+                enc.append(getattr(self, f'conv{i}').forward_sequence(enc[-1], None, nnz(f'conv{i}')))
+            cur = self.bottleneck[0].forward_sequence(enc[4])
+            cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
+            spikes, heads = [cur], []
+            if cl:
+                cur = cur.permute(0, 1, 3, 4, 2).contiguous()          # decoder runs on NHWC arrays [T, B, h, w, C]
         for lvl in (4, 3, 2, 1):
             stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
             if cl:
-                skip = enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
+                skip = enc[lvl - 1] if enc_cl else enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
                 cur = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'))
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
                 pd = head[0].forward_projected_cl(cur.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW

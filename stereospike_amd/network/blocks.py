@@ -22,6 +22,9 @@ FUSE_UPCONV = True
 # row-major GEMM per stage and the gather kernels read/write 16-B channel vectors (no MIOpen layout transposes, no
 # per-image batched GEMMs).  The neuron kernels are layout-agnostic.  False = NCHW decoder (bench.py --decoder-nhwc 0).
 DECODER_CHANNELS_LAST = True
+# Also keep the encoder / bottleneck activations in NHWC memory (torch channels_last): MIOpen then runs its NHWC-native
+# implicit-GEMM kernels without layout transposes and the decoder's skip tensors need no NCHW->NHWC copies.
+ENCODER_CHANNELS_LAST = True
 
 
 class MultiplyBy(nn.Module):
@@ -124,6 +127,14 @@ class SpikingStage(nn.Sequential):
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
 
 
+    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None):
+        """Encoder stage on NHWC arrays: x_seq [T, B, h, w, C] -> [T, B, h', w', C'].  The Conv2d sees a logical-NCHW
+        view with channels_last strides (no copy) and returns channels_last memory, i.e. again an NHWC array."""
+        T, B = x_seq.shape[:2]
+        y = _conv_cl(self[0], x_seq.flatten(0, 1))
+        y, scale = _fold_gain(self[1], y)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True)
+
     def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None):
         """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
         NNConvUpsampling."""
@@ -149,6 +160,18 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         return _connect(self.connect_function, self.conv2(self.conv1(x)), x, spiking=False)
+
+
+def _conv_cl(conv: nn.Module, x_arr: torch.Tensor) -> torch.Tensor:
+    """x_arr [NB, h, w, C] (NHWC array) -> conv -> [NB, h', w', C'] NHWC array, without layout copies when MIOpen returns
+    channels_last memory (it does for channels_last inputs).  The filter is moved to channels_last storage once (same
+    Parameter object, same values, same state_dict) so MIOpen does not re-lay it out every call."""
+    wt = conv.weight
+    if wt.dim() == 4 and not wt.is_contiguous(memory_format=torch.channels_last):
+        wt.data = wt.data.contiguous(memory_format=torch.channels_last)
+    y = conv(x_arr.permute(0, 3, 1, 2))
+    y = y.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
 
 
 def _connect(fn: str, out: torch.Tensor, identity: torch.Tensor, spiking: bool):
@@ -203,6 +226,19 @@ class SEWResBlock(nn.Module):
             return half(self.conv2, self.sn2, out, x_seq, nnz)
         out = half(self.conv2, self.sn2, out, None, nnz)
         return _connect(self.connect_function, out, x_seq, spiking=True)
+
+    def forward_sequence_cl(self, x_seq: torch.Tensor, nnz=None) -> torch.Tensor:
+        """NHWC-array form of forward_sequence ('ADD' connect function only)."""
+        if self.connect_function != 'ADD':
+            raise NotImplementedError('channels-last SEW block supports the ADD connect function only')
+        T, B = x_seq.shape[:2]
+
+        def half(conv, sn, inp, skip, cnt):
+            y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1)))
+            return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt, channels_last=True)
+
+        out = half(self.conv1, self.sn1, x_seq, None, None)
+        return half(self.conv2, self.sn2, out, x_seq, nnz)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_sequence(x.unsqueeze(0))[0]

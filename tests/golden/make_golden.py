@@ -335,12 +335,12 @@ def main():
               lambda: rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(),
                                sigmoid_alpha=SIGMOID_ALPHA), 4, 5, True)
     # config 2 family: PLIF model (train.py:120) binocular T=1 and T=5, LIF variant, monocular
-    plif = dict(tau=3., v_threshold=1.0, v_reset=0.0, use_plif=True, multiply_factor=10.)
+    plif = dict(tau=3., v_threshold=1.0, v_reset=0.0, use_plif=True, multiply_factor=30.)   # gain 10 leaves the tau=3 PLIF net silent beyond conv1
     gen_model(ref, 'plif_T1', lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**plif),
               lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **plif), 4, 1, True)
     gen_model(ref, 'plif_T5', lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**plif),
               lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **plif), 4, 5, True)
-    lif = dict(tau=3., v_threshold=1.0, v_reset=0.0, use_plif=False, multiply_factor=10.)
+    lif = dict(tau=3., v_threshold=1.0, v_reset=0.0, use_plif=False, multiply_factor=30.)
     gen_model(ref, 'lif_T1', lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**lif),
               lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **lif), 4, 1, True)
     gen_model(ref, 'mono_plif_T1',

@@ -312,3 +312,38 @@ def test_upconv_channels_last_vs_oracle_and_torch():
         gP = torch.empty(B, h, w, k * k * Cout, device=DEV)
         _lib.upconv_cl_bwd(g_cl.to(DEV), tables[1], tables[2], tables[4], tables[5], gP, B, k, Cout, h, w, H, W)
         assert bit_equal(gP, gref), (Cin, Cout)
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+@pytest.mark.parametrize('T,N', [(1, 8), (5, 4104), (10, 100003), (5, 16 * 32 * 65 * 87)])
+def test_x16_kernels_vs_numpy_oracle(dt, kind, T, N):
+    """16-bit activation I/O kernels (configs 2 / 5) == oracle/np_x16.py: spikes / h / v bit-exact, g_x bit-exact (ATan)."""
+    from oracle import np_x16
+    from stereospike_amd import _lib
+    name = 'f16' if dt == torch.float16 else 'bf16'
+    g = torch.Generator().manual_seed(T * 7 + N)
+    x = (torch.randn(T, N, generator=g) * 0.2).to(dt)
+    skip = torch.randint(0, 3, (T, N), generator=g).to(dt) if T % 2 == 1 else None
+    v0 = torch.randn(N, generator=g) * 0.5 if N % 2 == 0 else None
+    kw = dict(kind=kind, scale=10.0, tau=3.0, k=np.float32(1 / 3.) if kind == 'PLIF' else None, v_th=1.0, v_reset=0.0)
+    bits = lambda t: None if t is None else t.view(torch.int16).numpy().view(np.uint16)
+    ref = np_x16.neuron_fwd(bits(x), name, v_init=None if v0 is None else v0.numpy(), skip_bits=bits(skip), **kw)
+    xd, sd, vd = x.to(DEV), None if skip is None else skip.to(DEV), None if v0 is None else v0.to(DEV)
+    out, h, v = torch.empty_like(xd), torch.empty(T, N, device=DEV), torch.empty(N, device=DEV)
+    nnz = torch.zeros(2, dtype=torch.int64, device=DEV)
+    kd = None if kind != 'PLIF' else torch.tensor([1 / 3.], device=DEV)
+    _lib.neuron_fwd_x16(xd, vd, sd, out, h, v, nnz, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0)
+    assert np.array_equal(bits(out.cpu()), ref['out'])
+    assert bit_equal(h, ref['h']) and bit_equal(v, ref['v_last'])
+    assert int(nnz[1]) == int((np_x16.widen(ref['out'], name) != 0).sum())
+    go = torch.randn(T, N, generator=g).to(dt)
+    rb = np_x16.neuron_bwd(bits(go), ref['h'], name, v_init=None if v0 is None else v0.numpy(), surrogate='ATan', alpha=2.0, **kw)
+    gx, gvi = torch.empty_like(xd), torch.empty(N, device=DEV)
+    gk = torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+    ws = torch.empty(_lib.gk_ws_floats(), device=DEV) if kind == 'PLIF' else None
+    _lib.neuron_bwd_x16(go.to(DEV), None, h, vd, gx, gvi, gk, ws, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0, 0, 2.0, True)
+    assert np.array_equal(bits(gx.cpu()), rb['g_x'])
+    assert bit_equal(gvi, rb['g_v_init'])
+    if kind == 'PLIF':
+        assert abs(float(gk) - rb['g_k']) <= 1e-5 * abs(rb['g_k']) + 2e-7 * T * N

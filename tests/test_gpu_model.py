@@ -40,7 +40,7 @@ def _dump():
 def _product(name, **kw):
     from stereospike_amd.clock_driven import surrogate
     from stereospike_amd.network import SNN_models as S, ANN_models as A
-    plif = dict(tau=3., v_threshold=1.0, v_reset=0.0, multiply_factor=10.)
+    plif = dict(tau=3., v_threshold=1.0, v_reset=0.0, multiply_factor=30.)   # gain 10 leaves the tau=3 nets silent
     if name == 'StereoSpike':
         return S.StereoSpike(surrogate_function=surrogate.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
                              multiply_factor=10., **kw)
@@ -59,9 +59,9 @@ def _oracle(name, **kw):
     if name == 'StereoSpike':
         return rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(), **kw)
     if name in ('PLIFNet', 'LIFNet'):
-        return rn.build('PLIFNet', tau=3., use_plif=(name == 'PLIFNet'), multiply_factor=10., **kw)
+        return rn.build('PLIFNet', tau=3., use_plif=(name == 'PLIFNet'), multiply_factor=30., **kw)
     if name == 'PLIFNetMono':
-        return rn.build('PLIFNetMono', tau=3., use_plif=True, multiply_factor=10., **kw)
+        return rn.build('PLIFNetMono', tau=3., use_plif=True, multiply_factor=30., **kw)
     return rn.build('ANN', **kw)
 
 
@@ -273,6 +273,19 @@ def _free_running(tag, name, x, gt, H, W):
     return net, d, s
 
 
+@pytest.mark.parametrize('layout', ['nchw', 'decoder_nhwc', 'all_nhwc', 'two_op_miopen'])
+def test_free_running_small_every_execution_layout(layout, monkeypatch):
+    """The same network through every execution variant of the synapses (reference two-op up-convs on MIOpen; projected
+    NCHW; decoder in NHWC; whole network in NHWC) must meet the same bar."""
+    from stereospike_amd.network import blocks
+    monkeypatch.setattr(blocks, 'FUSE_UPCONV', layout != 'two_op_miopen')
+    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', layout in ('decoder_nhwc', 'all_nhwc'))
+    monkeypatch.setattr(blocks, 'ENCODER_CHANNELS_LAST', layout == 'all_nhwc')
+    x = synth_input(2, 3, 4, 77, 64, 80, lam=0.08)
+    gt = synth_label(2, 78, 64, 80)
+    _free_running(f'free_small_PLIFNet_{layout}', 'PLIFNet', x, gt, 64, 80)
+
+
 @pytest.mark.parametrize('name,C', [('StereoSpike', 4), ('PLIFNet', 4), ('LIFNet', 4), ('PLIFNetMono', 2), ('ANN', 4)])
 def test_free_running_small(name, C):
     """64x80 frames, B=2, T=3 with BPTT (membranes carried) — every model family."""
@@ -374,3 +387,65 @@ def test_reference_script_flow_with_dropin():
     assert len(pred) == 4 and len(spks) == 5 and pred[0].shape == (1, 1, 260, 346)
     assert [tuple(s.shape[1:]) for s in spks] == [(512, 17, 22), (256, 33, 44), (128, 65, 87), (64, 130, 173),
                                                   (32, 260, 346)]
+
+
+def test_dp_reducer_on_rccl_single_rank():
+    """The DP path on the real backend: one rank, backend "nccl" (= RCCL), collectives forced on.  Gradients living in the
+    flat buckets + async all-reduce from the grad hooks + fused Adam must give the same update as the plain path."""
+    import os
+    import torch.distributed as dist
+    from stereospike_amd.dp import GradientAllReducer
+    from stereospike_amd.engine import Trainer, synthetic_batch
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        x, gt = synthetic_batch(2, 3, H=64, W=80, seed=5, device=DEV, lam=0.08)
+        results = []
+        for use_dp in (False, True):
+            torch.manual_seed(7)
+            net = _product('PLIFNet', input_size=(64, 80)).to(DEV)
+            red = GradientAllReducer(net, bucket_bytes=4 << 20, reduce_single_rank=True) if use_dp else None
+            tr = Trainer(net, reducer=red)
+            losses = [float(tr.step(x, gt)[0]) for _ in range(3)]
+            results.append((losses, [p.detach().clone() for p in net.parameters()], None if red is None else len(red.buckets)))
+        (l0, p0, _), (l1, p1, nb) = results
+        assert nb > 1
+        assert l0 == l1, (l0, l1)
+        for a, b in zip(p0, p1):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_autocast_16bit_activations(dt):
+    """BASELINE configs 2 / 5: convs under torch.autocast (bf16 / fp16), activations stored in 16 bits between layers, the
+    fused neuron kernels' x16 variants keep membrane, h and all neuron arithmetic in fp32; decoder projections, I-pool
+    and loss stay fp32.  There is no reference for this mode (the reference is fp32-only) — the check is that training
+    runs, is finite, and stays statistically close to the fp32 run: per-layer firing rates within 0.03 absolute."""
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    torch.manual_seed(3)
+    net = _product('StereoSpike', input_size=(64, 80)).to(DEV)
+    x = synth_input(2, 3, 4, 31, 64, 80, lam=0.08).to(DEV)
+    gt = synth_label(2, 32, 64, 80).to(DEV)
+    with torch.no_grad():
+        functional.reset_net(net)
+        r32 = net.calculate_firing_rates(x)
+        with torch.autocast('cuda', dtype=dt):
+            functional.reset_net(net)
+            r16 = net.calculate_firing_rates(x)
+    for k in r32:
+        assert abs(float(r32[k]) - float(r16[k])) <= 0.03, (k, float(r32[k]), float(r16[k]))
+    functional.reset_net(net)
+    with torch.autocast('cuda', dtype=dt):
+        d, s = net.forward_sequence(x)
+        assert s[0].dtype == dt and d[0].dtype == torch.float32
+        loss = Total_Loss()(d, gt, s)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    from stereospike_amd.clock_driven import neuron
+    assert all(m.v.dtype == torch.float32 for m in net.modules() if isinstance(m, neuron.BaseNode))

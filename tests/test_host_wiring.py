@@ -81,20 +81,21 @@ def _pair(name, H, W):
         orc = rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(), input_size=(H, W))
         net = S.StereoSpike(surrogate_function=surrogate.ATan(), multiply_factor=10., input_size=(H, W))
     else:
-        orc = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=10., input_size=(H, W))
-        net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., use_plif=True, multiply_factor=10.,
+        orc = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=30., input_size=(H, W))
+        net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., use_plif=True, multiply_factor=30.,
                                                                              input_size=(H, W))
     net.load_state_dict(orc.state_dict())
     return orc, net
 
 
-@pytest.mark.parametrize('decoder_nhwc', [True, False])
+@pytest.mark.parametrize('decoder_nhwc', [True, False, 'all'])
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
 def test_single_step_graph_is_bit_identical_to_the_oracle_network(host_backend, name, decoder_nhwc, monkeypatch):
     from stereospike_amd.clock_driven import functional
     from stereospike_amd.network import blocks
     from stereospike_amd.network.loss import Total_Loss
-    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', decoder_nhwc)
+    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', bool(decoder_nhwc))
+    monkeypatch.setattr(blocks, 'ENCODER_CHANNELS_LAST', decoder_nhwc == 'all')
     H, W = 48, 64
     orc, net = _pair(name, H, W)
     x = synth_input(2, 1, 4, 5, H, W, lam=0.1)

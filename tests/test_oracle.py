@@ -125,8 +125,8 @@ def _same_machine(meta):
 
 @pytest.mark.parametrize('tag,name,kw,T', [
     ('stereospike_T1', 'StereoSpike', dict(multiply_factor=10.), 1),
-    ('plif_T5', 'PLIFNet', dict(tau=3., use_plif=True, multiply_factor=10.), 5),
-    ('mono_plif_T1', 'PLIFNetMono', dict(tau=3., use_plif=True, multiply_factor=10.), 1),
+    ('plif_T5', 'PLIFNet', dict(tau=3., use_plif=True, multiply_factor=30.), 5),
+    ('mono_plif_T1', 'PLIFNetMono', dict(tau=3., use_plif=True, multiply_factor=30.), 1),
     ('ann_T1', 'ANN', dict(), 1),
 ])
 def test_oracle_network_vs_reference_fixture(tag, name, kw, T):
@@ -177,3 +177,32 @@ def test_loss_and_mde_restatement_vs_pure_reference_fixture():
             L = rn.total_loss(preds, gt, spikes, penalize_spikes=pen, beta=0.5)
             assert float(L) == float(z[f'l{ci}_{"pen" if pen else "nopen"}_loss'])
         assert float(rn.mean_depth_error(preds[0].detach(), gt)) == float(z[f'l{ci}_mde'])
+
+
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+def test_x16_numpy_oracle_equals_c_oracle_on_widened_inputs(dtype, kind):
+    """oracle/np_x16.py (16-bit activation I/O, fp32 membrane) == oracle/ss_neuron_ref.c fed the widened inputs:
+    h / v bit-exact, outputs = nearest-even narrowing, so the low-precision mode adds nothing but the I/O rounding."""
+    from oracle import np_x16
+    rng = np.random.default_rng(11)
+    T, N = 5, 1000
+    xb = np_x16.narrow((rng.standard_normal((T, N)) * 0.2).astype(np.float32), dtype)
+    sb = np_x16.narrow(rng.integers(0, 3, (T, N)).astype(np.float32), dtype)
+    v0 = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    kw = dict(kind=kind, scale=10.0, tau=3.0, k=np.float32(1 / 3.) if kind == 'PLIF' else None, v_th=1.0, v_reset=0.0)
+    a = np_x16.neuron_fwd(xb, dtype, v_init=v0, skip_bits=sb, **kw)
+    b = c_oracle.neuron_fwd(np_x16.widen(xb, dtype), v_init=v0, skip_seq=np_x16.widen(sb, dtype), **kw)
+    assert bit_equal(a['h'], b['h']) and bit_equal(a['v_last'], b['v_last'])
+    assert np.array_equal(np_x16.widen(a['out'], dtype), b['out'])
+    gb = np_x16.narrow(rng.standard_normal((T, N)).astype(np.float32), dtype)
+    ga = np_x16.neuron_bwd(gb, a['h'], dtype, v_init=v0, surrogate='ATan', alpha=2.0, **kw)
+    gc = c_oracle.neuron_bwd(np_x16.widen(gb, dtype), b['h'], v_init=v0, surrogate='ATan', alpha=2.0, **kw)
+    assert np.array_equal(ga['g_x'], np_x16.narrow(gc['g_x'], dtype))
+    assert bit_equal(ga['g_v_init'], gc['g_v_init'])
+    # round trip of the bit conversions
+    f = rng.standard_normal(4096).astype(np.float32)
+    assert np.array_equal(np_x16.narrow(np_x16.widen(np_x16.narrow(f, dtype), dtype), dtype), np_x16.narrow(f, dtype))
+    t = torch.tensor(f)
+    td = t.to(torch.float16 if dtype == 'f16' else torch.bfloat16)
+    assert np.array_equal(np_x16.narrow(f, dtype), td.view(torch.int16).numpy().view(np.uint16))
