@@ -40,7 +40,9 @@ def parse():
     ap.add_argument('--model', default='StereoSpike', choices=['StereoSpike', 'PLIFNet'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    ap.add_argument('--miopen-find', type=int, default=0, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
+    ap.add_argument('--miopen-find', type=int, default=1,
+                    help='torch.backends.cudnn.benchmark = MIOpen find mode: picks the fastest solver per conv (measured '
+                         '73.8 vs 87.3 ms/step); the search costs ~3.5 min on a cold box, ~75 s with the in-tree find-db')
     ap.add_argument('--channels-last', type=int, default=0)
     ap.add_argument('--bucket-mb', type=float, default=20.0)
     ap.add_argument('--decoder-nhwc', type=int, default=1, help='1: decoder kept in NHWC memory (one GEMM per stage)')
@@ -172,10 +174,10 @@ def main():
         all_ms = sum(v['ms'] for k, v in summ.items() if k.startswith('neuron_'))
         all_bytes = sum(v['bytes'] for k, v in summ.items() if k.startswith('neuron_'))
 
-        def roof(d):
+        def roof(d, which='neuron_fwd'):
             ach = (d['bytes'] / 1e9) / (d['ms'] / 1e3) if d['ms'] > 0 else 0.0
             return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(),
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=_pmc_traffic(which),
                         launches=d['launches'], avg_launch_us=round(1e3 * d['ms'] / max(1, d['launches']), 2),
                         bytes_per_launch=int(d['bytes'] / max(1, d['launches'])))
         from stereospike_amd.network.metrics import MeanDepthError
@@ -193,7 +195,7 @@ def main():
                                     f'12 B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
                              **roof(fwd)),
             'roofline_bwd': dict(kernel='neuron_bwd_kernel (fused surrogate backward over T, fp32, 12 B/update), '
-                                        'largest launch shape', **roof(bwd)),
+                                        'largest launch shape', **roof(bwd, 'neuron_bwd')),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
                 ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
@@ -211,13 +213,14 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the forward kernel from the rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
-    by profiles/collect_pmc.sh with the guide's gfx950 correction: FETCH_SIZE doubled); None if not collected."""
+def _pmc_traffic(which='neuron_fwd'):
+    """HBM bytes per launch of the fused kernel at the dominant launch shape, from the rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, written by profiles/collect_pmc.sh with the guide's gfx950 correction: FETCH_SIZE doubled);
+    None if not collected."""
     p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get('neuron_fwd_train_bytes_per_launch')
+            return json.load(open(p)).get(which, {}).get('hbm_bytes_per_launch')
         except Exception:
             return None
     return None

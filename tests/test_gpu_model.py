@@ -167,7 +167,7 @@ def test_teacher_forced_stages(name):
     for lvl in (4, 3, 2, 1):
         inp = torch.stack(rec[f'predict_depth{lvl}']['inp']).to(DEV)            # [T, B, C, h, w]
         heads.append(pmods[f'predict_depth{lvl}'][0].forward_projected(inp.flatten(0, 1)).view(T, B, 1, H, W))
-    depth_seq = ipool(torch.stack(heads), 10.0, 0.0)
+    depth_seq = ipool(torch.stack(heads), float(pmods['predict_depth4'][1].scale_value), 0.0)
     for t in range(T):
         for k, lvl in enumerate((4, 3, 2, 1)):
             ref = depths[t][lvl - 1]
