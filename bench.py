@@ -22,7 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from stereospike_amd import miopen_cache  # noqa: E402
-miopen_cache.enable()                     # before torch/MIOpen initialise: in-tree kernel cache (see module doc)
+miopen_cache.enable(skip_naive_solvers=os.environ.get('SS_MIOPEN_SKIP_NAIVE', '1') == '1')   # before torch/MIOpen initialise
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -201,6 +201,15 @@ def main():
                 ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
                 achieved_GBps=round(all_bytes / 1e9 / (all_ms / 1e3), 1) if all_ms else 0.0,
                 share_of_step=round(all_ms / (1e3 * elapsed), 4)),
+            # HIP-event averages over ALL launches of each kernel instantiation, for comparison with the AverageNs column of
+            # the committed `rocprofv3 --kernel-trace --stats` CSV (profiles/): events add a few us per launch
+            'rocprof_check_avg_us': {
+                'neuron_fwd_kernel<0, 5, false, true, 4>': round(1e3 * summ['neuron_fwd_train']['ms'] / summ['neuron_fwd_train']['launches'], 1)
+                if 'neuron_fwd_train' in summ else None,
+                'neuron_fwd_kernel<0, 5, true, true, 4>': round(1e3 * summ['neuron_fwd_train+skip']['ms'] / summ['neuron_fwd_train+skip']['launches'], 1)
+                if 'neuron_fwd_train+skip' in summ else None,
+                'neuron_bwd_kernel<*>': round(1e3 * summ['neuron_bwd']['ms'] / summ['neuron_bwd']['launches'], 1)
+                if 'neuron_bwd' in summ else None},
             'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),

@@ -336,6 +336,11 @@ template <int DT> __device__ __forceinline__ float widen(unsigned short b)
 }
 template <int DT> __device__ __forceinline__ unsigned short narrow(float f)
 {
+    // The value to store is an fp32 result (rounded once already); keep hipcc from folding the producing multiply into
+    // v_fma_mixlo_f16, which would round the exact product straight to fp16 (single rounding) and break bit-parity with
+    // the "fp32 arithmetic, nearest-even narrowing on store" definition of oracle/np_x16.py (seen on the MI355X: ~1e-6
+    // of the g_x values differed by one fp16 ulp).
+    asm volatile("" : "+v"(f));
     if (DT == SS_DT_F16) return __half_as_ushort(__float2half_rn(f));
     unsigned u = __float_as_uint(f);                       // round to nearest even (NaN kept quiet)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);

@@ -8,8 +8,14 @@ import os
 CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'miopen_cache')
 
 
-def enable(path: str = CACHE_DIR):
+def enable(path: str = CACHE_DIR, skip_naive_solvers: bool = False):
+    """skip_naive_solvers: keep MIOpen's find mode from timing its `naive_conv_*` reference solvers (fp64-accumulating,
+    seconds per call at config-3 sizes: they were ~70 of the ~75 s of a find-mode start-up, profiles/r01/).  Only for
+    find-mode runs of the NHWC network, where tuned implicit-GEMM / CK solvers always exist."""
     os.makedirs(path, exist_ok=True)
     os.environ.setdefault('MIOPEN_USER_DB_PATH', path)
     os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', path)
+    if skip_naive_solvers:
+        for d in ('FWD', 'BWD', 'WRW'):
+            os.environ.setdefault(f'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{d}', '0')
     return path

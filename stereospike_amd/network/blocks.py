@@ -164,12 +164,15 @@ class ResBlock(nn.Module):
 
 def _conv_cl(conv: nn.Module, x_arr: torch.Tensor) -> torch.Tensor:
     """x_arr [NB, h, w, C] (NHWC array) -> conv -> [NB, h', w', C'] NHWC array, without layout copies when MIOpen returns
-    channels_last memory (it does for channels_last inputs).  The filter is moved to channels_last storage once (same
-    Parameter object, same values, same state_dict) so MIOpen does not re-lay it out every call."""
-    wt = conv.weight
-    if wt.dim() == 4 and not wt.is_contiguous(memory_format=torch.channels_last):
-        wt.data = wt.data.contiguous(memory_format=torch.channels_last)
-    y = conv(x_arr.permute(0, 3, 1, 2))
+    channels_last memory (it does for channels_last inputs).  The filter is handed to MIOpen as a channels_last copy
+    (72 MB for the whole network, ~0.03 ms per step); the Parameter itself keeps its standard layout, so optimisers,
+    the DP gradient buckets and state_dict never see a layout change."""
+    if isinstance(conv, nn.Conv2d):
+        w = conv.weight.contiguous(memory_format=torch.channels_last)
+        y = torch.nn.functional.conv2d(x_arr.permute(0, 3, 1, 2), w, conv.bias, conv.stride, conv.padding,
+                                       conv.dilation, conv.groups)
+    else:
+        y = conv(x_arr.permute(0, 3, 1, 2))
     y = y.permute(0, 2, 3, 1)
     return y if y.is_contiguous() else y.contiguous()
 
