@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='samples per GPU (config 3: 16)')
     ap.add_argument('--T', type=int, default=5)
     ap.add_argument('--model', default='StereoSpike', choices=['StereoSpike', 'PLIFNet'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'],
+                    help='f32 = the headline config; bf16 / f16 = 16-bit activations under torch.autocast with fp32 membrane '
+                         '(BASELINE.json configs 2 / 5) — reported as a separate line, never as the headline value')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--miopen-find', type=int, default=1,
@@ -131,6 +134,14 @@ def main():
         net = net.to(memory_format=torch.channels_last)
     reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20))) if world > 1 else None
     trainer = Trainer(net, reducer=reducer)
+    if a.dtype != 'f32':
+        amp_dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
+        plain_step = trainer.step
+
+        def amp_step(x_, gt_):
+            with torch.autocast('cuda', dtype=amp_dtype):
+                return plain_step(x_, gt_)
+        trainer.step = amp_step
     x, gt = synthetic_batch(a.batch, a.T, seed=2021 + rank, device=dev)     # resident in HBM before timing
 
     def sync():
@@ -185,7 +196,7 @@ def main():
             'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1e3 * elapsed / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
                                    f'(reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd',
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
@@ -214,7 +225,7 @@ def main():
                                                 if not k.startswith('neuron_')},
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.dtype == 'f32':
             out['cpu_baseline'] = cpu_baseline(a.model, a.T, a.cpu_seconds)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
         print(json.dumps(out), flush=True)

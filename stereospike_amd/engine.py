@@ -18,6 +18,14 @@ def synthetic_batch(B, T, C=4, H=260, W=346, seed=2021, device='cpu', lam=0.05, 
     return x.to(device), gt.to(device)
 
 
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Trainer:
     """reset -> T-step forward -> Total_Loss -> backward (gradient all-reduce overlapped when DP) -> Adam -> detach."""
 
@@ -36,7 +44,8 @@ class Trainer:
         out = net.forward_sequence(x)
         pred, spks = out if isinstance(out, tuple) else (out, None)
         loss = self.loss_module(pred, label, spks)             # train.py:238
-        loss.backward()
+        with torch.autocast('cuda', enabled=False) if loss.is_cuda else _null():
+            loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
         self.opt.step()
