@@ -22,7 +22,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from stereospike_amd import miopen_cache  # noqa: E402
-miopen_cache.enable(skip_naive_solvers=os.environ.get('SS_MIOPEN_SKIP_NAIVE', '1') == '1')   # before torch/MIOpen initialise
+_skip_naive = os.environ.get('SS_MIOPEN_SKIP_NAIVE', '1') == '1'
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # before torch / MIOpen initialise
+    miopen_cache.enable_per_rank(int(os.environ.get('LOCAL_RANK', '0')), skip_naive_solvers=_skip_naive)
+else:
+    miopen_cache.enable(skip_naive_solvers=_skip_naive)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -48,6 +52,8 @@ def parse():
                          '73.8 vs 87.3 ms/step); the search costs ~3.5 min on a cold box, ~75 s with the in-tree find-db')
     ap.add_argument('--channels-last', type=int, default=0)
     ap.add_argument('--bucket-mb', type=float, default=20.0)
+    ap.add_argument('--force-dp', action='store_true',
+                    help='validation aid for a 1-GPU box: build the RCCL process group and the gradient reducer even with one rank')
     ap.add_argument('--decoder-nhwc', type=int, default=1, help='1: decoder kept in NHWC memory (one GEMM per stage)')
     ap.add_argument('--encoder-nhwc', type=int, default=1, help='1: encoder/bottleneck activations in NHWC as well')
     ap.add_argument('--fuse-upconv', type=int, default=1,
@@ -113,9 +119,12 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU fallback for the product path'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dp = world > 1 or a.force_dp
+    if use_dp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
 
@@ -132,7 +141,7 @@ def main():
     net = build_net(a.model, dev)
     if a.channels_last:
         net = net.to(memory_format=torch.channels_last)
-    reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20))) if world > 1 else None
+    reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20)), reduce_single_rank=a.force_dp) if use_dp else None
     trainer = Trainer(net, reducer=reducer)
     if a.dtype != 'f32':
         amp_dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
@@ -145,7 +154,7 @@ def main():
     x, gt = synthetic_batch(a.batch, a.T, seed=2021 + rank, device=dev)     # resident in HBM before timing
 
     def sync():
-        if world > 1:
+        if use_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +174,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     TIMER.enabled = False
-    if world > 1:
+    if use_dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -229,7 +238,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(a.model, a.T, a.cpu_seconds)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dp:
         dist.destroy_process_group()
 
 

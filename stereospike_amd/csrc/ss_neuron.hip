@@ -33,9 +33,15 @@
 
 namespace {
 
-constexpr int kBlock = 256;          // 4 wavefronts of 64
-constexpr int kMaxGrid = 2048;       // 256 CUs x 8 workgroups/CU
-constexpr long long kGkWsFloats = kMaxGrid;
+#ifndef SS_BLOCK
+#define SS_BLOCK 256
+#endif
+#ifndef SS_MAX_GRID
+#define SS_MAX_GRID 2048
+#endif
+constexpr int kBlock = SS_BLOCK;         // 4 wavefronts of 64
+constexpr int kMaxGrid = SS_MAX_GRID;    // 256 CUs x 8 workgroups/CU (A/B-measured, profiles/r01/neuron_grid_variants.log)
+constexpr long long kGkWsFloats = kMaxGrid > 2048 ? kMaxGrid : 2048;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 

@@ -8,6 +8,19 @@ import os
 CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'miopen_cache')
 
 
+def enable_per_rank(local_rank: int, skip_naive_solvers: bool = False):
+    """One cache directory per process of a multi-GPU launch (seeded from the shared in-tree one): N ranks running MIOpen's
+    find search at the same time would otherwise contend for the same sqlite / text db files."""
+    import shutil
+    path = f'{CACHE_DIR}_rank{local_rank}'
+    if not os.path.isdir(path):
+        if os.path.isdir(CACHE_DIR):
+            shutil.copytree(CACHE_DIR, path, dirs_exist_ok=True)
+        else:
+            os.makedirs(path, exist_ok=True)
+    return enable(path, skip_naive_solvers)
+
+
 def enable(path: str = CACHE_DIR, skip_naive_solvers: bool = False):
     """skip_naive_solvers: keep MIOpen's find mode from timing its `naive_conv_*` reference solvers (fp64-accumulating,
     seconds per call at config-3 sizes: they were ~70 of the ~75 s of a find-mode start-up, profiles/r01/).  Only for
