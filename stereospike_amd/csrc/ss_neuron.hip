@@ -14,7 +14,8 @@
 //    LDS is used where lanes actually exchange data — the workgroup stage of the firing-rate / dL/dk reductions;
 //  * T is a template parameter for the common values so the T independent dwordx4 loads of a lane are all
 //    issued before the first dependent VALU op (T x 16 B in flight per lane); a runtime-T fallback exists;
-//  * grid = min(needed, 256 CUs x 8 workgroups) with a grid-stride loop, 256-thread workgroups (4 waves);
+//  * grid: one f4 per lane for the backward, <= 32768 workgroups + a short grid-stride loop for the forward (A/B-measured,
+//    see kMaxGrid below), 256-thread workgroups (4 waves);
 //  * firing-rate counters: per-lane integer count -> wavefront butterfly (__shfl_xor over 64 lanes) ->
 //    4 partials in LDS -> one 64-bit integer atomic per counter per workgroup (deterministic);
 //  * dL/dk (PLIF): per-lane fp32 -> wavefront butterfly -> LDS -> one partial per workgroup in the caller's
@@ -37,11 +38,19 @@ namespace {
 #define SS_BLOCK 256
 #endif
 #ifndef SS_MAX_GRID
-#define SS_MAX_GRID 2048
+#define SS_MAX_GRID 32768
+#endif
+#ifndef SS_MAX_GRID_BWD
+#define SS_MAX_GRID_BWD 1048576
 #endif
 constexpr int kBlock = SS_BLOCK;         // 4 wavefronts of 64
-constexpr int kMaxGrid = SS_MAX_GRID;    // 256 CUs x 8 workgroups/CU (A/B-measured, profiles/r01/neuron_grid_variants.log)
-constexpr long long kGkWsFloats = kMaxGrid > 2048 ? kMaxGrid : 2048;
+// Grid caps, A/B-measured in one process with interleaved rounds (profiles/r01/neuron_grid_variants*.log): the forward
+// (1 read + 2 write streams) is best with <= 32768 workgroups and a short grid-stride loop (+4 % over 2048), the backward
+// (2 reads + 1 write) with one vector per lane and no loop at all (+9 % over 2048: 5.47 vs 5.00 TB/s, above the device-copy rate).
+constexpr int kMaxGrid = SS_MAX_GRID;
+constexpr int kMaxGridBwd = SS_MAX_GRID_BWD;
+constexpr int kMaxGridGk = 2048;         // PLIF dL/dk: bounded number of workgroup partials (caller workspace, fixed-order 2nd pass)
+constexpr long long kGkWsFloats = kMaxGridGk;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -794,11 +803,11 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------
-inline int grid_for(long long work_items)
+inline int grid_for(long long work_items, int cap = kMaxGrid)
 {
     long long g = (work_items + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
-    if (g > kMaxGrid) g = kMaxGrid;
+    if (g > cap) g = cap;
     return (int)g;
 }
 
@@ -844,7 +853,8 @@ int launch_bwd(const BwdArgs& a, hipStream_t s, int* grid_out)
     const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.g_x_seq) &&
                      (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                      (!a.v_init || aligned16(a.v_init));
-    const int grid = vec ? grid_for(a.N / 4) : grid_for(a.N);
+    int grid = vec ? grid_for(a.N / 4, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
+    if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
     *grid_out = grid;
     if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4>), dim3(grid), dim3(kBlock), 0, s, a);
     else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1>), dim3(grid), dim3(kBlock), 0, s, a);
@@ -917,7 +927,8 @@ int dispatch_bwd16(const Bwd16Args& a, hipStream_t s, int* grid_out)
     const bool vec = (a.N % 8 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.g_x_seq) &&
                      (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                      (!a.v_init || aligned16(a.v_init));
-    const int grid = vec ? grid_for(a.N / 8) : grid_for(a.N);
+    int grid = vec ? grid_for(a.N / 8, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
+    if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
     *grid_out = grid;
     if (vec) hipLaunchKernelGGL((neuron_bwd16_kernel<KIND, SG, DT, 8>), dim3(grid), dim3(kBlock), 0, s, a);
     else     hipLaunchKernelGGL((neuron_bwd16_kernel<KIND, SG, DT, 1>), dim3(grid), dim3(kBlock), 0, s, a);
