@@ -6,6 +6,10 @@ GPU boxes) start in seconds.  Must be called before the first conv (ideally befo
 import os
 
 CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'miopen_cache')
+# Tracked seed: MIOpen's TEXT find-db / perf-db for this network's conv configurations on gfx950 (which solver won the
+# find search, measured on an MI355X; profiles/README.md).  Copied into the cache directory when that has none, so a
+# fresh checkout skips the ~2 min search; compiled kernels (the binary .ukdb) are not tracked and are rebuilt on demand.
+SEED_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'miopen_db')
 
 
 def enable_per_rank(local_rank: int, skip_naive_solvers: bool = False):
@@ -26,6 +30,11 @@ def enable(path: str = CACHE_DIR, skip_naive_solvers: bool = False):
     seconds per call at config-3 sizes: they were ~70 of the ~75 s of a find-mode start-up, profiles/r01/).  Only for
     find-mode runs of the NHWC network, where tuned implicit-GEMM / CK solvers always exist."""
     os.makedirs(path, exist_ok=True)
+    if os.path.isdir(SEED_DIR):
+        import shutil
+        for f in os.listdir(SEED_DIR):
+            if f.endswith('.txt') and not os.path.exists(os.path.join(path, f)):
+                shutil.copy(os.path.join(SEED_DIR, f), os.path.join(path, f))
     os.environ.setdefault('MIOPEN_USER_DB_PATH', path)
     os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', path)
     if skip_naive_solvers:
