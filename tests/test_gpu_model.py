@@ -454,3 +454,19 @@ def test_autocast_16bit_activations(dt):
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
     from stereospike_amd.clock_driven import neuron
     assert all(m.v.dtype == torch.float32 for m in net.modules() if isinstance(m, neuron.BaseNode))
+
+
+@pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
+def test_training_reduces_the_loss(name):
+    """End-to-end sanity of the fused backward (surrogate gradients, BPTT through T, I-pool, projected up-convs, Adam):
+    over-fitting one small batch must drive Total_Loss down substantially."""
+    from stereospike_amd.engine import Trainer, synthetic_batch
+    torch.manual_seed(11)
+    net = _product(name, input_size=(64, 80)).to(DEV)
+    tr = Trainer(net, lr=1e-3)
+    x, gt = synthetic_batch(2, 3, H=64, W=80, seed=9, device=DEV, lam=0.08)
+    losses = [float(tr.step(x, gt)[0]) for _ in range(60)]
+    REPORT[f'overfit_{name}'] = dict(first=losses[0], best=min(losses), last=losses[-1])
+    _dump()
+    assert all(np.isfinite(losses))
+    assert min(losses[-10:]) < 0.5 * losses[0], (losses[0], losses[-10:])

@@ -206,3 +206,13 @@ def test_x16_numpy_oracle_equals_c_oracle_on_widened_inputs(dtype, kind):
     t = torch.tensor(f)
     td = t.to(torch.float16 if dtype == 'f16' else torch.bfloat16)
     assert np.array_equal(np_x16.narrow(f, dtype), td.view(torch.int16).numpy().view(np.uint16))
+
+
+def test_c_oracle_under_address_and_ub_sanitizers():
+    """Every entry point of oracle/ss_neuron_ref.c on small ragged inputs under -fsanitize=address,undefined."""
+    import os
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+    subprocess.check_call(['make', '-s', '-C', root, '_build/ss_oracle_asan_check'])
+    out = subprocess.run([os.path.join(root, '_build', 'ss_oracle_asan_check')], capture_output=True, text=True)
+    assert out.returncode == 0 and 'rc=0' in out.stdout, out.stdout + out.stderr
