@@ -88,6 +88,10 @@ def cpu_baseline(model, T, budget_s):
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
     B = 1
     x, gt = synthetic_batch(B, T, seed=2021)
+    # eval MDE on identical (seed-2021 default-init) weights and inputs, before any update: the "eval MDE" half of the metric
+    with torch.no_grad():
+        d_eval = rn.run_sequence(net, x)[0]
+        eval_mde = float(rn.mean_depth_error(d_eval[0], gt))
 
     def step():
         out = rn.run_sequence(net, x)
@@ -105,7 +109,7 @@ def cpu_baseline(model, T, budget_s):
         el = time.perf_counter() - t0
         if (n >= 2 and el >= budget_s) or n >= 20 or el > 3 * budget_s:
             break
-    return dict(value=B * n / el, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+    return dict(value=B * n / el, unit='frames/s', cores=torch.get_num_threads(), kind='port', eval_mde_m=eval_mde,
                 sample=f'{model} binocular T={T} 260x346 fp32, B=1, {n} timed training iterations after 1 warm-up, '
                        f'eager unfused oracle port, torch {torch.__version__} CPU, {torch.get_num_threads()} threads '
                        f'of {os.cpu_count()} logical CPUs')
@@ -235,7 +239,19 @@ def main():
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
         if world == 1 and not a.no_cpu_baseline and a.dtype == 'f32':
+            # eval MDE of the product on the same weights (fresh seed-2021 net) and the same B = 1 input as the CPU port
+            from stereospike_amd.clock_driven import functional as _F
+            from stereospike_amd.engine import synthetic_batch as _sb
+            net0 = build_net(a.model, dev)
+            x0, gt0 = _sb(1, a.T, seed=2021, device=dev)
+            with torch.no_grad():
+                _F.reset_net(net0)
+                d0 = net0.forward_sequence(x0)[0]
+                out['eval_mde_m'] = round(float(MeanDepthError(d0[0], gt0)), 5)
+            del net0
             out['cpu_baseline'] = cpu_baseline(a.model, a.T, a.cpu_seconds)
+            out['eval_mde_rel_diff_vs_cpu'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m'])
+                                                    / out['cpu_baseline']['eval_mde_m'], 6)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
         print(json.dumps(out), flush=True)
     if use_dp:

@@ -470,3 +470,44 @@ def test_training_reduces_the_loss(name):
     _dump()
     assert all(np.isfinite(losses))
     assert min(losses[-10:]) < 0.5 * losses[0], (losses[0], losses[-10:])
+
+
+def test_free_running_odd_sizes_runtime_T():
+    """Frame size with odd pyramid levels (50x70 -> 25x35 -> 13x18 -> 7x9 -> 4x5), T = 7 (runtime-T kernel path), B = 3."""
+    x = synth_input(3, 7, 4, 123, 50, 70, lam=0.08)
+    gt = synth_label(3, 124, 50, 70)
+    _free_running('free_odd_50x70_T7_PLIFNet', 'PLIFNet', x, gt, 50, 70)
+
+
+def test_kernel_hyper_parameter_fuzz():
+    """Random (kind, scale, tau / k, v_th, v_reset, alpha, T, N, skip, v_init) against the C oracle: forward bit-exact,
+    ATan backward bit-exact, Sigmoid backward <= 1e-6."""
+    from test_gpu_kernels import hip_fwd, hip_bwd
+    from _util import c_oracle, bit_equal, rel_err
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        kind = ['IF', 'LIF', 'PLIF'][it % 3]
+        T = int(rng.integers(1, 13))
+        N = int(rng.integers(1, 5000)) * (4 if it % 2 else 1)
+        scale = float(rng.choice([0.5, 1.0, 3.0, 10.0, 30.0]))
+        v_th = float(rng.choice([0.5, 1.0, 2.0]))
+        v_reset = float(rng.choice([0.0, 0.1, -0.2]))
+        tau = float(rng.choice([1.5, 2.0, 3.0, 10.0]))
+        k = float(rng.uniform(0.05, 0.95)) if kind == 'PLIF' else None
+        alpha = float(rng.choice([1.0, 2.0, 4.0]))
+        x = (rng.standard_normal((T, N)) * 1.5 * v_th / scale).astype(np.float32)
+        skip = rng.integers(0, 3, (T, N)).astype(np.float32) if it % 4 == 0 else None
+        v0 = (rng.standard_normal(N) * 0.5).astype(np.float32) if it % 3 == 0 else None
+        kw = dict(kind=kind, scale=scale, tau=tau, k=k, v_th=v_th, v_reset=v_reset)
+        ref = c_oracle.neuron_fwd(x, v_init=v0, skip_seq=skip, **kw)
+        got = hip_fwd(x, v_init=v0, skip=skip, **kw)
+        assert np.array_equal(ref['out'], got['out']) and bit_equal(ref['h'], got['h']) and bit_equal(ref['v_last'], got['v_last']), (it, kw)
+        g = rng.standard_normal((T, N)).astype(np.float32)
+        gv = rng.standard_normal(N).astype(np.float32)
+        for sg in ('ATan', 'Sigmoid'):
+            rb = c_oracle.neuron_bwd(g, ref['h'], v_init=v0, g_v_last=gv, surrogate=sg, alpha=alpha, **kw)
+            gb = hip_bwd(g, ref['h'], v_init=v0, g_v_last=gv, surrogate=sg, alpha=alpha, **kw)
+            if sg == 'ATan':
+                assert bit_equal(rb['g_x'], gb['g_x']) and bit_equal(rb['g_v_init'], gb['g_v_init']), (it, kw, alpha)
+            else:
+                assert rel_err(gb['g_x'], rb['g_x']) < 1e-6, (it, kw, alpha)
