@@ -161,6 +161,15 @@ def test_oracle_network_vs_reference_fixture(tag, name, kw, T):
         assert mism == 0.0 if exact else mism <= 2e-3, (nm, mism)
     assert abs(float(loss) - float(z['loss'])) <= (0 if exact else 2e-3 * abs(float(z['loss'])))
     assert abs(float(mde) - float(z['mde'])) <= (0 if exact else 2e-3 * abs(float(z['mde'])))
+    # membranes carried over the T steps (state really is stateful: SURVEY.md §3.4)
+    import hashlib as _h
+    vs = {k: m.v for k, m in net.named_modules() if isinstance(m, sj.BaseNode) and isinstance(m.v, torch.Tensor)}
+    assert list(vs.keys()) == json.loads(str(z['v_names']))
+    if exact:
+        shas = [_h.sha256(v.detach().contiguous().numpy().tobytes()).hexdigest() for v in vs.values()]
+        assert shas == json.loads(str(z['v_sha']))
+    else:
+        assert np.allclose([v.detach().double().sum().item() for v in vs.values()], z['v_sum'], rtol=5e-2)
     if tag == 'stereospike_T1':      # one backward is enough for the CPU budget
         loss.backward()
         l2 = np.array([p.grad.double().norm().item() for p in net.parameters()])
