@@ -352,22 +352,29 @@ class _UpConvProjectedCL(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W):
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False):
+        # lowp (only under bf16 autocast): the three GEMMs take bf16 operands with fp32 accumulation / output, exactly what
+        # autocast does to the MIOpen convs of the encoder (spike inputs are exact in bf16; W and g_P are rounded).
+        # P, the gather, its adjoint and every output stay fp32.
         x_cl = x_cl.contiguous()
         NB, h, w, Cin = x_cl.shape
         Cout, kk = weight.shape[0], k * k
         Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()      # column index = tap*C_out + co
         src_y, _, _, src_x, _, _ = tables
-        out = torch.empty((NB, H, W, Cout), dtype=x_cl.dtype, device=x_cl.device)
+        out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=x_cl.device)
         n = P_CHUNK_BYTES // (Cout * kk * h * w * 4)
         n = NB if n < 4 else min(NB, n)
+        xg = x_cl.to(torch.bfloat16) if lowp else x_cl
+        Wg = Wt.to(torch.bfloat16) if lowp else Wt
         e0 = TIMER.start()
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
-            P = torch.mm(x_cl[c0:c1].view((c1 - c0) * h * w, Cin), Wt)             # [(n*h*w), kk*Cout]
+            xs = xg[c0:c1].view((c1 - c0) * h * w, Cin)
+            P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
             _lib.upconv_cl_fwd(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-        ctx.save_for_backward(x_cl, Wt)
+        ctx.save_for_backward(xg, Wt)
+        ctx.lowp = lowp
         ctx.tables, ctx.k, ctx.n = tables, k, n
         ctx.wshape = weight.shape
         ctx.has_bias = bias is not None
@@ -383,34 +390,42 @@ class _UpConvProjectedCL(torch.autograd.Function):
         Cout, kk = ctx.wshape[0], k * k
         H, W = g_out.shape[1:3]
         g_out = g_out.float().contiguous()
+        lowp = ctx.lowp
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g_x = torch.empty_like(x_cl) if need_x else None
+        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if need_x else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
+        if lowp:
+            W2 = W2.to(torch.bfloat16)
+        f32 = dict(out_dtype=torch.float32) if lowp else {}
         e0 = TIMER.start()
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
-            g_P = torch.empty((rows, kk * Cout), dtype=x_cl.dtype, device=x_cl.device)
+            g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
             _lib.upconv_cl_bwd(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+            if lowp:
+                g_P = g_P.to(torch.bfloat16)
             if need_x:
-                torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))                 # dgrad
+                g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
+                    torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
             if need_w:
                 xs = x_cl[c0:c1].view(rows, Cin)
                 S = max(1, rows // WGRAD_SPLIT_ROWS)
                 L = rows // S
                 if S > 1:
-                    g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout)).sum(0)
+                    g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout), **f32).sum(0)
                     if S * L < rows:
-                        g_Wt.addmm_(xs[S * L:].t(), g_P[S * L:])
+                        g_Wt += torch.mm(xs[S * L:].t(), g_P[S * L:], **f32)
                 else:
-                    g_Wt.addmm_(xs.t(), g_P)
+                    g_Wt += torch.mm(xs.t(), g_P, **f32)
         TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
         g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
         g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return g_x, g_w, g_b, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None
 
 
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out]."""
-    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W)
+    lowp = x_cl.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp)
