@@ -17,7 +17,6 @@ network is purely feed-forward this is mathematically the reference's step-by-st
 functional.reset_net).  `net.forward_sequence(x)` consumes all T frames of x [B, T, C, H, W] in one pass and
 returns what the last of T successive `net(...)` calls would return.
 """
-from typing import Optional
 
 import torch
 import torch.nn as nn
