@@ -184,6 +184,21 @@ int ss_upconv_cl_fwd_f32(const float* P, const int* src_y, const int* src_x, con
 int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                          float* g_P, long long NB, int k, int C, int h, int w, int H, int W, void* stream);
 
+/*
+ * Voxeliser — the step BEFORE the path: events -> per-pixel two-polarity count frames,
+ * /root/reference/datasets/MVSEC/utils.py:215-281 (mvsecCumulateSpikesIntoFrames; a python loop per event there).
+ *   events : [E][4] float64 row-major (X, Y, TIME, POLARITY), exactly the array the reference carries around
+ *   start, end : float64 [G] open-interval bounds of the G = n_chunks * frames_per_depth_map frames, evaluated by the
+ *                caller in the reference's own float64 expression order (utils.py:259-260) so boundary events match
+ *   counts : uint32 [G][2][H][W], zeroed here; counts[g][POLARITY == 1 ? 0 : 1][(int)Y][(int)X] += 1 for every event with
+ *            start[g] < TIME - events[0].TIME < end[g]   (strict on both sides; a time inside two overlapping intervals
+ *            counts twice, as in the reference).  Events whose truncated coordinates fall outside H x W are skipped
+ *            (the reference would raise IndexError: its rectifier keeps x == 346 / y == 260, utils.py:52-55).
+ * One lane per event, binary search over the bounds, integer atomics => deterministic.
+ */
+int ss_voxelize_f64(const double* events, long long E, const double* start, const double* end, int G,
+                    unsigned int* counts, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ def lib():
     L.ss_neuron_bwd_x16.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, i32, p]
     L.ss_neuron_fwd_x16.restype = i32
     L.ss_neuron_bwd_x16.restype = i32
+    L.ss_voxelize_f64.argtypes = [p, i64, p, p, i32, p, i32, i32, p]
+    L.ss_voxelize_f64.restype = i32
     L.ss_upconv_cl_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_cl_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
@@ -58,7 +60,7 @@ def lib():
 
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
-           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16')
+           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64')
 
 
 def _ptr(t, name, numel=None):
@@ -220,6 +222,19 @@ def upconv_cl_bwd(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, C, h, w, H, W):
                                         _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
                                         _f32(g_P, 'g_P', NB * k * k * C * h * w), NB, k, C, h, w, H, W, _stream(g_out))
     _check(rc, 'ss_upconv_cl_bwd_f32')
+
+
+def voxelize(events, start, end, counts, H, W):
+    _require_hip(events, 'events')
+    for t, name, dt in ((events, 'events', torch.float64), (start, 'start', torch.float64), (end, 'end', torch.float64),
+                        (counts, 'counts', torch.int32)):
+        if t.dtype != dt:
+            raise SSNeuronError(f'{name}: expected {dt}, got {t.dtype}')
+    E, G = events.shape[0], start.numel()
+    with torch.cuda.device(events.device):
+        rc = lib().ss_voxelize_f64(_ptr(events, 'events', E * 4), E, _ptr(start, 'start'), _ptr(end, 'end', G), G,
+                                   _ptr(counts, 'counts', G * 2 * H * W), H, W, _stream(events))
+    _check(rc, 'ss_voxelize_f64')
 
 
 def gk_ws_floats():

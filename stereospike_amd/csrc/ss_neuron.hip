@@ -801,6 +801,27 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// voxeliser: events -> two-polarity count frames (datasets/MVSEC/utils.py:215-281)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void voxelize_kernel(const double* __restrict__ ev, long long E, const double* __restrict__ start,
+                                                          const double* __restrict__ end, int G, unsigned* __restrict__ counts, int H, int W)
+{
+    const double t0 = ev[2];
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < E; i += (long long)gridDim.x * kBlock) {
+        const double* e = ev + i * 4;
+        const double t = e[2] - t0;
+        const long long x = (long long)e[0], y = (long long)e[1];          // int(): truncation toward zero
+        if (x < 0 || x >= W || y < 0 || y >= H) continue;
+        const int ch = (e[3] == 1.0) ? 0 : 1;
+        int lo = 0, hi = G;                                                // first g with start[g] >= t
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (start[mid] < t) lo = mid + 1; else hi = mid; }
+        for (int g = lo - 1; g >= 0 && g >= lo - 2; --g)                   // the last two frames that started before t
+            if (start[g] < t && t < end[g])
+                atomicAdd(&counts[(((long long)g * 2 + ch) * H + y) * W + x], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------
 inline int grid_for(long long work_items, int cap = kMaxGrid)
@@ -1136,6 +1157,17 @@ int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, c
     if (k == 1) return launch_cl_bwd<1>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
     if (k == 3) return launch_cl_bwd<3>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
     return launch_cl_bwd<5>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+}
+
+int ss_voxelize_f64(const double* events, long long E, const double* start, const double* end, int G,
+                    unsigned int* counts, int H, int W, void* stream)
+{
+    if (!start || !end || !counts || E < 0 || G <= 0 || H <= 0 || W <= 0 || (E > 0 && !events)) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)G * 2 * H * W, s) != hipSuccess) return SS_ELAUNCH;
+    if (E == 0) return SS_OK;
+    hipLaunchKernelGGL(voxelize_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, events, E, start, end, G, counts, H, W);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
 }  // extern "C"

@@ -316,8 +316,41 @@ def gen_model(ref, tag, make_ref, make_oracle, C, T, returns_spikes, seed=2021):
     save(f'model_{tag}.npz', **out)
 
 
+def gen_voxelizer():
+    """The reference's OWN voxeliser (datasets/MVSEC/utils.py:215-281), extracted from the file by name (the module itself
+    cannot be imported: cv2 / h5py / skimage are absent) and run on synthetic event streams; pins oracle/np_voxelize.py."""
+    import ast
+    from oracle import np_voxelize as nv
+    src = open('/root/reference/datasets/MVSEC/utils.py').read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'mvsecCumulateSpikesIntoFrames'][0]
+    ns = dict(np=np, tqdm=lambda it: it, LIDAR_FPS=20, print=lambda *a, **k: None)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'utils.py', 'exec'), ns)
+    ref_fn = ns['mvsecCumulateSpikesIntoFrames']
+    rng = np.random.default_rng(77)
+    out = {}
+    for ci, (n_chunks, nfpdm, E) in enumerate([(3, 1, 4000), (2, 5, 6000), (2, 25, 5000), (4, 2, 3000)]):
+        dur = n_chunks * 0.05
+        t = np.sort(rng.uniform(1000.0, 1000.0 + dur * 1.1, E))
+        ev = np.stack([rng.uniform(0, 345.99, E), rng.uniform(0, 259.99, E), t, rng.integers(0, 2, E).astype(np.float64)], 1)
+        ev[: E // 50, 3] = -1.0                               # MVSEC stores OFF as -1 in some files: "else" branch
+        # events exactly on frame boundaries (dropped by the strict inequalities)
+        st, en = nv.frame_bounds(n_chunks, nfpdm)
+        ev[10:10 + min(len(st), 20), 2] = ev[0, 2] + st[:20]
+        ev = ev[np.argsort(ev[:, 2], kind='stable')]
+        depth = np.zeros((n_chunks, 260, 346)); ts = ev[0, 2] + 0.05 * (1 + np.arange(n_chunks))
+        frames_ref, _ = ref_fn(ev.copy(), depth, ts.copy(), num_frames_per_depth_map=nfpdm)
+        mine = nv.cumulate_spikes_into_frames(ev, n_chunks, nfpdm)
+        assert np.array_equal(frames_ref, mine), 'oracle voxeliser != reference'
+        out[f'v{ci}_events'] = ev
+        out[f'v{ci}_cfg'] = np.array([n_chunks, nfpdm])
+        out[f'v{ci}_frames'] = frames_ref.astype(np.uint16)
+    out['n_cases'] = np.array(4)
+    save('voxelizer.npz', **out)
+
+
 def main():
     torch.set_num_threads(8)
+    gen_voxelizer()
     ref = load_reference()
     S, A = ref['SNN_models'], ref['ANN_models']
     gen_neuron_kat()

@@ -347,3 +347,29 @@ def test_x16_kernels_vs_numpy_oracle(dt, kind, T, N):
     assert bit_equal(gvi, rb['g_v_init'])
     if kind == 'PLIF':
         assert abs(float(gk) - rb['g_k']) <= 1e-5 * abs(rb['g_k']) + 2e-7 * T * N
+
+
+def test_voxelizer_vs_reference_fixture_and_oracle():
+    """HIP voxeliser == the reference's own output (fixture) bit for bit (integer counts), and == the numpy oracle on a
+    large random stream with colliding pixels and out-of-range coordinates."""
+    from oracle import np_voxelize as nv
+    from _util import load_npz
+    from stereospike_amd.data import mvsecCumulateSpikesIntoFrames
+    z = load_npz('voxelizer.npz')
+    for ci in range(int(z['n_cases'])):
+        n_chunks, nfpdm = (int(v) for v in z[f'v{ci}_cfg'])
+        ev = torch.tensor(z[f'v{ci}_events'], dtype=torch.float64, device=DEV)
+        fr = mvsecCumulateSpikesIntoFrames(ev, n_chunks, nfpdm)
+        assert fr.dtype == torch.float32 and tuple(fr.shape) == (n_chunks, nfpdm, 2, 260, 346)
+        assert np.array_equal(fr.cpu().numpy(), z[f'v{ci}_frames'].astype(np.float32))
+    rng = np.random.default_rng(5)
+    E = 2_000_000
+    t = np.sort(rng.uniform(5.0, 5.0 + 0.26, E))
+    ev = np.stack([rng.uniform(-2, 348, E), rng.uniform(-2, 262, E), t, rng.choice([1.0, 0.0, -1.0], E)], 1)
+    ev[:, :2] = np.where(rng.random((E, 2)) < 0.3, np.floor(ev[:, :2] / 8) * 8, ev[:, :2])     # many collisions
+    ref = nv.cumulate_spikes_into_frames(ev, 5, 5)
+    got = mvsecCumulateSpikesIntoFrames(torch.tensor(ev, device=DEV), 5, 5)
+    assert np.array_equal(got.cpu().numpy(), ref.astype(np.float32))
+    assert ref.max() > 3
+    empty = mvsecCumulateSpikesIntoFrames(torch.zeros(1, 4, dtype=torch.float64, device=DEV), 2, 1)
+    assert float(empty.sum()) == 0

@@ -225,3 +225,15 @@ def test_c_oracle_under_address_and_ub_sanitizers():
     subprocess.check_call(['make', '-s', '-C', root, '_build/ss_oracle_asan_check'])
     out = subprocess.run([os.path.join(root, '_build', 'ss_oracle_asan_check')], capture_output=True, text=True)
     assert out.returncode == 0 and 'rc=0' in out.stdout, out.stdout + out.stderr
+
+
+def test_voxelizer_oracle_vs_reference_fixture():
+    """oracle/np_voxelize.py == what the reference's own mvsecCumulateSpikesIntoFrames produced (tests/golden/voxelizer.npz),
+    including events sitting exactly on frame boundaries and the -1 polarity encoding."""
+    from oracle import np_voxelize as nv
+    z = load_npz('voxelizer.npz')
+    for ci in range(int(z['n_cases'])):
+        n_chunks, nfpdm = (int(v) for v in z[f'v{ci}_cfg'])
+        fr = nv.cumulate_spikes_into_frames(z[f'v{ci}_events'], n_chunks, nfpdm)
+        assert np.array_equal(fr, z[f'v{ci}_frames'].astype(np.float64))
+        assert fr.sum() > 0
