@@ -199,6 +199,29 @@ int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, c
 int ss_voxelize_f64(const double* events, long long E, const double* start, const double* end, int G,
                     unsigned int* counts, int H, int W, void* stream);
 
+/*
+ * Fused per-scale loss statistics — the step AFTER the path: /root/reference/network/loss.py:7-24
+ * (ScaleInvariant_Loss), :44-75 (GradientMatching_Loss) and network/metrics.py:83-95 (MeanDepthError) for ONE prediction
+ * map against the ground truth, batch-wide exactly as the reference (mask, n and the sums run over the whole [B,1,H,W] batch).
+ * With r = (gt is NaN) ? 0 : pred - gt  and Sobel cross-correlations with zero padding 1 (loss.py:61-69):
+ *   sums[0] = n  = #valid pixels         sums[1] = sum r          sums[2] = sum r^2
+ *   sums[3] = sum over valid pixels of |sobelX * r| + |sobelY * r|          sums[4] = sum |r|
+ * so that  ScaleInvariant = sums[2]/n - (sums[1]/n)^2,  GradientMatching = sums[3]/n,  MDE = sums[4]/n.
+ * Accumulation: fp32 per lane -> wavefront -> workgroup partial in fp64 (ws, ss_loss_ws_doubles() doubles) -> fixed-order
+ * fp64 second pass => deterministic.  sums are float64[5] in device memory.
+ */
+long long ss_loss_ws_doubles(void);
+int ss_loss_stats_f32(const float* pred, const float* gt, double* sums, double* ws, long long B, int H, int W, void* stream);
+
+/*
+ * Gradient of   c_si * ScaleInvariant + c_gm * GradientMatching   w.r.t. pred, with (c_si, c_gm) = coef[0], coef[1] read from
+ * DEVICE memory (they are the upstream gradients of the two terms — scale weight, alpha and d loss already folded in — and live on
+ * the device, so no host synchronisation is needed between loss.backward() and this launch):  g_pred = valid ? c_si*(2 r/n - 2 sums[1]/n^2) + (c_gm/n) * (sobelX^T[sgn(gx) m] + sobelY^T[sgn(gy) m]) : 0
+ * where m is the valid mask and sgn(0) = 0 (torch.abs backward).  sums are the forward's.
+ */
+int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, const float* coef, float* g_pred,
+                     long long B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,11 @@ def lib():
     L.ss_neuron_bwd_x16.restype = i32
     L.ss_voxelize_f64.argtypes = [p, i64, p, p, i32, p, i32, i32, p]
     L.ss_voxelize_f64.restype = i32
+    L.ss_loss_ws_doubles.restype = i64
+    L.ss_loss_stats_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
+    L.ss_loss_grad_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
+    L.ss_loss_stats_f32.restype = i32
+    L.ss_loss_grad_f32.restype = i32
     L.ss_upconv_cl_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_cl_bwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
@@ -60,7 +65,8 @@ def lib():
 
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
-           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64')
+           'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -235,6 +241,32 @@ def voxelize(events, start, end, counts, H, W):
         rc = lib().ss_voxelize_f64(_ptr(events, 'events', E * 4), E, _ptr(start, 'start'), _ptr(end, 'end', G), G,
                                    _ptr(counts, 'counts', G * 2 * H * W), H, W, _stream(events))
     _check(rc, 'ss_voxelize_f64')
+
+
+def loss_ws_doubles():
+    return int(lib().ss_loss_ws_doubles())
+
+
+def _f64(t, name, numel=None):
+    if t.dtype != torch.float64:
+        raise SSNeuronError(f'{name}: expected float64, got {t.dtype}')
+    return _ptr(t, name, numel)
+
+
+def loss_stats(pred, gt, sums, ws, B, H, W):
+    _require_hip(pred, 'pred')
+    with torch.cuda.device(pred.device):
+        rc = lib().ss_loss_stats_f32(_f32(pred, 'pred', B * H * W), _f32(gt, 'gt', B * H * W), _f64(sums, 'sums', 5),
+                                     _f64(ws, 'ws'), B, H, W, _stream(pred))
+    _check(rc, 'ss_loss_stats_f32')
+
+
+def loss_grad(pred, gt, sums, coef, g_pred, B, H, W):
+    _require_hip(pred, 'pred')
+    with torch.cuda.device(pred.device):
+        rc = lib().ss_loss_grad_f32(_f32(pred, 'pred', B * H * W), _f32(gt, 'gt', B * H * W), _f64(sums, 'sums', 5),
+                                    _f32(coef, 'coef', 2), _f32(g_pred, 'g_pred', B * H * W), B, H, W, _stream(pred))
+    _check(rc, 'ss_loss_grad_f32')
 
 
 def gk_ws_floats():

@@ -822,6 +822,132 @@ __global__ __launch_bounds__(kBlock) void voxelize_kernel(const double* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// fused loss statistics / gradient (network/loss.py:7-24,44-75; network/metrics.py:83-95)
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLossT = 16;                        // 16 x 16 output pixels per workgroup (256 lanes)
+constexpr int kLossMaxGrid = 65535;
+
+__device__ __forceinline__ float residual_at(const float* __restrict__ pred, const float* __restrict__ gt, int y, int x, int H, int W)
+{
+    if (y < 0 || y >= H || x < 0 || x >= W) return 0.f;               // zero padding of F.conv2d(..., padding=1)
+    const float g = gt[y * W + x];
+    return (g != g) ? 0.f : pred[y * W + x] - g;                        // NaN ground truth = invalid pixel -> residual 0
+}
+
+__global__ __launch_bounds__(256) void loss_stats_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         double* __restrict__ partials, int H, int W, int tiles_x, int tiles_per_img)
+{
+    __shared__ float r[kLossT + 2][kLossT + 2];
+    __shared__ float red[5][4];
+    const int tile = blockIdx.x % tiles_per_img, img = blockIdx.x / tiles_per_img;
+    const int y0 = (tile / tiles_x) * kLossT, x0 = (tile % tiles_x) * kLossT;
+    const float* p = pred + (long long)img * H * W;
+    const float* g = gt + (long long)img * H * W;
+    for (int i = threadIdx.x; i < (kLossT + 2) * (kLossT + 2); i += 256) {
+        const int ty = i / (kLossT + 2), tx = i % (kLossT + 2);
+        r[ty][tx] = residual_at(p, g, y0 + ty - 1, x0 + tx - 1, H, W);
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / kLossT, tx = threadIdx.x % kLossT;
+    const int y = y0 + ty, x = x0 + tx;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (y < H && x < W) {
+        const float gv = g[y * W + x];
+        if (gv == gv) {
+            const float rc = r[ty + 1][tx + 1];
+            // sobelX = [[1,0,-1],[2,0,-2],[1,0,-1]], sobelY = [[1,2,1],[0,0,0],[-1,-2,-1]]  (cross-correlation)
+            const float gx = (r[ty][tx] - r[ty][tx + 2]) + 2.f * (r[ty + 1][tx] - r[ty + 1][tx + 2]) + (r[ty + 2][tx] - r[ty + 2][tx + 2]);
+            const float gy = (r[ty][tx] + 2.f * r[ty][tx + 1] + r[ty][tx + 2]) - (r[ty + 2][tx] + 2.f * r[ty + 2][tx + 1] + r[ty + 2][tx + 2]);
+            v[0] = 1.f; v[1] = rc; v[2] = rc * rc; v[3] = fabsf(gx) + fabsf(gy); v[4] = fabsf(rc);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { const float w = wave_sum_f32(v[q]); if (lane == 0) red[q][wave] = w; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int q = threadIdx.x;
+        partials[(long long)blockIdx.x * 5 + q] = (double)red[q][0] + (double)red[q][1] + (double)red[q][2] + (double)red[q][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_finish_kernel(const double* __restrict__ partials, long long n, double* __restrict__ sums)
+{
+    __shared__ double s[5][256];
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (long long i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q] += partials[i * 5 + q];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) s[q][threadIdx.x] += s[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) sums[threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                        const double* __restrict__ sums, const float* __restrict__ coef,
+                                                        float* __restrict__ g_pred, int H, int W, int tiles_x, int tiles_per_img)
+{
+    __shared__ float r[kLossT + 4][kLossT + 4];          // residual, halo 2
+    __shared__ float sx[kLossT + 2][kLossT + 2];         // sgn(gx) * mask, halo 1
+    __shared__ float sy[kLossT + 2][kLossT + 2];
+    const int tile = blockIdx.x % tiles_per_img, img = blockIdx.x / tiles_per_img;
+    const int y0 = (tile / tiles_x) * kLossT, x0 = (tile % tiles_x) * kLossT;
+    const float* p = pred + (long long)img * H * W;
+    const float* g = gt + (long long)img * H * W;
+    for (int i = threadIdx.x; i < (kLossT + 4) * (kLossT + 4); i += 256) {
+        const int ty = i / (kLossT + 4), tx = i % (kLossT + 4);
+        r[ty][tx] = residual_at(p, g, y0 + ty - 2, x0 + tx - 2, H, W);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (kLossT + 2) * (kLossT + 2); i += 256) {
+        const int ty = i / (kLossT + 2), tx = i % (kLossT + 2);
+        const int y = y0 + ty - 1, x = x0 + tx - 1;
+        float vx = 0.f, vy = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float gv = g[y * W + x];
+            if (gv == gv) {
+                const int a = ty, b = tx;                // r index of (y-1, x-1) is [ty][tx]
+                const float gx = (r[a][b] - r[a][b + 2]) + 2.f * (r[a + 1][b] - r[a + 1][b + 2]) + (r[a + 2][b] - r[a + 2][b + 2]);
+                const float gy = (r[a][b] + 2.f * r[a][b + 1] + r[a][b + 2]) - (r[a + 2][b] + 2.f * r[a + 2][b + 1] + r[a + 2][b + 2]);
+                vx = (gx > 0.f) ? 1.f : (gx < 0.f ? -1.f : 0.f);
+                vy = (gy > 0.f) ? 1.f : (gy < 0.f ? -1.f : 0.f);
+            }
+        }
+        sx[ty][tx] = vx; sy[ty][tx] = vy;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / kLossT, tx = threadIdx.x % kLossT;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < H && x < W) {
+        const float gv = g[y * W + x];
+        float out = 0.f;
+        if (gv == gv) {
+            const float n = (float)sums[0], s1 = (float)sums[1], c_si = coef[0], c_gm = coef[1];
+            const float rc = r[ty + 2][tx + 2];
+            // adjoint of the cross-correlation: T(p) = sum_{p'} s(p') K[p - p'],  p' = p - d  =>  K[d] with d in [-1,1]^2
+            // sobelX[dy+1][dx+1] = {1,2,1}[dy+1] * {1,0,-1}[dx+1];  sobelY[dy+1][dx+1] = {1,0,-1}[dy+1] * {1,2,1}[dx+1]
+            const int a = ty + 1, b = tx + 1;            // s index of p
+            float T = 0.f;
+            // p' = p - d: d = (dy,dx);  sx[a - dy][b - dx] * sobelX[dy+1][dx+1]
+            T += sx[a + 1][b + 1] * 1.f + sx[a + 1][b - 1] * -1.f;      // dy = -1: row weight 1, dx = -1 -> +1, dx = +1 -> -1
+            T += sx[a][b + 1] * 2.f + sx[a][b - 1] * -2.f;              // dy = 0
+            T += sx[a - 1][b + 1] * 1.f + sx[a - 1][b - 1] * -1.f;      // dy = +1
+            T += sy[a + 1][b + 1] * 1.f + sy[a + 1][b] * 2.f + sy[a + 1][b - 1] * 1.f;      // dy = -1: +{1,2,1}
+            T += -(sy[a - 1][b + 1] * 1.f + sy[a - 1][b] * 2.f + sy[a - 1][b - 1] * 1.f);   // dy = +1: -{1,2,1}
+            out = c_si * (2.f * rc / n - 2.f * s1 / (n * n)) + (c_gm / n) * T;
+        }
+        g_pred[(long long)img * H * W + y * W + x] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------
 inline int grid_for(long long work_items, int cap = kMaxGrid)
@@ -1167,6 +1293,32 @@ int ss_voxelize_f64(const double* events, long long E, const double* start, cons
     if (hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)G * 2 * H * W, s) != hipSuccess) return SS_ELAUNCH;
     if (E == 0) return SS_OK;
     hipLaunchKernelGGL(voxelize_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, events, E, start, end, G, counts, H, W);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+long long ss_loss_ws_doubles(void) { return (long long)kLossMaxGrid * 5; }
+
+int ss_loss_stats_f32(const float* pred, const float* gt, double* sums, double* ws, long long B, int H, int W, void* stream)
+{
+    if (!pred || !gt || !sums || !ws || B <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    const int tx = (W + kLossT - 1) / kLossT, ty = (H + kLossT - 1) / kLossT;
+    const long long blocks = B * tx * ty;
+    if (blocks > kLossMaxGrid || (long long)H * W > 0x7fffffffLL) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(loss_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred, gt, ws, H, W, tx, tx * ty);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, ws, blocks, sums);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, const float* coef, float* g_pred,
+                     long long B, int H, int W, void* stream)
+{
+    if (!pred || !gt || !sums || !coef || !g_pred || B <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    const int tx = (W + kLossT - 1) / kLossT, ty = (H + kLossT - 1) / kLossT;
+    const long long blocks = B * tx * ty;
+    if (blocks > 0x7fffffffLL || (long long)H * W > 0x7fffffffLL) return SS_EINVAL;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pred, gt, sums,
+                       coef, g_pred, H, W, tx, tx * ty);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -181,6 +181,54 @@ def ipool(pd_seq: torch.Tensor, scale: float, v_reset: float, v_init: Optional[t
 
 
 # ----------------------------------------------------------------------------------------------------------
+# per-scale loss terms (the step after the path: SURVEY.md §8(f) rank 4)
+# ----------------------------------------------------------------------------------------------------------
+_fwd32 = torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: inputs -> fp32, autocast off inside
+_bwd32 = torch.amp.custom_bwd(device_type='cuda')
+
+
+
+class _ScaleLossTerms(torch.autograd.Function):
+    """pred, gt [B,1,H,W] -> fp32 [3] = (ScaleInvariant, GradientMatching, MeanDepthError) of the batch, from one statistics launch
+    (+ a fixed-order fp64 second pass); backward = one stencil launch.  /root/reference/network/loss.py:7-24, :44-75;
+    network/metrics.py:83-95.  Nothing but pred / gt is kept for backward (the 5 sums are recomputed into the gradient)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, pred, gt):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        H, W = pred.shape[-2:]
+        B = pred.numel() // (H * W)
+        ws = torch.empty(_lib.loss_ws_doubles(), dtype=torch.float64, device=pred.device)   # 2.6 MB from the stream-aware caching allocator
+        sums = torch.empty(5, dtype=torch.float64, device=pred.device)
+        _lib.loss_stats(pred, gt, sums, ws, B, H, W)
+        n = sums[0]
+        mean = sums[1:] / n                                   # E r, E r^2, E(|gx|+|gy|), E|r|   (fp64, 4 elements)
+        terms = torch.stack((mean[1] - mean[0] * mean[0], mean[2], mean[3])).float()
+        ctx.save_for_backward(pred, gt, sums)
+        ctx.dims = (B, H, W)
+        return terms
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, g_terms):
+        pred, gt, sums = ctx.saved_tensors
+        B, H, W = ctx.dims
+        coef = g_terms[:2].float().contiguous()               # d loss / d (SI, GM); the MDE term is a metric (no gradient)
+        g_pred = torch.empty_like(pred)
+        _lib.loss_grad(pred, gt, sums, coef, g_pred, B, H, W)
+        return g_pred, None
+
+
+def scale_loss_terms(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """fp32 [3]: ScaleInvariant_Loss(pred, gt), GradientMatching_Loss(pred, gt), MeanDepthError(pred, gt) — differentiable w.r.t.
+    pred through the first two."""
+    if pred.shape != gt.shape:
+        raise ValueError(f'pred {tuple(pred.shape)} and gt {tuple(gt.shape)} must have the same shape')
+    return _ScaleLossTerms.apply(pred, gt)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # predict_depth head synapse without the materialised up-sampled tensor
 # ----------------------------------------------------------------------------------------------------------
 def nearest_tables(in_size: int, out_size: int):
@@ -204,10 +252,6 @@ def nearest_tables(in_size: int, out_size: int):
 #               measured on MI355X, profiles/r01/upconv_variants.log)
 PROJECTION_IMPL = 'auto'
 P_CHUNK_BYTES = 96 << 20          # per-chunk size of P: comfortably inside the 256 MiB MALL next to x / out / g_out
-
-
-_fwd32 = torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)   # under autocast: inputs -> fp32, autocast off inside
-_bwd32 = torch.amp.custom_bwd(device_type='cuda')
 
 
 class _UpConv1(torch.autograd.Function):

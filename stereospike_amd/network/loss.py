@@ -74,6 +74,34 @@ def SpikePenalization_Loss(intermediary_spike_tensors):
     return total
 
 
+# On the MI355X the two terms of every scale come from one statistics kernel (+ one stencil kernel backward) instead of ~25
+# element-wise / reduction / convolution launches per scale; the functions above stay as the definition (and the CPU form).
+FUSED_LOSS = True
+
+
+def _on_device(t):
+    return t.is_cuda
+
+
+def _fusable(pred, gt):
+    return FUSED_LOSS and _on_device(pred) and pred.dim() == 4 and pred.shape[1] == 1 and pred.shape == gt.shape \
+        and pred.dtype == torch.float32 and gt.dtype == torch.float32
+
+
+def multiscale_terms(predicted, groundtruth, factors=(1., 1., 1., 1.)):
+    """(sum_k f_k ScaleInvariant_k, sum_k f_k GradientMatching_k, MeanDepthError of predicted[0] — the final depth map, the one
+    train.py:236 / test.py score) through the fused kernels."""
+    from .. import fused
+    si = gm = 0.0
+    mde = None
+    for factor, pred in zip(factors, predicted):
+        terms = fused.scale_loss_terms(pred, _rescale(groundtruth, pred).expand_as(pred))
+        si, gm = si + factor * terms[0], gm + factor * terms[1]
+        if mde is None:
+            mde = terms[2].detach()
+    return si, gm, mde
+
+
 class Total_Loss(nn.Module):
     """alpha = 0.5 for linear (metric) depth; scale_weights all 1; beta weighs the spike penalisation."""
 
@@ -85,6 +113,12 @@ class Total_Loss(nn.Module):
         self.beta = beta
 
     def forward(self, predicted, groundtruth, intermediary_spike_tensors=None):
+        if all(_fusable(p, _rescale(groundtruth, p)) for p in predicted):
+            si, gm, _ = multiscale_terms(predicted, groundtruth, self.scale_weights)
+            loss = si + self.alpha * gm
+            if self.penalize_spikes:
+                loss = loss + self.beta * SpikePenalization_Loss(intermediary_spike_tensors)
+            return loss
         loss = Multiscale_ScaleInvariant_Loss(predicted, groundtruth, self.scale_weights) + \
             self.alpha * MultiScale_GradientMatching_Loss(predicted, groundtruth, self.scale_weights)
         if self.penalize_spikes:

@@ -42,7 +42,12 @@ def log_to_lin_depths(depths_rect_log, Dmax=10, alpha=6.):
 
 def MeanDepthError(predicted, groundtruth):
     """Mean absolute depth error over the valid pixels (metres).  Invalid residuals are zeroed, so the sum over
-    the whole map equals the reference's sum over res[mask] without a data-dependent gather (no host sync)."""
+    the whole map equals the reference's sum over res[mask] without a data-dependent gather (no host sync).  On the MI355X
+    the sum comes from the fused statistics kernel (ss_loss_stats_f32)."""
+    from . import loss as _loss
+    if _loss._fusable(predicted, groundtruth):
+        from .. import fused
+        return fused.scale_loss_terms(predicted.detach(), groundtruth)[2]
     mask, n = _valid(groundtruth)
     res = torch.where(mask, predicted - groundtruth, torch.zeros((), dtype=predicted.dtype, device=predicted.device))
     return torch.sum(torch.abs(res)) / n

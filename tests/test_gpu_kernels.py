@@ -373,3 +373,81 @@ def test_voxelizer_vs_reference_fixture_and_oracle():
     assert ref.max() > 3
     empty = mvsecCumulateSpikesIntoFrames(torch.zeros(1, 4, dtype=torch.float64, device=DEV), 2, 1)
     assert float(empty.sum()) == 0
+
+
+def _loss_case(rng, B, H, W, nan_frac, scale=3.0):
+    pred = (rng.standard_normal((B, 1, H, W)) * scale).astype(np.float32)
+    gt = (rng.standard_normal((B, 1, H, W)) * scale + 5).astype(np.float32)
+    gt[rng.random(gt.shape) < nan_frac] = np.nan
+    if nan_frac >= 1.0:
+        gt[0, 0, H // 2, W // 2] = 1.0                    # one valid pixel: n = 1
+    return pred, gt
+
+
+@pytest.mark.parametrize('B,H,W,nan_frac', [(1, 1, 1, 0.0), (2, 15, 17, 0.3), (3, 33, 47, 0.5), (1, 16, 16, 0.0), (2, 48, 64, 1.0),
+                                            (1, 260, 346, 0.6), (16, 260, 346, 0.45)])
+def test_loss_statistics_and_gradient_kernels_vs_oracle(B, H, W, nan_frac):
+    """ss_loss_stats_f32: the 5 batch-wide sums within 1e-6 relative of the oracle's fp64 sums (fp32 wavefront partials, fp64 above);
+    ss_loss_grad_f32: BIT-EXACT against the oracle's fp32 formula given the same sums (the Sobel adjoint is small-integer exact)."""
+    from oracle import np_loss
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(B * 1000 + H)
+    pred, gt = _loss_case(rng, B, H, W, nan_frac)
+    pd, gd = torch.tensor(pred, device=DEV), torch.tensor(gt, device=DEV)
+    sums = torch.empty(5, dtype=torch.float64, device=DEV)
+    ws = torch.empty(_lib.loss_ws_doubles(), dtype=torch.float64, device=DEV)
+    _lib.loss_stats(pd, gd, sums, ws, B, H, W)
+    got = sums.cpu().numpy()
+    ref = np_loss.loss_stats(pred, gt)
+    assert got[0] == ref[0]
+    assert abs(got[1] - ref[1]) <= 1e-6 * ref[4] and abs(got[4] - ref[4]) <= 1e-6 * ref[4]
+    assert abs(got[2] - ref[2]) <= 1e-6 * ref[2] and abs(got[3] - ref[3]) <= 1e-6 * ref[3] + 1e-12
+    sums2 = torch.empty_like(sums)
+    _lib.loss_stats(pd, gd, sums2, ws, B, H, W)
+    assert torch.equal(sums, sums2)                       # deterministic (fixed-order reduction)
+    coef = torch.tensor([0.7, 0.35], dtype=torch.float32, device=DEV)
+    g = torch.full_like(pd, float('nan'))
+    _lib.loss_grad(pd, gd, sums, coef, g, B, H, W)
+    want = np_loss.loss_grad(pred, gt, got, coef.cpu().numpy())
+    assert bit_equal(g.cpu().numpy(), want)
+
+
+def test_fused_total_loss_vs_reference_fixture_and_unfused_form():
+    """Total_Loss on the device (fused kernels) against the reference's own loss value / MDE / d loss / d pred (fixture), and against the
+    torch-composed form of the same module (FUSED_LOSS = False) on a full-size batch."""
+    from _util import load_npz
+    from stereospike_amd.network import loss as L
+    from stereospike_amd import fused
+    z = load_npz('loss_metric.npz')
+    for ci in range(int(z['n_cases'])):
+        preds = [torch.tensor(z[f'l{ci}_pred{i}'], device=DEV, requires_grad=True) for i in range(4)]
+        gt = torch.tensor(z[f'l{ci}_gt'], device=DEV)
+        spikes = [torch.tensor(z[f'l{ci}_spk{i}'].astype(np.float32), device=DEV) for i in range(5)]
+        for pen in (False, True):
+            tag = 'pen' if pen else 'nopen'
+            loss = L.Total_Loss(penalize_spikes=pen, beta=0.5)(preds, gt, spikes)
+            ref = float(z[f'l{ci}_{tag}_loss'])
+            assert abs(float(loss) - ref) <= 2e-6 * abs(ref), (ci, pen)
+            grads = torch.autograd.grad(loss, preds)
+            for i, g in enumerate(grads):
+                want = z[f'l{ci}_{tag}_gpred{i}']
+                if want.ndim:
+                    assert float(np.abs(g.cpu().numpy() - want).max()) <= 1e-6 * float(np.abs(want).max()) + 1e-9
+        mde = fused.scale_loss_terms(preds[0].detach(), gt)[2]
+        assert abs(float(mde) - float(z[f'l{ci}_mde'])) <= 2e-6 * float(z[f'l{ci}_mde'])
+    rng = np.random.default_rng(3)
+    B, H, W = 16, 260, 346
+    gt = torch.tensor(_loss_case(rng, B, H, W, 0.45)[1], device=DEV)
+    preds = [torch.tensor(_loss_case(rng, B, H, W, 0.0)[0] + 5, device=DEV, requires_grad=True) for _ in range(4)]
+    out = {}
+    for fusedflag in (True, False):
+        L.FUSED_LOSS = fusedflag
+        try:
+            loss = L.Total_Loss(scale_weights=(1., 0.5, 0.25, 2.))(preds, gt)
+            out[fusedflag] = (float(loss), [g.clone() for g in torch.autograd.grad(loss, preds)])
+        finally:
+            L.FUSED_LOSS = True
+    assert abs(out[True][0] - out[False][0]) <= 2e-6 * abs(out[False][0])
+    for a, b in zip(out[True][1], out[False][1]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+        assert torch.equal(a == 0, b == 0) or float(((a == 0) != (b == 0)).float().mean()) < 1e-6

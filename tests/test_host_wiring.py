@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from _util import c_oracle, ref_network as rn, sj, synth_input, synth_label
+from oracle import np_loss
 
 
 def _p(t):
@@ -61,6 +62,18 @@ def host_backend(monkeypatch):
         assert L.ss_ref_upconv_cl_bwd_f32(_p(g_out), _p(y_lo), _p(y_hi), _p(x_lo), _p(x_hi), _p(g_P), NB, k, C, h, w, H,
                                           W) == 0
 
+    def loss_stats(pred, gt, sums, ws, B, H, W):
+        sums.copy_(torch.from_numpy(np_loss.loss_stats(pred.numpy().reshape(B, H, W), gt.numpy().reshape(B, H, W))))
+
+    def loss_grad(pred, gt, sums, coef, g_pred, B, H, W):
+        g = np_loss.loss_grad(pred.numpy().reshape(B, H, W), gt.numpy().reshape(B, H, W), sums.numpy(), coef.numpy())
+        g_pred.copy_(torch.from_numpy(g).view_as(g_pred))
+
+    from stereospike_amd.network import loss as loss_mod
+    monkeypatch.setattr(_lib, 'loss_stats', loss_stats)
+    monkeypatch.setattr(_lib, 'loss_grad', loss_grad)
+    monkeypatch.setattr(_lib, 'loss_ws_doubles', lambda: 1)
+    monkeypatch.setattr(loss_mod, '_on_device', lambda t: True)        # CPU tensors reach the (patched) fused-loss entry points
     monkeypatch.setattr(_lib, 'upconv_cl_fwd', upconv_cl_fwd)
     monkeypatch.setattr(_lib, 'upconv_cl_bwd', upconv_cl_bwd)
     monkeypatch.setattr(_lib, 'upconv1_fwd', upconv1_fwd)

@@ -188,6 +188,31 @@ def test_loss_and_mde_restatement_vs_pure_reference_fixture():
         assert float(rn.mean_depth_error(preds[0].detach(), gt)) == float(z[f'l{ci}_mde'])
 
 
+def test_loss_statistics_restatement_vs_pure_reference_fixture():
+    """oracle/np_loss.py (the checker of ss_loss_stats_f32 / ss_loss_grad_f32) against the reference's own loss values, MDE and
+    d loss / d pred stored in tests/golden/loss_metric.npz (generated by the reference's network/loss.py, network/metrics.py)."""
+    from oracle import np_loss
+    z = load_npz('loss_metric.npz')
+    for ci in range(int(z['n_cases'])):
+        gt = z[f'l{ci}_gt']
+        total, stats = 0.0, []
+        for i in range(4):
+            s = np_loss.loss_stats(z[f'l{ci}_pred{i}'], gt)
+            stats.append(s)
+            n = s[0]
+            total += (s[2] / n - (s[1] / n) ** 2) + 0.5 * s[3] / n
+        ref = float(z[f'l{ci}_nopen_loss'])
+        assert abs(total - ref) <= 2e-6 * abs(ref), (ci, total, ref)
+        assert abs(stats[0][4] / stats[0][0] - float(z[f'l{ci}_mde'])) <= 2e-6 * float(z[f'l{ci}_mde'])
+        for i in range(4):
+            want = z[f'l{ci}_nopen_gpred{i}']
+            if want.ndim == 0:
+                continue                                     # the full-size case stores no gradient maps
+            got = np_loss.loss_grad(z[f'l{ci}_pred{i}'], gt, stats[i], (1.0, 0.5))
+            assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max() + 1e-9, (ci, i)
+            assert np.array_equal(got == 0, want == 0)       # zero exactly at the invalid pixels
+
+
 @pytest.mark.parametrize('dtype', ['f16', 'bf16'])
 @pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
 def test_x16_numpy_oracle_equals_c_oracle_on_widened_inputs(dtype, kind):
