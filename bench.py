@@ -56,6 +56,8 @@ def parse():
                     help='validation aid for a 1-GPU box: build the RCCL process group and the gradient reducer even with one rank')
     ap.add_argument('--decoder-nhwc', type=int, default=1, help='1: decoder kept in NHWC memory (one GEMM per stage)')
     ap.add_argument('--encoder-nhwc', type=int, default=1, help='1: encoder/bottleneck activations in NHWC as well')
+    ap.add_argument('--recompute-h', type=int, default=1,
+                    help='1 (default): neuron backward recomputes h from the layer input (forward writes 8 B/update); 0: forward saves h_seq')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
     return ap.parse_args()
@@ -140,6 +142,8 @@ def main():
 
     from stereospike_amd.network import blocks as _blocks
     _blocks.FUSE_UPCONV = bool(a.fuse_upconv)
+    from stereospike_amd import fused as _fused_cfg
+    _fused_cfg.RECOMPUTE_H = bool(a.recompute_h)
     _blocks.DECODER_CHANNELS_LAST = bool(a.decoder_nhwc)
     _blocks.ENCODER_CHANNELS_LAST = bool(a.encoder_nhwc)
     net = build_net(a.model, dev)
@@ -205,6 +209,11 @@ def main():
                         launches=d['launches'], avg_launch_us=round(1e3 * d['ms'] / max(1, d['launches']), 2),
                         bytes_per_launch=int(d['bytes'] / max(1, d['launches'])))
         from stereospike_amd.network.metrics import MeanDepthError
+        from stereospike_amd import fused as _fused
+
+        def bpu(d):
+            return round(d['bytes'] / d['updates'], 1) if d['updates'] else 0
+        recompute_h = bool(_fused.RECOMPUTE_H)
         out = {
             'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -215,11 +224,12 @@ def main():
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
                        'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': 'default init, seed 2021, multiply_factor 10',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
-            'roofline': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, fp32, '
-                                    f'12 B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
+            'roofline': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
+                                    f'{bpu(fwd)} B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
                              **roof(fwd)),
-            'roofline_bwd': dict(kernel='neuron_bwd_kernel (fused surrogate backward over T, fp32, 12 B/update), '
-                                        'largest launch shape', **roof(bwd, 'neuron_bwd')),
+            'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
+                                        f'{", h recomputed from the layer input" if recompute_h else ""}), largest launch shape',
+                                 **roof(bwd, 'neuron_bwd')),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
                 ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
@@ -228,9 +238,9 @@ def main():
             # HIP-event averages over ALL launches of each kernel instantiation, for comparison with the AverageNs column of
             # the committed `rocprofv3 --kernel-trace --stats` CSV (profiles/): events add a few us per launch
             'rocprof_check_avg_us': {
-                'neuron_fwd_kernel<0, 5, false, true, 4>': round(1e3 * summ['neuron_fwd_train']['ms'] / summ['neuron_fwd_train']['launches'], 1)
+                'neuron_fwd_kernel<0, 5, false, %s, 4>' % ('false' if recompute_h else 'true'): round(1e3 * summ['neuron_fwd_train']['ms'] / summ['neuron_fwd_train']['launches'], 1)
                 if 'neuron_fwd_train' in summ else None,
-                'neuron_fwd_kernel<0, 5, true, true, 4>': round(1e3 * summ['neuron_fwd_train+skip']['ms'] / summ['neuron_fwd_train+skip']['launches'], 1)
+                'neuron_fwd_kernel<0, 5, true, %s, 4>' % ('false' if recompute_h else 'true'): round(1e3 * summ['neuron_fwd_train+skip']['ms'] / summ['neuron_fwd_train+skip']['launches'], 1)
                 if 'neuron_fwd_train+skip' in summ else None,
                 'neuron_bwd_kernel<*>': round(1e3 * summ['neuron_bwd']['ms'] / summ['neuron_bwd']['launches'], 1)
                 if 'neuron_bwd' in summ else None},

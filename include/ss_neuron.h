@@ -105,6 +105,21 @@ int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float
                       void* stream);
 
 /*
+ * The same backward WITHOUT the saved h_seq: h_t is recomputed inside the kernel from the layer input x_seq (the pointer given to
+ * ss_neuron_fwd_f32, unmodified since) and v_init with the forward kernel's exact arithmetic, all T values of a lane living in
+ * registers.  The forward is then called with h_seq = NULL and writes 4 B/update less (8 instead of 12); this launch reads x where
+ * the other reads h (12 B/update either way).  Results are bit-identical to ss_neuron_bwd_f32.  Only the compile-time time-step
+ * counts are supported: ss_neuron_bwd_rc_supported(T) != 0 (T in {1, 2, 4, 5, 8, 10}); otherwise SS_EINVAL — use the saved-h form.
+ */
+int ss_neuron_bwd_rc_supported(int T);
+int ss_neuron_bwd_rc_f32(const float* g_out_seq, const float* g_v_last, const float* x_seq, const float* v_init,
+                         float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                         int T, long long N,
+                         float scale, int kind, float tau, const float* k,
+                         float v_th, float v_reset, int surrogate, float alpha, int detach_reset,
+                         void* stream);
+
+/*
  * 16-bit activation I/O variants (BASELINE.json configs 2 and 5: bf16 / fp16 activations, fp32 membrane state).
  * x_seq, skip_seq, out_seq (and g_out_seq, g_x_seq) hold IEEE fp16 (dtype = SS_DT_F16) or bfloat16 (SS_DT_BF16) values;
  * every input is widened to fp32 on load, ALL arithmetic and the membrane (v_init, v_last, h_seq, g_v_*) stay fp32 exactly
@@ -122,6 +137,16 @@ int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float*
                       void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
                       int T, long long N, float scale, int kind, float tau, const float* k,
                       float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream);
+
+/* ss_neuron_bwd_rc_f32 for 16-bit activations: x_seq is the fp16 / bf16 layer input given to ss_neuron_fwd_x16 (called with
+ * h_seq = NULL: 4 B/update instead of 8); this launch moves 6 B/update instead of 8.  g_x / g_v_init bit-identical to
+ * ss_neuron_bwd_x16; dL/dk sums the same terms in another fp32 order (a lane owns 4 or 2 neurons here, 8 there). */
+int ss_neuron_bwd_rc_x16(const void* g_out_seq, const float* g_v_last, const void* x_seq, const float* v_init,
+                         void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                         int T, long long N,
+                         float scale, int kind, float tau, const float* k,
+                         float v_th, float v_reset, int surrogate, float alpha, int detach_reset,
+                         int dtype, void* stream);
 
 /*
  * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing

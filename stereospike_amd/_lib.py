@@ -37,6 +37,10 @@ def lib():
     L.ss_neuron_gk_ws_floats.restype = i64
     L.ss_neuron_fwd_f32.argtypes = [p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, p]
     L.ss_neuron_bwd_f32.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
+    L.ss_neuron_bwd_rc_f32.argtypes = L.ss_neuron_bwd_f32.argtypes
+    L.ss_neuron_bwd_rc_f32.restype = i32
+    L.ss_neuron_bwd_rc_supported.argtypes = [i32]
+    L.ss_neuron_bwd_rc_supported.restype = i32
     L.ss_ipool_fwd_f32.argtypes = [p, i64, i64, p, p, i32, i32, i64, f32, f32, p]
     L.ss_ipool_bwd_f32.argtypes = [p, p, p, i64, i64, p, i32, i32, i64, f32, p]
     L.ss_upconv1_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
@@ -45,6 +49,8 @@ def lib():
     L.ss_neuron_bwd_x16.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, i32, p]
     L.ss_neuron_fwd_x16.restype = i32
     L.ss_neuron_bwd_x16.restype = i32
+    L.ss_neuron_bwd_rc_x16.argtypes = L.ss_neuron_bwd_x16.argtypes
+    L.ss_neuron_bwd_rc_x16.restype = i32
     L.ss_voxelize_f64.argtypes = [p, i64, p, p, i32, p, i32, i32, p]
     L.ss_voxelize_f64.restype = i32
     L.ss_loss_ws_doubles.restype = i64
@@ -66,7 +72,7 @@ def lib():
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
-           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32')
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16')
 
 
 def _ptr(t, name, numel=None):
@@ -132,6 +138,24 @@ def neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_w
     _check(rc, 'ss_neuron_bwd_f32')
 
 
+def neuron_bwd_rc_supported(T):
+    return bool(lib().ss_neuron_bwd_rc_supported(int(T)))
+
+
+def neuron_bwd_rc(g_out_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                  v_th, v_reset, surrogate, alpha, detach_reset):
+    """Backward that recomputes h from the layer input (no saved h_seq); bit-identical to neuron_bwd."""
+    _require_hip(x_seq, 'x_seq')
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_bwd_rc_f32(_f32(g_out_seq, 'g_out_seq', T * N), _f32(g_v_last, 'g_v_last', N),
+                                        _f32(x_seq, 'x_seq', T * N), _f32(v_init, 'v_init', N),
+                                        _f32(g_x_seq, 'g_x_seq', T * N), _f32(g_v_init, 'g_v_init', N),
+                                        _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'),
+                                        T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
+                                        int(bool(detach_reset)), _stream(x_seq))
+    _check(rc, 'ss_neuron_bwd_rc_f32')
+
+
 DT_CODE = {torch.float16: 1, torch.bfloat16: 2}
 
 
@@ -169,6 +193,23 @@ def neuron_bwd_x16(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g
                                      _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha, int(bool(detach_reset)),
                                      DT_CODE[dt], _stream(h_seq))
     _check(rc, 'ss_neuron_bwd_x16')
+
+
+def neuron_bwd_rc_x16(g_out_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                      v_th, v_reset, surrogate, alpha, detach_reset):
+    """16-bit backward that recomputes h from the 16-bit layer input; bit-identical to neuron_bwd_x16."""
+    _require_hip(x_seq, 'x_seq')
+    dt = g_out_seq.dtype
+    if dt not in DT_CODE:
+        raise SSNeuronError(f'g_out_seq: expected float16 or bfloat16, got {dt}')
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_bwd_rc_x16(_x16(g_out_seq, 'g_out_seq', T * N, dt), _f32(g_v_last, 'g_v_last', N),
+                                        _x16(x_seq, 'x_seq', T * N, dt), _f32(v_init, 'v_init', N),
+                                        _x16(g_x_seq, 'g_x_seq', T * N, dt), _f32(g_v_init, 'g_v_init', N),
+                                        _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'), T, N, scale, kind, tau,
+                                        _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha, int(bool(detach_reset)),
+                                        DT_CODE[dt], _stream(x_seq))
+    _check(rc, 'ss_neuron_bwd_rc_x16')
 
 
 def ipool_fwd(pd_seq, stride_t, stride_k, v_init, depth_seq, T, K, M, scale, v_reset):

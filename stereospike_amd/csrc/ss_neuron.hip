@@ -230,9 +230,10 @@ struct BwdArgs {
     float* g_x_seq; float* g_v_init; float* g_k_partials;
     int T; long long N;
     float scale, tau, v_th, v_reset, alpha; const float* k; int detach_reset;
+    const float* x_seq;   // non-null (templated T only): h_seq is not read, h is recomputed from the layer input (ss_neuron_bwd_rc_f32)
 };
 
-template <int KIND, int SG, int TS, int VEC>
+template <int KIND, int SG, int TS, int VEC, bool RC = false>
 __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
         else { if constexpr (VEC == 4) gv = (f4){0.f, 0.f, 0.f, 0.f}; else gv = 0.f; }
         vec_t v0;   // membrane before step 0 (PLIF dL/dk only)
         if constexpr (VEC == 4) v0 = (f4){0.f, 0.f, 0.f, 0.f}; else v0 = 0.f;
-        if (want_gk) {
+        if (want_gk || RC) {
             if (a.v_init) v0 = reinterpret_cast<const vec_t*>(a.v_init)[i];
             else { if constexpr (VEC == 4) v0 = (f4){v_reset, v_reset, v_reset, v_reset}; else v0 = v_reset; }
         }
@@ -292,8 +293,30 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
 
         if constexpr (TS > 0) {
             vec_t gs[TS], hs[TS];
+            if constexpr (RC) {   // recompute h_t from the layer input with the forward kernel's exact arithmetic
+                const vec_t* xq = reinterpret_cast<const vec_t*>(a.x_seq) + i;
+                // issue order = consumption order: x ascending (forward recurrence), then g descending (reverse loop)
 #pragma unroll
-            for (int t = TS - 1; t >= 0; --t) { gs[t] = load_stream(gp + (long long)t * NV); hs[t] = load_stream(hp + (long long)t * NV); }
+                for (int t = 0; t < TS; ++t) hs[t] = load_stream(xq + (long long)t * NV);
+#pragma unroll
+                for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(gp + (long long)t * NV);
+                vec_t vv = v0;
+#pragma unroll
+                for (int t = 0; t < TS; ++t) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float x, v;
+                        if constexpr (VEC == 4) { x = hs[t][e]; v = vv[e]; } else { x = hs[t]; v = vv; }
+                        float h = charge<KIND>(v, x * scale, tau, k, v_reset);
+                        float z = heaviside(h - v_th);
+                        v = (1.f - z) * h + z * v_reset;
+                        if constexpr (VEC == 4) { hs[t][e] = h; vv[e] = v; } else { hs[t] = h; vv = v; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = TS - 1; t >= 0; --t) { gs[t] = load_stream(gp + (long long)t * NV); hs[t] = load_stream(hp + (long long)t * NV); }
+            }
 #pragma unroll
             for (int t = TS - 1; t >= 0; --t)
                 xp[(long long)t * NV] = step(gs[t], hs[t], hs[t > 0 ? t - 1 : 0], t == 0);
@@ -497,6 +520,110 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_kernel(Bwd16Args a)
                 for (int e = 0; e < 8; ++e) xv[e] = xb[e];
                 *reinterpret_cast<u16x8*>(a.g_x_seq + base) = xv;
             } else a.g_x_seq[base] = xb[0];
+        }
+        if (a.g_v_init) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a.g_v_init[i * VEC + e] = gv[e];
+        }
+    }
+    if (want_gk) {
+        __shared__ float s_k[kBlock / 64];
+        float w = wave_sum_f32(acc_k);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) s_k[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < kBlock / 64; ++q) s += s_k[q];
+            a.g_k_partials[blockIdx.x] = s;
+        }
+    }
+}
+
+// Backward with h recomputed from the 16-bit layer input (ss_neuron_bwd_rc_x16): compile-time T, a lane owns VEC consecutive
+// neurons (8 = one 16-B load per step for T <= 5; 4 for longer sequences to keep h_0..h_{T-1} (fp32) in registers at full occupancy).
+#ifndef SS_RC16_V5
+#define SS_RC16_V5 4
+#endif
+#ifndef SS_RC16_V10
+#define SS_RC16_V10 2
+#endif
+template <int VEC> struct U16Vec;
+template <> struct U16Vec<8> { typedef u16x8 type; };
+template <> struct U16Vec<4> { typedef unsigned short type __attribute__((ext_vector_type(4))); };
+template <> struct U16Vec<2> { typedef unsigned short type __attribute__((ext_vector_type(2))); };
+template <> struct U16Vec<1> { typedef unsigned short type; };
+
+template <int KIND, int SG, int DT, int TS, int VEC>
+__global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, const unsigned short* __restrict__ x_seq)
+{
+    typedef typename U16Vec<VEC>::type uvec_t;
+    const long long NV = a.N / VEC;
+    const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
+    const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset, alpha = a.alpha;
+    const float c_atan = (float)(M_PI / 2.0 * (double)alpha);
+    const float half_alpha = (float)((double)alpha / 2.0);
+    const bool detach = a.detach_reset != 0;
+    const bool want_gk = (KIND == SS_KIND_PLIF) && a.g_k_partials != nullptr;
+    float acc_k = 0.f;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
+        uvec_t xs[TS], gs[TS];
+#pragma unroll
+        for (int t = 0; t < TS; ++t) xs[t] = *reinterpret_cast<const uvec_t*>(x_seq + ((long long)t * NV + i) * VEC);
+#pragma unroll
+        for (int t = TS - 1; t >= 0; --t) gs[t] = *reinterpret_cast<const uvec_t*>(a.g_out_seq + ((long long)t * NV + i) * VEC);
+        float v0[VEC], gv[VEC], h[TS][VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v0[e] = a.v_init ? a.v_init[i * VEC + e] : v_reset;
+            gv[e] = a.g_v_last ? a.g_v_last[i * VEC + e] : 0.f;
+        }
+        {
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = v0[e];
+#pragma unroll
+            for (int t = 0; t < TS; ++t)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    unsigned short xb;
+                    if constexpr (VEC == 1) xb = xs[t]; else xb = xs[t][e];
+                    const float hh = charge<KIND>(v[e], widen<DT>(xb) * scale, tau, k, v_reset);
+                    const float z = heaviside(hh - v_th);
+                    v[e] = (1.f - z) * hh + z * v_reset;
+                    h[t][e] = hh;
+                }
+        }
+#pragma unroll
+        for (int t = TS - 1; t >= 0; --t) {
+            uvec_t xv;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                unsigned short gb;
+                if constexpr (VEC == 1) gb = gs[t]; else gb = gs[t][e];
+                const float he = h[t][e];
+                const float xh = he - v_th;
+                const float z = heaviside(xh);
+                float g_s = widen<DT>(gb);
+                if (!detach) g_s = g_s + (gv[e] * v_reset - gv[e] * he);
+                const float g_h = surrogate_grad<SG>(xh, alpha, c_atan, half_alpha, g_s) + gv[e] * (1.f - z);
+                float g_x;
+                if (KIND == SS_KIND_IF) { g_x = g_h; gv[e] = g_h; }
+                else if (KIND == SS_KIND_LIF) { g_x = g_h / tau; gv[e] = g_h - g_x; }
+                else {
+                    g_x = g_h * k; gv[e] = g_h - g_x;
+                    if (want_gk) {
+                        float v_prev;
+                        if (t == 0) v_prev = v0[e];
+                        else { const float hp = h[t > 0 ? t - 1 : 0][e]; const float zp = heaviside(hp - v_th); v_prev = (1.f - zp) * hp + zp * v_reset; }
+                        acc_k += g_h * ((he - v_prev) / k);
+                    }
+                }
+                const unsigned short ob = narrow<DT>(g_x * scale);
+                if constexpr (VEC == 1) xv = ob; else xv[e] = ob;
+            }
+            *reinterpret_cast<uvec_t*>(a.g_x_seq + ((long long)t * NV + i) * VEC) = xv;
         }
         if (a.g_v_init) {
 #pragma unroll
@@ -999,7 +1126,21 @@ int dispatch_fwd_T(const FwdArgs& a, hipStream_t s)
 template <int KIND, int SG, int TS>
 int launch_bwd(const BwdArgs& a, hipStream_t s, int* grid_out)
 {
-    const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.g_x_seq) &&
+    if (a.x_seq) {                                        // recompute needs h_0..h_{T-1} in registers: templated T only
+        if constexpr (TS == 0) return SS_EINVAL;
+        else {
+            const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.x_seq) && aligned16(a.g_x_seq) &&
+                             (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
+                             (!a.v_init || aligned16(a.v_init));
+            int grid = vec ? grid_for(a.N / 4, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
+            if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
+            *grid_out = grid;
+            if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+        }
+    }
+    const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.x_seq) && aligned16(a.g_x_seq) &&
                      (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                      (!a.v_init || aligned16(a.v_init));
     int grid = vec ? grid_for(a.N / 4, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
@@ -1085,6 +1226,35 @@ int dispatch_bwd16(const Bwd16Args& a, hipStream_t s, int* grid_out)
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
+template <int KIND, int SG, int DT, int TS>
+int launch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, hipStream_t s, int* grid_out)
+{
+    constexpr int V = (TS <= 5) ? SS_RC16_V5 : SS_RC16_V10;    // measured on the MI355X: tools/bench_rc16.py
+    const bool vec = (a.N % V == 0) && aligned16(a.g_out_seq) && aligned16(x_seq) && aligned16(a.g_x_seq) &&
+                     (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
+                     (!a.v_init || aligned16(a.v_init));
+    int grid = vec ? grid_for(a.N / V, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
+    if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
+    *grid_out = grid;
+    if (vec) hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, V>), dim3(grid), dim3(kBlock), 0, s, a, x_seq);
+    else     hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, 1>), dim3(grid), dim3(kBlock), 0, s, a, x_seq);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+template <int KIND, int SG, int DT>
+int dispatch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, hipStream_t s, int* grid_out)
+{
+    switch (a.T) {
+        case 1: return launch_bwd16_rc<KIND, SG, DT, 1>(a, x_seq, s, grid_out);
+        case 2: return launch_bwd16_rc<KIND, SG, DT, 2>(a, x_seq, s, grid_out);
+        case 4: return launch_bwd16_rc<KIND, SG, DT, 4>(a, x_seq, s, grid_out);
+        case 5: return launch_bwd16_rc<KIND, SG, DT, 5>(a, x_seq, s, grid_out);
+        case 8: return launch_bwd16_rc<KIND, SG, DT, 8>(a, x_seq, s, grid_out);
+        case 10: return launch_bwd16_rc<KIND, SG, DT, 10>(a, x_seq, s, grid_out);
+        default: return SS_EINVAL;
+    }
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -1114,15 +1284,16 @@ int ss_neuron_fwd_f32(const float* x_seq, const float* v_init, const float* skip
     }
 }
 
-int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
-                      float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
-                      int T, long long N, float scale, int kind, float tau, const float* k,
-                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+static int neuron_bwd_f32_impl(const float* g_out_seq, const float* g_v_last, const float* h_seq, const float* x_seq,
+                               const float* v_init, float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                               int T, long long N, float scale, int kind, float tau, const float* k,
+                               float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
 {
-    if (!g_out_seq || !h_seq || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
+    if (!g_out_seq || (!h_seq && !x_seq) || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
     if (kind < SS_KIND_IF || kind > SS_KIND_PLIF) return SS_EINVAL;
     if (surrogate != SS_SG_ATAN && surrogate != SS_SG_SIGMOID) return SS_EINVAL;
     if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
+    if (x_seq && g_x_seq == x_seq) return SS_EINVAL;      // a lane reads all of x before writing g_x, but keep the input intact
     const bool want_gk = (kind == SS_KIND_PLIF) && g_k != nullptr;
     if (want_gk && !g_k_ws) return SS_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1131,7 +1302,7 @@ int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float
         return SS_OK;
     }
     BwdArgs a{g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, want_gk ? g_k_ws : nullptr,
-              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset};
+              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset, x_seq};
     int grid = 0, rc;
     switch (kind) {
         case SS_KIND_IF: rc = dispatch_bwd_sg<SS_KIND_IF>(a, surrogate, s, &grid); break;
@@ -1144,6 +1315,31 @@ int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float
         if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     }
     return SS_OK;
+}
+
+int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
+                      float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+{
+    if (!h_seq) return SS_EINVAL;
+    return neuron_bwd_f32_impl(g_out_seq, g_v_last, h_seq, nullptr, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                               v_th, v_reset, surrogate, alpha, detach_reset, stream);
+}
+
+int ss_neuron_bwd_rc_supported(int T)
+{
+    return T == 1 || T == 2 || T == 4 || T == 5 || T == 8 || T == 10;
+}
+
+int ss_neuron_bwd_rc_f32(const float* g_out_seq, const float* g_v_last, const float* x_seq, const float* v_init,
+                         float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                         int T, long long N, float scale, int kind, float tau, const float* k,
+                         float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+{
+    if (!x_seq || !ss_neuron_bwd_rc_supported(T)) return SS_EINVAL;
+    return neuron_bwd_f32_impl(g_out_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                               v_th, v_reset, surrogate, alpha, detach_reset, stream);
 }
 
 int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_seq,
@@ -1168,15 +1364,16 @@ int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_s
 #undef SS_D16
 }
 
-int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
-                      void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
-                      int T, long long N, float scale, int kind, float tau, const float* k,
-                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+static int neuron_bwd_x16_impl(const void* g_out_seq, const float* g_v_last, const float* h_seq, const void* x_seq, const float* v_init,
+                               void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                               int T, long long N, float scale, int kind, float tau, const float* k,
+                               float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
 {
-    if (!g_out_seq || !h_seq || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
+    if (!g_out_seq || (!h_seq && !x_seq) || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
     if (kind < SS_KIND_IF || kind > SS_KIND_PLIF || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
     if (surrogate != SS_SG_ATAN && surrogate != SS_SG_SIGMOID) return SS_EINVAL;
     if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
+    if (x_seq && g_x_seq == x_seq) return SS_EINVAL;
     const bool want_gk = (kind == SS_KIND_PLIF) && g_k != nullptr;
     if (want_gk && !g_k_ws) return SS_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1186,8 +1383,10 @@ int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float*
     }
     Bwd16Args a{static_cast<const unsigned short*>(g_out_seq), g_v_last, h_seq, v_init, static_cast<unsigned short*>(g_x_seq),
                 g_v_init, want_gk ? g_k_ws : nullptr, T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset};
+    const unsigned short* xq = static_cast<const unsigned short*>(x_seq);
     int grid = 0, rc;
-#define SS_B16(KK, SGG) (dtype == SS_DT_F16 ? dispatch_bwd16<KK, SGG, SS_DT_F16>(a, s, &grid) : dispatch_bwd16<KK, SGG, SS_DT_BF16>(a, s, &grid))
+#define SS_B16D(KK, SGG, DTT) (xq ? dispatch_bwd16_rc<KK, SGG, DTT>(a, xq, s, &grid) : dispatch_bwd16<KK, SGG, DTT>(a, s, &grid))
+#define SS_B16(KK, SGG) (dtype == SS_DT_F16 ? SS_B16D(KK, SGG, SS_DT_F16) : SS_B16D(KK, SGG, SS_DT_BF16))
 #define SS_B16S(KK) (surrogate == SS_SG_ATAN ? SS_B16(KK, SS_SG_ATAN) : SS_B16(KK, SS_SG_SIGMOID))
     switch (kind) {
         case SS_KIND_IF: rc = SS_B16S(SS_KIND_IF); break;
@@ -1196,12 +1395,33 @@ int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float*
     }
 #undef SS_B16S
 #undef SS_B16
+#undef SS_B16D
     if (rc != SS_OK) return rc;
     if (want_gk) {
         hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(kBlock), 0, s, g_k_ws, grid, g_k);
         if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     }
     return SS_OK;
+}
+
+int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float* h_seq, const float* v_init,
+                      void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                      int T, long long N, float scale, int kind, float tau, const float* k,
+                      float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+{
+    if (!h_seq) return SS_EINVAL;
+    return neuron_bwd_x16_impl(g_out_seq, g_v_last, h_seq, nullptr, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                               v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream);
+}
+
+int ss_neuron_bwd_rc_x16(const void* g_out_seq, const float* g_v_last, const void* x_seq, const float* v_init,
+                         void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                         int T, long long N, float scale, int kind, float tau, const float* k,
+                         float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+{
+    if (!x_seq || !ss_neuron_bwd_rc_supported(T)) return SS_EINVAL;
+    return neuron_bwd_x16_impl(g_out_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                               v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream);
 }
 
 int ss_ipool_fwd_f32(const float* pd_seq, long long stride_t, long long stride_k, const float* v_init,

@@ -70,6 +70,13 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+# Training keeps the layer INPUT (the conv output, which autograd would otherwise free) instead of a separately written h_seq and
+# recomputes h inside the backward kernel: the forward launch writes 8 instead of 12 B/update, the backward reads the same 12.
+# With 16-bit activations: 4 instead of 8 B/update forward, 6 instead of 8 backward.  Applies to the compile-time time-step counts
+# (ss_neuron_bwd_rc_supported); any other T saves h.
+RECOMPUTE_H = True
+
+
 class _FusedNeuron(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz):
@@ -85,7 +92,8 @@ class _FusedNeuron(torch.autograd.Function):
         if skip_seq is not None and skip_seq.dtype != x_seq.dtype:
             skip_seq = skip_seq.to(x_seq.dtype)                      # spikes are small integers: exact in every format
         out_seq = torch.empty_like(x_seq)
-        h_seq = torch.empty(x_seq.shape, dtype=torch.float32, device=x_seq.device) if need_grad else None
+        recompute = need_grad and RECOMPUTE_H and _lib.neuron_bwd_rc_supported(T)
+        h_seq = torch.empty(x_seq.shape, dtype=torch.float32, device=x_seq.device) if (need_grad and not recompute) else None
         v_last = torch.empty(x_seq.shape[1:], dtype=torch.float32, device=x_seq.device)
         if v_init is not None and v_init.dtype != torch.float32:
             v_init = v_init.float()
@@ -93,7 +101,7 @@ class _FusedNeuron(torch.autograd.Function):
         (_lib.neuron_fwd_x16 if half else _lib.neuron_fwd)(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N,
                                                           cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
         es = 2 if half else 4
-        per = es * (2 + (1 if skip_seq is not None else 0)) + (4 if need_grad else 0)
+        per = es * (2 + (1 if skip_seq is not None else 0)) + (4 if h_seq is not None else 0)
         TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if skip_seq is not None else ''),
                    per * T * N, T * N)
         ctx.cfg = cfg
@@ -102,7 +110,11 @@ class _FusedNeuron(torch.autograd.Function):
         ctx.has_skip = skip_seq is not None
         ctx.io_dtype = x_seq.dtype
         ctx.set_materialize_grads(False)
-        if need_grad:
+        ctx.recompute = recompute
+        if recompute:
+            # the backward kernel rebuilds h_0..h_{T-1} in registers from x_seq and v_init (same arithmetic, bit-identical)
+            ctx.save_for_backward(x_seq, v_init, k)
+        elif need_grad:
             # h_seq is all the backward needs (z_t, v_{t-1} are recomputed from it); the OUTPUT is not saved because
             # the reference mutates it in place (blocks.py:171).  v_init only feeds the PLIF dL/dk term at t = 0.
             keep_v = v_init if (cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]) else None
@@ -111,7 +123,7 @@ class _FusedNeuron(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out_seq, g_v_last):
-        h_seq, v_init, k = ctx.saved_tensors
+        h_seq, v_init, k = ctx.saved_tensors          # h_seq is x_seq (activation dtype) when ctx.recompute
         cfg, T, N = ctx.cfg, ctx.T, ctx.N
         half = ctx.io_dtype in (torch.float16, torch.bfloat16)
         if g_out_seq is None:
@@ -121,17 +133,20 @@ class _FusedNeuron(torch.autograd.Function):
             g_v_last = g_v_last.float().contiguous()
         g_x_seq = torch.empty(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
         want_gv = ctx.has_vinit and ctx.needs_input_grad[1]
-        g_v_init = torch.empty(h_seq.shape[1:], dtype=h_seq.dtype, device=h_seq.device) if want_gv else None
+        g_v_init = torch.empty(h_seq.shape[1:], dtype=torch.float32, device=h_seq.device) if want_gv else None
         want_gk = cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]
         g_k = g_k_ws = None
         if want_gk:
-            g_k = torch.empty((), dtype=h_seq.dtype, device=h_seq.device)
-            g_k_ws = torch.empty(_lib.gk_ws_floats(), dtype=h_seq.dtype, device=h_seq.device)
+            g_k = torch.empty((), dtype=torch.float32, device=h_seq.device)
+            g_k_ws = torch.empty(_lib.gk_ws_floats(), dtype=torch.float32, device=h_seq.device)
         e0 = TIMER.start()
-        (_lib.neuron_bwd_x16 if half else _lib.neuron_bwd)(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
-                                                          T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset,
-                                                          cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, 'neuron_bwd', (8 if half else 12) * T * N, T * N)
+        if ctx.recompute:
+            bwd = _lib.neuron_bwd_rc_x16 if half else _lib.neuron_bwd_rc
+        else:
+            bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
+        bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+            T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
+        TIMER.stop(e0, 'neuron_bwd', ((6 if ctx.recompute else 8) if half else 12) * T * N, T * N)
         g_skip = g_out_seq if (ctx.has_skip and ctx.needs_input_grad[2]) else None   # identity
         return g_x_seq, g_v_init, g_skip, g_k, None, None
 

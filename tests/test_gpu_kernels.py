@@ -347,6 +347,21 @@ def test_x16_kernels_vs_numpy_oracle(dt, kind, T, N):
     assert bit_equal(gvi, rb['g_v_init'])
     if kind == 'PLIF':
         assert abs(float(gk) - rb['g_k']) <= 1e-5 * abs(rb['g_k']) + 2e-7 * T * N
+    # recompute form (h rebuilt from the 16-bit layer input; the forward then runs without h_seq): bit-identical
+    out2, v2 = torch.empty_like(xd), torch.empty(N, device=DEV)
+    _lib.neuron_fwd_x16(xd, vd, sd, out2, None, v2, None, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0)
+    assert torch.equal(out2.view(torch.int16), out.view(torch.int16)) and torch.equal(v2, v)
+    for detach in (True, False):
+        gx1, gv1 = torch.empty_like(xd), torch.empty(N, device=DEV)
+        gx2, gv2 = torch.empty_like(xd), torch.empty(N, device=DEV)
+        gk1 = torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+        gk2 = torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+        gvl = torch.randn(N, generator=g).to(DEV)
+        _lib.neuron_bwd_x16(go.to(DEV), gvl, h, vd, gx1, gv1, gk1, ws, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0, 0, 2.0, detach)
+        _lib.neuron_bwd_rc_x16(go.to(DEV), gvl, xd, vd, gx2, gv2, gk2, ws, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0, 0, 2.0, detach)
+        assert torch.equal(gx1.view(torch.int16), gx2.view(torch.int16)) and torch.equal(gv1.view(torch.int32), gv2.view(torch.int32))
+        if kind == 'PLIF':     # lane width differs (8 vs 4 / 2 neurons): same terms, another fp32 summation order
+            assert abs(float(gk1) - float(gk2)) <= 1e-5 * abs(float(gk1)) + 2e-7 * T * N
 
 
 def test_voxelizer_vs_reference_fixture_and_oracle():
@@ -451,3 +466,44 @@ def test_fused_total_loss_vs_reference_fixture_and_unfused_form():
     for a, b in zip(out[True][1], out[False][1]):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
         assert torch.equal(a == 0, b == 0) or float(((a == 0) != (b == 0)).float().mean()) < 1e-6
+
+
+@pytest.mark.parametrize('surrogate', ['ATan', 'Sigmoid'])
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+@pytest.mark.parametrize('T,N', [(1, 1000), (2, 4096), (4, 777), (5, 260 * 346 * 4), (8, 4100), (10, 64 * 1024 + 3)])
+def test_backward_with_recomputed_h_is_bit_identical(kind, T, N, surrogate):
+    """ss_neuron_bwd_rc_f32 (h rebuilt in registers from x_seq / v_init) == ss_neuron_bwd_f32 fed the forward's saved h_seq, bit for
+    bit on g_x, g_v_init and dL/dk — and == the C oracle (ATan) — for every compile-time T, the vector and the scalar-tail path,
+    detach_reset on and off; unsupported T is refused."""
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(T * 7 + N)
+    x = (rng.standard_normal((T, N)) * 0.25).astype(np.float32)
+    v0 = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    g = rng.standard_normal((T, N)).astype(np.float32)
+    gvl = rng.standard_normal(N).astype(np.float32)
+    k = float(np.float32(1 / 3.)) if kind == 'PLIF' else None
+    kw = dict(kind=kind, scale=7.5, tau=2.5, k=k, v_th=1.0, v_reset=0.25)
+    alpha = 2.0 if surrogate == 'ATan' else 4.0
+    assert _lib.neuron_bwd_rc_supported(T) and not _lib.neuron_bwd_rc_supported(3)
+    for v_init in (v0, None):
+        f = hip_fwd(x, v_init=v_init, **kw)
+        for detach in (True, False):
+            a = hip_bwd(g, f['h'], v_init=v_init, g_v_last=gvl, surrogate=surrogate, alpha=alpha, detach_reset=detach, **kw)
+            gd, xd, vd, gvd = _dev(g), _dev(x), _dev(v_init), _dev(gvl)
+            g_x = torch.full_like(xd, float('nan'))
+            g_vi = torch.empty(N, device=DEV)
+            g_k = torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+            ws = torch.empty(_lib.gk_ws_floats(), device=DEV) if kind == 'PLIF' else None
+            kd = None if k is None else torch.tensor([k], dtype=torch.float32, device=DEV)
+            _lib.neuron_bwd_rc(gd, gvd, xd, vd, g_x, g_vi, g_k, ws, T, N, kw['scale'], KIND[kind], kw['tau'], kd, kw['v_th'],
+                               kw['v_reset'], SG[surrogate], alpha, detach)
+            assert bit_equal(g_x.cpu().numpy(), a['g_x']) and bit_equal(g_vi.cpu().numpy(), a['g_v_init'])
+            if kind == 'PLIF':
+                assert float(g_k.item()) == a['g_k']
+            assert torch.equal(xd.cpu(), torch.from_numpy(x))          # the layer input is left intact
+    if surrogate == 'ATan' and N <= 70000:
+        ref = c_oracle.neuron_bwd(g, f['h'], v_init=None, g_v_last=gvl, surrogate='ATan', alpha=alpha, detach_reset=False, **kw)
+        assert bit_equal(g_x.cpu().numpy(), ref['g_x'])
+    xd3 = torch.zeros(3, 8, device=DEV)
+    with pytest.raises(_lib.SSNeuronError):
+        _lib.neuron_bwd_rc(xd3, None, xd3, None, torch.empty_like(xd3), None, None, None, 3, 8, 1.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)

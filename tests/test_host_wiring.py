@@ -42,6 +42,15 @@ def host_backend(monkeypatch):
                                      int(detach_reset))
         assert rc == 0
 
+    def neuron_bwd_rc(g_out_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                      v_th, v_reset, surrogate, alpha, detach_reset):
+        # stand-in for the in-kernel recompute: oracle forward from the saved layer input, then the oracle backward
+        h, o, vl = torch.empty_like(x_seq), torch.empty_like(x_seq), torch.empty(N)
+        assert L.ss_ref_neuron_fwd_f32(_p(x_seq), _p(v_init), None, _p(o), _p(h), _p(vl), None, T, N, scale, kind, tau, _p(k),
+                                       v_th, v_reset) == 0
+        neuron_bwd(g_out_seq, g_v_last, h, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k, v_th, v_reset,
+                   surrogate, alpha, detach_reset)
+
     def ipool_fwd(pd_seq, st, sk, v_init, depth_seq, T, K, M, scale, v_reset):
         assert L.ss_ref_ipool_fwd_f32(_p(pd_seq), st, sk, _p(v_init), _p(depth_seq), T, K, M, scale, v_reset) == 0
 
@@ -80,6 +89,8 @@ def host_backend(monkeypatch):
     monkeypatch.setattr(_lib, 'upconv1_bwd', upconv1_bwd)
     monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
     monkeypatch.setattr(_lib, 'neuron_bwd', neuron_bwd)
+    monkeypatch.setattr(_lib, 'neuron_bwd_rc', neuron_bwd_rc)
+    monkeypatch.setattr(_lib, 'neuron_bwd_rc_supported', lambda T: T in (1, 2, 4, 5, 8, 10))
     monkeypatch.setattr(_lib, 'ipool_fwd', ipool_fwd)
     monkeypatch.setattr(_lib, 'ipool_bwd', ipool_bwd)
     monkeypatch.setattr(_lib, 'gk_ws_floats', lambda: 1)
