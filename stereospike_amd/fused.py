@@ -267,6 +267,7 @@ def nearest_tables(in_size: int, out_size: int):
 #               measured on MI355X, profiles/r01/upconv_variants.log)
 PROJECTION_IMPL = 'auto'
 P_CHUNK_BYTES = 96 << 20          # per-chunk size of P: comfortably inside the 256 MiB MALL next to x / out / g_out
+P_MAX_BYTES_CL = 16 << 30         # NHWC path: ONE GEMM over the whole batch unless P would exceed this (then the largest chunks that fit)
 
 
 class _UpConv1(torch.autograd.Function):
@@ -406,8 +407,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
               then the channels-last gather kernel (ss_upconv_cl_fwd_f32);
     backward: g_P = gather adjoint (ss_upconv_cl_bwd_f32); dgrad g_x = g_P @ W^T (one GEMM); wgrad g_W = x^T @ g_P as a
               split-K batched GEMM (the contraction runs over all NB*h*w rows) summed over the splits.
-    Frames are walked in chunks whose P stays inside the Infinity Cache when a chunk holds >= 4 frames, else in one
-    pass with P in HBM (same policy as the NCHW path)."""
+    The whole batch goes through in one pass (P in HBM); frames are chunked only when P would exceed P_MAX_BYTES_CL."""
 
     @staticmethod
     @_fwd32
@@ -421,8 +421,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
         Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()      # column index = tap*C_out + co
         src_y, _, _, src_x, _, _ = tables
         out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=x_cl.device)
-        n = P_CHUNK_BYTES // (Cout * kk * h * w * 4)
-        n = NB if n < 4 else min(NB, n)
+        # one pass: measured on the MI355X (profiles/r01/chunk_sweep*.log) cache-sized chunks lose more in GEMM efficiency (M = n*h*w
+        # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
+        n = max(1, min(NB, P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
         xg = x_cl.to(torch.bfloat16) if lowp else x_cl
         Wg = Wt.to(torch.bfloat16) if lowp else Wt
         e0 = TIMER.start()

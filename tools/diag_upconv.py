@@ -17,7 +17,11 @@ layers = [('deconv4', 512, 256, 5, (17, 22), (33, 44)), ('deconv3', 256, 128, 5,
 which = os.environ.get('WHICH', 'projected,miopen').split(',')
 from stereospike_amd import fused
 fused.PROJECTION_IMPL = os.environ.get('PROJ', 'auto')
-print('PROJECTION_IMPL', fused.PROJECTION_IMPL)
+fused.P_CHUNK_BYTES = int(os.environ.get('CHUNK_MB', fused.P_CHUNK_BYTES >> 20)) << 20
+only = os.environ.get('LAYERS')
+if only:
+    layers = [l for l in layers if l[0] in only.split(',')]
+print('PROJECTION_IMPL', fused.PROJECTION_IMPL, 'chunk MB', fused.P_CHUNK_BYTES >> 20)
 for name, ci, co, k, insz, up in layers:
     m = NNConvUpsampling(ci, co, k, up, bias=(co == 1)).to(dev)
     x = (torch.rand(NB, ci, *insz, device=dev) < 0.3).float().requires_grad_()
@@ -48,6 +52,8 @@ for name, ci, co, k, insz, up in layers:
               f'peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB', flush=True)
     del m, x
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+if os.environ.get('QUIET'):
+    sys.exit(0)
 for d in ('~/.cache/miopen', '~/.config/miopen', miopen_cache.CACHE_DIR, '/tmp'):
     p = os.path.expanduser(d)
     if os.path.exists(p):
