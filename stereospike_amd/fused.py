@@ -398,7 +398,7 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
 # ----------------------------------------------------------------------------------------------------------
 # channels-last (NHWC) form of the same up-conv: the decoder's fast path
 # ----------------------------------------------------------------------------------------------------------
-WGRAD_SPLIT_ROWS = 16384          # split-K granularity of the weight-gradient GEMM (K = NB*h*w rows)
+WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient GEMM (K = NB*h*w rows); MI355X sweep: profiles/r01/wgrad_split_sweep.log
 
 
 class _UpConvProjectedCL(torch.autograd.Function):
