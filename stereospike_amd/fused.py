@@ -401,6 +401,23 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
 WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient GEMM (K = NB*h*w rows); MI355X sweep: profiles/r01/wgrad_split_sweep.log
 
 
+# Forward projection of a stage whose input is a spike tensor (values 0 / 1 / 2: exact in bf16): the fp32 weight is split into three
+# bf16 terms W = Wh + Wm + Wl (8 + 8 + 8 mantissa bits: exact), and P = [X X X](bf16) @ [Wh; Wm; Wl](bf16) runs on the bf16 MFMA
+# path with fp32 accumulation.  Every product is exact, so the result has the error profile of the fp32 GEMM (same 1e-6 relative
+# difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
+EXACT_SPLIT_GEMM = True
+EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
+ASSERT_EXACT_SPLIT = False         # tests: verify (with a host sync) that the input really is bf16-exact
+
+
+def _split3_bf16(Wt):
+    Wh = Wt.to(torch.bfloat16)
+    r = Wt - Wh.float()
+    Wm = r.to(torch.bfloat16)
+    Wl = (r - Wm.float()).to(torch.bfloat16)
+    return torch.cat((Wh, Wm, Wl), 0)                                 # [3K, N]
+
+
 class _UpConvProjectedCL(torch.autograd.Function):
     """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
     forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
@@ -411,7 +428,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False):
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False):
         # lowp (only under bf16 autocast): the three GEMMs take bf16 operands with fp32 accumulation / output, exactly what
         # autocast does to the MIOpen convs of the encoder (spike inputs are exact in bf16; W and g_P are rounded).
         # P, the gather, its adjoint and every output stay fp32.
@@ -426,11 +443,22 @@ class _UpConvProjectedCL(torch.autograd.Function):
         n = max(1, min(NB, P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
         xg = x_cl.to(torch.bfloat16) if lowp else x_cl
         Wg = Wt.to(torch.bfloat16) if lowp else Wt
+        exact = spikes_in and not lowp and EXACT_SPLIT_GEMM and Cin >= EXACT_SPLIT_MIN_K
+        if exact:
+            if ASSERT_EXACT_SPLIT:
+                assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
+            W3 = _split3_bf16(Wt)
         e0 = TIMER.start()
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
             xs = xg[c0:c1].view((c1 - c0) * h * w, Cin)
-            P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
+            if exact:
+                x3 = torch.empty((xs.shape[0], 3, Cin), dtype=torch.bfloat16, device=xs.device)
+                x3.copy_(xs.unsqueeze(1))                                                  # one cast kernel writing the 3 copies
+                P = torch.mm(x3.view(-1, 3 * Cin), W3, out_dtype=torch.float32)
+                del x3
+            else:
+                P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
             _lib.upconv_cl_fwd(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
         ctx.save_for_backward(xg, Wt)
@@ -482,10 +510,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
         TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
         g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
         g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return g_x, g_w, g_b, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None
 
 
-def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int):
-    """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out]."""
+def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False):
+    """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
+    spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection."""
     lowp = x_cl.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp)
+    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in)

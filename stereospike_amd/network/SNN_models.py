@@ -147,7 +147,7 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
             if cl:
                 skip = enc[lvl - 1] if enc_cl else enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
-                cur = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'))
+                cur = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True)   # cur: spikes (+ SEW / skip adds)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
                 pd = head[0].forward_projected_cl(cur.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW
             else:

@@ -93,13 +93,13 @@ class NNConvUpsampling(_UpConv):
                                 Hu - k + 1, Wu - k + 1)
 
 
-    def forward_projected_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
-        """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array)."""
+    def forward_projected_cl(self, x_cl: torch.Tensor, spikes_in: bool = False) -> torch.Tensor:
+        """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array).  spikes_in: x_cl is a spike tensor."""
         conv = self.up[1]
         k = conv.kernel_size[0]
         Hu, Wu = self.up[0].size
         return upconv_projected_cl(x_cl, conv.weight, conv.bias, self._tables(x_cl.shape[1], x_cl.shape[2], x_cl.device),
-                                   k, Hu - k + 1, Wu - k + 1)
+                                   k, Hu - k + 1, Wu - k + 1, spikes_in)
 
 
 class BilinConvUpsampling(_UpConv):
@@ -135,11 +135,11 @@ class SpikingStage(nn.Sequential):
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True)
 
-    def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None):
+    def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None, spikes_in: bool = False):
         """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
-        NNConvUpsampling."""
+        NNConvUpsampling.  spikes_in: x_seq is the output of a spiking layer (+ spike skip adds)."""
         T, B = x_seq.shape[:2]
-        y = self[0].forward_projected_cl(x_seq.flatten(0, 1))
+        y = self[0].forward_projected_cl(x_seq.flatten(0, 1), spikes_in)
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True)
 

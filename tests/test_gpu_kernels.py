@@ -507,3 +507,39 @@ def test_backward_with_recomputed_h_is_bit_identical(kind, T, N, surrogate):
     xd3 = torch.zeros(3, 8, device=DEV)
     with pytest.raises(_lib.SSNeuronError):
         _lib.neuron_bwd_rc(xd3, None, xd3, None, torch.empty_like(xd3), None, None, None, 3, 8, 1.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+
+
+@pytest.mark.parametrize('Cin,Cout,hw,HW', [(512, 256, (17, 22), (33, 44)), (128, 64, (9, 11), (18, 23))])
+def test_exact_bf16x3_projection_has_fp32_gemm_accuracy(Cin, Cout, hw, HW):
+    """The decoder's forward projection on spike inputs (fused.EXACT_SPLIT_GEMM: fp32 weight split into 3 bf16 terms, bf16 MFMA,
+    fp32 accumulate) against a float64 reference: its error is at the level of the plain fp32 GEMM's (stated: <= 1.5x that error
+    + 1e-7 of max|out|), backward untouched (same tensors, bit for bit), non-spike input refused in checking mode."""
+    from stereospike_amd import fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    torch.manual_seed(7)
+    k, NB = 5, 6
+    m = NNConvUpsampling(Cin, Cout, k, HW, bias=False).to(DEV)
+    x = torch.randint(0, 3, (NB, hw[0], hw[1], Cin), device=DEV).float()
+    g = torch.randn(NB, HW[0], HW[1], Cout, device=DEV)
+    outs = {}
+    for exact in (True, False):
+        fused.EXACT_SPLIT_GEMM, fused.ASSERT_EXACT_SPLIT = exact, True
+        try:
+            xin = x.clone().requires_grad_()
+            y = m.forward_projected_cl(xin, spikes_in=True)
+            gx, gw = torch.autograd.grad(y, (xin, m.up[1].weight), g)
+            outs[exact] = (y.detach(), gx, gw)
+        finally:
+            fused.EXACT_SPLIT_GEMM, fused.ASSERT_EXACT_SPLIT = True, False
+    ref = torch.nn.functional.conv2d(m.up[0](x.permute(0, 3, 1, 2).double()), m.up[1].weight.double()).permute(0, 2, 3, 1)
+    e_exact = float((outs[True][0].double() - ref).abs().max())
+    e_fp32 = float((outs[False][0].double() - ref).abs().max())
+    assert e_exact <= 1.5 * e_fp32 + 1e-7 * float(ref.abs().max()), (e_exact, e_fp32)
+    assert e_exact <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][2], outs[False][2])
+    fused.ASSERT_EXACT_SPLIT = True
+    try:
+        with pytest.raises(AssertionError):
+            m.forward_projected_cl(x + 0.3, spikes_in=True)
+    finally:
+        fused.ASSERT_EXACT_SPLIT = False

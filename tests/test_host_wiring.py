@@ -79,6 +79,8 @@ def host_backend(monkeypatch):
         g_pred.copy_(torch.from_numpy(g).view_as(g_pred))
 
     from stereospike_amd.network import loss as loss_mod
+    from stereospike_amd import fused as fused_mod
+    monkeypatch.setattr(fused_mod, 'EXACT_SPLIT_GEMM', False)         # torch.mm(bf16, bf16, out_dtype=fp32) exists on the GPU only
     monkeypatch.setattr(_lib, 'loss_stats', loss_stats)
     monkeypatch.setattr(_lib, 'loss_grad', loss_grad)
     monkeypatch.setattr(_lib, 'loss_ws_doubles', lambda: 1)
