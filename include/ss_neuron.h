@@ -225,6 +225,17 @@ int ss_voxelize_f64(const double* events, long long E, const double* start, cons
                     unsigned int* counts, int H, int W, void* stream);
 
 /*
+ * Operand preparation for the exact bf16x3 GEMM form of the encoder / bottleneck convolutions whose input is a spike tensor
+ * (/root/reference/network/SNN_models.py:83-101: conv2..conv4, blocks.py:146-159: the SEW bottleneck convs): the convolution itself is a
+ * library GEMM (PyTorch-ROCm / hipBLASLt, bf16 operands, fp32 accumulate); these two entry points build its operands.
+ *   ss_im2col_cl_bf16: x fp32 NHWC [NB][h][w][C] (C % 8 == 0) -> A bf16 [NB*ho*wo][k*k*C], A[(nb,oy,ox)][(ky,kx,c)] =
+ *                      x[nb][oy*stride-pad+ky][ox*stride-pad+kx][c] (0 outside), narrowed to nearest-even bf16 (exact for spike counts).
+ *   ss_split3_bf16   : g fp32 [M][N] (N % 4 == 0) -> g3 bf16 [M][3N] = [hi | mid | lo], hi + mid + lo == g exactly.
+ */
+int ss_im2col_cl_bf16(const float* x, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, void* stream);
+int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream);
+
+/*
  * Fused per-scale loss statistics — the step AFTER the path: /root/reference/network/loss.py:7-24
  * (ScaleInvariant_Loss), :44-75 (GradientMatching_Loss) and network/metrics.py:83-95 (MeanDepthError) for ONE prediction
  * map against the ground truth, batch-wide exactly as the reference (mask, n and the sums run over the whole [B,1,H,W] batch).

@@ -54,6 +54,10 @@ def lib():
     L.ss_voxelize_f64.argtypes = [p, i64, p, p, i32, p, i32, i32, p]
     L.ss_voxelize_f64.restype = i32
     L.ss_loss_ws_doubles.restype = i64
+    L.ss_im2col_cl_bf16.argtypes = [p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_split3_bf16.argtypes = [p, p, i64, i32, p]
+    L.ss_im2col_cl_bf16.restype = i32
+    L.ss_split3_bf16.restype = i32
     L.ss_loss_stats_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
     L.ss_loss_grad_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     L.ss_loss_stats_f32.restype = i32
@@ -72,7 +76,7 @@ def lib():
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
-           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16')
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16')
 
 
 def _ptr(t, name, numel=None):
@@ -282,6 +286,21 @@ def voxelize(events, start, end, counts, H, W):
         rc = lib().ss_voxelize_f64(_ptr(events, 'events', E * 4), E, _ptr(start, 'start'), _ptr(end, 'end', G), G,
                                    _ptr(counts, 'counts', G * 2 * H * W), H, W, _stream(events))
     _check(rc, 'ss_voxelize_f64')
+
+
+def im2col_cl_bf16(x, A, NB, h, w, C, k, stride, pad, ho, wo):
+    _require_hip(x, 'x')
+    with torch.cuda.device(x.device):
+        rc = lib().ss_im2col_cl_bf16(_f32(x, 'x', NB * h * w * C), _x16(A, 'A', NB * ho * wo * k * k * C, torch.bfloat16),
+                                     NB, h, w, C, k, stride, pad, ho, wo, _stream(x))
+    _check(rc, 'ss_im2col_cl_bf16')
+
+
+def split3_bf16(g, g3, M, N):
+    _require_hip(g, 'g')
+    with torch.cuda.device(g.device):
+        rc = lib().ss_split3_bf16(_f32(g, 'g', M * N), _x16(g3, 'g3', 3 * M * N, torch.bfloat16), M, N, _stream(g))
+    _check(rc, 'ss_split3_bf16')
 
 
 def loss_ws_doubles():

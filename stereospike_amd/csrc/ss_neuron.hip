@@ -928,6 +928,67 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// operand preparation for the exact bf16x3 GEMM form of the encoder / bottleneck convs on spike inputs (fused.py::_SpikeConvCL)
+// ---------------------------------------------------------------------------------------------------
+// im2col of an NHWC fp32 array into a bf16 patch matrix A[(nb, oy, ox)][(ky, kx, c)], zero padding, stride s.  A lane converts 8
+// consecutive channels of one (row, tap): two 16-B loads, one 16-B store; the k*k-fold re-read of x is served by L2.
+__global__ __launch_bounds__(kBlock) void im2col_cl_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ A,
+                                                                long long rows, int h, int w, int C, int k, int stride, int pad,
+                                                                int ho, int wo)
+{
+    const int C8 = C / 8;
+    const long long per_row = (long long)k * k * C8;
+    const long long total = rows * per_row;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const long long row = i / per_row;
+        const int r = (int)(i - row * per_row);
+        const int tap = r / C8, c8 = r - tap * C8;
+        const int ky = tap / k, kx = tap - ky * k;
+        const int ox = (int)(row % wo);
+        const long long t = row / wo;
+        const int oy = (int)(t % ho);
+        const long long nb = t / ho;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+            const float* src = x + ((nb * h + iy) * (long long)w + ix) * C + c8 * 8;
+            const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = narrow<SS_DT_BF16>(a[e]); o[4 + e] = narrow<SS_DT_BF16>(b[e]); }
+        }
+        *reinterpret_cast<u16x8*>(A + (row * (long long)k * k + tap) * C + c8 * 8) = o;
+    }
+}
+
+// g fp32 [M][N] -> g3 bf16 [M][3N] = [hi | mid | lo] with hi = bf16(g), mid = bf16(g - hi), lo = bf16(g - hi - mid): the three terms
+// sum to g exactly unless g needs more than 24 significant bits below its leading one (never for fp32).
+__global__ __launch_bounds__(kBlock) void split3_bf16_kernel(const float* __restrict__ g, unsigned short* __restrict__ g3,
+                                                             long long M, int N)
+{
+    const int N4 = N / 4;
+    const long long total = M * N4;
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const long long m = i / N4;
+        const int n4 = (int)(i - m * N4);
+        const f4 v = *reinterpret_cast<const f4*>(g + m * N + n4 * 4);
+        u16x4 hi, mid, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned short bh = narrow<SS_DT_BF16>(v[e]);
+            const float r1 = v[e] - widen<SS_DT_BF16>(bh);
+            const unsigned short bm = narrow<SS_DT_BF16>(r1);
+            const float r2 = r1 - widen<SS_DT_BF16>(bm);
+            hi[e] = bh; mid[e] = bm; lo[e] = narrow<SS_DT_BF16>(r2);
+        }
+        unsigned short* dst = g3 + m * 3 * N + n4 * 4;
+        *reinterpret_cast<u16x4*>(dst) = hi;
+        *reinterpret_cast<u16x4*>(dst + N) = mid;
+        *reinterpret_cast<u16x4*>(dst + 2 * N) = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // voxeliser: events -> two-polarity count frames (datasets/MVSEC/utils.py:215-281)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void voxelize_kernel(const double* __restrict__ ev, long long E, const double* __restrict__ start,
@@ -1513,6 +1574,26 @@ int ss_voxelize_f64(const double* events, long long E, const double* start, cons
     if (hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)G * 2 * H * W, s) != hipSuccess) return SS_ELAUNCH;
     if (E == 0) return SS_OK;
     hipLaunchKernelGGL(voxelize_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, events, E, start, end, G, counts, H, W);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_im2col_cl_bf16(const float* x, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, void* stream)
+{
+    if (!x || !A || NB <= 0 || h <= 0 || w <= 0 || C <= 0 || C % 8 != 0 || k <= 0 || stride <= 0 || pad < 0 || ho <= 0 || wo <= 0) return SS_EINVAL;
+    if ((ho - 1) * stride - pad + k - 1 >= h + pad || (wo - 1) * stride - pad + k - 1 >= w + pad) return SS_EINVAL;
+    if (!aligned16(x) || !aligned16(A)) return SS_EINVAL;
+    const long long rows = NB * ho * wo;
+    const long long total = rows * k * k * (C / 8);
+    hipLaunchKernelGGL(im2col_cl_bf16_kernel, dim3(grid_for(total, kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       x, static_cast<unsigned short*>(A), rows, h, w, C, k, stride, pad, ho, wo);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream)
+{
+    if (!g || !g3 || M <= 0 || N <= 0 || N % 4 != 0 || !aligned16(g) || !aligned16(g3)) return SS_EINVAL;
+    hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(M * (N / 4), kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       g, static_cast<unsigned short*>(g3), M, N);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

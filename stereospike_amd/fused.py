@@ -513,6 +513,77 @@ class _UpConvProjectedCL(torch.autograd.Function):
         return g_x, g_w, g_b, None, None, None, None, None, None
 
 
+class _SpikeConvCL(torch.autograd.Function):
+    """Conv2d on a spike tensor (NHWC array [NB, h, w, C_in], values exact in bf16) as exact bf16x3 GEMMs on the bf16 MFMA path:
+    forward : A = im2col(x) in bf16 (ss_im2col_cl_bf16, kept for backward);  y = A @ [Wh | Wm | Wl], the three column blocks summed;
+    wgrad   : g_W = A^T @ [gh | gm | gl] (ss_split3_bf16 of the fp32 output gradient), blocks summed — both with fp32 accumulation and
+              exact products, i.e. the accuracy of the fp32 convolution at 1.3 - 2.4x MIOpen's fp32 speed (profiles/r01/conv_as_gemm.log);
+    dgrad   : dense fp32 x dense fp32 — stays MIOpen's fp32 data-gradient convolution (aten.convolution_backward, input mask only).
+    The reference call sites: conv3 / conv4 (SNN_models.py:91-101) and the SEW bottleneck convs (blocks.py:146-159)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x_cl, weight, stride, pad):
+        x_cl = x_cl.contiguous()
+        NB, h, w, Cin = x_cl.shape
+        Cout, _, k, _ = weight.shape
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        M, K = NB * ho * wo, k * k * Cin
+        if ASSERT_EXACT_SPLIT:
+            assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
+        A = torch.empty((M, K), dtype=torch.bfloat16, device=x_cl.device)
+        _lib.im2col_cl_bf16(x_cl, A, NB, h, w, Cin, k, stride, pad, ho, wo)
+        Wt = weight.permute(2, 3, 1, 0).reshape(K, Cout)                          # row index = (ky, kx, c): the im2col column order
+        Wh = Wt.to(torch.bfloat16)
+        r = Wt - Wh.float()
+        Wm = r.to(torch.bfloat16)
+        Wl = (r - Wm.float()).to(torch.bfloat16)
+        y3 = torch.mm(A, torch.cat((Wh, Wm, Wl), 1), out_dtype=torch.float32)   # [M, 3*Cout]
+        y = y3.view(M, 3, Cout).sum(1).view(NB, ho, wo, Cout)
+        ctx.save_for_backward(A, weight)
+        ctx.geom = (NB, h, w, Cin, Cout, k, stride, pad, ho, wo)
+        return y
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, g):
+        A, weight = ctx.saved_tensors
+        NB, h, w, Cin, Cout, k, stride, pad, ho, wo = ctx.geom
+        M, K = NB * ho * wo, k * k * Cin
+        g = g.float().contiguous()
+        g_x = g_w = None
+        if ctx.needs_input_grad[1]:
+            g3 = torch.empty((M, 3 * Cout), dtype=torch.bfloat16, device=g.device)
+            _lib.split3_bf16(g, g3, M, Cout)
+            gw3 = torch.mm(A.t(), g3, out_dtype=torch.float32)                    # [K, 3*Cout]
+            g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
+        if ctx.needs_input_grad[0]:
+            x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+            g_x = torch.ops.aten.convolution_backward(
+                g.permute(0, 3, 1, 2), x_meta, weight.contiguous(memory_format=torch.channels_last), None,
+                [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            g_x = g_x.permute(0, 2, 3, 1)
+            if not g_x.is_contiguous():
+                g_x = g_x.contiguous()
+        return g_x, g_w, None, None
+
+
+SPIKE_CONV_MIN_CIN = 128           # conv3 (128), conv4 (256), bottleneck (512); below: im2col traffic outweighs the MFMA gain
+
+
+def spike_conv_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
+    """conv (nn.Conv2d, square kernel, no bias / groups / dilation) on a spike NHWC array through _SpikeConvCL, or None when the
+    exact-split form does not apply (caller then uses the MIOpen convolution)."""
+    k = conv.kernel_size[0]
+    ok = (EXACT_SPLIT_GEMM and x_cl.is_cuda and x_cl.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
+          and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size == (k, k)
+          and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and not isinstance(conv.padding, str)
+          and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= SPIKE_CONV_MIN_CIN)
+    if not ok:
+        return None
+    return _SpikeConvCL.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0])
+
+
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
     spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection."""

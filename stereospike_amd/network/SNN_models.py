@@ -130,9 +130,9 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         if enc_cl:          # whole network on NHWC arrays [T, B, h, w, C]: no layout copies anywhere
             enc = [self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'))]
             for i in range(1, 5):
-                enc.append(getattr(self, f'conv{i}').forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}')))
-            cur = self.bottleneck[0].forward_sequence_cl(enc[4])
-            cur = self.bottleneck[1].forward_sequence_cl(cur, nnz('rconv'))
+                enc.append(getattr(self, f'conv{i}').forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True))
+            cur = self.bottleneck[0].forward_sequence_cl(enc[4], spikes_in=True)          # enc[*], cur: spike tensors
+            cur = self.bottleneck[1].forward_sequence_cl(cur, nnz('rconv'), spikes_in=True)
             spikes, heads = [cur.permute(0, 1, 4, 2, 3)], []
         else:
             enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]

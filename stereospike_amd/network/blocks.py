@@ -127,11 +127,12 @@ class SpikingStage(nn.Sequential):
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
 
 
-    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None):
+    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False):
         """Encoder stage on NHWC arrays: x_seq [T, B, h, w, C] -> [T, B, h', w', C'].  The Conv2d sees a logical-NCHW
-        view with channels_last strides (no copy) and returns channels_last memory, i.e. again an NHWC array."""
+        view with channels_last strides (no copy) and returns channels_last memory, i.e. again an NHWC array.
+        spikes_in: x_seq is the output of a spiking layer."""
         T, B = x_seq.shape[:2]
-        y = _conv_cl(self[0], x_seq.flatten(0, 1))
+        y = _conv_cl(self[0], x_seq.flatten(0, 1), spikes_in)
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True)
 
@@ -162,11 +163,18 @@ class ResBlock(nn.Module):
         return _connect(self.connect_function, self.conv2(self.conv1(x)), x, spiking=False)
 
 
-def _conv_cl(conv: nn.Module, x_arr: torch.Tensor) -> torch.Tensor:
+def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False) -> torch.Tensor:
     """x_arr [NB, h, w, C] (NHWC array) -> conv -> [NB, h', w', C'] NHWC array, without layout copies when MIOpen returns
     channels_last memory (it does for channels_last inputs).  The filter is handed to MIOpen as a channels_last copy
     (72 MB for the whole network, ~0.03 ms per step); the Parameter itself keeps its standard layout, so optimisers,
-    the DP gradient buckets and state_dict never see a layout change."""
+    the DP gradient buckets and state_dict never see a layout change.
+    spikes_in: x_arr is the output of a spiking layer (small integers) — wide layers then run as exact bf16x3 GEMMs
+    (fused.spike_conv_cl) instead of MIOpen's fp32 convolution."""
+    if spikes_in and isinstance(conv, nn.Conv2d):
+        from ..fused import spike_conv_cl
+        y = spike_conv_cl(x_arr, conv)
+        if y is not None:
+            return y
     if isinstance(conv, nn.Conv2d):
         w = conv.weight.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x_arr.permute(0, 3, 1, 2), w, conv.bias, conv.stride, conv.padding,
@@ -230,18 +238,19 @@ class SEWResBlock(nn.Module):
         out = half(self.conv2, self.sn2, out, None, nnz)
         return _connect(self.connect_function, out, x_seq, spiking=True)
 
-    def forward_sequence_cl(self, x_seq: torch.Tensor, nnz=None) -> torch.Tensor:
-        """NHWC-array form of forward_sequence ('ADD' connect function only)."""
+    def forward_sequence_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False) -> torch.Tensor:
+        """NHWC-array form of forward_sequence ('ADD' connect function only).  spikes_in: x_seq is a spike tensor (the inner
+        activation always is)."""
         if self.connect_function != 'ADD':
             raise NotImplementedError('channels-last SEW block supports the ADD connect function only')
         T, B = x_seq.shape[:2]
 
-        def half(conv, sn, inp, skip, cnt):
-            y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1)))
+        def half(conv, sn, inp, skip, cnt, spk):
+            y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1), spk))
             return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt, channels_last=True)
 
-        out = half(self.conv1, self.sn1, x_seq, None, None)
-        return half(self.conv2, self.sn2, out, x_seq, nnz)
+        out = half(self.conv1, self.sn1, x_seq, None, None, spikes_in)
+        return half(self.conv2, self.sn2, out, x_seq, nnz, True)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_sequence(x.unsqueeze(0))[0]

@@ -543,3 +543,55 @@ def test_exact_bf16x3_projection_has_fp32_gemm_accuracy(Cin, Cout, hw, HW):
             m.forward_projected_cl(x + 0.3, spikes_in=True)
     finally:
         fused.ASSERT_EXACT_SPLIT = False
+
+
+@pytest.mark.parametrize('Cin,Cout,k,s,pad,hw', [(512, 512, 3, 1, 1, (17, 22)), (256, 512, 5, 2, 2, (33, 44)), (128, 256, 5, 2, 2, (21, 30)),
+                                                   (8, 4, 3, 2, 0, (7, 9)), (256, 512, 5, 2, 2, (4, 5)), (512, 512, 3, 1, 1, (2, 3)),
+                                                   (128, 256, 5, 2, 2, (8, 10))])
+def test_spike_conv_as_exact_bf16x3_gemm(Cin, Cout, k, s, pad, hw):
+    """ss_im2col_cl_bf16 == the patch matrix of torch's unfold, bit for bit; ss_split3_bf16 terms sum back to the fp32 input exactly;
+    fused._SpikeConvCL (forward + weight gradient as bf16x3 GEMMs, data gradient on MIOpen) against a float64 convolution: errors at the
+    level of the fp32 convolution's own (stated: <= 2x + 1e-7 of max)."""
+    import torch.nn.functional as F
+    from stereospike_amd import _lib, fused
+    torch.manual_seed(3)
+    NB = 5
+    h, w = hw
+    x = torch.randint(0, 3, (NB, h, w, Cin), device=DEV).float()
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    M, K = NB * ho * wo, k * k * Cin
+    A = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    _lib.im2col_cl_bf16(x, A, NB, h, w, Cin, k, s, pad, ho, wo)
+    cols = F.unfold(x.permute(0, 3, 1, 2), k, padding=pad, stride=s)              # [NB, Cin*k*k, L], row index = (c, ky, kx)
+    ref = cols.view(NB, Cin, k * k, ho * wo).permute(0, 3, 2, 1).reshape(M, K)     # -> (ky, kx, c) column order
+    assert torch.equal(A.float(), ref)
+    g = torch.randn(M, Cout, device=DEV) * torch.logspace(-6, 3, M, device=DEV).unsqueeze(1)
+    g3 = torch.empty(M, 3 * Cout, dtype=torch.bfloat16, device=DEV)
+    _lib.split3_bf16(g, g3, M, Cout)
+    parts = g3.view(M, 3, Cout).float()
+    assert torch.equal((parts[:, 0].double() + parts[:, 1].double() + parts[:, 2].double()).float(), g)
+    if Cin < fused.SPIKE_CONV_MIN_CIN:
+        return
+    conv = torch.nn.Conv2d(Cin, Cout, k, s, pad, bias=False).to(DEV)
+    gy = torch.randn(NB, ho, wo, Cout, device=DEV)
+    fused.ASSERT_EXACT_SPLIT = True
+    try:
+        xin = x.clone().requires_grad_()
+        y = fused.spike_conv_cl(xin, conv)
+        assert y is not None and tuple(y.shape) == (NB, ho, wo, Cout)
+        gx, gw = torch.autograd.grad(y, (xin, conv.weight), gy)
+    finally:
+        fused.ASSERT_EXACT_SPLIT = False
+    xr = x.clone().requires_grad_()
+    y32 = F.conv2d(xr.permute(0, 3, 1, 2), conv.weight, None, s, pad)
+    gx32, gw32 = torch.autograd.grad(y32, (xr, conv.weight), gy.permute(0, 3, 1, 2))
+    xd = x.double().requires_grad_()
+    wd = conv.weight.detach().double().requires_grad_()
+    y64 = F.conv2d(xd.permute(0, 3, 1, 2), wd, None, s, pad)
+    gx64, gw64 = torch.autograd.grad(y64, (xd, wd), gy.double().permute(0, 3, 1, 2))
+
+    def err(a, b):
+        return float((a.double() - b).abs().max())
+    assert err(y.permute(0, 3, 1, 2), y64) <= 2 * err(y32, y64) + 1e-7 * float(y64.abs().max())
+    assert err(gw, gw64) <= 2 * err(gw32, gw64) + 1e-7 * float(gw64.abs().max())
+    assert err(gx, gx64) <= 2 * err(gx32, gx64) + 1e-7 * float(gx64.abs().max())
