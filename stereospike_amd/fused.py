@@ -555,7 +555,11 @@ class _SpikeConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g3 = torch.empty((M, 3 * Cout), dtype=torch.bfloat16, device=g.device)
             _lib.split3_bf16(g, g3, M, Cout)
-            gw3 = torch.mm(A.t(), g3, out_dtype=torch.float32)                    # [K, 3*Cout]
+            S = next(d for d in (SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)   # split-K: the output is only K x 3*Cout
+            if S > 1:
+                gw3 = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g3.view(S, M // S, 3 * Cout), out_dtype=torch.float32).sum(0)
+            else:
+                gw3 = torch.mm(A.t(), g3, out_dtype=torch.float32)                # [K, 3*Cout]
             g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
         if ctx.needs_input_grad[0]:
             x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
@@ -568,6 +572,7 @@ class _SpikeConvCL(torch.autograd.Function):
         return g_x, g_w, None, None
 
 
+SPIKE_CONV_WGRAD_SPLIT = 8         # profiles/r01/wgrad_splitk.log
 SPIKE_CONV_MIN_CIN = 128           # conv3 (128), conv4 (256), bottleneck (512); below: im2col traffic outweighs the MFMA gain
 
 
