@@ -61,6 +61,7 @@ def parse():
     ap.add_argument('--wgrad-split-rows', type=int, default=None, help='decoder weight-gradient split-K rows per slice (default fused.WGRAD_SPLIT_ROWS)')
     ap.add_argument('--exact-split', type=int, default=1,
                     help='1 (default): decoder forward projections of spike inputs as exact bf16x3 GEMMs on the bf16 MFMA path; 0: plain fp32 GEMM')
+    ap.add_argument('--split-wgrad-min-k', type=int, default=None, help='fused.EXACT_SPLIT_WGRAD_MIN_K override (experiments)')
     ap.add_argument('--spike-conv-min-cin', type=int, default=None, help='fused.SPIKE_CONV_MIN_CIN override (experiments)')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
@@ -149,6 +150,8 @@ def main():
     from stereospike_amd import fused as _fused_cfg
     _fused_cfg.RECOMPUTE_H = bool(a.recompute_h)
     _fused_cfg.EXACT_SPLIT_GEMM = bool(a.exact_split)
+    if a.split_wgrad_min_k is not None:
+        _fused_cfg.EXACT_SPLIT_WGRAD_MIN_K = a.split_wgrad_min_k
     if a.spike_conv_min_cin is not None:
         _fused_cfg.SPIKE_CONV_MIN_CIN = a.spike_conv_min_cin
     if a.wgrad_split_rows:

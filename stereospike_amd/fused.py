@@ -407,6 +407,8 @@ WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient G
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
 EXACT_SPLIT_GEMM = True
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
+EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
+                                   # to pay for the extra 10 B/element split pass over g_P (profiles/r01/split_wgrad_sweep.log)
 ASSERT_EXACT_SPLIT = False         # tests: verify (with a host sync) that the input really is bf16-exact
 
 
@@ -463,6 +465,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
         ctx.save_for_backward(xg, Wt)
         ctx.lowp = lowp
+        ctx.exact = exact
         ctx.tables, ctx.k, ctx.n = tables, k, n
         ctx.wshape = weight.shape
         ctx.has_bias = bias is not None
@@ -497,7 +500,18 @@ class _UpConvProjectedCL(torch.autograd.Function):
             if need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
-            if need_w:
+            if need_w and ctx.exact and Cin >= EXACT_SPLIT_WGRAD_MIN_K:
+                # x is a spike tensor: g_Wt = x^T @ (gh + gm + gl) with exact products on the bf16 MFMA path (one extra 10 B/element pass
+                # over g_P for the split — pays only where the GEMM is compute-bound, i.e. the widest stage)
+                g3 = torch.empty((rows, 3 * kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
+                _lib.split3_bf16(g_P, g3, rows, kk * Cout)
+                xb = x_cl[c0:c1].view(rows, Cin).to(torch.bfloat16)
+                S = next(d for d in (SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if rows % d == 0)
+                gw3 = torch.bmm(xb.view(S, rows // S, Cin).transpose(1, 2), g3.view(S, rows // S, 3 * kk * Cout),
+                                out_dtype=torch.float32).sum(0) if S > 1 else torch.mm(xb.t(), g3, out_dtype=torch.float32)
+                g_Wt += gw3.view(Cin, 3, kk * Cout).sum(1)
+                del g3, gw3
+            elif need_w:
                 xs = x_cl[c0:c1].view(rows, Cin)
                 S = max(1, rows // WGRAD_SPLIT_ROWS)
                 L = rows // S

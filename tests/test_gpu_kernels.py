@@ -531,12 +531,20 @@ def test_exact_bf16x3_projection_has_fp32_gemm_accuracy(Cin, Cout, hw, HW):
             outs[exact] = (y.detach(), gx, gw)
         finally:
             fused.EXACT_SPLIT_GEMM, fused.ASSERT_EXACT_SPLIT = True, False
-    ref = torch.nn.functional.conv2d(m.up[0](x.permute(0, 3, 1, 2).double()), m.up[1].weight.double()).permute(0, 2, 3, 1)
+    wd = m.up[1].weight.detach().double().requires_grad_()
+    ref = torch.nn.functional.conv2d(m.up[0](x.permute(0, 3, 1, 2).double()), wd).permute(0, 2, 3, 1)
+    gw_ref, = torch.autograd.grad(ref, wd, g.double())
     e_exact = float((outs[True][0].double() - ref).abs().max())
     e_fp32 = float((outs[False][0].double() - ref).abs().max())
     assert e_exact <= 1.5 * e_fp32 + 1e-7 * float(ref.abs().max()), (e_exact, e_fp32)
     assert e_exact <= 1e-5 * float(ref.abs().max())
-    assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][2], outs[False][2])
+    assert torch.equal(outs[True][1], outs[False][1])              # data gradient: the same fp32 GEMM either way
+    # weight gradient: bf16x3 form for wide stages (EXACT_SPLIT_WGRAD_MIN_K), else the same fp32 GEMM
+    ew_exact = float((outs[True][2].double() - gw_ref).abs().max())
+    ew_fp32 = float((outs[False][2].double() - gw_ref).abs().max())
+    assert ew_exact <= 1.5 * ew_fp32 + 1e-7 * float(gw_ref.abs().max()), (ew_exact, ew_fp32)
+    if Cin < fused.EXACT_SPLIT_WGRAD_MIN_K:
+        assert torch.equal(outs[True][2], outs[False][2])
     fused.ASSERT_EXACT_SPLIT = True
     try:
         with pytest.raises(AssertionError):
