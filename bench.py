@@ -63,6 +63,7 @@ def parse():
                     help='1 (default): decoder forward projections of spike inputs as exact bf16x3 GEMMs on the bf16 MFMA path; 0: plain fp32 GEMM')
     ap.add_argument('--split-wgrad-min-k', type=int, default=None, help='fused.EXACT_SPLIT_WGRAD_MIN_K override (experiments)')
     ap.add_argument('--spike-conv-min-cin', type=int, default=None, help='fused.SPIKE_CONV_MIN_CIN override (experiments)')
+    ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
     return ap.parse_args()
@@ -147,6 +148,7 @@ def main():
 
     from stereospike_amd.network import blocks as _blocks
     _blocks.FUSE_UPCONV = bool(a.fuse_upconv)
+    _blocks.FORK_OUTPUTS = bool(a.fork_outputs)
     from stereospike_amd import fused as _fused_cfg
     _fused_cfg.RECOMPUTE_H = bool(a.recompute_h)
     _fused_cfg.EXACT_SPLIT_GEMM = bool(a.exact_split)

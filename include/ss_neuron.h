@@ -120,6 +120,22 @@ int ss_neuron_bwd_rc_f32(const float* g_out_seq, const float* g_v_last, const fl
                          void* stream);
 
 /*
+ * The backward for an output with TWO consumers (the fork the reference's graph makes wherever a spike tensor feeds both the next
+ * synapse and a skip / SEW add / prediction head: SNN_models.py:157-186, blocks.py:161-171).  PyTorch's autograd would sum the two
+ * incoming gradients in a separate pass (12 B per element); here g_out2_seq (nullable) is added on load: g = g_out + g_out2 (one fp32
+ * rounding, the same value the separate add produces) for 4 B per element.  Exactly one of h_seq (saved-h form) / x_seq (recompute
+ * form, supported T only) is non-NULL; g_out2_seq requires the recompute form (else SS_EINVAL: add the gradients beforehand);
+ * g_sum_seq (nullable, needs g_out2_seq): the summed gradient g is also written out — it is dL/dskip_seq of a stage that has both a
+ * fused skip add and a forked output (the decoder stages).  Everything else as ss_neuron_bwd_f32.
+ */
+int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, float* g_sum_seq, const float* g_v_last, const float* h_seq, const float* x_seq,
+                           const float* v_init, float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                           int T, long long N,
+                           float scale, int kind, float tau, const float* k,
+                           float v_th, float v_reset, int surrogate, float alpha, int detach_reset,
+                           void* stream);
+
+/*
  * 16-bit activation I/O variants (BASELINE.json configs 2 and 5: bf16 / fp16 activations, fp32 membrane state).
  * x_seq, skip_seq, out_seq (and g_out_seq, g_x_seq) hold IEEE fp16 (dtype = SS_DT_F16) or bfloat16 (SS_DT_BF16) values;
  * every input is widened to fp32 on load, ALL arithmetic and the membrane (v_init, v_last, h_seq, g_v_*) stay fp32 exactly

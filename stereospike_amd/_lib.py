@@ -39,6 +39,8 @@ def lib():
     L.ss_neuron_bwd_f32.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
     L.ss_neuron_bwd_rc_f32.argtypes = L.ss_neuron_bwd_f32.argtypes
     L.ss_neuron_bwd_rc_f32.restype = i32
+    L.ss_neuron_bwd_fork_f32.argtypes = [p, p, p, p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
+    L.ss_neuron_bwd_fork_f32.restype = i32
     L.ss_neuron_bwd_rc_supported.argtypes = [i32]
     L.ss_neuron_bwd_rc_supported.restype = i32
     L.ss_ipool_fwd_f32.argtypes = [p, i64, i64, p, p, i32, i32, i64, f32, f32, p]
@@ -76,7 +78,7 @@ def lib():
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
-           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16')
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -140,6 +142,21 @@ def neuron_bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_w
                                      T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
                                      int(bool(detach_reset)), _stream(h_seq))
     _check(rc, 'ss_neuron_bwd_f32')
+
+
+def neuron_bwd_fork(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, h_seq, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                    v_th, v_reset, surrogate, alpha, detach_reset):
+    """Backward with an optional second output gradient added on load; exactly one of h_seq / x_seq is given."""
+    _require_hip(g_out_seq, 'g_out_seq')
+    with torch.cuda.device(g_out_seq.device):
+        rc = lib().ss_neuron_bwd_fork_f32(_f32(g_out_seq, 'g_out_seq', T * N), _f32(g_out2_seq, 'g_out2_seq', T * N),
+                                          _f32(g_sum_seq, 'g_sum_seq', T * N),
+                                          _f32(g_v_last, 'g_v_last', N), _f32(h_seq, 'h_seq', T * N), _f32(x_seq, 'x_seq', T * N),
+                                          _f32(v_init, 'v_init', N), _f32(g_x_seq, 'g_x_seq', T * N), _f32(g_v_init, 'g_v_init', N),
+                                          _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'),
+                                          T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
+                                          int(bool(detach_reset)), _stream(g_out_seq))
+    _check(rc, 'ss_neuron_bwd_fork_f32')
 
 
 def neuron_bwd_rc_supported(T):

@@ -77,15 +77,17 @@ class BaseNode(nn.Module):
         return torch.full_like(like, float(v))
 
     def forward_sequence(self, x_seq: torch.Tensor, scale: float = 1., skip_seq: Optional[torch.Tensor] = None,
-                         nnz: Optional[torch.Tensor] = None, channels_last: bool = False) -> torch.Tensor:
+                         nnz: Optional[torch.Tensor] = None, channels_last: bool = False, fork: bool = False):
         """x_seq [T, ...]: T steps from the current membrane; returns out_seq [T, ...] and carries v forward.
         The kernel is element-wise, so any memory layout works as long as x, skip and v share it; with
         channels_last=True x_seq is an NHWC array [T, B, H, W, C] and `self.v` keeps its logical [B, C, H, W] shape
-        (a permuted view of the NHWC membrane)."""
-        out_seq, v_last = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0], channels_last),
-                                       skip_seq=skip_seq, k=self._k(), nnz=nnz)
+        (a permuted view of the NHWC membrane).  fork=True returns (out_seq, out_seq') — two handles on the same spikes for an output
+        with two consumers (next synapse + skip / head); their gradients are summed inside the backward kernel."""
+        res = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0], channels_last),
+                           skip_seq=skip_seq, k=self._k(), nnz=nnz, fork=fork)
+        v_last = res[1]
         self.v = v_last.permute(0, 3, 1, 2) if channels_last else v_last
-        return out_seq
+        return (res[0], res[2]) if fork else res[0]
 
     def forward_fused(self, x: torch.Tensor, scale: float = 1., skip: Optional[torch.Tensor] = None,
                       nnz: Optional[torch.Tensor] = None) -> torch.Tensor:

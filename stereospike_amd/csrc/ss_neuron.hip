@@ -231,9 +231,11 @@ struct BwdArgs {
     int T; long long N;
     float scale, tau, v_th, v_reset, alpha; const float* k; int detach_reset;
     const float* x_seq;   // non-null (templated T only): h_seq is not read, h is recomputed from the layer input (ss_neuron_bwd_rc_f32)
+    const float* g_out2_seq;  // nullable: gradient from a second consumer of out_seq, added on load (ss_neuron_bwd_fork_f32)
+    float* g_sum_seq;         // nullable (with g_out2_seq): g_out + g_out2 written out = dL/dskip_seq of a stage that has both
 };
 
-template <int KIND, int SG, int TS, int VEC, bool RC = false>
+template <int KIND, int SG, int TS, int VEC, bool RC = false, bool G2 = false>
 __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
@@ -300,6 +302,19 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
                 for (int t = 0; t < TS; ++t) hs[t] = load_stream(xq + (long long)t * NV);
 #pragma unroll
                 for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(gp + (long long)t * NV);
+                if constexpr (G2) {   // second consumer's gradient, added on load
+                    const vec_t* gp2 = reinterpret_cast<const vec_t*>(a.g_out2_seq) + i;
+                    vec_t g2[TS];
+#pragma unroll
+                    for (int t = TS - 1; t >= 0; --t) g2[t] = load_stream(gp2 + (long long)t * NV);
+#pragma unroll
+                    for (int t = TS - 1; t >= 0; --t) gs[t] += g2[t];
+                    if (a.g_sum_seq) {   // wave-uniform
+                        vec_t* sp = reinterpret_cast<vec_t*>(a.g_sum_seq) + i;
+#pragma unroll
+                        for (int t = TS - 1; t >= 0; --t) sp[(long long)t * NV] = gs[t];
+                    }
+                }
                 vec_t vv = v0;
 #pragma unroll
                 for (int t = 0; t < TS; ++t) {
@@ -1190,18 +1205,23 @@ int launch_bwd(const BwdArgs& a, hipStream_t s, int* grid_out)
     if (a.x_seq) {                                        // recompute needs h_0..h_{T-1} in registers: templated T only
         if constexpr (TS == 0) return SS_EINVAL;
         else {
-            const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.x_seq) && aligned16(a.g_x_seq) &&
+            const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.g_out2_seq) && aligned16(a.g_sum_seq) && aligned16(a.x_seq) && aligned16(a.g_x_seq) &&
                              (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                              (!a.v_init || aligned16(a.v_init));
             int grid = vec ? grid_for(a.N / 4, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
             if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
             *grid_out = grid;
-            if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4, true>), dim3(grid), dim3(kBlock), 0, s, a);
-            else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            if (a.g_out2_seq) {
+                if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4, true, true>), dim3(grid), dim3(kBlock), 0, s, a);
+                else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1, true, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            } else {
+                if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4, true>), dim3(grid), dim3(kBlock), 0, s, a);
+                else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            }
             return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
         }
     }
-    const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.h_seq) && aligned16(a.x_seq) && aligned16(a.g_x_seq) &&
+    const bool vec = (a.N % 4 == 0) && aligned16(a.g_out_seq) && aligned16(a.g_out2_seq) && aligned16(a.h_seq) && aligned16(a.x_seq) && aligned16(a.g_x_seq) &&
                      (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                      (!a.v_init || aligned16(a.v_init));
     int grid = vec ? grid_for(a.N / 4, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
@@ -1345,7 +1365,7 @@ int ss_neuron_fwd_f32(const float* x_seq, const float* v_init, const float* skip
     }
 }
 
-static int neuron_bwd_f32_impl(const float* g_out_seq, const float* g_v_last, const float* h_seq, const float* x_seq,
+static int neuron_bwd_f32_impl(const float* g_out_seq, const float* g_out2_seq, float* g_sum_seq, const float* g_v_last, const float* h_seq, const float* x_seq,
                                const float* v_init, float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
                                int T, long long N, float scale, int kind, float tau, const float* k,
                                float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
@@ -1363,7 +1383,7 @@ static int neuron_bwd_f32_impl(const float* g_out_seq, const float* g_v_last, co
         return SS_OK;
     }
     BwdArgs a{g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, want_gk ? g_k_ws : nullptr,
-              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset, x_seq};
+              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset, x_seq, g_out2_seq, g_out2_seq ? g_sum_seq : nullptr};
     int grid = 0, rc;
     switch (kind) {
         case SS_KIND_IF: rc = dispatch_bwd_sg<SS_KIND_IF>(a, surrogate, s, &grid); break;
@@ -1384,7 +1404,7 @@ int ss_neuron_bwd_f32(const float* g_out_seq, const float* g_v_last, const float
                       float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
 {
     if (!h_seq) return SS_EINVAL;
-    return neuron_bwd_f32_impl(g_out_seq, g_v_last, h_seq, nullptr, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+    return neuron_bwd_f32_impl(g_out_seq, nullptr, nullptr, g_v_last, h_seq, nullptr, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
                                v_th, v_reset, surrogate, alpha, detach_reset, stream);
 }
 
@@ -1399,8 +1419,22 @@ int ss_neuron_bwd_rc_f32(const float* g_out_seq, const float* g_v_last, const fl
                          float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
 {
     if (!x_seq || !ss_neuron_bwd_rc_supported(T)) return SS_EINVAL;
-    return neuron_bwd_f32_impl(g_out_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+    return neuron_bwd_f32_impl(g_out_seq, nullptr, nullptr, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
                                v_th, v_reset, surrogate, alpha, detach_reset, stream);
+}
+
+int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, float* g_sum_seq, const float* g_v_last, const float* h_seq, const float* x_seq,
+                           const float* v_init, float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                           int T, long long N, float scale, int kind, float tau, const float* k,
+                           float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+{
+    if ((h_seq != nullptr) == (x_seq != nullptr)) return SS_EINVAL;          // exactly one of saved h / layer input
+    if (x_seq && !ss_neuron_bwd_rc_supported(T)) return SS_EINVAL;
+    if (g_out2_seq && !x_seq) return SS_EINVAL;                              // the fused second gradient exists in the recompute form only
+    if (g_out2_seq && (g_out2_seq == g_x_seq)) return SS_EINVAL;
+    if (g_sum_seq && (!g_out2_seq || g_sum_seq == g_x_seq)) return SS_EINVAL;
+    return neuron_bwd_f32_impl(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, h_seq, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind,
+                               tau, k, v_th, v_reset, surrogate, alpha, detach_reset, stream);
 }
 
 int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_seq,

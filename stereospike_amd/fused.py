@@ -79,7 +79,7 @@ RECOMPUTE_H = True
 
 class _FusedNeuron(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz):
+    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False):
         T = x_seq.shape[0]
         N = x_seq.numel() // T
         x_seq = x_seq.contiguous()
@@ -119,16 +119,27 @@ class _FusedNeuron(torch.autograd.Function):
             # the reference mutates it in place (blocks.py:171).  v_init only feeds the PLIF dL/dk term at t = 0.
             keep_v = v_init if (cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]) else None
             ctx.save_for_backward(h_seq, keep_v, k)
+        if fork:
+            # a second handle on the same memory for the second consumer: autograd then delivers the two gradients separately and the
+            # backward kernel adds them on load (ss_neuron_bwd_fork_f32) instead of a separate 12 B/element accumulation pass
+            return out_seq, v_last, out_seq.view_as(out_seq)
         return out_seq, v_last
 
     @staticmethod
-    def backward(ctx, g_out_seq, g_v_last):
+    def backward(ctx, g_out_seq, g_v_last, g_out2_seq=None):
         h_seq, v_init, k = ctx.saved_tensors          # h_seq is x_seq (activation dtype) when ctx.recompute
         cfg, T, N = ctx.cfg, ctx.T, ctx.N
         half = ctx.io_dtype in (torch.float16, torch.bfloat16)
         if g_out_seq is None:
+            g_out_seq, g_out2_seq = g_out2_seq, None
+        if g_out_seq is None:
             g_out_seq = torch.zeros(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
         g_out_seq = g_out_seq.to(ctx.io_dtype).contiguous()
+        fuse2 = g_out2_seq is not None and ctx.recompute and not half
+        if g_out2_seq is not None:
+            g_out2_seq = g_out2_seq.to(ctx.io_dtype).contiguous()
+            if not fuse2:
+                g_out_seq, g_out2_seq = g_out_seq + g_out2_seq, None
         if g_v_last is not None:
             g_v_last = g_v_last.float().contiguous()
         g_x_seq = torch.empty(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
@@ -140,24 +151,31 @@ class _FusedNeuron(torch.autograd.Function):
             g_k = torch.empty((), dtype=torch.float32, device=h_seq.device)
             g_k_ws = torch.empty(_lib.gk_ws_floats(), dtype=torch.float32, device=h_seq.device)
         e0 = TIMER.start()
-        if ctx.recompute:
-            bwd = _lib.neuron_bwd_rc_x16 if half else _lib.neuron_bwd_rc
+        want_gskip = ctx.has_skip and ctx.needs_input_grad[2]
+        g_sum = torch.empty_like(g_out_seq) if (fuse2 and want_gskip) else None
+        if fuse2:
+            _lib.neuron_bwd_fork(g_out_seq, g_out2_seq, g_sum, g_v_last, None, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+                                 T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
         else:
-            bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
-        bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
-            T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, 'neuron_bwd', ((6 if ctx.recompute else 8) if half else 12) * T * N, T * N)
-        g_skip = g_out_seq if (ctx.has_skip and ctx.needs_input_grad[2]) else None   # identity
-        return g_x_seq, g_v_init, g_skip, g_k, None, None
+            if ctx.recompute:
+                bwd = _lib.neuron_bwd_rc_x16 if half else _lib.neuron_bwd_rc
+            else:
+                bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
+            bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+                T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
+        TIMER.stop(e0, 'neuron_bwd+fork' if fuse2 else 'neuron_bwd', ((6 if ctx.recompute else 8) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
+        g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
+        return g_x_seq, g_v_init, g_skip, g_k, None, None, None
 
 
 def fused_neuron(x_seq: torch.Tensor, cfg: NeuronCfg, v_init: Optional[torch.Tensor] = None,
                  skip_seq: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None,
-                 nnz: Optional[torch.Tensor] = None):
-    """x_seq: [T, ...] conv output (before the gain).  Returns (out_seq [T, ...], v_last [...])."""
+                 nnz: Optional[torch.Tensor] = None, fork: bool = False):
+    """x_seq: [T, ...] conv output (before the gain).  Returns (out_seq [T, ...], v_last [...]) — with fork=True a third value: a
+    second handle on out_seq for its second consumer (the two gradients are then added inside the backward kernel)."""
     if cfg.kind == _lib.KIND_PLIF and k is None:
         raise _lib.SSNeuronError('PLIF needs k = sigmoid(w) as a 0-dim HIP tensor')
-    return _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz)
+    return _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz, fork)
 
 
 class _IPool(torch.autograd.Function):

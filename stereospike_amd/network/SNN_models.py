@@ -128,9 +128,18 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         enc_cl = cl and _blocks.ENCODER_CHANNELS_LAST and all(
             getattr(b, 'connect_function', 'ADD') == 'ADD' for b in self.bottleneck)
         if enc_cl:          # whole network on NHWC arrays [T, B, h, w, C]: no layout copies anywhere
-            enc = [self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'))]
-            for i in range(1, 5):
-                enc.append(getattr(self, f'conv{i}').forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True))
+            # every encoder output has two consumers (next conv + decoder skip): forked handles, gradients summed in the neuron backward
+            fork = _blocks.FORK_OUTPUTS
+
+            def two(r):
+                return r if fork else (r, r)
+            a, b = two(self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'), fork=fork))
+            enc, enc_skip = [a], [b]
+            for i in range(1, 4):
+                a, b = two(getattr(self, f'conv{i}').forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True, fork=fork))
+                enc.append(a)
+                enc_skip.append(b)
+            enc.append(self.conv4.forward_sequence_conv_cl(enc[-1], nnz('conv4'), spikes_in=True))
             cur = self.bottleneck[0].forward_sequence_cl(enc[4], spikes_in=True)          # enc[*], cur: spike tensors
             cur = self.bottleneck[1].forward_sequence_cl(cur, nnz('rconv'), spikes_in=True)
             spikes, heads = [cur.permute(0, 1, 4, 2, 3)], []
@@ -146,10 +155,12 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         for lvl in (4, 3, 2, 1):
             stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
             if cl:
-                skip = enc[lvl - 1] if enc_cl else enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
-                cur = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True)   # cur: spikes (+ SEW / skip adds)
+                skip = enc_skip[lvl - 1] if enc_cl else enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
+                # the stage output feeds the next stage and its prediction head: forked handles again
+                r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_blocks.FORK_OUTPUTS)
+                cur, cur_head = r if _blocks.FORK_OUTPUTS else (r, r)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
-                pd = head[0].forward_projected_cl(cur.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW
+                pd = head[0].forward_projected_cl(cur_head.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW
             else:
                 cur = stage.forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
                 spikes.append(cur)

@@ -25,6 +25,8 @@ DECODER_CHANNELS_LAST = True
 # Also keep the encoder / bottleneck activations in NHWC memory (torch channels_last): MIOpen then runs its NHWC-native
 # implicit-GEMM kernels without layout transposes and the decoder's skip tensors need no NCHW->NHWC copies.
 ENCODER_CHANNELS_LAST = True
+# outputs with two consumers (next synapse + skip / head) are handed out as two handles; the neuron backward adds the two gradients on load
+FORK_OUTPUTS = True
 
 
 class MultiplyBy(nn.Module):
@@ -127,22 +129,23 @@ class SpikingStage(nn.Sequential):
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
 
 
-    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False):
+    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False, fork: bool = False):
         """Encoder stage on NHWC arrays: x_seq [T, B, h, w, C] -> [T, B, h', w', C'].  The Conv2d sees a logical-NCHW
         view with channels_last strides (no copy) and returns channels_last memory, i.e. again an NHWC array.
         spikes_in: x_seq is the output of a spiking layer."""
         T, B = x_seq.shape[:2]
         y = _conv_cl(self[0], x_seq.flatten(0, 1), spikes_in)
         y, scale = _fold_gain(self[1], y)
-        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True, fork=fork)
 
-    def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None, spikes_in: bool = False):
+    def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None, spikes_in: bool = False,
+                            fork: bool = False):
         """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
         NNConvUpsampling.  spikes_in: x_seq is the output of a spiking layer (+ spike skip adds)."""
         T, B = x_seq.shape[:2]
         y = self[0].forward_projected_cl(x_seq.flatten(0, 1), spikes_in)
         y, scale = _fold_gain(self[1], y)
-        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True, fork=fork)
 
 
 class ResBlock(nn.Module):

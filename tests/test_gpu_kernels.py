@@ -603,3 +603,32 @@ def test_spike_conv_as_exact_bf16x3_gemm(Cin, Cout, k, s, pad, hw):
     assert err(y.permute(0, 3, 1, 2), y64) <= 2 * err(y32, y64) + 1e-7 * float(y64.abs().max())
     assert err(gw, gw64) <= 2 * err(gw32, gw64) + 1e-7 * float(gw64.abs().max())
     assert err(gx, gx64) <= 2 * err(gx32, gx64) + 1e-7 * float(gx64.abs().max())
+
+
+@pytest.mark.parametrize('kind', ['IF', 'PLIF'])
+@pytest.mark.parametrize('T,N', [(5, 4096 * 3), (5, 1003), (10, 8192), (1, 64)])
+def test_backward_with_forked_output_gradients(kind, T, N):
+    """ss_neuron_bwd_fork_f32: two output gradients added on load == the recompute backward fed their fp32 sum, bit for bit (g_x, g_v_init,
+    dL/dk); g_sum_seq == g1 + g2; the saved-h form refuses a second gradient."""
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(N + T)
+    x = _dev((rng.standard_normal((T, N)) * 0.25).astype(np.float32))
+    g1 = _dev(rng.standard_normal((T, N)).astype(np.float32))
+    g2 = _dev((rng.standard_normal((T, N)) * 3).astype(np.float32))
+    v0 = _dev((rng.standard_normal(N) * 0.5).astype(np.float32))
+    k = torch.tensor([0.3], device=DEV) if kind == 'PLIF' else None
+    args = (T, N, 7.5, KIND[kind], 2.0, k, 1.0, 0.0, SG['ATan'], 2.0, True)
+    ws = torch.empty(_lib.gk_ws_floats(), device=DEV) if kind == 'PLIF' else None
+    gx_a, gv_a, gk_a = torch.empty_like(x), torch.empty(N, device=DEV), (torch.zeros(1, device=DEV) if kind == 'PLIF' else None)
+    _lib.neuron_bwd_rc(g1 + g2, None, x, v0, gx_a, gv_a, gk_a, ws, *args)
+    gx_b, gv_b, gk_b = torch.empty_like(x), torch.empty(N, device=DEV), (torch.zeros(1, device=DEV) if kind == 'PLIF' else None)
+    gsum = torch.full_like(x, float('nan'))
+    _lib.neuron_bwd_fork(g1, g2, gsum, None, None, x, v0, gx_b, gv_b, gk_b, ws, *args)
+    assert torch.equal(gx_a, gx_b) and torch.equal(gv_a, gv_b) and torch.equal(gsum, g1 + g2)
+    if kind == 'PLIF':
+        assert float(gk_a) == float(gk_b)
+    gx_c = torch.empty_like(x)
+    _lib.neuron_bwd_fork(g1, g2, None, None, None, x, v0, gx_c, None, None if kind != 'PLIF' else torch.zeros(1, device=DEV), ws, *args)
+    assert torch.equal(gx_c, gx_a)
+    with pytest.raises(_lib.SSNeuronError):
+        _lib.neuron_bwd_fork(g1, g2, None, None, x, None, v0, gx_c, None, None, None, *args)      # saved-h form + second gradient

@@ -51,6 +51,15 @@ def host_backend(monkeypatch):
         neuron_bwd(g_out_seq, g_v_last, h, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k, v_th, v_reset,
                    surrogate, alpha, detach_reset)
 
+    def neuron_bwd_fork(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, h_seq, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale,
+                        kind, tau, k, v_th, v_reset, surrogate, alpha, detach_reset):
+        g = g_out_seq if g_out2_seq is None else g_out_seq + g_out2_seq
+        if g_sum_seq is not None:
+            g_sum_seq.copy_(g)
+        assert x_seq is not None and h_seq is None
+        neuron_bwd_rc(g, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k, v_th, v_reset,
+                      surrogate, alpha, detach_reset)
+
     def ipool_fwd(pd_seq, st, sk, v_init, depth_seq, T, K, M, scale, v_reset):
         assert L.ss_ref_ipool_fwd_f32(_p(pd_seq), st, sk, _p(v_init), _p(depth_seq), T, K, M, scale, v_reset) == 0
 
@@ -92,6 +101,7 @@ def host_backend(monkeypatch):
     monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
     monkeypatch.setattr(_lib, 'neuron_bwd', neuron_bwd)
     monkeypatch.setattr(_lib, 'neuron_bwd_rc', neuron_bwd_rc)
+    monkeypatch.setattr(_lib, 'neuron_bwd_fork', neuron_bwd_fork)
     monkeypatch.setattr(_lib, 'neuron_bwd_rc_supported', lambda T: T in (1, 2, 4, 5, 8, 10))
     monkeypatch.setattr(_lib, 'ipool_fwd', ipool_fwd)
     monkeypatch.setattr(_lib, 'ipool_bwd', ipool_bwd)
