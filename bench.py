@@ -210,8 +210,12 @@ def main():
         fwd_shapes = {k: v for k, v in shapes.items() if k[0] == 'neuron_fwd_train'}
         dom = max(fwd_shapes, key=lambda k: k[1]) if fwd_shapes else None
         fwd = fwd_shapes.get(dom, zero)
-        bwd_shapes = {k: v for k, v in shapes.items() if k[0] == 'neuron_bwd'}
-        bwd = bwd_shapes.get(max(bwd_shapes, key=lambda k: k[1]), zero) if bwd_shapes else zero
+        # backward: the launch group with the most updates; at equal size the forked form without the extra g_sum store (the bottom
+        # layer: 16 B/update), which is also the variant the PMC passes measure (tools/pmc_target.py)
+        pref = {'neuron_bwd+fork': 2, 'neuron_bwd': 1, 'neuron_bwd+fork+sum': 0}
+        bwd_shapes = {k: v for k, v in shapes.items() if k[0] in pref}
+        bwd = bwd_shapes.get(max(bwd_shapes, key=lambda k: (k[1], pref[k[0]])), zero) if bwd_shapes else zero
+        bwd_tag = max(bwd_shapes, key=lambda k: (k[1], pref[k[0]]))[0] if bwd_shapes else 'neuron_bwd'
         fwd_all = [v for k, v in summ.items() if k.startswith('neuron_fwd')]
         all_ms = sum(v['ms'] for k, v in summ.items() if k.startswith('neuron_'))
         all_bytes = sum(v['bytes'] for k, v in summ.items() if k.startswith('neuron_'))
@@ -247,7 +251,8 @@ def main():
                                         f'{bpu(fwd)} B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
                                  **roof(fwd)),
             'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
-                                        f'{", h recomputed from the layer input" if recompute_h else ""}), largest launch shape',
+                                        f'{", h recomputed from the layer input" if recompute_h else ""}'
+                                        f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}), largest launch shape',
                                  **roof(bwd, 'neuron_bwd')),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
@@ -261,8 +266,8 @@ def main():
                 if 'neuron_fwd_train' in summ else None,
                 'neuron_fwd_kernel<0, 5, true, %s, 4>' % ('false' if recompute_h else 'true'): round(1e3 * summ['neuron_fwd_train+skip']['ms'] / summ['neuron_fwd_train+skip']['launches'], 1)
                 if 'neuron_fwd_train+skip' in summ else None,
-                'neuron_bwd_kernel<*>': round(1e3 * summ['neuron_bwd']['ms'] / summ['neuron_bwd']['launches'], 1)
-                if 'neuron_bwd' in summ else None},
+                'neuron_bwd_kernel<*>': round(1e3 * sum(v['ms'] for k, v in summ.items() if k.startswith('neuron_bwd'))
+                                              / max(1, sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_bwd'))), 1)},
             'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),

@@ -38,7 +38,7 @@ def mean_counter(sub, counter):
 fetch, nf = mean_counter('fetch', 'FETCH_SIZE')
 write, nw = mean_counter('write', 'WRITE_SIZE')
 T, N = 5, 16 * 32 * 260 * 346
-per_update = {'neuron_fwd': 8 if mode == 'rc' else 12, 'neuron_bwd': 12}
+per_update = {'neuron_fwd': 8 if mode == 'rc' else 12, 'neuron_bwd': 16 if mode == 'rc' else 12}
 res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, tools/pmc_target.py {mode}',
        'mode': mode, 'algorithmic_bytes_per_update': per_update,
        'algorithmic_bytes_per_launch': {k: v * T * N for k, v in per_update.items()},

@@ -163,7 +163,7 @@ class _FusedNeuron(torch.autograd.Function):
                 bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
             bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                 T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, 'neuron_bwd+fork' if fuse2 else 'neuron_bwd', ((6 if ctx.recompute else 8) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
+        TIMER.stop(e0, ('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd', ((6 if ctx.recompute else 8) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
         g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
         return g_x_seq, g_v_init, g_skip, g_k, None, None, None
 
