@@ -9,8 +9,9 @@ A "step" is one full training iteration on one batch of synthetic input per GPU:
 (convs on PyTorch-ROCm, every neuron layer one fused HIP launch) -> Total_Loss -> backward (fused surrogate
 backward; with N > 1 the RCCL gradient all-reduce overlapped) -> Adam step -> detach.  Inputs are resident in HBM
 when the timed region starts.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
-  roofline     — the fused neuron forward kernel (dominant hand-written kernel): algorithmic bytes / HIP-event time
-                 over the launches inside the timed region, vs the 8 TB/s HBM3E peak;
+  roofline     — the dominant fused neuron kernel (whichever of forward / backward took more of the timed region; roofline_fwd and
+                 roofline_bwd carry both): algorithmic bytes / HIP-event time over its launches inside the timed region, vs the
+                 8 TB/s HBM3E peak, with the counter-measured HBM bytes per launch as `traffic`;
   cpu_baseline — the oracle's unfused eager-PyTorch port of the same training step on the host cores (N = 1 only).
 """
 import argparse

@@ -948,31 +948,26 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
 // im2col of an NHWC fp32 array into a bf16 patch matrix A[(nb, oy, ox)][(ky, kx, c)], zero padding, stride s.  A lane converts 8
 // consecutive channels of one (row, tap): two 16-B loads, one 16-B store; the k*k-fold re-read of x is served by L2.
 __global__ __launch_bounds__(kBlock) void im2col_cl_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ A,
-                                                                long long rows, int h, int w, int C, int k, int stride, int pad,
-                                                                int ho, int wo)
+                                                                int h, int w, int C, int k, int stride, int pad, int ho, int wo)
 {
-    const int C8 = C / 8;
-    const long long per_row = (long long)k * k * C8;
-    const long long total = rows * per_row;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const long long row = i / per_row;
-        const int r = (int)(i - row * per_row);
-        const int tap = r / C8, c8 = r - tap * C8;
-        const int ky = tap / k, kx = tap - ky * k;
-        const int ox = (int)(row % wo);
-        const long long t = row / wo;
-        const int oy = (int)(t % ho);
-        const long long nb = t / ho;
-        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
-            const float* src = x + ((nb * h + iy) * (long long)w + ix) * C + c8 * 8;
-            const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+    // blockIdx.x = patch row (nb, oy, ox): its decomposition is wave-uniform (scalar ALU); blockIdx.y * 256 + lane = (tap, 8-channel group)
+    const unsigned row = blockIdx.x;
+    const unsigned C8 = (unsigned)C / 8;
+    const unsigned r = blockIdx.y * kBlock + threadIdx.x;
+    if (r >= (unsigned)(k * k) * C8) return;
+    const unsigned ox = row % (unsigned)wo, t = row / (unsigned)wo;
+    const unsigned oy = t % (unsigned)ho, nb = t / (unsigned)ho;
+    const unsigned tap = r / C8, c8 = r - tap * C8;
+    const unsigned ky = tap / (unsigned)k, kx = tap - ky * (unsigned)k;
+    const int iy = (int)(oy * stride + ky) - pad, ix = (int)(ox * stride + kx) - pad;
+    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+        const float* src = x + (((long long)nb * h + iy) * w + ix) * C + c8 * 8;
+        const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = narrow<SS_DT_BF16>(a[e]); o[4 + e] = narrow<SS_DT_BF16>(b[e]); }
-        }
-        *reinterpret_cast<u16x8*>(A + (row * (long long)k * k + tap) * C + c8 * 8) = o;
+        for (int e = 0; e < 4; ++e) { o[e] = narrow<SS_DT_BF16>(a[e]); o[4 + e] = narrow<SS_DT_BF16>(b[e]); }
     }
+    *reinterpret_cast<u16x8*>(A + ((long long)row * (k * k) + tap) * C + c8 * 8) = o;
 }
 
 // g fp32 [M][N] -> g3 bf16 [M][3N] = [hi | mid | lo] with hi = bf16(g), mid = bf16(g - hi), lo = bf16(g - hi - mid): the three terms
@@ -1617,9 +1612,10 @@ int ss_im2col_cl_bf16(const float* x, void* A, long long NB, int h, int w, int C
     if ((ho - 1) * stride - pad + k - 1 >= h + pad || (wo - 1) * stride - pad + k - 1 >= w + pad) return SS_EINVAL;
     if (!aligned16(x) || !aligned16(A)) return SS_EINVAL;
     const long long rows = NB * ho * wo;
-    const long long total = rows * k * k * (C / 8);
-    hipLaunchKernelGGL(im2col_cl_bf16_kernel, dim3(grid_for(total, kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       x, static_cast<unsigned short*>(A), rows, h, w, C, k, stride, pad, ho, wo);
+    const long long per_row = (long long)k * k * (C / 8);
+    if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
+    hipLaunchKernelGGL(im2col_cl_bf16_kernel, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), x, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
