@@ -566,3 +566,25 @@ def test_kernel_hyper_parameter_fuzz():
                 assert bit_equal(rb['g_x'], gb['g_x']) and bit_equal(rb['g_v_init'], gb['g_v_init']), (it, kw, alpha)
             else:
                 assert rel_err(gb['g_x'], rb['g_x']) < 1e-6, (it, kw, alpha)
+
+
+def test_graphed_inference_replays_the_eager_forward_bit_for_bit():
+    """engine.GraphedInference: reset -> T-step forward captured into a HIP graph once, replayed per sample; outputs identical to the eager
+    path for several different inputs (fp32 and bf16 activations)."""
+    from stereospike_amd.clock_driven import functional, surrogate
+    from stereospike_amd.engine import GraphedInference
+    from stereospike_amd.network.SNN_models import StereoSpike
+    torch.manual_seed(5)
+    H, W = 64, 80
+    net = StereoSpike(surrogate_function=surrogate.ATan(), multiply_factor=10., input_size=(H, W)).to(DEV).eval()
+    xs = [synth_input(1, 3, 4, 50 + i, H, W, lam=0.1).to(DEV) for i in range(3)]
+    for amp_dtype in (None, torch.bfloat16):
+        gi = GraphedInference(net, xs[0], amp_dtype=amp_dtype)
+        for x in xs + xs[:1]:
+            functional.reset_net(net)
+            with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype or torch.float32, enabled=amp_dtype is not None):
+                d_ref, s_ref = net.forward_sequence(x)
+            d_ref, s_ref = [t.clone() for t in d_ref], [t.clone() for t in s_ref]
+            d, s = gi(x)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(d, d_ref)) and all(torch.equal(a, b) for a, b in zip(s, s_ref))
