@@ -271,6 +271,7 @@ def main():
                                               / max(1, sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_bwd'))), 1)},
             'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
+            'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
         # `roofline` = the dominant kernel of the path: whichever of the two fused neuron kernels took more of the timed region
