@@ -833,6 +833,26 @@ __global__ __launch_bounds__(kBlock) void upconv1_bwd_kernel(const float* __rest
     }
 }
 
+// XCD-aware workgroup remap (guide T1): the dispatcher places workgroup b on XCD b % 8, each XCD with a private L2.  The gather kernels'
+// neighbouring workgroups (adjacent pixels of a row, and the rows above / below) read the same P / g_out lines, so each XCD is given a
+// CONTIGUOUS chunk of the linear workgroup range instead of every 8th one.  Bijective for any workgroup count.  Measured
+// (profiles/r01/bench_gather_xcd.log): forward gather 3.24 -> 2.76 ms per step over the four decoder stages; the (write-bound) adjoint +1 %.
+#ifndef SS_CL_BWD_ROWSCAN
+#define SS_CL_BWD_ROWSCAN 1
+#endif
+#ifndef SS_XCD_REMAP
+#define SS_XCD_REMAP 1
+#endif
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+{
+#if SS_XCD_REMAP
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#else
+    return bid;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------
 // channels-last gather kernels (decoder kept in NHWC: P is the row-major output of ONE GEMM, no transposes)
 // ---------------------------------------------------------------------------------------------------
@@ -843,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __re
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
     const unsigned CV = (unsigned)C / VEC;                            // channel vectors per pixel
-    const unsigned idx = blockIdx.x * kBlock + threadIdx.x;           // (pixel, channel vector) of one image
+    const unsigned idx = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;   // (pixel, channel vector) of one image
     if (idx >= (unsigned)(H * W) * CV) return;
     const unsigned pix = idx / CV, cv = idx - pix * CV;
     const unsigned y = pix / (unsigned)W, x = pix - y * (unsigned)W;
@@ -879,7 +899,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
     const unsigned CV = (unsigned)C / VEC;
-    const unsigned idx = blockIdx.x * kBlock + threadIdx.x;           // (source pixel, channel vector) of one image
+    const unsigned idx = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;   // (source pixel, channel vector) of one image
     if (idx >= (unsigned)(h * w) * CV) return;
     const unsigned sp = idx / CV, cv = idx - sp * CV;
     const unsigned iy = sp / (unsigned)w, ix = sp - iy * (unsigned)w;
@@ -891,6 +911,52 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
     for (int img = blockIdx.y; img < NB; img += gridDim.y) {
         const float* g = g_out + (long long)img * (H * W) * C + cv * VEC;
         float* gp = g_P + ((long long)img * (h * w) + sp) * KKC + cv * VEC;
+#if SS_CL_BWD_ROWSCAN
+        if (ry >= 1 && ry <= 3 && rx <= 3) {
+            // one pass over the ry + K - 1 window rows, top to bottom: each row is loaded ONCE ((K+2) vectors), reduced to its K
+            // horizontal-tap sums cs[kx], and combined with the sums of the previous one / two rows (kept in registers) into the
+            // vertical tap that this row completes — (ry+4)(rx+4) = 36..49 loads per lane instead of 3*7*K = 105, same summation
+            // order (rows oldest first, columns left to right inside a row) => bit-identical to the per-tap form.
+            vec_t p1[K], p2[K];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) { p1[kx] = zero; p2[kx] = zero; }
+#pragma unroll 1
+            for (int j = 0; j < ry + K - 1; ++j) {
+                const int y = ylo - (K - 1) + j;
+                vec_t cs[K];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) cs[kx] = zero;
+                if (y >= 0 && y < H) {
+                    vec_t row[K + 2];
+#pragma unroll
+                    for (int c = 0; c < K + 2; ++c) {
+                        const int x = xlo - (K - 1) + c;
+                        const bool ok = x >= 0 && x < W && c < K - 1 + rx;
+                        row[c] = ok ? *reinterpret_cast<const vec_t*>(g + (long long)(y * W + x) * C) : zero;
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const int b0 = K - 1 - kx;
+                        if (rx > 0) cs[kx] += row[b0];
+                        if (rx > 1) cs[kx] += row[b0 + 1];
+                        if (rx > 2) cs[kx] += row[b0 + 2];
+                    }
+                }
+                const int ky = (K - 2) + ry - j;                      // the vertical tap whose last row this is
+                if (j >= ry - 1 && ky >= 0) {
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        vec_t acc = zero;
+                        if (ry > 2) acc += p2[kx];
+                        if (ry > 1) acc += p1[kx];
+                        acc += cs[kx];
+                        *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc;
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) { p2[kx] = p1[kx]; p1[kx] = cs[kx]; }
+            }
+#else
         if (ry <= 3 && rx <= 3) {
             // per vertical tap: up to 3 rows of a (K+2)-wide window, row sums shared between the K horizontal taps
             // (rows re-read per ky hit L1; the ky loop is kept rolled so the kernel stays below ~100 VGPRs instead of 255)
@@ -924,6 +990,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc[kx];
             }
+#endif
         } else {
             for (int ky = 0; ky < K; ++ky) {
                 const int y0 = max(ylo - ky, 0), y1 = min(yhi - ky, H);

@@ -40,6 +40,12 @@ for name, Cout, (h, w), (H, W) in (('deconv4', 256, (17, 22), (33, 44)), ('decon
                 res.setdefault((lname, tag), []).append(e0.elapsed_time(e1) / 3 * 1e3)
             if rnd == 0:
                 outs[lname], gps[lname] = out, gP
+    big = torch.empty(Pm.numel(), device=dev)
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True); big.fill_(1.0); e0.record()
+    for _ in range(3): big.fill_(2.0)
+    e1.record(); torch.cuda.synchronize()
+    print(f'{name} pure fill of a P-sized buffer ({big.numel() * 4 / 1e9:.2f} GB): {big.numel() * 4 * 3 / e0.elapsed_time(e1) / 1e6:.1f} GB/s (write-only ceiling)')
+    del big
     ref = next(iter(outs))
     same = all(torch.equal(outs[ref], o) for o in outs.values()) and all(torch.equal(gps[ref], o) for o in gps.values())
     nbytes = 4 * (Pm.numel() + g.numel())
