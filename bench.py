@@ -64,6 +64,9 @@ def parse():
                     help='1 (default): decoder forward projections of spike inputs as exact bf16x3 GEMMs on the bf16 MFMA path; 0: plain fp32 GEMM')
     ap.add_argument('--split-wgrad-min-k', type=int, default=None, help='fused.EXACT_SPLIT_WGRAD_MIN_K override (experiments)')
     ap.add_argument('--spike-conv-min-cin', type=int, default=None, help='fused.SPIKE_CONV_MIN_CIN override (experiments)')
+    ap.add_argument('--gemm-tuning', type=int, default=1,
+                    help='1 (default): load the tracked TunableOp record (GEMM algorithm per shape) read-only; 2: tune unseen shapes and '
+                         'write gpurun_out/tunableop_results.csv; 0: library defaults')
     ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
@@ -140,6 +143,17 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    if a.gemm_tuning:
+        from stereospike_amd import gemm_tuning
+        if a.gemm_tuning == 2:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            out_csv = os.path.join(ROOT, 'gpurun_out', 'tunableop_results.csv')
+            if not os.path.exists(out_csv) and os.path.exists(gemm_tuning.SEED):
+                import shutil
+                shutil.copy(gemm_tuning.SEED, out_csv)
+            gemm_tuning.enable(local, tuning=True, filename=out_csv)
+        else:
+            gemm_tuning.enable(local)
 
     from stereospike_amd import _lib
     from stereospike_amd.dp import GradientAllReducer

@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--out', default='results/checkpoints')
     a = ap.parse_args()
     device = torch.device('cuda:0')
+    from stereospike_amd import gemm_tuning
+    gemm_tuning.enable(0)
     from stereospike_amd.clock_driven import functional, surrogate
     from stereospike_amd.engine import synthetic_batch
     from stereospike_amd.network.loss import Total_Loss

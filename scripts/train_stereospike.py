@@ -44,6 +44,8 @@ def main():
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', 1), ('RANK', 0), ('LOCAL_RANK', 0)))
     torch.cuda.set_device(local)
+    from stereospike_amd import gemm_tuning
+    gemm_tuning.enable(local)                                  # tracked GEMM-algorithm record, read-only
     device = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group('nccl', device_id=device)

@@ -161,3 +161,18 @@ def test_blocks_upsampling_vs_reference_fixture():
 def test_pyramid_sizes():
     from stereospike_amd.network.SNN_models import _pyramid
     assert _pyramid((260, 346)) == [(260, 346), (130, 173), (65, 87), (33, 44), (17, 22)]
+
+
+def test_gemm_tuning_record_is_wellformed_and_loader_is_inert_without_a_gpu():
+    """The tracked TunableOp record: validator header for the image's library versions + one line per GEMM shape; the loader does
+    nothing (returns None) when there is no HIP device."""
+    import csv
+    from stereospike_amd import gemm_tuning
+    rows = list(csv.reader(open(gemm_tuning.SEED)))
+    validators = {r[1]: r[2] for r in rows if r[0] == 'Validator'}
+    assert {'PT_VERSION', 'HIPBLASLT_VERSION', 'ROCBLAS_VERSION', 'GCN_ARCH_NAME'} <= set(validators)
+    assert validators['GCN_ARCH_NAME'].startswith('gfx950')
+    ops = [r for r in rows if r[0] != 'Validator']
+    assert len(ops) >= 25 and all(len(r) == 4 and r[0].startswith('Gemm') and float(r[3]) > 0 for r in ops)
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable(0) is None

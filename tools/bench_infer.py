@@ -13,6 +13,8 @@ ap.add_argument('--graph', type=int, default=0, help='1: replay a captured HIP g
 ap.add_argument('--steps', type=int, default=20); ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'])
 a = ap.parse_args()
 torch.backends.cudnn.benchmark = True
+from stereospike_amd import gemm_tuning
+gemm_tuning.enable(0)
 from stereospike_amd.clock_driven import functional, surrogate
 from stereospike_amd.engine import synthetic_batch
 from stereospike_amd.network.SNN_models import StereoSpike
