@@ -30,3 +30,11 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    # GPU runs exercise the shipped default configuration: GEMM algorithms from the tracked TunableOp record (read-only)
+    import torch
+    if torch.cuda.is_available():
+        from stereospike_amd import gemm_tuning
+        gemm_tuning.enable(0)
