@@ -11,6 +11,8 @@ from torch.profiler import profile, ProfilerActivity
 sys.argv = [sys.argv[0]]
 import bench
 torch.backends.cudnn.benchmark = True
+from stereospike_amd import gemm_tuning
+gemm_tuning.enable(0)
 dev = torch.device('cuda:0')
 from stereospike_amd.engine import Trainer, synthetic_batch
 net = bench.build_net('StereoSpike', dev)
