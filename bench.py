@@ -63,6 +63,7 @@ def parse():
     ap.add_argument('--exact-split', type=int, default=1,
                     help='1 (default): decoder forward projections of spike inputs as exact bf16x3 GEMMs on the bf16 MFMA path; 0: plain fp32 GEMM')
     ap.add_argument('--split-wgrad-min-k', type=int, default=None, help='fused.EXACT_SPLIT_WGRAD_MIN_K override (experiments)')
+    ap.add_argument('--spike-wgrad-split', type=int, default=None, help='fused.SPIKE_CONV_WGRAD_SPLIT override (experiments)')
     ap.add_argument('--spike-conv-min-cin', type=int, default=None, help='fused.SPIKE_CONV_MIN_CIN override (experiments)')
     ap.add_argument('--gemm-tuning', type=int, default=1,
                     help='1 (default): load the tracked TunableOp record (GEMM algorithm per shape) read-only; 2: tune unseen shapes and '
@@ -169,6 +170,8 @@ def main():
     _fused_cfg.EXACT_SPLIT_GEMM = bool(a.exact_split)
     if a.split_wgrad_min_k is not None:
         _fused_cfg.EXACT_SPLIT_WGRAD_MIN_K = a.split_wgrad_min_k
+    if a.spike_wgrad_split is not None:
+        _fused_cfg.SPIKE_CONV_WGRAD_SPLIT = a.spike_wgrad_split
     if a.spike_conv_min_cin is not None:
         _fused_cfg.SPIKE_CONV_MIN_CIN = a.spike_conv_min_cin
     if a.wgrad_split_rows:
