@@ -38,15 +38,15 @@ namespace {
 #define SS_BLOCK 256
 #endif
 #ifndef SS_MAX_GRID
-#define SS_MAX_GRID 32768
+#define SS_MAX_GRID 1048576
 #endif
 #ifndef SS_MAX_GRID_BWD
 #define SS_MAX_GRID_BWD 1048576
 #endif
 constexpr int kBlock = SS_BLOCK;         // 4 wavefronts of 64
-// Grid caps, A/B-measured in one process with interleaved rounds (profiles/r01/neuron_grid_variants*.log): the forward
-// (1 read + 2 write streams) is best with <= 32768 workgroups and a short grid-stride loop (+4 % over 2048), the backward
-// (2 reads + 1 write) with one vector per lane and no loop at all (+9 % over 2048: 5.47 vs 5.00 TB/s, above the device-copy rate).
+// Grid caps, A/B-measured in one process with interleaved rounds (profiles/r01/neuron_grid_variants*.log, neuron_variants_v2/v3.log):
+// both kernels are best with one vector per lane and no grid-stride loop (forward 8 B/update form: +4 % over a 32768-workgroup cap;
+// backward +9 % over 2048).
 constexpr int kMaxGrid = SS_MAX_GRID;
 constexpr int kMaxGridBwd = SS_MAX_GRID_BWD;
 constexpr int kMaxGridGk = 2048;         // PLIF dL/dk: bounded number of workgroup partials (caller workspace, fixed-order 2nd pass)
@@ -57,12 +57,28 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // Streaming-access policy of the neuron kernels (A/B-measured with tools/bench_kernels.py, see profiles/):
 //   SS_NT_H  : h_seq is written once and read only by the backward pass, much later => non-temporal store
 //   SS_NT_X  : x_seq (conv output) / g_out are read exactly once                   => non-temporal load
+//   SS_NT_OUT: out_seq / g_x_seq are written once and read by the NEXT kernel (a conv / GEMM), far larger than the caches at the
+//              layers that matter                                                  => non-temporal store
+// Default on for X and OUT since the round-1 A/B of the shipped forms (forward 8 B/update, forked recompute backward, 2.3e8 updates;
+// profiles/r01/neuron_variants_v3.log): forward 5.48 -> 6.55 TB/s, backward 5.18 -> 5.50 TB/s; inside bench.py the 260 neuron launches
+// of a step 4.52 -> 4.24 ms.
 #ifndef SS_NT_H
-#define SS_NT_H 0
+#define SS_NT_H 1
 #endif
 #ifndef SS_NT_X
-#define SS_NT_X 0
+#define SS_NT_X 1
 #endif
+#ifndef SS_NT_OUT
+#define SS_NT_OUT 1
+#endif
+template <typename V> __device__ __forceinline__ void store_out(V* p, V v)
+{
+#if SS_NT_OUT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 template <typename V> __device__ __forceinline__ V load_stream(const V* p)
 {
 #if SS_NT_X
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
                     if constexpr (VEC == 4) { hv[e] = h; ov[e] = o; vv[e] = v; } else { hv = h; ov = o; vv = v; }
                 }
                 if (SAVE_H) store_h(hp + (long long)t * NV, hv);
-                op[(long long)t * NV] = ov;
+                store_out(op + (long long)t * NV, ov);
             }
         } else {
             // runtime T: one step of look-ahead, latency otherwise hidden by occupancy
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
             }
 #pragma unroll
             for (int t = TS - 1; t >= 0; --t)
-                xp[(long long)t * NV] = step(gs[t], hs[t], hs[t > 0 ? t - 1 : 0], t == 0);
+                store_out(xp + (long long)t * NV, step(gs[t], hs[t], hs[t > 0 ? t - 1 : 0], t == 0));
         } else {
             vec_t gn = gp[(long long)(T - 1) * NV], hn = hp[(long long)(T - 1) * NV];
             for (int t = T - 1; t >= 0; --t) {
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
             unsigned short xb[VEC], sb[VEC], ob[VEC];
             float h[VEC];
             if constexpr (VEC == 8) {
-                const u16x8 xv = *reinterpret_cast<const u16x8*>(a.x_seq + base);
+                const u16x8 xv = load_stream(reinterpret_cast<const u16x8*>(a.x_seq + base));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xb[e] = xv[e];
                 if (SKIP) {
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
                 u16x8 ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = ob[e];
-                *reinterpret_cast<u16x8*>(a.out_seq + base) = ov;
+                store_out(reinterpret_cast<u16x8*>(a.out_seq + base), ov);
                 if (SAVE_H) {
                     *reinterpret_cast<f4*>(a.h_seq + base) = (f4){h[0], h[1], h[2], h[3]};
                     *reinterpret_cast<f4*>(a.h_seq + base + 4) = (f4){h[4], h[5], h[6], h[7]};
@@ -585,9 +601,9 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
         uvec_t xs[TS], gs[TS];
 #pragma unroll
-        for (int t = 0; t < TS; ++t) xs[t] = *reinterpret_cast<const uvec_t*>(x_seq + ((long long)t * NV + i) * VEC);
+        for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const uvec_t*>(x_seq + ((long long)t * NV + i) * VEC));
 #pragma unroll
-        for (int t = TS - 1; t >= 0; --t) gs[t] = *reinterpret_cast<const uvec_t*>(a.g_out_seq + ((long long)t * NV + i) * VEC);
+        for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.g_out_seq + ((long long)t * NV + i) * VEC));
         float v0[VEC], gv[VEC], h[TS][VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -638,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
                 const unsigned short ob = narrow<DT>(g_x * scale);
                 if constexpr (VEC == 1) xv = ob; else xv[e] = ob;
             }
-            *reinterpret_cast<uvec_t*>(a.g_x_seq + ((long long)t * NV + i) * VEC) = xv;
+            store_out(reinterpret_cast<uvec_t*>(a.g_x_seq + ((long long)t * NV + i) * VEC), xv);
         }
         if (a.g_v_init) {
 #pragma unroll
@@ -840,6 +856,20 @@ __global__ __launch_bounds__(kBlock) void upconv1_bwd_kernel(const float* __rest
 #ifndef SS_CL_BWD_ROWSCAN
 #define SS_CL_BWD_ROWSCAN 1
 #endif
+// gather outputs (out / g_P): non-temporal stores make the kernels faster in isolation (adjoint 363 -> 271 us at deconv3) but the STEP
+// slower (55.3 -> 56.4 ms): their consumer runs right after and finds part of the tensor in the 256 MiB Infinity Cache.  Off.
+// (profiles/r01/nt_gather_ab.log)
+#ifndef SS_NT_GATHER
+#define SS_NT_GATHER 0
+#endif
+template <typename V> __device__ __forceinline__ void store_gather(V* p, V v)
+{
+#if SS_NT_GATHER
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 #ifndef SS_XCD_REMAP
 #define SS_XCD_REMAP 1
 #endif
@@ -887,7 +917,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __re
         for (int ky = 0; ky < K; ++ky)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const vec_t*>(Pn + off[ky][kx]);
-        *reinterpret_cast<vec_t*>(out + ((long long)img * (H * W) + pix) * C + cv * VEC) = acc + b;
+        store_gather(reinterpret_cast<vec_t*>(out + ((long long)img * (H * W) + pix) * C + cv * VEC), (vec_t)(acc + b));
     }
 }
 
@@ -950,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
                         if (ry > 2) acc += p2[kx];
                         if (ry > 1) acc += p1[kx];
                         acc += cs[kx];
-                        *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc;
+                        store_gather(reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C), acc);
                     }
                 }
 #pragma unroll
