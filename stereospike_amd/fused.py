@@ -448,7 +448,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False):
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None):
         # lowp (only under bf16 autocast): the three GEMMs take bf16 operands with fp32 accumulation / output, exactly what
         # autocast does to the MIOpen convs of the encoder (spike inputs are exact in bf16; W and g_P are rounded).
         # P, the gather, its adjoint and every output stay fp32.
@@ -482,7 +482,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _lib.upconv_cl_fwd(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
         ctx.save_for_backward(xg, Wt)
-        ctx.lowp = lowp
+        # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
+        # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
+        ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
         ctx.exact = exact
         ctx.tables, ctx.k, ctx.n = tables, k, n
         ctx.wshape = weight.shape
@@ -518,7 +520,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             if need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
-            if need_w and ctx.exact and Cin >= EXACT_SPLIT_WGRAD_MIN_K:
+            if need_w and ctx.exact and not lowp and Cin >= EXACT_SPLIT_WGRAD_MIN_K:
                 # x is a spike tensor: g_Wt = x^T @ (gh + gm + gl) with exact products on the bf16 MFMA path (one extra 10 B/element pass
                 # over g_P for the split — pays only where the GEMM is compute-bound, i.e. the widest stage)
                 g3 = torch.empty((rows, 3 * kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
@@ -531,6 +533,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 del g3, gw3
             elif need_w:
                 xs = x_cl[c0:c1].view(rows, Cin)
+                if lowp and xs.dtype != torch.bfloat16:
+                    xs = xs.to(torch.bfloat16)                                    # spikes: exact
                 S = max(1, rows // WGRAD_SPLIT_ROWS)
                 L = rows // S
                 if S > 1:
@@ -542,7 +546,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
         g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
         g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return g_x, g_w, g_b, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -624,5 +628,7 @@ def spike_conv_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
     spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection."""
-    lowp = x_cl.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in)
+    amp = x_cl.is_cuda and torch.is_autocast_enabled('cuda')
+    lowp = amp and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    lowp_bwd = amp and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16)
+    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd)

@@ -8,6 +8,7 @@ from stereospike_amd import miopen_cache
 miopen_cache.enable(skip_naive_solvers=True)
 import torch
 from torch.profiler import profile, ProfilerActivity
+_B, _T, _DT = int(os.environ.get('PB', 16)), int(os.environ.get('PT', 5)), os.environ.get('PDT', 'f32')   # PB / PT / PDT: batch, T, f32|bf16|f16
 sys.argv = [sys.argv[0]]
 import bench
 torch.backends.cudnn.benchmark = True
@@ -17,7 +18,15 @@ dev = torch.device('cuda:0')
 from stereospike_amd.engine import Trainer, synthetic_batch
 net = bench.build_net('StereoSpike', dev)
 tr = Trainer(net)
-x, gt = synthetic_batch(16, 5, seed=2021, device=dev)
+x, gt = synthetic_batch(_B, _T, seed=2021, device=dev)
+if _DT != 'f32':
+    _plain = tr.step
+    _amp = torch.bfloat16 if _DT == 'bf16' else torch.float16
+
+    def _amp_step(x_, gt_):
+        with torch.autocast('cuda', dtype=_amp):
+            return _plain(x_, gt_)
+    tr.step = _amp_step
 for _ in range(3):
     tr.step(x, gt)
 torch.cuda.synchronize()
