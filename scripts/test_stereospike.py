@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--T', type=int, default=1)
     ap.add_argument('--multiply-factor', type=float, default=10.)
     ap.add_argument('--out', default='results/checkpoints')
+    ap.add_argument('--graph', type=int, default=1, help='1: replay the forward as one HIP graph per sample (engine.GraphedInference)')
     a = ap.parse_args()
     device = torch.device('cuda:0')
     from stereospike_amd import gemm_tuning
@@ -35,11 +36,18 @@ def main():
     loss_module = Total_Loss(alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=False)
     net.eval()
     tot_loss, tot_mde, rates = 0.0, 0.0, None
+    graphed = None
     with torch.no_grad():
         for i in range(a.samples):
             x, label = synthetic_batch(1, a.T, seed=10 ** 6 + i, device=device)
-            functional.reset_net(net)                                           # test.py:140
-            pred, spks = net.forward_sequence(x)                                # test.py:150
+            if a.graph:
+                if graphed is None:
+                    from stereospike_amd.engine import GraphedInference
+                    graphed = GraphedInference(net, x)                          # reset_net + forward captured once
+                pred, spks = graphed(x)                                         # test.py:140,150
+            else:
+                functional.reset_net(net)                                       # test.py:140
+                pred, spks = net.forward_sequence(x)                            # test.py:150
             tot_loss += float(loss_module(pred, label, spks))
             tot_mde += float(MeanDepthError(pred[0], label))
             functional.reset_net(net)
