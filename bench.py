@@ -68,6 +68,9 @@ def parse():
     ap.add_argument('--gemm-tuning', type=int, default=1,
                     help='1 (default): load the tracked TunableOp record (GEMM algorithm per shape) read-only; 2: tune unseen shapes and '
                          'write gpurun_out/tunableop_results.csv; 0: library defaults')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='1: replay the whole training iteration as one HIP graph (engine.GraphedTrainer; single GPU, for small host-bound '
+                         'steps such as config 2: --T 1 --batch 8); the per-kernel roofline legs are not available in this mode')
     ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
@@ -183,7 +186,11 @@ def main():
         net = net.to(memory_format=torch.channels_last)
     reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20)), reduce_single_rank=a.force_dp) if use_dp else None
     trainer = Trainer(net, reducer=reducer)
-    if a.dtype != 'f32':
+    if a.graph:
+        assert not use_dp, '--graph is single-GPU'
+        from stereospike_amd.engine import GraphedTrainer
+        trainer = GraphedTrainer(net, amp_dtype={'bf16': torch.bfloat16, 'f16': torch.float16}.get(a.dtype))
+    elif a.dtype != 'f32':
         amp_dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
         plain_step = trainer.step
 

@@ -40,6 +40,9 @@ def main():
     ap.add_argument('--penalize-spikes', action='store_true')
     ap.add_argument('--beta', type=float, default=1.)
     ap.add_argument('--out', default='results/checkpoints')
+    ap.add_argument('--graph', type=int, default=-1,
+                    help='replay each training iteration as one HIP graph (engine.GraphedTrainer): 1 on, 0 off, -1 (default) on for '
+                         'single-GPU runs with batch * T <= 16, where an iteration is host-bound (the reference trains at batch 1)')
     a = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', 1), ('RANK', 0), ('LOCAL_RANK', 0)))
@@ -53,7 +56,7 @@ def main():
 
     from stereospike_amd.clock_driven import surrogate
     from stereospike_amd.dp import GradientAllReducer
-    from stereospike_amd.engine import Trainer, synthetic_batch
+    from stereospike_amd.engine import GraphedTrainer, Trainer, synthetic_batch
     from stereospike_amd.network.loss import Total_Loss
     from stereospike_amd.network.metrics import MeanDepthError
     from stereospike_amd.network.SNN_models import StereoSpike, fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike
@@ -67,7 +70,9 @@ def main():
     net = net.to(device)
     reducer = GradientAllReducer(net) if world > 1 else None
     loss_module = Total_Loss(alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=a.penalize_spikes, beta=a.beta)
-    trainer = Trainer(net, lr=a.lr, reducer=reducer, loss_module=loss_module)
+    use_graph = (a.graph == 1 or (a.graph == -1 and a.batch * a.T <= 16)) and world == 1
+    evaluator = Trainer(net, lr=a.lr, reducer=reducer, loss_module=loss_module)
+    trainer = GraphedTrainer(net, lr=a.lr, loss_module=loss_module) if use_graph else evaluator
     os.makedirs(a.out, exist_ok=True)
     log = open(os.path.join(a.out, 'training_logs.txt'), 'w+') if rank == 0 else None
 
@@ -86,7 +91,7 @@ def main():
         vl, vm = 0.0, 0.0
         for it in range(max(1, a.iters // 10)):
             x, label = synthetic_batch(1, a.T, seed=10 ** 6 + it, device=device)
-            l, m = trainer.evaluate(x, label)
+            l, m = evaluator.evaluate(x, label)
             vl += float(l)
             vm += float(m)
         n_val = max(1, a.iters // 10)

@@ -100,3 +100,62 @@ class GraphedInference:
         self.static_x.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedTrainer:
+    """One whole training iteration — reset -> T-step forward -> Total_Loss -> backward -> Adam — captured ONCE into a HIP graph and
+    replayed per batch (single GPU).  For small steps (e.g. BASELINE.json config 2: T = 1, B = 8) the ~900 launches of an iteration
+    are host-bound: 12.9 ms per step against 6.3 ms of GPU work (profiles/README.md); a replay is one launch.  Large steps (config 3)
+    are GPU-bound and gain nothing — use Trainer there.
+
+    Same arithmetic as Trainer.step (the captured work IS that code): Adam with `capturable=True` and a tensor learning rate, so the
+    MultiStepLR schedule (train.py:127) keeps working without a re-capture.  Inputs must keep the shape / dtype of the first batch."""
+
+    def __init__(self, net, lr=2e-4, weight_decay=0.0, loss_module=None, amp_dtype=None, warmup=3):
+        dev = next(net.parameters()).device
+        assert dev.type == 'cuda', 'GraphedTrainer needs the MI355X (HIP graphs)'
+        self.net, self.dev = net, dev
+        self.opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(lr, device=dev), weight_decay=weight_decay, fused=True,
+                                    capturable=True)
+        self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=[8, 42, 60], gamma=0.5)
+        self.loss_module = loss_module or Total_Loss(alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=False)
+        self.amp = dict(device_type='cuda', dtype=amp_dtype or torch.float32, enabled=amp_dtype is not None)
+        self.warmup = warmup
+        self.graph = None
+
+    def _iteration(self):
+        net = self.net
+        functional.reset_net(net)
+        with torch.autocast(**self.amp):
+            out = net.forward_sequence(self.static_x)
+            pred, spks = out if isinstance(out, tuple) else (out, None)
+            loss = self.loss_module(pred, self.static_gt, spks)
+        loss.backward()
+        self.opt.step()
+        return loss.detach(), pred[0].detach()
+
+    def _capture(self, x, label):
+        self.static_x, self.static_gt = x.clone(), label.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):          # eager warm-up iterations (they train: MIOpen find, GEMM record, Adam state allocation)
+            for _ in range(self.warmup):
+                self.opt.zero_grad(set_to_none=True)
+                self._iteration()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.opt.zero_grad(set_to_none=True)    # gradients are (re)created inside the capture: every replay overwrites them
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self._iteration()
+
+    def step(self, x, label):
+        """The first call runs `warmup` eager iterations on this batch and captures; it then replays once, like every later call.
+        Returns (loss, final depth map) as STATIC tensors (overwritten by the next call)."""
+        if self.graph is None:
+            self._capture(x, label)
+        self.static_x.copy_(x, non_blocking=True)
+        self.static_gt.copy_(label, non_blocking=True)
+        self.graph.replay()
+        functional.reset_net(self.net)          # python-side state only; the captured work starts from reset itself
+        return self.static_out
