@@ -245,6 +245,15 @@ def main():
         all_ms = sum(v['ms'] for k, v in summ.items() if k.startswith('neuron_'))
         all_bytes = sum(v['bytes'] for k, v in summ.items() if k.startswith('neuron_'))
 
+        def inst(tags, name):
+            # every launch of one kernel instantiation (all layer shapes): the numbers to hold against its row of the committed
+            # `rocprofv3 --kernel-trace --stats` CSV (AverageNs), and the bandwidth over all of them
+            ds = [summ[t] for t in tags if t in summ]
+            n, ms, by = sum(d['launches'] for d in ds), sum(d['ms'] for d in ds), sum(d['bytes'] for d in ds)
+            return dict(rocprof_kernel_name=name, launches=n, avg_launch_us=round(1e3 * ms / max(1, n), 2),
+                        achieved_GBps=round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0,
+                        frac=round(by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0)
+
         def roof(d, which='neuron_fwd'):
             ach = (d['bytes'] / 1e9) / (d['ms'] / 1e3) if d['ms'] > 0 else 0.0
             traffic = _pmc_traffic(which)
@@ -274,11 +283,17 @@ def main():
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
             'roofline_fwd': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
                                         f'{bpu(fwd)} B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
-                                 **roof(fwd)),
+                                 **roof(fwd),
+                                 all_launches_of_this_instantiation=inst(
+                                     ['neuron_fwd_train'], f'neuron_fwd_kernel<0, {a.T}, false, {"false" if recompute_h else "true"}, 4>')),
             'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
                                         f'{", h recomputed from the layer input" if recompute_h else ""}'
                                         f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}), largest launch shape',
-                                 **roof(bwd, 'neuron_bwd')),
+                                 **roof(bwd, 'neuron_bwd'),
+                                 all_launches_of_this_instantiation=inst(
+                                     ['neuron_bwd+fork', 'neuron_bwd+fork+sum'] if 'fork' in bwd_tag else ['neuron_bwd'],
+                                     f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true>' if 'fork' in bwd_tag
+                                     else f'neuron_bwd_kernel<*, *, {a.T}, 4, {"true" if recompute_h else "false"}, false>')),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
                 ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
