@@ -225,6 +225,14 @@ int ss_upconv_cl_fwd_f32(const float* P, const int* src_y, const int* src_x, con
 int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                          float* g_P, long long NB, int k, int C, int h, int w, int H, int W, void* stream);
 
+/* The same pair for the 16-bit activation modes (decoder stages, k = 5): the stage output `out` (forward) and its gradient `g_out`
+ * (adjoint) are fp16 / bf16 in HBM (dtype = SS_DT_F16 / SS_DT_BF16) — narrowed to nearest-even on store, widened on load — so the
+ * following neuron layer runs its x16 kernels; P, g_P, the bias and every sum stay fp32. */
+int ss_upconv_cl_fwd_x16(const float* P, const int* src_y, const int* src_x, const float* bias, void* out,
+                         long long NB, int k, int C, int h, int w, int H, int W, int dtype, void* stream);
+int ss_upconv_cl_bwd_x16(const void* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                         float* g_P, long long NB, int k, int C, int h, int w, int H, int W, int dtype, void* stream);
+
 /*
  * Voxeliser — the step BEFORE the path: events -> per-pixel two-polarity count frames,
  * /root/reference/datasets/MVSEC/utils.py:215-281 (mvsecCumulateSpikesIntoFrames; a python loop per event there).

@@ -886,10 +886,44 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
 // ---------------------------------------------------------------------------------------------------
 // channels-last gather kernels (decoder kept in NHWC: P is the row-major output of ONE GEMM, no transposes)
 // ---------------------------------------------------------------------------------------------------
-template <int K, int VEC>
+// ACT = 0: fp32 activations; SS_DT_F16 / SS_DT_BF16: the stage OUTPUT (forward) / its gradient (adjoint) live in HBM as 16-bit values
+// (16-bit activation modes: the following neuron layer then runs its x16 kernels); P, g_P and all sums stay fp32.
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+template <int ACT, int VEC> __device__ __forceinline__ typename std::conditional<VEC == 4, f4, float>::type
+load_act(const void* base, long long e)
+{
+    if constexpr (ACT == 0) {
+        if constexpr (VEC == 4) return *reinterpret_cast<const f4*>(static_cast<const float*>(base) + e);
+        else return static_cast<const float*>(base)[e];
+    } else {
+        const unsigned short* p = static_cast<const unsigned short*>(base) + e;
+        if constexpr (VEC == 4) {
+            const u16x4 v = *reinterpret_cast<const u16x4*>(p);
+            return (f4){widen<ACT>(v[0]), widen<ACT>(v[1]), widen<ACT>(v[2]), widen<ACT>(v[3])};
+        } else return widen<ACT>(*p);
+    }
+}
+template <int ACT, int VEC> __device__ __forceinline__ void
+store_act(void* base, long long e, typename std::conditional<VEC == 4, f4, float>::type v)
+{
+    if constexpr (ACT == 0) {
+        if constexpr (VEC == 4) store_gather(reinterpret_cast<f4*>(static_cast<float*>(base) + e), v);
+        else static_cast<float*>(base)[e] = v;
+    } else {
+        unsigned short* p = static_cast<unsigned short*>(base) + e;
+        if constexpr (VEC == 4) {
+            u16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = narrow<ACT>(v[i]);
+            *reinterpret_cast<u16x4*>(p) = o;
+        } else *p = narrow<ACT>(v);
+    }
+}
+
+template <int K, int VEC, int ACT = 0>
 __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __restrict__ P, const int* __restrict__ src_y,
                                                                const int* __restrict__ src_x, const float* __restrict__ bias,
-                                                               float* __restrict__ out, int NB, int C, int h, int w, int H, int W)
+                                                               void* __restrict__ out, int NB, int C, int h, int w, int H, int W)
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
     const unsigned CV = (unsigned)C / VEC;                            // channel vectors per pixel
@@ -917,12 +951,12 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __re
         for (int ky = 0; ky < K; ++ky)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const vec_t*>(Pn + off[ky][kx]);
-        store_gather(reinterpret_cast<vec_t*>(out + ((long long)img * (H * W) + pix) * C + cv * VEC), (vec_t)(acc + b));
+        store_act<ACT, VEC>(out, ((long long)img * (H * W) + pix) * C + cv * VEC, (vec_t)(acc + b));
     }
 }
 
-template <int K, int VEC>
-__global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __restrict__ g_out, const int* __restrict__ y_lo,
+template <int K, int VEC, int ACT = 0>
+__global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __restrict__ g_out, const int* __restrict__ y_lo,
                                                                const int* __restrict__ y_hi, const int* __restrict__ x_lo,
                                                                const int* __restrict__ x_hi, float* __restrict__ g_P,
                                                                int NB, int C, int h, int w, int H, int W)
@@ -939,7 +973,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
     vec_t zero;
     if constexpr (VEC == 4) zero = (f4){0.f, 0.f, 0.f, 0.f}; else zero = 0.f;
     for (int img = blockIdx.y; img < NB; img += gridDim.y) {
-        const float* g = g_out + (long long)img * (H * W) * C + cv * VEC;
+        const long long gbase = (long long)img * (H * W) * C + cv * VEC;     // element offset of this lane's channels in g_out
         float* gp = g_P + ((long long)img * (h * w) + sp) * KKC + cv * VEC;
 #if SS_CL_BWD_ROWSCAN
         if (ry >= 1 && ry <= 3 && rx <= 3) {
@@ -962,7 +996,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
                     for (int c = 0; c < K + 2; ++c) {
                         const int x = xlo - (K - 1) + c;
                         const bool ok = x >= 0 && x < W && c < K - 1 + rx;
-                        row[c] = ok ? *reinterpret_cast<const vec_t*>(g + (long long)(y * W + x) * C) : zero;
+                        row[c] = ok ? load_act<ACT, VEC>(g_out, gbase + (long long)(y * W + x) * C) : zero;
                     }
 #pragma unroll
                     for (int kx = 0; kx < K; ++kx) {
@@ -1004,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
                         for (int c = 0; c < K + 2; ++c) {
                             const int x = xlo - (K - 1) + c;
                             const bool ok = x >= 0 && x < W && c < K - 1 + rx;
-                            row[c] = ok ? *reinterpret_cast<const vec_t*>(g + (long long)(y * W + x) * C) : zero;
+                            row[c] = ok ? load_act<ACT, VEC>(g_out, gbase + (long long)(y * W + x) * C) : zero;
                         }
 #pragma unroll
                         for (int kx = 0; kx < K; ++kx) {
@@ -1029,7 +1063,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const float* __re
                     vec_t acc = zero;
                     for (int y = y0; y < y1; ++y) {
                         vec_t cs = zero;
-                        for (int x = x0; x < x1; ++x) cs += *reinterpret_cast<const vec_t*>(g + (long long)(y * W + x) * C);
+                        for (int x = x0; x < x1; ++x) cs += load_act<ACT, VEC>(g_out, gbase + (long long)(y * W + x) * C);
                         acc += cs;
                     }
                     *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc;
@@ -1345,27 +1379,27 @@ int dispatch_bwd_sg(const BwdArgs& a, int surrogate, hipStream_t s, int* grid_ou
                                    : dispatch_bwd_T<KIND, SS_SG_SIGMOID>(a, s, grid_out);
 }
 
-template <int K>
-int launch_cl_fwd(const float* P, const int* sy, const int* sx, const float* bias, float* out, int NB, int C, int h, int w,
+template <int K, int ACT = 0>
+int launch_cl_fwd(const float* P, const int* sy, const int* sx, const float* bias, void* out, int NB, int C, int h, int w,
                          int H, int W, hipStream_t s)
 {
     const bool vec = (C % 4 == 0) && aligned16(P) && aligned16(out) && (!bias || aligned16(bias));
     const long long per_img = (long long)H * W * (vec ? C / 4 : C);
     const dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
-    if (vec) hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 4>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
-    else     hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 1>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
+    if (vec) hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 4, ACT>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
+    else     hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 1, ACT>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
-template <int K>
-int launch_cl_bwd(const float* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi, float* g_P,
+template <int K, int ACT = 0>
+int launch_cl_bwd(const void* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi, float* g_P,
                          int NB, int C, int h, int w, int H, int W, hipStream_t s)
 {
     const bool vec = (C % 4 == 0) && aligned16(g_out) && aligned16(g_P);
     const long long per_img = (long long)h * w * (vec ? C / 4 : C);
     const dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
-    if (vec) hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 4>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
-    else     hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 1>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
+    if (vec) hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 4, ACT>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
+    else     hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 1, ACT>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -1690,6 +1724,30 @@ int ss_upconv_cl_bwd_f32(const float* g_out, const int* y_lo, const int* y_hi, c
     if (k == 1) return launch_cl_bwd<1>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
     if (k == 3) return launch_cl_bwd<3>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
     return launch_cl_bwd<5>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+}
+
+int ss_upconv_cl_fwd_x16(const float* P, const int* src_y, const int* src_x, const float* bias, void* out,
+                         long long NB, int k, int C, int h, int w, int H, int W, int dtype, void* stream)
+{
+    if (!P || !src_y || !src_x || !out || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 5 || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;            // decoder stages only (k = 5)
+    if (NB > 0x7fffffffLL || (long long)H * W * C > 0x7fffffffLL || (long long)k * k * C * h * w > 0x7fffffffLL) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == SS_DT_F16 ? launch_cl_fwd<5, SS_DT_F16>(P, src_y, src_x, bias, out, (int)NB, C, h, w, H, W, s)
+                              : launch_cl_fwd<5, SS_DT_BF16>(P, src_y, src_x, bias, out, (int)NB, C, h, w, H, W, s);
+}
+
+int ss_upconv_cl_bwd_x16(const void* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                         float* g_P, long long NB, int k, int C, int h, int w, int H, int W, int dtype, void* stream)
+{
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 5 || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (NB > 0x7fffffffLL || (long long)H * W * C > 0x7fffffffLL || (long long)k * k * C * h * w > 0x7fffffffLL) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == SS_DT_F16 ? launch_cl_bwd<5, SS_DT_F16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s)
+                              : launch_cl_bwd<5, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
 }
 
 int ss_voxelize_f64(const double* events, long long E, const double* start, const double* end, int G,

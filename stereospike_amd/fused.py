@@ -424,6 +424,7 @@ WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient G
 # path with fp32 accumulation.  Every product is exact, so the result has the error profile of the fp32 GEMM (same 1e-6 relative
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
 EXACT_SPLIT_GEMM = True
+ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
                                    # to pay for the extra 10 B/element split pass over g_P (profiles/r01/split_wgrad_sweep.log)
@@ -447,26 +448,38 @@ class _UpConvProjectedCL(torch.autograd.Function):
     The whole batch goes through in one pass (P in HBM); frames are chunked only when P would exceed P_MAX_BYTES_CL."""
 
     @staticmethod
-    @_fwd32
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None):
+    @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None):
         # lowp (only under bf16 autocast): the three GEMMs take bf16 operands with fp32 accumulation / output, exactly what
         # autocast does to the MIOpen convs of the encoder (spike inputs are exact in bf16; W and g_P are rounded).
         # P, the gather, its adjoint and every output stay fp32.
+        # act_dtype (fp16 / bf16, decoder stages under 16-bit autocast): the stage output is written by the gather as 16-bit activations,
+        # its gradient is read as such by the adjoint; the input may itself be a 16-bit spike tensor (exact)
         x_cl = x_cl.contiguous()
+        ctx.x_dtype = x_cl.dtype
+        half_in = x_cl.dtype in (torch.float16, torch.bfloat16)
+        weight = weight.float()
+        if bias is not None:
+            bias = bias.float()
         NB, h, w, Cin = x_cl.shape
         Cout, kk = weight.shape[0], k * k
         Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()      # column index = tap*C_out + co
         src_y, _, _, src_x, _, _ = tables
-        out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=x_cl.device)
+        out = torch.empty((NB, H, W, Cout), dtype=act_dtype or torch.float32, device=x_cl.device)
         # one pass: measured on the MI355X (profiles/r01/chunk_sweep*.log) cache-sized chunks lose more in GEMM efficiency (M = n*h*w
         # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
         n = max(1, min(NB, P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
-        xg = x_cl.to(torch.bfloat16) if lowp else x_cl
-        Wg = Wt.to(torch.bfloat16) if lowp else Wt
         exact = spikes_in and not lowp and EXACT_SPLIT_GEMM and Cin >= EXACT_SPLIT_MIN_K
+        if lowp:
+            xg = x_cl if x_cl.dtype == torch.bfloat16 else x_cl.to(torch.bfloat16)
+        elif exact or not half_in:
+            xg = x_cl                                   # exact: any dtype feeds the bf16 triple copy; plain fp32 path: fp32
+        else:
+            xg = x_cl.float()                           # 16-bit input on the plain fp32 GEMM path (narrow stages, heads)
+        Wg = Wt.to(torch.bfloat16) if lowp else Wt
         if exact:
             if ASSERT_EXACT_SPLIT:
-                assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
+                assert bool((x_cl.to(torch.bfloat16).float() == x_cl.float()).all()), 'spikes_in=True but the input is not exact in bf16'
             W3 = _split3_bf16(Wt)
         e0 = TIMER.start()
         for c0 in range(0, NB, n):
@@ -479,7 +492,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 del x3
             else:
                 P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
-            _lib.upconv_cl_fwd(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
+            (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
         ctx.save_for_backward(xg, Wt)
         # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
@@ -492,7 +505,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         return out
 
     @staticmethod
-    @_bwd32
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g_out):
         x_cl, Wt = ctx.saved_tensors
         k, n = ctx.k, ctx.n
@@ -500,7 +513,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
         NB, h, w, Cin = x_cl.shape
         Cout, kk = ctx.wshape[0], k * k
         H, W = g_out.shape[1:3]
-        g_out = g_out.float().contiguous()
+        g16 = g_out.dtype in (torch.float16, torch.bfloat16) and k == 5       # 16-bit gradient read directly by the adjoint kernel
+        g_out = g_out.contiguous() if g16 else g_out.float().contiguous()
         lowp = ctx.lowp
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if need_x else None
@@ -514,7 +528,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
             g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
-            _lib.upconv_cl_bwd(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+            (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
             if lowp:
                 g_P = g_P.to(torch.bfloat16)
             if need_x:
@@ -535,6 +549,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 xs = x_cl[c0:c1].view(rows, Cin)
                 if lowp and xs.dtype != torch.bfloat16:
                     xs = xs.to(torch.bfloat16)                                    # spikes: exact
+                elif not lowp and xs.dtype != torch.float32:
+                    xs = xs.float()
                 S = max(1, rows // WGRAD_SPLIT_ROWS)
                 L = rows // S
                 if S > 1:
@@ -545,8 +561,10 @@ class _UpConvProjectedCL(torch.autograd.Function):
                     g_Wt += torch.mm(xs.t(), g_P, **f32)
         TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
         g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
-        g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return g_x, g_w, g_b, None, None, None, None, None, None, None
+        g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if g_x is not None and g_x.dtype != ctx.x_dtype:
+            g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -629,6 +647,10 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
     spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection."""
     amp = x_cl.is_cuda and torch.is_autocast_enabled('cuda')
-    lowp = amp and torch.get_autocast_dtype('cuda') == torch.bfloat16
-    lowp_bwd = amp and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16)
-    return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd)
+    adt = torch.get_autocast_dtype('cuda') if amp else None
+    lowp = amp and adt == torch.bfloat16
+    lowp_bwd = amp and adt in (torch.bfloat16, torch.float16)
+    # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
+    act_dtype = adt if (lowp_bwd and k == 5 and ACT16_GATHER) else None
+    with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype)

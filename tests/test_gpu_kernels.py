@@ -632,3 +632,26 @@ def test_backward_with_forked_output_gradients(kind, T, N):
     assert torch.equal(gx_c, gx_a)
     with pytest.raises(_lib.SSNeuronError):
         _lib.neuron_bwd_fork(g1, g2, None, None, x, None, v0, gx_c, None, None, None, *args)      # saved-h form + second gradient
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_upconv_cl_x16_equals_fp32_gather_with_narrowed_io(dt):
+    """ss_upconv_cl_fwd_x16 == nearest-even narrowing of ss_upconv_cl_fwd_f32's output; ss_upconv_cl_bwd_x16 on a 16-bit gradient ==
+    ss_upconv_cl_bwd_f32 on the same values widened — both bit for bit (the 16-bit modes change the I/O format only)."""
+    from stereospike_amd import _lib
+    from stereospike_amd.fused import nearest_tables
+    torch.manual_seed(1)
+    NB, C, k, (h, w), (H, W) = 3, 64, 5, (9, 11), (18, 23)
+    sy, ylo, yhi = (t.to(DEV) for t in nearest_tables(h, H + k - 1))
+    sx, xlo, xhi = (t.to(DEV) for t in nearest_tables(w, W + k - 1))
+    P = torch.randn(NB, h, w, k * k * C, device=DEV)
+    o32 = torch.empty(NB, H, W, C, device=DEV)
+    o16 = torch.empty(NB, H, W, C, device=DEV, dtype=dt)
+    _lib.upconv_cl_fwd(P, sy, sx, None, o32, NB, k, C, h, w, H, W)
+    _lib.upconv_cl_fwd_x16(P, sy, sx, None, o16, NB, k, C, h, w, H, W)
+    assert torch.equal(o16, o32.to(dt))
+    g16 = torch.randn(NB, H, W, C, device=DEV).to(dt)
+    gp_a, gp_b = torch.empty_like(P), torch.empty_like(P)
+    _lib.upconv_cl_bwd(g16.float(), ylo, yhi, xlo, xhi, gp_a, NB, k, C, h, w, H, W)
+    _lib.upconv_cl_bwd_x16(g16, ylo, yhi, xlo, xhi, gp_b, NB, k, C, h, w, H, W)
+    assert torch.equal(gp_a, gp_b)
