@@ -233,6 +233,11 @@ int ss_upconv_cl_fwd_x16(const float* P, const int* src_y, const int* src_x, con
 int ss_upconv_cl_bwd_x16(const void* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                          float* g_P, long long NB, int k, int C, int h, int w, int H, int W, int dtype, void* stream);
 
+/* Adjoint gather writing g_P directly as bf16 (nearest-even narrowing of the fp32 sums) — for the 16-bit modes, whose backward GEMMs
+ * take bf16 operands: no fp32 g_P round trip and no separate cast pass.  g_dtype: 0 = fp32 g_out, SS_DT_F16 / SS_DT_BF16 = 16-bit. */
+int ss_upconv_cl_bwd_lowp(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                          void* g_P_bf16, long long NB, int k, int C, int h, int w, int H, int W, void* stream);
+
 /*
  * Voxeliser — the step BEFORE the path: events -> per-pixel two-polarity count frames,
  * /root/reference/datasets/MVSEC/utils.py:215-281 (mvsecCumulateSpikesIntoFrames; a python loop per event there).

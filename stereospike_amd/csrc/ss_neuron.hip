@@ -955,10 +955,11 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __re
     }
 }
 
-template <int K, int VEC, int ACT = 0>
+// GP = 0: g_P written as fp32; SS_DT_BF16: g_P written as bf16 (the 16-bit modes' backward GEMMs take bf16 operands: no separate cast pass)
+template <int K, int VEC, int ACT = 0, int GP = 0>
 __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __restrict__ g_out, const int* __restrict__ y_lo,
                                                                const int* __restrict__ y_hi, const int* __restrict__ x_lo,
-                                                               const int* __restrict__ x_hi, float* __restrict__ g_P,
+                                                               const int* __restrict__ x_hi, void* __restrict__ g_P,
                                                                int NB, int C, int h, int w, int H, int W)
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
     if constexpr (VEC == 4) zero = (f4){0.f, 0.f, 0.f, 0.f}; else zero = 0.f;
     for (int img = blockIdx.y; img < NB; img += gridDim.y) {
         const long long gbase = (long long)img * (H * W) * C + cv * VEC;     // element offset of this lane's channels in g_out
-        float* gp = g_P + ((long long)img * (h * w) + sp) * KKC + cv * VEC;
+        const long long gpo = ((long long)img * (h * w) + sp) * KKC + cv * VEC;   // element offset of this lane's channels in g_P
 #if SS_CL_BWD_ROWSCAN
         if (ry >= 1 && ry <= 3 && rx <= 3) {
             // one pass over the ry + K - 1 window rows, top to bottom: each row is loaded ONCE ((K+2) vectors), reduced to its K
@@ -1014,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
                         if (ry > 2) acc += p2[kx];
                         if (ry > 1) acc += p1[kx];
                         acc += cs[kx];
-                        store_gather(reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C), acc);
+                        store_act<GP, VEC>(g_P, gpo + (ky * K + kx) * C, acc);
                     }
                 }
 #pragma unroll
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
                     }
                 }
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc[kx];
+                for (int kx = 0; kx < K; ++kx) store_act<GP, VEC>(g_P, gpo + (ky * K + kx) * C, acc[kx]);
             }
 #endif
         } else {
@@ -1066,7 +1067,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
                         for (int x = x0; x < x1; ++x) cs += load_act<ACT, VEC>(g_out, gbase + (long long)(y * W + x) * C);
                         acc += cs;
                     }
-                    *reinterpret_cast<vec_t*>(gp + (ky * K + kx) * C) = acc;
+                    store_act<GP, VEC>(g_P, gpo + (ky * K + kx) * C, acc);
                 }
             }
         }
@@ -1391,15 +1392,15 @@ int launch_cl_fwd(const float* P, const int* sy, const int* sx, const float* bia
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
-template <int K, int ACT = 0>
-int launch_cl_bwd(const void* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi, float* g_P,
+template <int K, int ACT = 0, int GP = 0>
+int launch_cl_bwd(const void* g_out, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi, void* g_P,
                          int NB, int C, int h, int w, int H, int W, hipStream_t s)
 {
     const bool vec = (C % 4 == 0) && aligned16(g_out) && aligned16(g_P);
     const long long per_img = (long long)h * w * (vec ? C / 4 : C);
     const dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
-    if (vec) hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 4, ACT>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
-    else     hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 1, ACT>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
+    if (vec) hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 4, ACT, GP>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
+    else     hipLaunchKernelGGL((upconv_cl_bwd_kernel<K, 1, ACT, GP>), grid, dim3(kBlock), 0, s, g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, C, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -1748,6 +1749,19 @@ int ss_upconv_cl_bwd_x16(const void* g_out, const int* y_lo, const int* y_hi, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     return dtype == SS_DT_F16 ? launch_cl_bwd<5, SS_DT_F16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s)
                               : launch_cl_bwd<5, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+}
+
+int ss_upconv_cl_bwd_lowp(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                          void* g_P_bf16, long long NB, int k, int C, int h, int w, int H, int W, void* stream)
+{
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P_bf16 || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (k != 5 || (g_dtype != 0 && g_dtype != SS_DT_F16 && g_dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (NB > 0x7fffffffLL || (long long)H * W * C > 0x7fffffffLL || (long long)k * k * C * h * w > 0x7fffffffLL) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_dtype == 0) return launch_cl_bwd<5, 0, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P_bf16, (int)NB, C, h, w, H, W, s);
+    if (g_dtype == SS_DT_F16) return launch_cl_bwd<5, SS_DT_F16, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P_bf16, (int)NB, C, h, w, H, W, s);
+    return launch_cl_bwd<5, SS_DT_BF16, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P_bf16, (int)NB, C, h, w, H, W, s);
 }
 
 int ss_voxelize_f64(const double* events, long long E, const double* start, const double* end, int G,

@@ -527,10 +527,15 @@ class _UpConvProjectedCL(torch.autograd.Function):
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
-            g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
-            (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
-            if lowp:
-                g_P = g_P.to(torch.bfloat16)
+            if lowp and k == 5:
+                # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
+                g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
+                _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+            else:
+                g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
+                (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+                if lowp:
+                    g_P = g_P.to(torch.bfloat16)
             if need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad

@@ -655,3 +655,11 @@ def test_upconv_cl_x16_equals_fp32_gather_with_narrowed_io(dt):
     _lib.upconv_cl_bwd(g16.float(), ylo, yhi, xlo, xhi, gp_a, NB, k, C, h, w, H, W)
     _lib.upconv_cl_bwd_x16(g16, ylo, yhi, xlo, xhi, gp_b, NB, k, C, h, w, H, W)
     assert torch.equal(gp_a, gp_b)
+    # ss_upconv_cl_bwd_lowp: g_P written as bf16 == nearest-even narrowing of the fp32 adjoint, for 16-bit and fp32 gradients
+    gp_c = torch.empty(P.shape, dtype=torch.bfloat16, device=DEV)
+    _lib.upconv_cl_bwd_lowp(g16, ylo, yhi, xlo, xhi, gp_c, NB, k, C, h, w, H, W)
+    assert torch.equal(gp_c, gp_a.to(torch.bfloat16))
+    g32 = torch.randn(NB, H, W, C, device=DEV)
+    _lib.upconv_cl_bwd(g32, ylo, yhi, xlo, xhi, gp_a, NB, k, C, h, w, H, W)
+    _lib.upconv_cl_bwd_lowp(g32, ylo, yhi, xlo, xhi, gp_c, NB, k, C, h, w, H, W)
+    assert torch.equal(gp_c, gp_a.to(torch.bfloat16))
