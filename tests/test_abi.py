@@ -85,3 +85,20 @@ def test_product_never_imports_the_oracle():
                 assert 'ss_ref_' not in src and 'libss_oracle' not in src, os.path.join(d, f)
     out = subprocess.check_output(['ldd', os.path.join(pkg, 'lib', 'libss_neuron.so')]).decode()
     assert 'oracle' not in out
+
+
+def test_c_caller_compiles_and_links(tmp_path):
+    """examples/c_caller.c — a plain C99 program using only include/ss_neuron.h — compiles and links against the built shared library
+    (no torch, no C++): the boundary really is a C ABI.  (It is run on the MI355X by tests/test_gpu_kernels.py.)"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'stereospike_amd', 'lib')
+    if shutil.which('gcc') is None or not os.path.exists('/opt/rocm/lib'):
+        pytest.skip('needs gcc and the ROCm runtime libraries')
+    exe = str(tmp_path / 'c_caller')
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I' + os.path.join(root, 'include'), os.path.join(root, 'examples', 'c_caller.c'),
+                        '-L' + lib_dir, '-lss_neuron', '-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath-link,/opt/rocm/lib', '-o', exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(exe)

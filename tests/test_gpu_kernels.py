@@ -663,3 +663,27 @@ def test_upconv_cl_x16_equals_fp32_gather_with_narrowed_io(dt):
     _lib.upconv_cl_bwd(g32, ylo, yhi, xlo, xhi, gp_a, NB, k, C, h, w, H, W)
     _lib.upconv_cl_bwd_lowp(g32, ylo, yhi, xlo, xhi, gp_c, NB, k, C, h, w, H, W)
     assert torch.equal(gp_c, gp_a.to(torch.bfloat16))
+
+
+def test_c_caller_runs_against_the_library():
+    """examples/c_caller.c built with gcc and run on the device: the C-ABI used from plain C (no Python, no torch in that process)."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'stereospike_amd', 'lib')
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc on this box')
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')           # the HIP runtime the library was loaded with in-process
+    hip_dir = '/opt/rocm/lib' if os.path.exists('/opt/rocm/lib/libamdhip64.so') else torch_lib
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, 'c_caller')
+        r = subprocess.run(['gcc', '-std=c99', '-I' + os.path.join(root, 'include'), os.path.join(root, 'examples', 'c_caller.c'),
+                            '-L' + lib_dir, '-lss_neuron', '-L' + hip_dir, '-lamdhip64', '-Wl,-rpath-link,' + hip_dir, '-o', exe],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ':' + hip_dir + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
+        r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert 'spikes out of 20480 updates' in r.stdout and ' 0 spikes' not in r.stdout, r.stdout
