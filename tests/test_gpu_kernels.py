@@ -578,6 +578,12 @@ def test_spike_conv_as_exact_bf16x3_gemm(Cin, Cout, k, s, pad, hw):
     _lib.split3_bf16(g, g3, M, Cout)
     parts = g3.view(M, 3, Cout).float()
     assert torch.equal((parts[:, 0].double() + parts[:, 1].double() + parts[:, 2].double()).float(), g)
+    if M * K <= 2_000_000:                                       # against the numpy oracle, bit for bit
+        from oracle import np_operands as no
+        A_ref, _ = no.im2col_cl(x.cpu().numpy(), k, s, pad)
+        assert np.array_equal(A.float().cpu().numpy(), A_ref)
+        hi, mid, lo = no.split3(g.cpu().numpy())
+        assert np.array_equal(parts.cpu().numpy(), np.stack((hi, mid, lo), 1))
     if Cin < fused.SPIKE_CONV_MIN_CIN:
         return
     conv = torch.nn.Conv2d(Cin, Cout, k, s, pad, bias=False).to(DEV)

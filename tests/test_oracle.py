@@ -262,3 +262,25 @@ def test_voxelizer_oracle_vs_reference_fixture():
         fr = nv.cumulate_spikes_into_frames(z[f'v{ci}_events'], n_chunks, nfpdm)
         assert np.array_equal(fr, z[f'v{ci}_frames'].astype(np.float64))
         assert fr.sum() > 0
+
+
+def test_exact_split_operand_oracle_identities():
+    """oracle/np_operands.py (checker of ss_im2col_cl_bf16 / ss_split3_bf16): the three bf16 terms sum back to every fp32 value exactly;
+    im2col(x) @ (Wh + Wm + Wl) equals torch's conv2d on spike inputs to fp32 summation-order accuracy; each product is exact."""
+    from oracle import np_operands as no
+    rng = np.random.default_rng(0)
+    g = (rng.standard_normal(20000) * np.logspace(-20, 20, 20000)).astype(np.float32)
+    hi, mid, lo = no.split3(g)
+    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), g)
+    for t in (hi, mid, lo):                                        # each term is a bf16 value: low 16 bits clear
+        assert not (t.view(np.uint32) & 0xffff).any()
+    for (Cin, Cout, k, s, p, hw) in ((16, 8, 3, 1, 1, (6, 7)), (8, 4, 5, 2, 2, (9, 11)), (8, 4, 3, 2, 0, (7, 9))):
+        x = rng.integers(0, 3, (2, hw[0], hw[1], Cin)).astype(np.float32)
+        W = (rng.standard_normal((Cout, Cin, k, k)) * 0.1).astype(np.float32)
+        A, (ho, wo) = no.im2col_cl(x, k, s, p)
+        assert np.array_equal(A, no.im2col_cl(x, k, s, p)[0]) and set(np.unique(A)) <= {0.0, 1.0, 2.0}
+        Wt = W.transpose(2, 3, 1, 0).reshape(k * k * Cin, Cout)
+        Wh, Wm, Wl = no.split3(Wt)
+        y = (A.astype(np.float64) @ Wh + A.astype(np.float64) @ Wm + A.astype(np.float64) @ Wl).reshape(2, ho, wo, Cout)
+        ref = torch.nn.functional.conv2d(torch.tensor(x).permute(0, 3, 1, 2).double(), torch.tensor(W).double(), None, s, p)
+        assert np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-12      # exact products, float64 accumulation on both sides
