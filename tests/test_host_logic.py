@@ -176,3 +176,13 @@ def test_gemm_tuning_record_is_wellformed_and_loader_is_inert_without_a_gpu():
     assert len(ops) >= 25 and all(len(r) == 4 and r[0].startswith('Gemm') and float(r[3]) > 0 for r in ops)
     if not torch.cuda.is_available():
         assert gemm_tuning.enable(0) is None
+
+
+def test_graph_helpers_refuse_cpu_loudly():
+    """engine.GraphedInference / GraphedTrainer are HIP-graph features: on CPU tensors they fail with a clear message, never fall back."""
+    from stereospike_amd.engine import GraphedInference, GraphedTrainer
+    net = torch.nn.Linear(2, 2)
+    with pytest.raises(AssertionError, match='MI355X'):
+        GraphedInference(net, torch.zeros(1, 1, 4, 8, 8))
+    with pytest.raises(AssertionError, match='MI355X'):
+        GraphedTrainer(net)
