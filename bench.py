@@ -22,9 +22,37 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def launcher_command(gpus, argv, env):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: the command that re-executes this script as N ranks (one
+    process per GPU, RCCL rendezvous on 127.0.0.1).  None when this process is already a rank (WORLD_SIZE set) or N == 1."""
+    if gpus <= 1 or 'WORLD_SIZE' in env:
+        return None
+    port = env.get('MASTER_PORT', str(29500 + (os.getpid() % 499)))
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', port, os.path.abspath(__file__)] + list(argv)
+
+
+def _early_gpus(argv):
+    for i, t in enumerate(argv):
+        if t == '--gpus' and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if t.startswith('--gpus='):
+            return int(t.split('=', 1)[1])
+    return 1
+
+
+if __name__ == '__main__':
+    _cmd = launcher_command(_early_gpus(sys.argv[1:]), sys.argv[1:], os.environ)
+    if _cmd is not None:                                  # before torch / MIOpen initialise in this (parent) process
+        import subprocess
+        _env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        sys.exit(subprocess.call(_cmd, env=_env))
+
 from stereospike_amd import miopen_cache  # noqa: E402
 _skip_naive = os.environ.get('SS_MIOPEN_SKIP_NAIVE', '1') == '1'
-if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # before torch / MIOpen initialise
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:      # before torch / MIOpen initialise: one MIOpen cache directory per rank
     miopen_cache.enable_per_rank(int(os.environ.get('LOCAL_RANK', '0')), skip_naive_solvers=_skip_naive)
 else:
     miopen_cache.enable(skip_naive_solvers=_skip_naive)
@@ -48,6 +76,8 @@ def parse():
                          '(BASELINE.json configs 2 / 5) — reported as a separate line, never as the headline value')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-b16-seconds', type=float, default=10.0,
+                    help='time budget of the second CPU-port leg at the bench batch size (1 warm-up + >= 1 timed iteration); 0 disables')
     ap.add_argument('--miopen-find', type=int, default=1,
                     help='torch.backends.cudnn.benchmark = MIOpen find mode: picks the fastest solver per conv (measured '
                          '73.8 vs 87.3 ms/step); the search costs ~3.5 min on a cold box, ~75 s with the in-tree find-db')
@@ -90,7 +120,7 @@ def build_net(model, device):
     return net.to(device)
 
 
-def cpu_baseline(model, T, budget_s):
+def cpu_baseline(model, T, budget_s, B=1, min_iters=2):
     """The oracle's eager port (oracle/ref_network.py on oracle/sj_clock_driven.py — the reference's op sequence)
     running the same training step on the host cores: B = 1, T = 5, 1 warm-up + >= 2 timed iterations within
     ~budget_s seconds.  Reported, not a target."""
@@ -102,7 +132,6 @@ def cpu_baseline(model, T, budget_s):
     else:
         net = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=30.)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
-    B = 1
     x, gt = synthetic_batch(B, T, seed=2021)
     # eval MDE on identical (seed-2021 default-init) weights and inputs, before any update: the "eval MDE" half of the metric
     with torch.no_grad():
@@ -123,10 +152,10 @@ def cpu_baseline(model, T, budget_s):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if (n >= 2 and el >= budget_s) or n >= 20 or el > 3 * budget_s:
+        if (n >= min_iters and el >= budget_s) or n >= 20 or el > 3 * budget_s:
             break
     return dict(value=B * n / el, unit='frames/s', cores=torch.get_num_threads(), kind='port', eval_mde_m=eval_mde,
-                sample=f'{model} binocular T={T} 260x346 fp32, B=1, {n} timed training iterations after 1 warm-up, '
+                sample=f'{model} binocular T={T} 260x346 fp32, B={B}, {n} timed training iterations after 1 warm-up, '
                        f'eager unfused oracle port, torch {torch.__version__} CPU, {torch.get_num_threads()} threads '
                        f'of {os.cpu_count()} logical CPUs')
 
@@ -136,6 +165,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (spawns the ranks itself) '
+                         f'or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU fallback for the product path'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -145,7 +177,6 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    assert world == a.gpus or world == 1, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     if a.gemm_tuning:
         from stereospike_amd import gemm_tuning
@@ -260,6 +291,8 @@ def main():
             avg_us = 1e3 * d['ms'] / max(1, d['launches'])
             return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                        traffic_source='profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_target.py, '
+                                       'committed; not measured in this run)' if traffic else None,
                         launches=d['launches'], avg_launch_us=round(avg_us, 2),
                         bytes_per_launch=int(d['bytes'] / max(1, d['launches'])),
                         # counter-measured HBM bytes (incl. the O(N) v_last write the per-update figure leaves out) over the same time
@@ -273,7 +306,7 @@ def main():
         recompute_h = bool(_fused.RECOMPUTE_H)
         out = {
             'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
-            'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if use_dp else 1, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1e3 * elapsed / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
@@ -330,6 +363,8 @@ def main():
                 out['eval_mde_m'] = round(float(MeanDepthError(d0[0], gt0)), 5)
             del net0
             out['cpu_baseline'] = cpu_baseline(a.model, a.T, a.cpu_seconds)
+            if a.cpu_b16_seconds > 0:                     # the CPU port at the bench's own batch size as well
+                out['cpu_baseline_B16'] = cpu_baseline(a.model, a.T, a.cpu_b16_seconds, B=a.batch, min_iters=1)
             out['eval_mde_rel_diff_vs_cpu'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m'])
                                                     / out['cpu_baseline']['eval_mde_m'], 6)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)

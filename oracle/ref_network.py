@@ -183,6 +183,32 @@ def run_sequence(net, x_seq):
     return out
 
 
+# ---- float64-convolution mode ------------------------------------------------------------------------------
+class float64_convs:
+    """Context manager: every nn.Conv2d of `net` evaluates its convolution in float64 and rounds ONCE to fp32 (forward and, through
+    autograd, both gradients) — the reference graph with the synapse arithmetic taken to (almost) infinite precision.  This is the
+    yard-stick for the product's synapse forms: MIOpen's fp32 convolutions, fp32 GEMM + gather, exact bf16x3 MFMA GEMMs all differ from
+    each other by fp32 summation order; each is held against THIS value instead of against another fp32 summation order
+    (tests/_pinned.py).  Neuron arithmetic, gains, adds, I-pool, loss stay the fp32 op-by-op restatement."""
+
+    def __init__(self, net):
+        self.convs = [m for m in net.modules() if isinstance(m, nn.Conv2d)]
+
+    def __enter__(self):
+        for c in self.convs:
+            def fwd(inp, weight, bias, c=c):
+                y = F.conv2d(inp.double(), weight.double(), None if bias is None else bias.double(), c.stride, c.padding,
+                             c.dilation, c.groups)
+                return y.float()
+            c._conv_forward = fwd
+        return self
+
+    def __exit__(self, *a):
+        for c in self.convs:
+            c.__dict__.pop('_conv_forward', None)
+        return False
+
+
 # ---- loss.py / metrics.py ------------------------------------------------------------------------------
 def _masked_residual(pred, gt):
     mask = ~torch.isnan(gt)

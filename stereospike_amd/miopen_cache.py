@@ -41,3 +41,21 @@ def enable(path: str = CACHE_DIR, skip_naive_solvers: bool = False):
         for d in ('FWD', 'BWD', 'WRW'):
             os.environ.setdefault(f'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{d}', '0')
     return path
+
+
+def enable_hermetic(kernel_cache: str = CACHE_DIR):
+    """For the test suite: MIOpen's solver choice must not depend on untracked state.  The user find-db / perf-db directory is a FRESH
+    temporary directory seeded only from the tracked `miopen_db/` text records (never the git-ignored `lib/miopen_cache/` that bench.py
+    find-mode runs keep appending to); only the compiled-kernel cache (binaries: they change start-up time, not which solver runs) is
+    shared with the in-tree directory.  Must be called before the first convolution."""
+    import shutil
+    import tempfile
+    db = tempfile.mkdtemp(prefix='ss_miopen_userdb_')
+    if os.path.isdir(SEED_DIR):
+        for f in os.listdir(SEED_DIR):
+            if f.endswith('.txt'):
+                shutil.copy(os.path.join(SEED_DIR, f), os.path.join(db, f))
+    os.makedirs(kernel_cache, exist_ok=True)
+    os.environ['MIOPEN_USER_DB_PATH'] = db
+    os.environ.setdefault('MIOPEN_CUSTOM_CACHE_DIR', kernel_cache)
+    return db

@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 from stereospike_amd import miopen_cache  # noqa: E402
-miopen_cache.enable()          # share the in-tree MIOpen kernel cache with bench.py (cold compiles take minutes)
+# hermetic solver selection: a fresh find-db directory seeded from the TRACKED miopen_db/ only; the compiled-kernel cache (start-up time,
+# not numerics) is shared with the in-tree directory bench.py uses
+miopen_cache.enable_hermetic()
 
 import torch  # noqa: E402
 

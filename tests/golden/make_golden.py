@@ -316,6 +316,54 @@ def gen_model(ref, tag, make_ref, make_oracle, C, T, returns_spikes, seed=2021):
     save(f'model_{tag}.npz', **out)
 
 
+STAGE_NAMES = ('bottom', 'conv1', 'conv2', 'conv3', 'conv4', 'bottleneck.0', 'bottleneck.1', 'deconv4', 'deconv3', 'deconv2', 'deconv1')
+
+
+def gen_stage_records(ref, tag, make_ref, C, T, seed=2021):
+    """stages_<tag>.npz: the output of every spiking stage of the REFERENCE's own model (forward hooks on its modules) at every time
+    step, bit-packed, on exactly the weights / inputs of model_<tag>.npz.  Lets the GPU suite hold each product stage against the
+    reference TEACHER-FORCED (stage input = the reference's own tensor), i.e. without the chaotic cascade of a free-running comparison.
+    Spiking stages emit 0/1 (one bit plane); the SEW blocks emit 0..3 (two planes)."""
+    torch.manual_seed(seed)
+    net = make_ref()
+    x = synth_input(1, T, C, seed + 1)
+    rec = {n: [] for n in STAGE_NAMES}
+    mods = dict(net.named_modules())
+    hooks = [mods[n].register_forward_hook(lambda m, i, o, n=n: rec[n].append(o.detach().clone())) for n in STAGE_NAMES]
+    sj.reset_net(net)
+    with torch.no_grad():
+        for t in range(T):
+            res = net(x[:, t:t + 1])
+    for h in hooks:
+        h.remove()
+    depths, spikes = res if isinstance(res, tuple) else (res, None)
+    z = np.load(os.path.join(HERE, f'model_{tag}.npz'))
+    assert str(z['state_sha']) == state_sha_fresh(make_ref, seed), 'weights differ from model fixture'
+    for i, d in enumerate(depths):
+        assert np.array_equal(d.numpy(), z[f'depth{i + 1}']), 'this run does not reproduce the model fixture'
+    out = dict(T=np.array(T), C=np.array(C), seed=np.array(seed), names=np.array(json.dumps(STAGE_NAMES)))
+    for n in STAGE_NAMES:
+        a = torch.stack(rec[n]).numpy()                         # [T, 1, C, H, W] float
+        u = a.astype(np.uint8)
+        assert np.array_equal(u.astype(np.float32), a) and u.max() <= 3
+        out[f'{n}_shape'] = np.array(u.shape)
+        out[f'{n}_p0'] = np.packbits(u & 1)
+        if n.startswith('bottleneck'):
+            out[f'{n}_p1'] = np.packbits((u >> 1) & 1)
+        else:
+            assert u.max() <= 1
+    if spikes is not None:                                        # consistency with the model fixture's returned spike tensors
+        add4 = rec['deconv4'][-1] + rec['conv3'][-1]
+        assert np.array_equal(add4.numpy().astype(np.uint8), z['out_add4'])
+        assert np.array_equal(rec['bottleneck.1'][-1].numpy().astype(np.uint8), z['out_rconv'])
+    save(f'stages_{tag}.npz', **out)
+
+
+def state_sha_fresh(make_ref, seed):
+    torch.manual_seed(seed)
+    return state_sha(make_ref())
+
+
 def gen_voxelizer():
     """The reference's OWN voxeliser (datasets/MVSEC/utils.py:215-281), extracted from the file by name (the module itself
     cannot be imported: cv2 / h5py / skimage are absent) and run on synthetic event streams; pins oracle/np_voxelize.py."""
@@ -350,37 +398,38 @@ def gen_voxelizer():
 
 def main():
     torch.set_num_threads(8)
-    gen_voxelizer()
+    stages_only = '--stages' in sys.argv
+    if not stages_only:
+        gen_voxelizer()
     ref = load_reference()
     S, A = ref['SNN_models'], ref['ANN_models']
-    gen_neuron_kat()
-    gen_loss_metric(ref)
-    gen_blocks(ref)
-    # config 3 network: StereoSpike, ATan outside / Sigmoid inside the bottleneck (train.py:118), gain 10 so neurons fire
-    gen_model(ref, 'stereospike_T1',
-              lambda: S.StereoSpike(surrogate_function=sj.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
-                                    multiply_factor=10.),
-              lambda: rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(),
-                               sigmoid_alpha=SIGMOID_ALPHA), 4, 1, True)
-    gen_model(ref, 'stereospike_T5',
-              lambda: S.StereoSpike(surrogate_function=sj.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
-                                    multiply_factor=10.),
-              lambda: rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(),
-                               sigmoid_alpha=SIGMOID_ALPHA), 4, 5, True)
-    # config 2 family: PLIF model (train.py:120) binocular T=1 and T=5, LIF variant, monocular
     plif = dict(tau=3., v_threshold=1.0, v_reset=0.0, use_plif=True, multiply_factor=30.)   # gain 10 leaves the tau=3 PLIF net silent beyond conv1
-    gen_model(ref, 'plif_T1', lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**plif),
-              lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **plif), 4, 1, True)
-    gen_model(ref, 'plif_T5', lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**plif),
-              lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **plif), 4, 5, True)
     lif = dict(tau=3., v_threshold=1.0, v_reset=0.0, use_plif=False, multiply_factor=30.)
-    gen_model(ref, 'lif_T1', lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**lif),
-              lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **lif), 4, 1, True)
-    gen_model(ref, 'mono_plif_T1',
-              lambda: S.fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike(**plif),
-              lambda: rn.build('PLIFNetMono', sigmoid_alpha=SIGMOID_ALPHA, **plif), 2, 1, False)
-    # config 1: the equivalent ANN (CPU plumbing case)
-    gen_model(ref, 'ann_T1', lambda: A.StereoSpike_equivalentANN(), lambda: rn.build('ANN'), 4, 1, False)
+    mk_ss = lambda: S.StereoSpike(surrogate_function=sj.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0., multiply_factor=10.)
+    mk_plif = lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**plif)
+    mk_lif = lambda: S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(**lif)
+    mk_mono = lambda: S.fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike(**plif)
+    if not stages_only:
+        gen_neuron_kat()
+        gen_loss_metric(ref)
+        gen_blocks(ref)
+        # config 3 network: StereoSpike, ATan outside / Sigmoid inside the bottleneck (train.py:118), gain 10 so neurons fire
+        orc_ss = lambda: rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(), sigmoid_alpha=SIGMOID_ALPHA)
+        gen_model(ref, 'stereospike_T1', mk_ss, orc_ss, 4, 1, True)
+        gen_model(ref, 'stereospike_T5', mk_ss, orc_ss, 4, 5, True)
+        # config 2 family: PLIF model (train.py:120) binocular T=1 and T=5, LIF variant, monocular
+        gen_model(ref, 'plif_T1', mk_plif, lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **plif), 4, 1, True)
+        gen_model(ref, 'plif_T5', mk_plif, lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **plif), 4, 5, True)
+        gen_model(ref, 'lif_T1', mk_lif, lambda: rn.build('PLIFNet', sigmoid_alpha=SIGMOID_ALPHA, **lif), 4, 1, True)
+        gen_model(ref, 'mono_plif_T1', mk_mono, lambda: rn.build('PLIFNetMono', sigmoid_alpha=SIGMOID_ALPHA, **plif), 2, 1, False)
+        # config 1: the equivalent ANN (CPU plumbing case)
+        gen_model(ref, 'ann_T1', lambda: A.StereoSpike_equivalentANN(), lambda: rn.build('ANN'), 4, 1, False)
+    # per-stage records of the reference's own modules (teacher-forcing data for the GPU suite); `--stages` writes only these
+    gen_stage_records(ref, 'stereospike_T1', mk_ss, 4, 1)
+    gen_stage_records(ref, 'lif_T1', mk_lif, 4, 1)
+    gen_stage_records(ref, 'mono_plif_T1', mk_mono, 2, 1)
+    gen_stage_records(ref, 'plif_T1', mk_plif, 4, 1)
+    gen_stage_records(ref, 'plif_T5', mk_plif, 4, 5)
 
 
 if __name__ == '__main__':

@@ -1,21 +1,11 @@
-"""End-to-end GPU parity: the product modules (fused HIP neuron path + PyTorch-ROCm convs) against the CPU oracle
-network (oracle/ref_network.py, pinned bit-for-bit to the reference's own network/*.py by tests/golden/make_golden.py).
+"""GPU parity, part 2 (part 1 — the shipped default configuration end to end, trajectory-pinned and against the reference's own
+per-stage tensors — is tests/test_gpu_00_default_path.py and runs first): the product modules against the live CPU oracle network
+(oracle/ref_network.py, pinned bit-for-bit to the reference's own network/*.py by tests/golden/make_golden.py).
 
-Bit-exact spike masks are only meaningful at the kernel boundary (tests/test_gpu_kernels.py): the MIOpen convs differ
-from oneDNN by ~2e-7 relative, a membrane within that distance of the threshold flips its spike, and — measured on the
-MI355X, gpurun_out/parity_report.json — the random-weight, gain-10 network is CHAOTIC: one flipped spike moves
-25 x C_out downstream membranes by ~0.5, so a handful of flips at conv4 becomes percents of flips three layers later
-and grows with T.  Three complementary checks therefore make the end-to-end statement:
-
-  1. TEACHER-FORCED, per stage (no cascade): every product stage is fed the ORACLE's input for that stage and must
-     reproduce the oracle's output — spike mismatch <= 2e-4 (only neurons within a conv-ulp of threshold may differ),
-     weight / input gradients <= 2e-3 relative L2.  Composition of the stages is covered on CPU by
-     tests/test_host_wiring.py (bit-identical graph) and the kernels by tests/test_gpu_kernels.py (bit-exact).
-  2. FREE-RUNNING, calibrated against the oracle's own sensitivity: the oracle is run a second time with every conv
-     output perturbed by one random ulp-scale factor (1 + u * 2^-22, u in {-1,0,1}) — the size of the MIOpen-vs-oneDNN
-     difference — and the product's deviation from the oracle must stay within 4x that noise floor (+ small absolute
-     terms written below) for spikes, depths, loss, MDE.
-  3. Golden fixtures / firing rates / drop-in script flow.
+Contents: per-stage teacher-forced parity against the LIVE oracle including stage gradients (NCHW fp32 forms and the NHWC
+exact-split forms); the PLIF T = 1 fixture's firing-rate dict through the in-kernel counters; sequence vs step-wise evaluation;
+the reference's script flow through install_dropin(); the DP reducer on RCCL (one rank); 16-bit activation modes; over-fitting
+sanity; kernel hyper-parameter fuzz; HIP-graph inference / training.
 """
 import json
 import os
@@ -37,41 +27,7 @@ def _dump():
         json.dump(REPORT, f, indent=1)
 
 
-def _product(name, **kw):
-    from stereospike_amd.clock_driven import surrogate
-    from stereospike_amd.network import SNN_models as S, ANN_models as A
-    plif = dict(tau=3., v_threshold=1.0, v_reset=0.0, multiply_factor=30.)   # gain 10 leaves the tau=3 nets silent
-    if name == 'StereoSpike':
-        return S.StereoSpike(surrogate_function=surrogate.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
-                             multiply_factor=10., **kw)
-    if name == 'PLIFNet':
-        return S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(use_plif=True, **plif, **kw)
-    if name == 'LIFNet':
-        return S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(use_plif=False, **plif, **kw)
-    if name == 'PLIFNetMono':
-        return S.fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike(use_plif=True, **plif, **kw)
-    if name == 'ANN':
-        return A.StereoSpike_equivalentANN(**kw)
-    raise ValueError(name)
-
-
-def _oracle(name, **kw):
-    if name == 'StereoSpike':
-        return rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan(), **kw)
-    if name in ('PLIFNet', 'LIFNet'):
-        return rn.build('PLIFNet', tau=3., use_plif=(name == 'PLIFNet'), multiply_factor=30., **kw)
-    if name == 'PLIFNetMono':
-        return rn.build('PLIFNetMono', tau=3., use_plif=True, multiply_factor=30., **kw)
-    return rn.build('ANN', **kw)
-
-
-def _pair(name, H, W, seed=2021):
-    torch.manual_seed(seed)
-    orc = _oracle(name, input_size=(H, W))
-    net = _product(name, input_size=(H, W))
-    assert list(net.state_dict().keys()) == list(orc.state_dict().keys())
-    net.load_state_dict(orc.state_dict())
-    return orc, net.to(DEV)
+from _models import product as _product, pair as _pair  # noqa: E402
 
 
 # ======================================================================================================
@@ -221,146 +177,6 @@ def test_teacher_forced_full_resolution():
             assert rep[st] <= 2e-4, (st, rep[st])
     REPORT['teacher_forced_full_res'] = rep
     _dump()
-
-
-# ======================================================================================================
-# 2. free-running, calibrated against the oracle's own ulp sensitivity
-# ======================================================================================================
-def _run_oracle(orc, x, gt, perturb_seed=None, perturb_kind='ulp'):
-    hooks = []
-    if perturb_seed is not None:
-        g = torch.Generator().manual_seed(perturb_seed)
-
-        def hook_ulp(mod, inp, out):
-            # one unit in the last place of the RESULT: the sensitivity to the smallest possible change of a conv output
-            u = torch.randint(-1, 2, out.shape, generator=g).to(out.dtype)
-            return out * (1.0 + u * 2.0 ** -22)
-
-        def hook(mod, inp, out):
-            # what another fp32 summation order does to a convolution: +-1 ulp of the MAGNITUDE of the accumulation (sum |w| |x|), not of
-            # the (possibly cancelled) result.  Measured on the MI355X (tools: profiles/r01/conv_as_gemm.log): MIOpen's fp32 convs differ
-            # from a float64 convolution by 1e-6 .. 1e-5 absolute on outputs of magnitude 3, i.e. 4 .. 40 ulp of the result.
-            u = torch.randint(-1, 2, out.shape, generator=g).to(out.dtype)
-            mag = torch.nn.functional.conv2d(inp[0].abs(), mod.weight.abs(), None, mod.stride, mod.padding, mod.dilation, mod.groups)
-            return out + u * mag * 2.0 ** -23
-        for m in orc.modules():
-            if isinstance(m, torch.nn.Conv2d):
-                hooks.append(m.register_forward_hook(hook_ulp if perturb_kind == 'ulp' else hook))
-    orc.zero_grad()
-    res = rn.run_sequence(orc, x)
-    d, s = res if isinstance(res, tuple) else (res, [])
-    L = rn.total_loss(d, gt, s)
-    mde = rn.mean_depth_error(d[0].detach(), gt)
-    L.backward()
-    for h in hooks:
-        h.remove()
-    grads = {k: p.grad.clone() for k, p in orc.named_parameters()}
-    return [t.detach() for t in d], [t.detach() for t in s], float(L), float(mde), grads
-
-
-def _deviation(d, s, L, mde, d_ref, s_ref, L_ref, mde_ref):
-    scale = max(float(t.abs().max()) for t in d_ref)
-    return dict(
-        depth_mean_abs=max(float((a.cpu() - b).abs().mean()) for a, b in zip(d, d_ref)) / scale,
-        spike_mismatch=max([float((a.cpu() != b).float().mean()) for a, b in zip(s, s_ref)] or [0.0]),
-        loss_rel=abs(L - L_ref) / abs(L_ref), mde_rel=abs(mde - mde_ref) / abs(mde_ref))
-
-
-def _free_running(tag, name, x, gt, H, W, exact_split=False):
-    """exact_split=False: the product with its bf16x3 GEMM forms switched off (every conv / projection is the library's fp32 one, as
-    in the oracle) against the oracle's ONE-ULP sensitivity — isolates the hand-written kernels, which must add nothing.
-    exact_split=True: the shipped default (fused.EXACT_SPLIT_GEMM) against the oracle's sensitivity to an fp32 SUMMATION-ORDER change
-    of its convolutions — the exact-product GEMMs are closer to a float64 convolution than MIOpen's fp32 convs
-    (test_spike_conv_as_exact_bf16x3_gemm) but round differently, and these networks amplify that like any other ulp-level change."""
-    from stereospike_amd import fused
-    prev = fused.EXACT_SPLIT_GEMM
-    fused.EXACT_SPLIT_GEMM = exact_split
-    try:
-        return _free_running_impl(tag, name, x, gt, H, W, 'sum_order' if exact_split else 'ulp')
-    finally:
-        fused.EXACT_SPLIT_GEMM = prev
-
-
-def _free_running_impl(tag, name, x, gt, H, W, perturb_kind):
-    from stereospike_amd.clock_driven import functional
-    from stereospike_amd.network.loss import Total_Loss
-    from stereospike_amd.network.metrics import MeanDepthError
-    orc, net = _pair(name, H, W)
-    returns_spikes = name not in ('PLIFNetMono', 'ANN')
-    d_ref, s_ref, L_ref, mde_ref, g_ref = _run_oracle(orc, x, gt)
-    floor = None
-    seeds = (123, 124, 125) if (perturb_kind == 'sum_order' and H * W <= 128 * 128) else (123,)
-    for seed in seeds:                                                      # the noise floor: worst of a few perturbations
-        d_p, s_p, L_p, mde_p, g_p = _run_oracle(orc, x, gt, perturb_seed=seed, perturb_kind=perturb_kind)
-        f = _deviation(d_p, s_p, L_p, mde_p, d_ref, s_ref, L_ref, mde_ref)
-        f['grad_cos_min'] = min(float(torch.dot(g_p[k].flatten().double(), g_ref[k].flatten().double()) /
-                                      (g_p[k].double().norm() * g_ref[k].double().norm() + 1e-300))
-                                for k in g_ref if g_ref[k].numel() >= 1000)
-        floor = f if floor is None else {k: (min(floor[k], f[k]) if k == 'grad_cos_min' else max(floor[k], f[k])) for k in f}
-
-    functional.reset_net(net)
-    xg, gg = x.to(DEV), gt.to(DEV)
-    res = net(xg) if name == 'ANN' else net.forward_sequence(xg)
-    d, s = res if returns_spikes else (res, [])
-    L = Total_Loss()(d, gg, s)
-    mde = MeanDepthError(d[0].detach(), gg)
-    L.backward()
-    torch.cuda.synchronize()
-    got = _deviation([t.detach() for t in d], [t.detach() for t in s], float(L), float(mde), d_ref, s_ref, L_ref, mde_ref)
-    got['grad_cos_min'] = min(float(torch.dot(p.grad.detach().cpu().flatten().double(), g_ref[k].flatten().double()) /
-                                    (p.grad.detach().cpu().double().norm() * g_ref[k].double().norm() + 1e-300))
-                              for k, p in net.named_parameters() if p.numel() >= 1000)
-    REPORT[tag] = dict(product_vs_oracle=got, oracle_noise_floor=floor, noise_model=perturb_kind, loss=[float(L), L_ref],
-                       mde=[float(mde), mde_ref])
-    _dump()
-    if perturb_kind == 'sum_order':
-        # loss / MDE are functions of the depth maps: with a handful of perturbation seeds their own floors are small-sample, so the
-        # depth floor bounds them too
-        floor = dict(floor, loss_rel=max(floor['loss_rel'], floor['depth_mean_abs']), mde_rel=max(floor['mde_rel'], floor['depth_mean_abs']))
-    # bars: within 4x the oracle's own one-ulp sensitivity, plus absolute terms for the non-chaotic cases
-    # (absolute terms = what a spike mismatch of 2e-4 is worth: measured 4.6e-5 mismatch <-> 3.2e-5 depth, 4e-6 loss)
-    assert got['spike_mismatch'] <= 4 * floor['spike_mismatch'] + 2e-4, REPORT[tag]
-    assert got['depth_mean_abs'] <= 4 * floor['depth_mean_abs'] + 2e-4, REPORT[tag]
-    assert got['loss_rel'] <= 4 * floor['loss_rel'] + 2e-4, REPORT[tag]
-    assert got['mde_rel'] <= 4 * floor['mde_rel'] + 2e-4, REPORT[tag]
-    assert 1 - got['grad_cos_min'] <= 4 * (1 - floor['grad_cos_min']) + 2e-4, REPORT[tag]
-    return net, d, s
-
-
-@pytest.mark.parametrize('layout', ['nchw', 'decoder_nhwc', 'all_nhwc', 'two_op_miopen', 'all_nhwc_exact_split'])
-def test_free_running_small_every_execution_layout(layout, monkeypatch):
-    """The same network through every execution variant of the synapses (reference two-op up-convs on MIOpen; projected
-    NCHW; decoder in NHWC; whole network in NHWC; the shipped default = whole network in NHWC with the exact bf16x3 GEMM forms)."""
-    from stereospike_amd.network import blocks
-    monkeypatch.setattr(blocks, 'FUSE_UPCONV', layout != 'two_op_miopen')
-    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', layout in ('decoder_nhwc', 'all_nhwc', 'all_nhwc_exact_split'))
-    monkeypatch.setattr(blocks, 'ENCODER_CHANNELS_LAST', layout in ('all_nhwc', 'all_nhwc_exact_split'))
-    x = synth_input(2, 3, 4, 77, 64, 80, lam=0.08)
-    gt = synth_label(2, 78, 64, 80)
-    _free_running(f'free_small_PLIFNet_{layout}', 'PLIFNet', x, gt, 64, 80, exact_split=layout.endswith('exact_split'))
-
-
-@pytest.mark.parametrize('exact_split', [False, True])
-@pytest.mark.parametrize('name,C', [('StereoSpike', 4), ('PLIFNet', 4), ('LIFNet', 4), ('PLIFNetMono', 2), ('ANN', 4)])
-def test_free_running_small(name, C, exact_split):
-    """64x80 frames, B=2, T=3 with BPTT (membranes carried) — every model family, strict form and shipped default."""
-    T = 1 if name == 'ANN' else 3
-    x = synth_input(2, T, C, 77, 64, 80, lam=0.08)
-    gt = synth_label(2, 78, 64, 80)
-    _free_running(f'free_small_{name}' + ('_default' if exact_split else ''), name, x, gt, 64, 80, exact_split=exact_split)
-
-
-def test_free_running_full_resolution_stereospike_T5():
-    """BASELINE config 3 network at 260x346, B=1, T=5; inputs are the committed fixture's (the reference's own
-    SNN_models.py produced its expected outputs, which the live oracle must still reproduce statistically)."""
-    z = load_npz('model_stereospike_T5.npz')
-    x = torch.tensor(z['x'].astype(np.float32))
-    gt = torch.tensor(z['gt'])
-    net, d, s = _free_running('free_full_stereospike_T5', 'StereoSpike', x, gt, 260, 346, exact_split=True)
-    # firing statistics against the fixture: densities of the 5 returned tensors within 1 % absolute
-    for nm, t in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), s):
-        ref_density = float((z[nm] != 0).mean())
-        assert abs(float(t.count_nonzero()) / t.numel() - ref_density) <= 1e-2, nm
 
 
 # ======================================================================================================
@@ -525,13 +341,6 @@ def test_training_reduces_the_loss(name):
     _dump()
     assert all(np.isfinite(losses))
     assert min(losses[-10:]) < 0.5 * losses[0], (losses[0], losses[-10:])
-
-
-def test_free_running_odd_sizes_runtime_T():
-    """Frame size with odd pyramid levels (50x70 -> 25x35 -> 13x18 -> 7x9 -> 4x5), T = 7 (runtime-T kernel path), B = 3."""
-    x = synth_input(3, 7, 4, 123, 50, 70, lam=0.08)
-    gt = synth_label(3, 124, 50, 70)
-    _free_running('free_odd_50x70_T7_PLIFNet', 'PLIFNet', x, gt, 50, 70)
 
 
 def test_kernel_hyper_parameter_fuzz():

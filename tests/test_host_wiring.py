@@ -183,3 +183,23 @@ def test_sequence_path_equals_stepwise_oracle(host_backend):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     net.detach()
     assert all(not m.v.requires_grad for m in net.modules() if hasattr(m, 'v') and torch.is_tensor(m.v))
+
+
+@pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
+def test_pinned_oracle_machinery_on_the_host_backend(host_backend, name):
+    """tests/_pinned.py (the end-to-end parity protocol of the GPU suite) exercised on CPU: product python layer over the C-oracle
+    kernels vs the trajectory-pinned float64-conv oracle.  Whole-network forward + loss + composed backward over T = 3 steps."""
+    from _pinned import pinned_parity
+    H, W = 48, 64
+    orc, net = _pair(name, H, W)
+    x = synth_input(2, 3, 4, 7, H, W, lam=0.1)
+    gt = synth_label(2, 8, H, W)
+    rep = pinned_parity(orc, net, x, gt)
+    assert len(rep['layers']) == 13
+    assert rep['flip_frac_max'] <= 2e-4 and rep['margin_max'] <= 1e-3, rep['layers']
+    assert rep['depth_max_abs_rel'] <= 1e-5 and rep['loss_rel'] <= 1e-5 and rep['mde_rel'] <= 1e-5, rep
+    assert rep['grad_rel_l2_max'] <= 2e-3, rep['grad_rel_l2']
+    # the protocol must SEE a wrong kernel: the same comparison with the product's gain off by one ulp-scale factor of 1e-3 fails loudly
+    net.bottom[1].scale_value = net.bottom[1].scale_value * 1.05
+    bad = pinned_parity(orc, net, x, gt)
+    assert bad['layers']['bottom.2']['max_margin'] > 1e-2 and bad['layers']['bottom.2']['flip_frac'] > 1e-3, bad['layers']['bottom.2']
