@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` to ss_neuron_bwd_f32 when g_k != NULL. */
@@ -163,6 +163,65 @@ int ss_neuron_bwd_rc_x16(const void* g_out_seq, const float* g_v_last, const voi
                          float scale, int kind, float tau, const float* k,
                          float v_th, float v_reset, int surrogate, float alpha, int detach_reset,
                          int dtype, void* stream);
+
+/*
+ * ss_neuron_bwd_fork_f32 for 16-bit activations (recompute form only): g_out_seq and g_out2_seq are the 16-bit gradients of the two
+ * consumers of out_seq; the kernel widens both and adds them in fp32 (no 16-bit rounding of the sum, unlike autograd's accumulation
+ * kernel); g_sum_seq (nullable) receives that sum narrowed once = dL/dskip_seq of a stage with a fused skip add.
+ */
+int ss_neuron_bwd_fork_x16(const void* g_out_seq, const void* g_out2_seq, void* g_sum_seq, const float* g_v_last, const void* x_seq,
+                           const float* v_init, void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                           int T, long long N, float scale, int kind, float tau, const float* k,
+                           float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream);
+
+/*
+ * Extended forward (descriptor form; ABI 2).  Same arithmetic as ss_neuron_fwd_f32 / ss_neuron_fwd_x16 plus
+ *
+ *  - 2-BIT PACKED SPIKE TENSORS (the reference's spike tensors take the values 0..3 only:
+ *    /root/reference/network/SNN_models.py:171-192, blocks.py:171).  Layout: [T][N/16] 32-bit words, neuron n of step t in bits
+ *    2*(n%16)+{0,1} of word t*(N/16) + n/16, code = out value (z + skip).  out_packed != NULL writes the output packed; out_seq may then
+ *    be NULL (forward 4.25 B/update instead of 8: read x 4 + write 0.25) or also be written for a consumer that needs fp32.
+ *    skip_packed != NULL reads the skip operand from a packed tensor (0.25 B/update instead of 4).  fp32 activations, compile-time
+ *    T (ss_neuron_bwd_rc_supported(T)), N % 16 == 0, h_seq == NULL (training recomputes h: ss_neuron_bwd_rc_f32); else SS_EINVAL.
+ *    Readers for the consumers: ss_unpack_spikes, ss_im2col_cl_bf16_packed, and skip_packed itself.
+ *  - FIRING-RATE COUNTERS WITHOUT SAME-ADDRESS ATOMICS: with cnt_ws (ss_neuron_cnt_ws_words(N) 32-bit words) every workgroup stores
+ *    its two partial counts and a one-workgroup second pass adds their sum to nnz[0..1]; the launch keeps its full grid (with
+ *    cnt_ws == NULL the atomics form bounds the grid to 2048 workgroups).  Integer sums: deterministic either way.
+ *
+ * act_dtype: 0 = fp32 activations (x_seq / skip_seq / out_seq are float*), SS_DT_F16 / SS_DT_BF16 = 16-bit activations (no packed I/O).
+ * `size` must be sizeof(ss_neuron_fwd_desc) (lets the struct grow without breaking old callers).
+ */
+typedef struct ss_neuron_fwd_desc {
+    unsigned int size;
+    int act_dtype;
+    const void* x_seq;
+    const float* v_init;                 /* nullable => v_reset */
+    const void* skip_seq;                /* nullable; dense skip operand (act_dtype elements) */
+    const unsigned int* skip_packed;     /* nullable; packed skip operand (exclusive with skip_seq) */
+    void* out_seq;                       /* nullable when out_packed is given */
+    unsigned int* out_packed;            /* nullable */
+    float* h_seq;                        /* nullable */
+    float* v_last;
+    unsigned long long* nnz;             /* nullable, [2] */
+    unsigned int* cnt_ws;                /* nullable; requires nnz */
+    int T;
+    long long N;
+    float scale;
+    int kind;
+    float tau;
+    const float* k;
+    float v_th, v_reset;
+} ss_neuron_fwd_desc;
+int ss_neuron_fwd_ex(const ss_neuron_fwd_desc* desc, void* stream);
+long long ss_neuron_cnt_ws_words(long long N);
+
+/* packed [n/16 words] -> dense values 0..3 as fp32 (out_dtype 0), fp16 or bf16.  copies > 1 (K-concatenated exact bf16x3 GEMM operand
+ * [X X X]): the n values are rows of row_len elements and every row is written `copies` times back to back (output rows are
+ * copies*row_len long).  n % 16 == 0; with copies > 1: row_len % 8 == 0 and n % row_len == 0. */
+int ss_unpack_spikes(const unsigned int* packed, void* out, long long n, int out_dtype, int row_len, int copies, void* stream);
+/* ss_im2col_cl_bf16 with the NHWC input given as a packed spike tensor (C % 8 == 0, NB*h*w*C % 16 == 0). */
+int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB, int h, int w, int C, int k, int stride, int pad,
+                             int ho, int wo, void* stream);
 
 /*
  * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing

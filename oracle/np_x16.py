@@ -53,10 +53,13 @@ def neuron_fwd(x_bits, dtype, *, kind='IF', scale=1.0, tau=2.0, k=None, v_th=1.0
 
 
 def neuron_bwd(g_bits, h, dtype, *, kind='IF', scale=1.0, tau=2.0, k=None, v_th=1.0, v_reset=0.0, v_init=None,
-               g_v_last=None, surrogate='ATan', alpha=2.0):
+               g_v_last=None, surrogate='ATan', alpha=2.0, g2_bits=None):
+    """g2_bits: gradient of a second consumer of the output (ss_neuron_bwd_fork_x16): the two widened values are added in fp32 and the
+    sum is used unrounded; `g_sum` = that sum narrowed once (dL/dskip of a stage with a fused skip add)."""
     T, N = h.shape
     gv = np.zeros(N, F32) if g_v_last is None else np.asarray(g_v_last, F32).copy()
     gx = np.empty((T, N), np.uint16)
+    gsum = np.empty((T, N), np.uint16) if g2_bits is not None else None
     acc_k = 0.0
     c = F32(math.pi / 2.0 * alpha)
     ha = F32(alpha / 2.0)
@@ -64,6 +67,9 @@ def neuron_bwd(g_bits, h, dtype, *, kind='IF', scale=1.0, tau=2.0, k=None, v_th=
         xh = h[t] - F32(v_th)
         z = (xh >= 0).astype(F32)
         g = widen(g_bits[t], dtype)
+        if g2_bits is not None:
+            g = g + widen(g2_bits[t], dtype)
+            gsum[t] = narrow(g, dtype)
         if surrogate == 'ATan':
             u = xh * c
             sg = (F32(1) / (u * u + F32(1)) * ha) * g
@@ -86,4 +92,4 @@ def neuron_bwd(g_bits, h, dtype, *, kind='IF', scale=1.0, tau=2.0, k=None, v_th=
                 v_prev = np.full(N, v_reset, F32) if v_init is None else np.asarray(v_init, F32)
             acc_k += float(np.sum((g_h * ((h[t] - v_prev) / F32(k))).astype(np.float64)))
         gx[t] = narrow(g_x * F32(scale), dtype)
-    return dict(g_x=gx, g_v_init=gv, g_k=acc_k if kind == 'PLIF' else None)
+    return dict(g_x=gx, g_v_init=gv, g_k=acc_k if kind == 'PLIF' else None, g_sum=gsum)

@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1
@@ -20,6 +20,14 @@ _lib = None
 
 class SSNeuronError(RuntimeError):
     pass
+
+
+class FwdDesc(C.Structure):
+    """struct ss_neuron_fwd_desc (include/ss_neuron.h)."""
+    _fields_ = [('size', C.c_uint), ('act_dtype', C.c_int), ('x_seq', C.c_void_p), ('v_init', C.c_void_p), ('skip_seq', C.c_void_p),
+                ('skip_packed', C.c_void_p), ('out_seq', C.c_void_p), ('out_packed', C.c_void_p), ('h_seq', C.c_void_p),
+                ('v_last', C.c_void_p), ('nnz', C.c_void_p), ('cnt_ws', C.c_void_p), ('T', C.c_int), ('N', C.c_longlong),
+                ('scale', C.c_float), ('kind', C.c_int), ('tau', C.c_float), ('k', C.c_void_p), ('v_th', C.c_float), ('v_reset', C.c_float)]
 
 
 def lib():
@@ -72,6 +80,16 @@ def lib():
     L.ss_upconv_cl_bwd_lowp.restype = i32
     L.ss_upconv_cl_fwd_x16.restype = i32
     L.ss_upconv_cl_bwd_x16.restype = i32
+    L.ss_neuron_bwd_fork_x16.argtypes = [p, p, p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, i32, p]
+    L.ss_neuron_bwd_fork_x16.restype = i32
+    L.ss_neuron_fwd_ex.argtypes = [C.POINTER(FwdDesc), p]
+    L.ss_neuron_fwd_ex.restype = i32
+    L.ss_neuron_cnt_ws_words.argtypes = [i64]
+    L.ss_neuron_cnt_ws_words.restype = i64
+    L.ss_unpack_spikes.argtypes = [p, p, i64, i32, i32, i32, p]
+    L.ss_unpack_spikes.restype = i32
+    L.ss_im2col_cl_bf16_packed.argtypes = [p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_im2col_cl_bf16_packed.restype = i32
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
               L.ss_upconv1_fwd_f32, L.ss_upconv1_bwd_f32, L.ss_upconv_cl_fwd_f32, L.ss_upconv_cl_bwd_f32):
         f.restype = i32
@@ -84,7 +102,8 @@ def lib():
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
-           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp')
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
+           'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed')
 
 
 def _ptr(t, name, numel=None):
@@ -389,3 +408,77 @@ def loss_grad(pred, gt, sums, coef, g_pred, B, H, W):
 
 def gk_ws_floats():
     return int(lib().ss_neuron_gk_ws_floats())
+
+
+# ---- ABI 2: descriptor forward (packed spikes, counter partials), forked x16 backward, packed readers ---------------------------
+def cnt_ws_words(N):
+    return int(lib().ss_neuron_cnt_ws_words(int(N)))
+
+
+def neuron_fwd_ex(x_seq, v_init, skip_seq, skip_packed, out_seq, out_packed, h_seq, v_last, nnz, cnt_ws, T, N, scale, kind, tau, k,
+                  v_th, v_reset):
+    """ss_neuron_fwd_ex: x_seq fp32 / fp16 / bf16 [T, N]; packed tensors are int32 [T, N/16] (2 bits per neuron)."""
+    _require_hip(x_seq, 'x_seq')
+    dt = x_seq.dtype
+    code = 0 if dt == torch.float32 else DT_CODE.get(dt)
+    if code is None:
+        raise SSNeuronError(f'x_seq: expected float32, float16 or bfloat16, got {dt}')
+    for t, name in ((skip_seq, 'skip_seq'), (out_seq, 'out_seq')):
+        if t is not None and t.dtype != dt:
+            raise SSNeuronError(f'{name}: expected {dt}, got {t.dtype}')
+    for t, name in ((skip_packed, 'skip_packed'), (out_packed, 'out_packed')):
+        if t is not None and (t.dtype != torch.int32 or t.numel() != T * (N // 16) or N % 16):
+            raise SSNeuronError(f'{name}: expected int32 [T, N/16] with N % 16 == 0')
+    if nnz is not None and (nnz.dtype != torch.int64 or nnz.numel() != 2):
+        raise SSNeuronError('nnz must be an int64 tensor of 2 elements')
+    if cnt_ws is not None and (cnt_ws.dtype != torch.int32 or cnt_ws.numel() < cnt_ws_words(N)):
+        raise SSNeuronError(f'cnt_ws: expected int32 with >= {cnt_ws_words(N)} elements')
+    def addr(t, name, numel=None, f32=False):          # validated device address (None -> NULL)
+        (_f32 if f32 else _ptr)(t, name, numel)
+        return None if t is None else t.data_ptr()
+    d = FwdDesc(C.sizeof(FwdDesc), code, addr(x_seq, 'x_seq', T * N), addr(v_init, 'v_init', N, True), addr(skip_seq, 'skip_seq', T * N),
+                addr(skip_packed, 'skip_packed'), addr(out_seq, 'out_seq', T * N), addr(out_packed, 'out_packed'),
+                addr(h_seq, 'h_seq', T * N, True), addr(v_last, 'v_last', N, True), addr(nnz, 'nnz'), addr(cnt_ws, 'cnt_ws'),
+                T, N, scale, kind, tau, addr(k, 'k', 1, True), v_th, v_reset)
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_fwd_ex(C.byref(d), _stream(x_seq))
+    _check(rc, 'ss_neuron_fwd_ex')
+
+
+def neuron_bwd_fork_x16(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                        v_th, v_reset, surrogate, alpha, detach_reset):
+    _require_hip(x_seq, 'x_seq')
+    dt = g_out_seq.dtype
+    if dt not in DT_CODE:
+        raise SSNeuronError(f'g_out_seq: expected float16 or bfloat16, got {dt}')
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_bwd_fork_x16(_x16(g_out_seq, 'g_out_seq', T * N, dt), _x16(g_out2_seq, 'g_out2_seq', T * N, dt),
+                                          _x16(g_sum_seq, 'g_sum_seq', T * N, dt), _f32(g_v_last, 'g_v_last', N),
+                                          _x16(x_seq, 'x_seq', T * N, dt), _f32(v_init, 'v_init', N),
+                                          _x16(g_x_seq, 'g_x_seq', T * N, dt), _f32(g_v_init, 'g_v_init', N),
+                                          _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'), T, N, scale, kind, tau,
+                                          _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha, int(bool(detach_reset)),
+                                          DT_CODE[dt], _stream(x_seq))
+    _check(rc, 'ss_neuron_bwd_fork_x16')
+
+
+def unpack_spikes(packed, out, n, row_len=0, copies=1):
+    """packed int32 [n/16] -> out (fp32 / fp16 / bf16, n * copies elements)."""
+    _require_hip(packed, 'packed')
+    code = 0 if out.dtype == torch.float32 else DT_CODE.get(out.dtype)
+    if code is None or packed.dtype != torch.int32:
+        raise SSNeuronError('unpack_spikes: packed must be int32, out float32 / float16 / bfloat16')
+    with torch.cuda.device(packed.device):
+        rc = lib().ss_unpack_spikes(_ptr(packed, 'packed', n // 16), _ptr(out, 'out', n * copies), n, code, row_len, copies, _stream(packed))
+    _check(rc, 'ss_unpack_spikes')
+
+
+def im2col_cl_bf16_packed(x_packed, A, NB, h, w, C_, k, stride, pad, ho, wo):
+    _require_hip(x_packed, 'x_packed')
+    if x_packed.dtype != torch.int32:
+        raise SSNeuronError('x_packed: expected int32')
+    with torch.cuda.device(x_packed.device):
+        rc = lib().ss_im2col_cl_bf16_packed(_ptr(x_packed, 'x_packed', NB * h * w * C_ // 16),
+                                            _x16(A, 'A', NB * ho * wo * k * k * C_, torch.bfloat16), NB, h, w, C_, k, stride, pad, ho, wo,
+                                            _stream(x_packed))
+    _check(rc, 'ss_im2col_cl_bf16_packed')

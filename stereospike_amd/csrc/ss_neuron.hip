@@ -145,10 +145,63 @@ struct FwdArgs {
     float* out_seq; float* h_seq; float* v_last; unsigned long long* nnz;
     int T; long long N;
     float scale, tau, v_th, v_reset; const float* k;
+    // ss_neuron_fwd_ex only (PK instantiations): 2-bit packed spike I/O, 16 neurons per 32-bit word, [T][N/16] words
+    const unsigned* skip_packed;   // nullable: the skip operand read from a packed spike tensor instead of skip_seq
+    unsigned* out_packed;          // nullable: out (z + skip, values 0..3) written packed; out_seq may then be NULL (4.25 B/update forward)
+    unsigned* cnt_ws;              // nullable (with nnz): per-workgroup counter partials, summed by cnt_finish_kernel in a fixed order
 };
 
+// out values 0..3 of VEC consecutive neurons of one lane -> 2*VEC bits; 16 / VEC neighbouring lanes share one word
+template <int VEC> __device__ __forceinline__ void store_packed(unsigned* words, long long i, unsigned bits)
+{
+    constexpr int LPW = 16 / VEC;                     // lanes per word: 4 (VEC = 4), 2 (VEC = 8)
+    unsigned w = bits;
+#pragma unroll
+    for (int s = 1; s < LPW; ++s) w |= (unsigned)__shfl_down((int)bits, s, 64) << (2 * VEC * s);
+    if ((threadIdx.x & (LPW - 1)) == 0) words[i / LPW] = w;
+}
+template <int VEC> __device__ __forceinline__ unsigned load_packed(const unsigned* words, long long i)
+{
+    constexpr int LPW = 16 / VEC;
+    return (words[i / LPW] >> (2 * VEC * (int)(threadIdx.x & (LPW - 1)))) & ((1u << (2 * VEC)) - 1u);
+}
+
+// counter epilogue shared by the forward kernels: lane counts -> wavefront butterfly -> LDS -> per-workgroup partial (cnt_ws) or atomics
+__device__ __forceinline__ void count_epilogue(unsigned c_spk, unsigned c_out, unsigned long long* nnz, unsigned* cnt_ws)
+{
+    __shared__ unsigned s_cnt[2][SS_BLOCK / 64];
+    unsigned ws = wave_sum_u32(c_spk), wo = wave_sum_u32(c_out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[0][wave] = ws; s_cnt[1][wave] = wo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ts = 0, to = 0;
+#pragma unroll
+        for (int w = 0; w < SS_BLOCK / 64; ++w) { ts += s_cnt[0][w]; to += s_cnt[1][w]; }
+        if (cnt_ws) { cnt_ws[2 * blockIdx.x] = (unsigned)ts; cnt_ws[2 * blockIdx.x + 1] = (unsigned)to; }
+        else { if (ts) atomicAdd(&nnz[0], ts); if (to) atomicAdd(&nnz[1], to); }
+    }
+}
+
+// second pass of the counters: one workgroup sums the per-workgroup partials (integers: any order gives the same result) and adds
+// them to nnz[0..1].  Replaces one same-address 64-bit atomic per workgroup (~12 ns each, serialised: 1 ms at 45 000 workgroups).
+__global__ __launch_bounds__(SS_BLOCK) void cnt_finish_kernel(const unsigned* __restrict__ ws, int n, unsigned long long* nnz)
+{
+    __shared__ unsigned long long s[2][SS_BLOCK];
+    unsigned long long a0 = 0, a1 = 0;
+    for (int i = threadIdx.x; i < n; i += SS_BLOCK) { a0 += ws[2 * i]; a1 += ws[2 * i + 1]; }
+    s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = SS_BLOCK / 2; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) { s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (s[0][0]) atomicAdd(&nnz[0], s[0][0]); if (s[1][0]) atomicAdd(&nnz[1], s[1][0]); }
+}
+
 // VEC = 4: lane owns one f4 per time step; VEC = 1: scalar tail / unaligned fallback.
-template <int KIND, int TS, bool SKIP, bool SAVE_H, int VEC>
+// PK: the ss_neuron_fwd_ex form with 2-bit packed spike output and / or packed skip input (VEC = 4, compile-time T only)
+template <int KIND, int TS, bool SKIP, bool SAVE_H, int VEC, bool PK = false>
 __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
 {
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
@@ -168,7 +221,44 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
         if (a.v_init) vv = reinterpret_cast<const vec_t*>(a.v_init)[i];
         else { if constexpr (VEC == 4) vv = (f4){v_reset, v_reset, v_reset, v_reset}; else vv = v_reset; }
 
-        if constexpr (TS > 0) {
+        if constexpr (PK) {
+            static_assert(!PK || (TS > 0 && VEC == 4 && !SAVE_H), "packed I/O: compile-time T, 16-B lanes, no saved h");
+            const long long NW = a.N / 16;                 // packed words per time step
+            f4 xs[TS > 0 ? TS : 1];
+            unsigned sb[TS > 0 ? TS : 1];
+            const bool skip_pk = SKIP && a.skip_packed != nullptr;
+#pragma unroll
+            for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const f4*>(xp) + (long long)t * NV);
+            if (SKIP) {
+                if (skip_pk) {
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) sb[t] = load_packed<4>(a.skip_packed + (long long)t * NW, i);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {   // dense skip: small integers 0..3, exact in the 2-bit code
+                        const f4 sv = reinterpret_cast<const f4*>(sp)[(long long)t * NV];
+                        sb[t] = (unsigned)sv[0] | ((unsigned)sv[1] << 2) | ((unsigned)sv[2] << 4) | ((unsigned)sv[3] << 6);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                f4 ov;
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h = charge<KIND>(vv[e], xs[t][e] * scale, tau, k, v_reset);
+                    const float z = heaviside(h - v_th);
+                    vv[e] = (1.f - z) * h + z * v_reset;
+                    const unsigned code = (unsigned)(z != 0.f) + (SKIP ? ((sb[t] >> (2 * e)) & 3u) : 0u);
+                    c_spk += (z != 0.f); c_out += (code != 0u);
+                    bits |= code << (2 * e);
+                    ov[e] = (float)code;
+                }
+                if (a.out_seq) store_out(reinterpret_cast<f4*>(op) + (long long)t * NV, ov);
+                if (a.out_packed) store_packed<4>(a.out_packed + (long long)t * NW, i, bits);
+            }
+        } else if constexpr (TS > 0) {
             // all T loads of this lane are independent of the recurrence: issue them up front
             vec_t xs[TS];
             vec_t ss[SKIP ? TS : 1];
@@ -222,20 +312,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
         reinterpret_cast<vec_t*>(a.v_last)[i] = vv;
     }
 
-    if (a.nnz) {   // wave-uniform
-        __shared__ unsigned s_cnt[2][kBlock / 64];
-        unsigned ws = wave_sum_u32(c_spk), wo = wave_sum_u32(c_out);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_cnt[0][wave] = ws; s_cnt[1][wave] = wo; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long ts = 0, to = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) { ts += s_cnt[0][w]; to += s_cnt[1][w]; }
-            if (ts) atomicAdd(&a.nnz[0], ts);
-            if (to) atomicAdd(&a.nnz[1], to);
-        }
-    }
+    if (a.nnz) count_epilogue(c_spk, c_out, a.nnz, a.cnt_ws);   // wave-uniform
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -397,6 +474,11 @@ __global__ __launch_bounds__(kBlock) void gk_finish_kernel(const float* partials
 // neurons = one 16-B load of x, one 16-B store of out and two 16-B stores of h per time step.
 // ---------------------------------------------------------------------------------------------------
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+template <int VEC> struct U16Vec;
+template <> struct U16Vec<8> { typedef u16x8 type; };
+template <> struct U16Vec<4> { typedef unsigned short type __attribute__((ext_vector_type(4))); };
+template <> struct U16Vec<2> { typedef unsigned short type __attribute__((ext_vector_type(2))); };
+template <> struct U16Vec<1> { typedef unsigned short type; };
 
 template <int DT> __device__ __forceinline__ float widen(unsigned short b)
 {
@@ -421,11 +503,15 @@ struct Fwd16Args {
     unsigned short* out_seq; float* h_seq; float* v_last; unsigned long long* nnz;
     int T; long long N;
     float scale, tau, v_th, v_reset; const float* k;
+    unsigned* cnt_ws;              // nullable (with nnz): per-workgroup counter partials (ss_neuron_fwd_ex)
 };
 
-template <int KIND, int DT, bool SKIP, bool SAVE_H, int VEC>
+// TS > 0: compile-time T, all T (independent) loads of a lane issued before the recurrence starts, like the fp32 kernel; TS = 0: run-time T.
+template <int KIND, int DT, int TS, bool SKIP, bool SAVE_H, int VEC>
 __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
 {
+    typedef typename U16Vec<VEC>::type uvec_t;
+    const int T = (TS > 0) ? TS : a.T;
     const long long NV = a.N / VEC;
     const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
     const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset;
@@ -434,57 +520,57 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
         float v[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v[e] = a.v_init ? a.v_init[i * VEC + e] : v_reset;
-        for (int t = 0; t < a.T; ++t) {
-            const long long base = ((long long)t * NV + i) * VEC;
-            unsigned short xb[VEC], sb[VEC], ob[VEC];
+
+        auto step = [&](uvec_t xv, uvec_t sv, long long base) {
+            uvec_t ov;
             float h[VEC];
-            if constexpr (VEC == 8) {
-                const u16x8 xv = load_stream(reinterpret_cast<const u16x8*>(a.x_seq + base));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xb[e] = xv[e];
-                if (SKIP) {
-                    const u16x8 sv = *reinterpret_cast<const u16x8*>(a.skip_seq + base);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sb[e] = sv[e];
-                }
-            } else { xb[0] = a.x_seq[base]; if (SKIP) sb[0] = a.skip_seq[base]; }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const float hh = charge<KIND>(v[e], widen<DT>(xb[e]) * scale, tau, k, v_reset);
+                unsigned short xb, sb = 0;
+                if constexpr (VEC == 1) { xb = xv; if (SKIP) sb = sv; } else { xb = xv[e]; if (SKIP) sb = sv[e]; }
+                const float hh = charge<KIND>(v[e], widen<DT>(xb) * scale, tau, k, v_reset);
                 const float z = heaviside(hh - v_th);
                 v[e] = (1.f - z) * hh + z * v_reset;
-                const float o = SKIP ? z + widen<DT>(sb[e]) : z;
+                const float o = SKIP ? z + widen<DT>(sb) : z;
                 c_spk += (z != 0.f); c_out += (o != 0.f);
-                h[e] = hh; ob[e] = narrow<DT>(o);
+                h[e] = hh;
+                if constexpr (VEC == 1) ov = narrow<DT>(o); else ov[e] = narrow<DT>(o);
             }
-            if constexpr (VEC == 8) {
-                u16x8 ov;
+            store_out(reinterpret_cast<uvec_t*>(a.out_seq + base), ov);
+            if (SAVE_H) {
+                if constexpr (VEC % 4 == 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = ob[e];
-                store_out(reinterpret_cast<u16x8*>(a.out_seq + base), ov);
-                if (SAVE_H) {
-                    *reinterpret_cast<f4*>(a.h_seq + base) = (f4){h[0], h[1], h[2], h[3]};
-                    *reinterpret_cast<f4*>(a.h_seq + base + 4) = (f4){h[4], h[5], h[6], h[7]};
+                    for (int q = 0; q < VEC / 4; ++q)
+                        *reinterpret_cast<f4*>(a.h_seq + base + 4 * q) = (f4){h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) a.h_seq[base + e] = h[e];
                 }
-            } else { a.out_seq[base] = ob[0]; if (SAVE_H) a.h_seq[base] = h[0]; }
+            }
+        };
+
+        if constexpr (TS > 0) {
+            uvec_t xs[TS], ss[SKIP ? TS : 1];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                const long long base = ((long long)t * NV + i) * VEC;
+                xs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.x_seq + base));
+                if (SKIP) ss[t] = *reinterpret_cast<const uvec_t*>(a.skip_seq + base);
+            }
+#pragma unroll
+            for (int t = 0; t < TS; ++t) step(xs[t], ss[SKIP ? t : 0], ((long long)t * NV + i) * VEC);
+        } else {
+            for (int t = 0; t < T; ++t) {
+                const long long base = ((long long)t * NV + i) * VEC;
+                uvec_t xv = load_stream(reinterpret_cast<const uvec_t*>(a.x_seq + base)), sv = xv;
+                if (SKIP) sv = *reinterpret_cast<const uvec_t*>(a.skip_seq + base);
+                step(xv, sv, base);
+            }
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) a.v_last[i * VEC + e] = v[e];
     }
-    if (a.nnz) {
-        __shared__ unsigned s_cnt[2][kBlock / 64];
-        unsigned ws = wave_sum_u32(c_spk), wo = wave_sum_u32(c_out);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_cnt[0][wave] = ws; s_cnt[1][wave] = wo; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long ts = 0, to = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) { ts += s_cnt[0][w]; to += s_cnt[1][w]; }
-            if (ts) atomicAdd(&a.nnz[0], ts);
-            if (to) atomicAdd(&a.nnz[1], to);
-        }
-    }
+    if (a.nnz) count_epilogue(c_spk, c_out, a.nnz, a.cnt_ws);
 }
 
 struct Bwd16Args {
@@ -580,14 +666,12 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_kernel(Bwd16Args a)
 #ifndef SS_RC16_V10
 #define SS_RC16_V10 2
 #endif
-template <int VEC> struct U16Vec;
-template <> struct U16Vec<8> { typedef u16x8 type; };
-template <> struct U16Vec<4> { typedef unsigned short type __attribute__((ext_vector_type(4))); };
-template <> struct U16Vec<2> { typedef unsigned short type __attribute__((ext_vector_type(2))); };
-template <> struct U16Vec<1> { typedef unsigned short type; };
 
-template <int KIND, int SG, int DT, int TS, int VEC>
-__global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, const unsigned short* __restrict__ x_seq)
+// G2: a second consumer's 16-bit gradient is added on load (fp32 sum of the two widened values — not rounded to 16 bits in between,
+// unlike autograd's accumulation); g_sum_seq (nullable) receives that sum narrowed once: dL/dskip of a stage that has both.
+template <int KIND, int SG, int DT, int TS, int VEC, bool G2 = false>
+__global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, const unsigned short* __restrict__ x_seq,
+                                                                 const unsigned short* __restrict__ g_out2_seq, unsigned short* __restrict__ g_sum_seq)
 {
     typedef typename U16Vec<VEC>::type uvec_t;
     const long long NV = a.N / VEC;
@@ -604,6 +688,11 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
         for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const uvec_t*>(x_seq + ((long long)t * NV + i) * VEC));
 #pragma unroll
         for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.g_out_seq + ((long long)t * NV + i) * VEC));
+        uvec_t g2[G2 ? TS : 1];
+        if constexpr (G2) {
+#pragma unroll
+            for (int t = TS - 1; t >= 0; --t) g2[t] = load_stream(reinterpret_cast<const uvec_t*>(g_out2_seq + ((long long)t * NV + i) * VEC));
+        }
         float v0[VEC], gv[VEC], h[TS][VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -628,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
         }
 #pragma unroll
         for (int t = TS - 1; t >= 0; --t) {
-            uvec_t xv;
+            uvec_t xv, sumv;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 unsigned short gb;
@@ -637,6 +726,13 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
                 const float xh = he - v_th;
                 const float z = heaviside(xh);
                 float g_s = widen<DT>(gb);
+                if constexpr (G2) {
+                    unsigned short gb2;
+                    if constexpr (VEC == 1) gb2 = g2[t]; else gb2 = g2[t][e];
+                    g_s = g_s + widen<DT>(gb2);
+                    const unsigned short sb = narrow<DT>(g_s);
+                    if constexpr (VEC == 1) sumv = sb; else sumv[e] = sb;
+                }
                 if (!detach) g_s = g_s + (gv[e] * v_reset - gv[e] * he);
                 const float g_h = surrogate_grad<SG>(xh, alpha, c_atan, half_alpha, g_s) + gv[e] * (1.f - z);
                 float g_x;
@@ -655,6 +751,7 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
                 if constexpr (VEC == 1) xv = ob; else xv[e] = ob;
             }
             store_out(reinterpret_cast<uvec_t*>(a.g_x_seq + ((long long)t * NV + i) * VEC), xv);
+            if constexpr (G2) { if (g_sum_seq) *reinterpret_cast<uvec_t*>(g_sum_seq + ((long long)t * NV + i) * VEC) = sumv; }
         }
         if (a.g_v_init) {
 #pragma unroll
@@ -1131,6 +1228,61 @@ __global__ __launch_bounds__(kBlock) void split3_bf16_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2-bit packed spike tensors: readers for the consumers of a packed neuron output
+// ---------------------------------------------------------------------------------------------------
+// code (0..3) -> bf16 bit pattern of the same small integer: 0x0000, 0x3F80, 0x4000, 0x4040
+#define SS_CODE_LUT 0x404040003F800000ull
+__device__ __forceinline__ unsigned short code_to_bf16(unsigned c) { return (unsigned short)((SS_CODE_LUT >> (16 * c)) & 0xFFFFu); }
+
+// packed [n_words] -> dense values.  OUT: 0 = fp32, SS_DT_F16, SS_DT_BF16.  A lane expands one byte (4 neurons); `copies` > 1 writes the
+// same 4 values `copies` times with stride `copy_stride` elements: the [X X X] operand of the K-concatenated exact bf16x3 GEMM, where
+// a row of C values is followed by its two repetitions (row length C, copies = 3, copy_stride = C, rows become 3*C long).
+template <int OUT>
+__global__ __launch_bounds__(kBlock) void unpack_spikes_kernel(const unsigned* __restrict__ packed, void* __restrict__ out, long long n4,
+                                                               int C, int copies)
+{
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+        const unsigned b = (packed[i >> 2] >> (8 * (int)(i & 3))) & 0xFFu;
+        const unsigned c0 = b & 3u, c1 = (b >> 2) & 3u, c2 = (b >> 4) & 3u, c3 = b >> 6;
+        long long e = i * 4;
+        if (copies > 1) { const long long row = e / C; e = row * (long long)C * copies + (e - row * C); }
+        for (int q = 0; q < copies; ++q, e += C) {
+            if constexpr (OUT == 0) {
+                *reinterpret_cast<f4*>(static_cast<float*>(out) + e) = (f4){(float)c0, (float)c1, (float)c2, (float)c3};
+            } else {
+                u16x4 o;
+                if constexpr (OUT == SS_DT_BF16) { o[0] = code_to_bf16(c0); o[1] = code_to_bf16(c1); o[2] = code_to_bf16(c2); o[3] = code_to_bf16(c3); }
+                else { o[0] = narrow<SS_DT_F16>((float)c0); o[1] = narrow<SS_DT_F16>((float)c1); o[2] = narrow<SS_DT_F16>((float)c2); o[3] = narrow<SS_DT_F16>((float)c3); }
+                *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(out) + e) = o;
+            }
+        }
+    }
+}
+
+// im2col_cl_bf16_kernel reading its NHWC input from a packed spike tensor: 8 channels = 16 bits of one word (C % 8 == 0)
+__global__ __launch_bounds__(kBlock) void im2col_cl_bf16_packed_kernel(const unsigned* __restrict__ xp, unsigned short* __restrict__ A,
+                                                                       int h, int w, int C, int k, int stride, int pad, int ho, int wo)
+{
+    const unsigned row = blockIdx.x;
+    const unsigned C8 = (unsigned)C / 8;
+    const unsigned r = blockIdx.y * kBlock + threadIdx.x;
+    if (r >= (unsigned)(k * k) * C8) return;
+    const unsigned ox = row % (unsigned)wo, t = row / (unsigned)wo;
+    const unsigned oy = t % (unsigned)ho, nb = t / (unsigned)ho;
+    const unsigned tap = r / C8, c8 = r - tap * C8;
+    const unsigned ky = tap / (unsigned)k, kx = tap - ky * (unsigned)k;
+    const int iy = (int)(oy * stride + ky) - pad, ix = (int)(ox * stride + kx) - pad;
+    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+        const long long e = (((long long)nb * h + iy) * w + ix) * C + c8 * 8;
+        const unsigned bits = (xp[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = code_to_bf16((bits >> (2 * q)) & 3u);
+    }
+    *reinterpret_cast<u16x8*>(A + ((long long)row * (k * k) + tap) * C + c8 * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // voxeliser: events -> two-polarity count frames (datasets/MVSEC/utils.py:215-281)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void voxelize_kernel(const double* __restrict__ ev, long long E, const double* __restrict__ start,
@@ -1290,6 +1442,13 @@ inline int grid_for(long long work_items, int cap = kMaxGrid)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+inline int finish_counts(unsigned long long* nnz, unsigned* cnt_ws, int grid, hipStream_t s)
+{
+    if (!nnz || !cnt_ws) return SS_OK;
+    hipLaunchKernelGGL(cnt_finish_kernel, dim3(1), dim3(kBlock), 0, s, cnt_ws, grid, nnz);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
 template <int KIND, int TS, bool SKIP, bool SAVE_H>
 int launch_fwd(const FwdArgs& a, hipStream_t s)
 {
@@ -1297,17 +1456,39 @@ int launch_fwd(const FwdArgs& a, hipStream_t s)
                      (!a.v_init || aligned16(a.v_init)) && (!SKIP || aligned16(a.skip_seq)) &&
                      (!SAVE_H || aligned16(a.h_seq));
     if (a.N == 0) return SS_OK;
-    // with firing-rate counters on, keep the number of workgroups (= same-address 64-bit atomics) small: measured 3.3 vs 5.6 TB/s
-    const int cap = a.nnz ? kMaxGridGk : kMaxGrid;
-    if (vec) hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, SAVE_H, 4>), dim3(grid_for(a.N / 4, cap)), dim3(kBlock), 0, s, a);
-    else     hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, SAVE_H, 1>), dim3(grid_for(a.N, cap)), dim3(kBlock), 0, s, a);
-    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+    // firing-rate counters: with a partials workspace (ss_neuron_fwd_ex) the launch keeps its full grid; without one every workgroup
+    // issues same-address 64-bit atomics, so their number is bounded (measured 3.3 vs 5.6 TB/s at 45 000 workgroups)
+    const int cap = (a.nnz && !a.cnt_ws) ? kMaxGridGk : kMaxGrid;
+    const int grid = vec ? grid_for(a.N / 4, cap) : grid_for(a.N, cap);
+    if (vec) hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, SAVE_H, 4>), dim3(grid), dim3(kBlock), 0, s, a);
+    else     hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, SAVE_H, 1>), dim3(grid), dim3(kBlock), 0, s, a);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    return finish_counts(a.nnz, a.cnt_ws, grid, s);
+}
+
+// packed spike output / packed skip input (ss_neuron_fwd_ex): 16-B lanes, compile-time T, no saved h
+template <int KIND, int TS, bool SKIP>
+int launch_fwd_pk(const FwdArgs& a, hipStream_t s)
+{
+    if constexpr (TS == 0) return SS_EINVAL;
+    else {
+        if (a.N == 0) return SS_OK;
+        const bool ok = (a.N % 16 == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
+                        (!a.v_init || aligned16(a.v_init)) && (!a.skip_seq || aligned16(a.skip_seq)) && !a.h_seq;
+        if (!ok) return SS_EINVAL;
+        const int cap = (a.nnz && !a.cnt_ws) ? kMaxGridGk : kMaxGrid;
+        const int grid = grid_for(a.N / 4, cap);
+        hipLaunchKernelGGL((neuron_fwd_kernel<KIND, TS, SKIP, false, 4, true>), dim3(grid), dim3(kBlock), 0, s, a);
+        if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+        return finish_counts(a.nnz, a.cnt_ws, grid, s);
+    }
 }
 
 template <int KIND, int TS>
 int dispatch_fwd_flags(const FwdArgs& a, hipStream_t s)
 {
-    const bool skip = a.skip_seq != nullptr, save_h = a.h_seq != nullptr;
+    const bool skip = a.skip_seq != nullptr || a.skip_packed != nullptr, save_h = a.h_seq != nullptr;
+    if (a.out_packed || a.skip_packed) return skip ? launch_fwd_pk<KIND, TS, true>(a, s) : launch_fwd_pk<KIND, TS, false>(a, s);
     if (skip) return save_h ? launch_fwd<KIND, TS, true, true>(a, s) : launch_fwd<KIND, TS, true, false>(a, s);
     return save_h ? launch_fwd<KIND, TS, false, true>(a, s) : launch_fwd<KIND, TS, false, false>(a, s);
 }
@@ -1404,20 +1585,43 @@ int launch_cl_bwd(const void* g_out, const int* y_lo, const int* y_hi, const int
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
-template <int KIND, int DT>
-int dispatch_fwd16(const Fwd16Args& a, hipStream_t s)
+#ifndef SS_F16_V5
+#define SS_F16_V5 8
+#endif
+#ifndef SS_F16_V10
+#define SS_F16_V10 4
+#endif
+template <int KIND, int DT, int TS>
+int launch_fwd16(const Fwd16Args& a, hipStream_t s)
 {
+    // lane width: 8 neurons (one 16-B load per step) while all T loads fit comfortably in registers, 4 for the longer sequences
+    constexpr int V = (TS == 0 || TS <= 5) ? SS_F16_V5 : SS_F16_V10;
     const bool skip = a.skip_seq != nullptr, save_h = a.h_seq != nullptr;
-    const bool vec = (a.N % 8 == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
+    const bool vec = (a.N % V == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
                      (!a.v_init || aligned16(a.v_init)) && (!skip || aligned16(a.skip_seq)) && (!save_h || aligned16(a.h_seq));
-    const int cap = a.nnz ? kMaxGridGk : kMaxGrid;
-    const int grid = vec ? grid_for(a.N / 8, cap) : grid_for(a.N, cap);
-#define SS_L16(SK, SH) do { if (vec) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, SK, SH, 8>), dim3(grid), dim3(kBlock), 0, s, a); \
-                            else hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, SK, SH, 1>), dim3(grid), dim3(kBlock), 0, s, a); } while (0)
+    const int cap = (a.nnz && !a.cnt_ws) ? kMaxGridGk : kMaxGrid;
+    const int grid = vec ? grid_for(a.N / V, cap) : grid_for(a.N, cap);
+#define SS_L16(SK, SH) do { if (vec) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, SK, SH, V>), dim3(grid), dim3(kBlock), 0, s, a); \
+                            else hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, SK, SH, 1>), dim3(grid), dim3(kBlock), 0, s, a); } while (0)
     if (skip) { if (save_h) SS_L16(true, true); else SS_L16(true, false); }
     else      { if (save_h) SS_L16(false, true); else SS_L16(false, false); }
 #undef SS_L16
-    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    return finish_counts(a.nnz, a.cnt_ws, grid, s);
+}
+
+template <int KIND, int DT>
+int dispatch_fwd16(const Fwd16Args& a, hipStream_t s)
+{
+    switch (a.T) {
+        case 1: return launch_fwd16<KIND, DT, 1>(a, s);
+        case 2: return launch_fwd16<KIND, DT, 2>(a, s);
+        case 4: return launch_fwd16<KIND, DT, 4>(a, s);
+        case 5: return launch_fwd16<KIND, DT, 5>(a, s);
+        case 8: return launch_fwd16<KIND, DT, 8>(a, s);
+        case 10: return launch_fwd16<KIND, DT, 10>(a, s);
+        default: return launch_fwd16<KIND, DT, 0>(a, s);
+    }
 }
 
 template <int KIND, int SG, int DT>
@@ -1435,30 +1639,35 @@ int dispatch_bwd16(const Bwd16Args& a, hipStream_t s, int* grid_out)
 }
 
 template <int KIND, int SG, int DT, int TS>
-int launch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, hipStream_t s, int* grid_out)
+int launch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsigned short* g2, unsigned short* g_sum, hipStream_t s, int* grid_out)
 {
     constexpr int V = (TS <= 5) ? SS_RC16_V5 : SS_RC16_V10;    // measured on the MI355X: tools/bench_rc16.py
-    const bool vec = (a.N % V == 0) && aligned16(a.g_out_seq) && aligned16(x_seq) && aligned16(a.g_x_seq) &&
+    const bool vec = (a.N % V == 0) && aligned16(a.g_out_seq) && aligned16(x_seq) && aligned16(a.g_x_seq) && aligned16(g2) && aligned16(g_sum) &&
                      (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                      (!a.v_init || aligned16(a.v_init));
     int grid = vec ? grid_for(a.N / V, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
     if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
     *grid_out = grid;
-    if (vec) hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, V>), dim3(grid), dim3(kBlock), 0, s, a, x_seq);
-    else     hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, 1>), dim3(grid), dim3(kBlock), 0, s, a, x_seq);
+    if (g2) {
+        if (vec) hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, V, true>), dim3(grid), dim3(kBlock), 0, s, a, x_seq, g2, g_sum);
+        else     hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, 1, true>), dim3(grid), dim3(kBlock), 0, s, a, x_seq, g2, g_sum);
+    } else {
+        if (vec) hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, V>), dim3(grid), dim3(kBlock), 0, s, a, x_seq, g2, g_sum);
+        else     hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, 1>), dim3(grid), dim3(kBlock), 0, s, a, x_seq, g2, g_sum);
+    }
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
 template <int KIND, int SG, int DT>
-int dispatch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, hipStream_t s, int* grid_out)
+int dispatch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsigned short* g2, unsigned short* g_sum, hipStream_t s, int* grid_out)
 {
     switch (a.T) {
-        case 1: return launch_bwd16_rc<KIND, SG, DT, 1>(a, x_seq, s, grid_out);
-        case 2: return launch_bwd16_rc<KIND, SG, DT, 2>(a, x_seq, s, grid_out);
-        case 4: return launch_bwd16_rc<KIND, SG, DT, 4>(a, x_seq, s, grid_out);
-        case 5: return launch_bwd16_rc<KIND, SG, DT, 5>(a, x_seq, s, grid_out);
-        case 8: return launch_bwd16_rc<KIND, SG, DT, 8>(a, x_seq, s, grid_out);
-        case 10: return launch_bwd16_rc<KIND, SG, DT, 10>(a, x_seq, s, grid_out);
+        case 1: return launch_bwd16_rc<KIND, SG, DT, 1>(a, x_seq, g2, g_sum, s, grid_out);
+        case 2: return launch_bwd16_rc<KIND, SG, DT, 2>(a, x_seq, g2, g_sum, s, grid_out);
+        case 4: return launch_bwd16_rc<KIND, SG, DT, 4>(a, x_seq, g2, g_sum, s, grid_out);
+        case 5: return launch_bwd16_rc<KIND, SG, DT, 5>(a, x_seq, g2, g_sum, s, grid_out);
+        case 8: return launch_bwd16_rc<KIND, SG, DT, 8>(a, x_seq, g2, g_sum, s, grid_out);
+        case 10: return launch_bwd16_rc<KIND, SG, DT, 10>(a, x_seq, g2, g_sum, s, grid_out);
         default: return SS_EINVAL;
     }
 }
@@ -1483,7 +1692,7 @@ int ss_neuron_fwd_f32(const float* x_seq, const float* v_init, const float* skip
     if (kind < SS_KIND_IF || kind > SS_KIND_PLIF) return SS_EINVAL;
     if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
     if (out_seq == x_seq) return SS_EINVAL;
-    FwdArgs a{x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k};
+    FwdArgs a{x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (kind) {
         case SS_KIND_IF: return dispatch_fwd_T<SS_KIND_IF>(a, s);
@@ -1575,7 +1784,7 @@ int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_s
     if (out_seq == x_seq) return SS_EINVAL;
     if (N == 0) return SS_OK;
     Fwd16Args a{static_cast<const unsigned short*>(x_seq), v_init, static_cast<const unsigned short*>(skip_seq),
-                static_cast<unsigned short*>(out_seq), h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k};
+                static_cast<unsigned short*>(out_seq), h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define SS_D16(KK) (dtype == SS_DT_F16 ? dispatch_fwd16<KK, SS_DT_F16>(a, s) : dispatch_fwd16<KK, SS_DT_BF16>(a, s))
     switch (kind) {
@@ -1586,7 +1795,7 @@ int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_s
 #undef SS_D16
 }
 
-static int neuron_bwd_x16_impl(const void* g_out_seq, const float* g_v_last, const float* h_seq, const void* x_seq, const float* v_init,
+static int neuron_bwd_x16_impl(const void* g_out_seq, const void* g_out2_seq, void* g_sum_seq, const float* g_v_last, const float* h_seq, const void* x_seq, const float* v_init,
                                void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
                                int T, long long N, float scale, int kind, float tau, const float* k,
                                float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
@@ -1607,7 +1816,9 @@ static int neuron_bwd_x16_impl(const void* g_out_seq, const float* g_v_last, con
                 g_v_init, want_gk ? g_k_ws : nullptr, T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset};
     const unsigned short* xq = static_cast<const unsigned short*>(x_seq);
     int grid = 0, rc;
-#define SS_B16D(KK, SGG, DTT) (xq ? dispatch_bwd16_rc<KK, SGG, DTT>(a, xq, s, &grid) : dispatch_bwd16<KK, SGG, DTT>(a, s, &grid))
+    const unsigned short* g2q = static_cast<const unsigned short*>(g_out2_seq);
+    unsigned short* gsq = g2q ? static_cast<unsigned short*>(g_sum_seq) : nullptr;
+#define SS_B16D(KK, SGG, DTT) (xq ? dispatch_bwd16_rc<KK, SGG, DTT>(a, xq, g2q, gsq, s, &grid) : dispatch_bwd16<KK, SGG, DTT>(a, s, &grid))
 #define SS_B16(KK, SGG) (dtype == SS_DT_F16 ? SS_B16D(KK, SGG, SS_DT_F16) : SS_B16D(KK, SGG, SS_DT_BF16))
 #define SS_B16S(KK) (surrogate == SS_SG_ATAN ? SS_B16(KK, SS_SG_ATAN) : SS_B16(KK, SS_SG_SIGMOID))
     switch (kind) {
@@ -1632,7 +1843,7 @@ int ss_neuron_bwd_x16(const void* g_out_seq, const float* g_v_last, const float*
                       float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
 {
     if (!h_seq) return SS_EINVAL;
-    return neuron_bwd_x16_impl(g_out_seq, g_v_last, h_seq, nullptr, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+    return neuron_bwd_x16_impl(g_out_seq, nullptr, nullptr, g_v_last, h_seq, nullptr, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
                                v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream);
 }
 
@@ -1642,8 +1853,85 @@ int ss_neuron_bwd_rc_x16(const void* g_out_seq, const float* g_v_last, const voi
                          float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
 {
     if (!x_seq || !ss_neuron_bwd_rc_supported(T)) return SS_EINVAL;
-    return neuron_bwd_x16_impl(g_out_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+    return neuron_bwd_x16_impl(g_out_seq, nullptr, nullptr, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
                                v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream);
+}
+
+int ss_neuron_bwd_fork_x16(const void* g_out_seq, const void* g_out2_seq, void* g_sum_seq, const float* g_v_last, const void* x_seq,
+                           const float* v_init, void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
+                           int T, long long N, float scale, int kind, float tau, const float* k,
+                           float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+{
+    if (!x_seq || !g_out2_seq || !ss_neuron_bwd_rc_supported(T)) return SS_EINVAL;
+    if (g_out2_seq == g_x_seq || (g_sum_seq && g_sum_seq == g_x_seq)) return SS_EINVAL;
+    return neuron_bwd_x16_impl(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind,
+                               tau, k, v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream);
+}
+
+long long ss_neuron_cnt_ws_words(long long N)
+{
+    if (N < 0) return 0;
+    return 2 * ((N + kBlock - 1) / kBlock) + 2;          // covers the scalar launch (one neuron per lane); the 16-B form uses a quarter
+}
+
+int ss_neuron_fwd_ex(const ss_neuron_fwd_desc* d, void* stream)
+{
+    if (!d || d->size != sizeof(ss_neuron_fwd_desc)) return SS_EINVAL;
+    if (!d->x_seq || !d->v_last || d->T <= 0 || d->N < 0 || (!d->out_seq && !d->out_packed)) return SS_EINVAL;
+    if (d->kind < SS_KIND_IF || d->kind > SS_KIND_PLIF || (d->kind == SS_KIND_PLIF && !d->k)) return SS_EINVAL;
+    if (d->out_seq == d->x_seq || (d->skip_seq && d->skip_packed)) return SS_EINVAL;
+    if (d->cnt_ws && !d->nnz) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d->act_dtype == 0) {
+        if ((d->out_packed || d->skip_packed) && (d->h_seq || d->N % 16 != 0 || !ss_neuron_bwd_rc_supported(d->T))) return SS_EINVAL;
+        FwdArgs a{static_cast<const float*>(d->x_seq), d->v_init, static_cast<const float*>(d->skip_seq), static_cast<float*>(d->out_seq),
+                  d->h_seq, d->v_last, d->nnz, d->T, d->N, d->scale, d->tau, d->v_th, d->v_reset, d->k, d->skip_packed, d->out_packed, d->cnt_ws};
+        switch (d->kind) {
+            case SS_KIND_IF: return dispatch_fwd_T<SS_KIND_IF>(a, s);
+            case SS_KIND_LIF: return dispatch_fwd_T<SS_KIND_LIF>(a, s);
+            default: return dispatch_fwd_T<SS_KIND_PLIF>(a, s);
+        }
+    }
+    if (d->act_dtype != SS_DT_F16 && d->act_dtype != SS_DT_BF16) return SS_EINVAL;
+    if (d->out_packed || d->skip_packed || !d->out_seq) return SS_EINVAL;          // packed I/O: fp32 activations only
+    if (d->N == 0) return SS_OK;
+    Fwd16Args a{static_cast<const unsigned short*>(d->x_seq), d->v_init, static_cast<const unsigned short*>(d->skip_seq),
+                static_cast<unsigned short*>(d->out_seq), d->h_seq, d->v_last, d->nnz, d->T, d->N, d->scale, d->tau, d->v_th, d->v_reset, d->k, d->cnt_ws};
+#define SS_D16(KK) (d->act_dtype == SS_DT_F16 ? dispatch_fwd16<KK, SS_DT_F16>(a, s) : dispatch_fwd16<KK, SS_DT_BF16>(a, s))
+    switch (d->kind) {
+        case SS_KIND_IF: return SS_D16(SS_KIND_IF);
+        case SS_KIND_LIF: return SS_D16(SS_KIND_LIF);
+        default: return SS_D16(SS_KIND_PLIF);
+    }
+#undef SS_D16
+}
+
+int ss_unpack_spikes(const unsigned int* packed, void* out, long long n, int out_dtype, int row_len, int copies, void* stream)
+{
+    if (!packed || !out || n < 0 || n % 16 != 0 || copies < 1 || !aligned16(out)) return SS_EINVAL;
+    if (out_dtype != 0 && out_dtype != SS_DT_F16 && out_dtype != SS_DT_BF16) return SS_EINVAL;
+    if (copies > 1 && (row_len <= 0 || row_len % 8 != 0 || n % row_len != 0)) return SS_EINVAL;
+    if (n == 0) return SS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n4 = n / 4;
+    const int grid = grid_for(n4, kMaxGridBwd), C = copies > 1 ? row_len : 4;
+    if (out_dtype == 0) hipLaunchKernelGGL(unpack_spikes_kernel<0>, dim3(grid), dim3(kBlock), 0, s, packed, out, n4, C, copies);
+    else if (out_dtype == SS_DT_F16) hipLaunchKernelGGL(unpack_spikes_kernel<SS_DT_F16>, dim3(grid), dim3(kBlock), 0, s, packed, out, n4, C, copies);
+    else hipLaunchKernelGGL(unpack_spikes_kernel<SS_DT_BF16>, dim3(grid), dim3(kBlock), 0, s, packed, out, n4, C, copies);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, void* stream)
+{
+    if (!x_packed || !A || NB <= 0 || h <= 0 || w <= 0 || C <= 0 || C % 8 != 0 || k <= 0 || stride <= 0 || pad < 0 || ho <= 0 || wo <= 0) return SS_EINVAL;
+    if ((ho - 1) * stride - pad + k - 1 >= h + pad || (wo - 1) * stride - pad + k - 1 >= w + pad) return SS_EINVAL;
+    if (!aligned16(A) || (NB * h * w * C) % 16 != 0) return SS_EINVAL;
+    const long long rows = NB * ho * wo;
+    const long long per_row = (long long)k * k * (C / 8);
+    if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
+    hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), x_packed, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
 int ss_ipool_fwd_f32(const float* pd_seq, long long stride_t, long long stride_k, const float* v_init,

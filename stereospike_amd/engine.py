@@ -29,9 +29,19 @@ class _null:
 class Trainer:
     """reset -> T-step forward -> Total_Loss -> backward (gradient all-reduce overlapped when DP) -> Adam -> detach."""
 
-    def __init__(self, net, lr=2e-4, weight_decay=0.0, reducer=None, loss_module=None):
+    def __init__(self, net, lr=2e-4, weight_decay=0.0, reducer=None, loss_module=None, amp_dtype=None, count_rates=False):
+        """amp_dtype: None (fp32, the reference) | torch.bfloat16 | torch.float16 — 16-bit activations under torch.autocast with fp32
+        membranes (BASELINE.json configs 2 / 5).  With float16 the activation GRADIENTS are fp16 as well: d loss / d pred is ~1e-6
+        (Total_Loss normalises by ~1e6 valid pixels), below fp16's smallest normal 6.1e-5, so the loss is scaled by a dynamic
+        torch.amp.GradScaler and the fp32 weight gradients are unscaled inside the fused Adam step (no host synchronisation).
+        count_rates: firing rates of the 14 layers from the fused kernels' counters inside this very forward (config 5); the latest
+        dict (device scalars) is `self.last_rates`."""
         self.net = net
         on_gpu = next(net.parameters()).is_cuda
+        self.amp_dtype = amp_dtype
+        self.scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 16) if (amp_dtype == torch.float16 and on_gpu) else None
+        self.count_rates = count_rates
+        self.last_rates = None
         # one fused multi-tensor launch for the 21-34 parameter tensors instead of ~10 kernels per tensor
         self.opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=weight_decay, fused=on_gpu)
         self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=[8, 42, 60], gamma=0.5)  # train.py:127
@@ -41,14 +51,21 @@ class Trainer:
     def step(self, x, label):
         net = self.net
         functional.reset_net(net)                              # train.py:221
-        out = net.forward_sequence(x)
-        pred, spks = out if isinstance(out, tuple) else (out, None)
-        loss = self.loss_module(pred, label, spks)             # train.py:238
+        rates = {} if self.count_rates else None
+        with (torch.autocast('cuda', dtype=self.amp_dtype) if self.amp_dtype is not None else _null()):
+            out = net.forward_sequence(x, rates) if rates is not None else net.forward_sequence(x)
+            pred, spks = out if isinstance(out, tuple) else (out, None)
+            loss = self.loss_module(pred, label, spks)         # train.py:238
+        self.last_rates = rates
         with torch.autocast('cuda', enabled=False) if loss.is_cuda else _null():
-            loss.backward()
+            (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
+        if self.scaler is not None:
+            self.scaler.step(self.opt)                         # fused Adam takes grad_scale / found_inf tensors: unscale + skip-on-inf on device
+            self.scaler.update()
+        else:
+            self.opt.step()
         if self.reducer is not None:
             self.reducer.zero_grad()
         else:
@@ -120,6 +137,7 @@ class GraphedTrainer:
         self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=[8, 42, 60], gamma=0.5)
         self.loss_module = loss_module or Total_Loss(alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=False)
         self.amp = dict(device_type='cuda', dtype=amp_dtype or torch.float32, enabled=amp_dtype is not None)
+        self.scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 16) if amp_dtype == torch.float16 else None   # see Trainer
         self.warmup = warmup
         self.graph = None
 
@@ -130,20 +148,38 @@ class GraphedTrainer:
             out = net.forward_sequence(self.static_x)
             pred, spks = out if isinstance(out, tuple) else (out, None)
             loss = self.loss_module(pred, self.static_gt, spks)
-        loss.backward()
-        self.opt.step()
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            loss.backward()
+            self.opt.step()
         return loss.detach(), pred[0].detach()
 
     def _capture(self, x, label):
         self.static_x, self.static_gt = x.clone(), label.clone()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(side):          # eager warm-up iterations (they train: MIOpen find, GEMM record, Adam state allocation)
+        # the eager warm-up iterations (MIOpen find, GEMM record, allocator pools, Adam state allocation) must not TRAIN: parameters and
+        # BatchNorm buffers are restored and the optimiser state they created is zeroed in place afterwards, so the first replay is
+        # training step 1 exactly like the eager Trainer's first step
+        snap = [t.detach().clone() for t in list(self.net.parameters()) + list(self.net.buffers())]
+        with torch.cuda.stream(side):
             for _ in range(self.warmup):
                 self.opt.zero_grad(set_to_none=True)
                 self._iteration()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
+        with torch.no_grad():
+            for t, s0 in zip(list(self.net.parameters()) + list(self.net.buffers()), snap):
+                t.copy_(s0)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        if self.scaler is not None:
+            self.scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 16)
         self.opt.zero_grad(set_to_none=True)    # gradients are (re)created inside the capture: every replay overwrites them
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

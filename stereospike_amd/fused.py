@@ -98,8 +98,14 @@ class _FusedNeuron(torch.autograd.Function):
         if v_init is not None and v_init.dtype != torch.float32:
             v_init = v_init.float()
         e0 = TIMER.start()
-        (_lib.neuron_fwd_x16 if half else _lib.neuron_fwd)(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N,
-                                                          cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
+        if nnz is not None:
+            # firing-rate counters: per-workgroup partials + one fixed second pass (full grid, no same-address atomics)
+            cnt_ws = torch.empty(_lib.cnt_ws_words(N), dtype=torch.int32, device=x_seq.device)
+            _lib.neuron_fwd_ex(x_seq, v_init, skip_seq, None, out_seq, None, h_seq, v_last, nnz, cnt_ws, T, N,
+                               cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
+        else:
+            (_lib.neuron_fwd_x16 if half else _lib.neuron_fwd)(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N,
+                                                              cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
         es = 2 if half else 4
         per = es * (2 + (1 if skip_seq is not None else 0)) + (4 if h_seq is not None else 0)
         TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if skip_seq is not None else ''),
@@ -135,7 +141,7 @@ class _FusedNeuron(torch.autograd.Function):
         if g_out_seq is None:
             g_out_seq = torch.zeros(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
         g_out_seq = g_out_seq.to(ctx.io_dtype).contiguous()
-        fuse2 = g_out2_seq is not None and ctx.recompute and not half
+        fuse2 = g_out2_seq is not None and ctx.recompute
         if g_out2_seq is not None:
             g_out2_seq = g_out2_seq.to(ctx.io_dtype).contiguous()
             if not fuse2:
@@ -153,7 +159,10 @@ class _FusedNeuron(torch.autograd.Function):
         e0 = TIMER.start()
         want_gskip = ctx.has_skip and ctx.needs_input_grad[2]
         g_sum = torch.empty_like(g_out_seq) if (fuse2 and want_gskip) else None
-        if fuse2:
+        if fuse2 and half:
+            _lib.neuron_bwd_fork_x16(g_out_seq, g_out2_seq, g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+                                     T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
+        elif fuse2:
             _lib.neuron_bwd_fork(g_out_seq, g_out2_seq, g_sum, g_v_last, None, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                                  T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
         else:
@@ -163,7 +172,7 @@ class _FusedNeuron(torch.autograd.Function):
                 bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
             bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                 T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, ('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd', ((6 if ctx.recompute else 8) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
+        TIMER.stop(e0, ('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd', (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
         g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
         return g_x_seq, g_v_init, g_skip, g_k, None, None, None
 

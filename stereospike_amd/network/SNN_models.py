@@ -149,6 +149,9 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 enc.append(getattr(self, f'conv{i}').forward_sequence(enc[-1], None, nnz(f'conv{i}')))
             cur = self.bottleneck[0].forward_sequence(enc[4])
             cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
+            if count and getattr(self.bottleneck[1], 'connect_function', 'ADD') != 'ADD':
+                # the in-kernel counter saw sn2's output BEFORE the (unfused) connect function; the reference counts out_rconv itself
+                cnt['rconv'] = torch.stack((cnt['rconv'][0], torch.count_nonzero(cur)))
             spikes, heads = [cur], []
             if cl:
                 cur = cur.permute(0, 1, 3, 4, 2).contiguous()          # decoder runs on NHWC arrays [T, B, h, w, C]
@@ -180,9 +183,14 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         pool.v = depth_seq[T - 1, 3]
         return depth_seq, [s[T - 1] for s in spikes], cnt, (T, B)
 
-    def forward_sequence(self, x: torch.Tensor):
-        """x [B, T, C, H, W]: all T frames in one pass, membranes carried from their current state."""
-        depth_seq, spikes, _, (T, _) = self._run(x.transpose(0, 1).contiguous())
+    def forward_sequence(self, x: torch.Tensor, rates: dict = None):
+        """x [B, T, C, H, W]: all T frames in one pass, membranes carried from their current state.
+        rates: optional dict, filled with the 15 firing-rate entries of `calculate_firing_rates` over ALL T steps of this pass (0-dim
+        device tensors, no host synchronisation) from the counters the fused neuron kernels accumulate anyway-loaded data with
+        (wavefront reductions; BASELINE.json config 5) — the training step's own forward, not a second one."""
+        depth_seq, spikes, cnt, (T, _) = self._run(x.transpose(0, 1).contiguous(), count=rates is not None)
+        if rates is not None:
+            rates.update(self._rates(cnt, T))
         depths = [depth_seq[T - 1, k] for k in (3, 2, 1, 0)]          # [depth1, depth2, depth3, depth4]
         return (depths, spikes) if self._returns_spikes else depths
 
@@ -194,6 +202,9 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         """Density count_nonzero / numel of the 14 named tensors, from the counters the fused kernels accumulate
         (wavefront reductions + integer atomics) instead of a second pass over every tensor."""
         _, _, cnt, (T, B) = self._run(x[:, 0:1].transpose(0, 1).contiguous(), count=True)
+        return self._rates(cnt, T)
+
+    def _rates(self, cnt, T):
         rates = {k: 0. for k in _RATE_KEYS}
 
         def numel(stage_name):

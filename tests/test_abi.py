@@ -23,7 +23,10 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32',
                                   'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16',
                                   'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32',
-                                  'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp'])
+                                  'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
+                                  # ABI 2
+                                  'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes',
+                                  'ss_im2col_cl_bf16_packed'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -34,7 +37,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == 1
+    assert L.ss_abi_version() == 2
+    assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
     exported = {l.split()[-1] for l in out.splitlines() if ' T ' in l}
@@ -53,6 +57,12 @@ def test_argument_validation_without_a_gpu():
                                None) == -22
     assert L.ss_ipool_fwd_f32(None, 0, 0, None, None, 1, 4, 4, 1.0, 0.0, None) == -22
     assert L.ss_ipool_bwd_f32(None, None, None, 0, 0, None, 1, 4, 4, 1.0, None) == -22
+    d = _lib.FwdDesc()
+    assert L.ss_neuron_fwd_ex(None, None) == -22 and L.ss_neuron_fwd_ex(ctypes.byref(d), None) == -22      # NULL / size field not set
+    d.size = ctypes.sizeof(_lib.FwdDesc)
+    assert L.ss_neuron_fwd_ex(ctypes.byref(d), None) == -22                                                # no buffers
+    assert L.ss_unpack_spikes(None, None, 16, 0, 0, 1, None) == -22
+    assert L.ss_im2col_cl_bf16_packed(None, None, 1, 4, 4, 8, 3, 1, 1, 4, 4, None) == -22
 
 
 def test_product_fails_loudly_on_cpu_tensors():

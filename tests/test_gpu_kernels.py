@@ -693,3 +693,157 @@ def test_c_caller_runs_against_the_library():
         r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 0, (r.stdout, r.stderr)
         assert 'spikes out of 20480 updates' in r.stdout and ' 0 spikes' not in r.stdout, r.stdout
+
+
+# ======================================================================================================
+# ABI 2: descriptor forward (2-bit packed spikes, counter partials), forked x16 backward, packed readers
+# ======================================================================================================
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+@pytest.mark.parametrize('T,N', [(1, 16), (5, 4096 + 16), (10, 16 * 1001), (5, 32 * 65 * 87 * 4), (4, 48)])
+def test_packed_spike_io_vs_oracle(kind, T, N):
+    """ss_neuron_fwd_ex: packed output == pack(oracle output) bit for bit (with and without the dense output, with a dense and a packed
+    skip operand), v_last and the counters unchanged; unpack(packed) == the dense tensor (oracle/np_pack.py)."""
+    from oracle import np_pack
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(T * 31 + N)
+    x = (rng.standard_normal((T, N)) * 0.2).astype(np.float32)
+    skip = rng.integers(0, 3, (T, N)).astype(np.float32)
+    v0 = (rng.standard_normal(N) * 0.5).astype(np.float32) if N % 32 == 0 else None
+    kw = dict(kind=kind, scale=10.0, tau=3.0, k=np.float32(1 / 3.) if kind == 'PLIF' else None, v_th=1.0, v_reset=0.0)
+    kd = None if kind != 'PLIF' else torch.tensor([1 / 3.], device=DEV)
+    xd, vd = _dev(x), _dev(v0)
+    for use_skip in (False, True):
+        ref = c_oracle.neuron_fwd(x, v_init=v0, skip_seq=skip if use_skip else None, **kw)
+        want = np_pack.pack(ref['out']).view(np.int32)
+        sk_dense = _dev(skip) if use_skip else None
+        sk_packed = torch.from_numpy(np_pack.pack(skip).view(np.int32)).to(DEV) if use_skip else None
+        for skip_form in (('dense', 'packed') if use_skip else ('none',)):
+            for with_dense in (True, False):
+                out = torch.empty(T, N, device=DEV) if with_dense else None
+                pk = torch.zeros(T, N // 16, dtype=torch.int32, device=DEV)
+                v = torch.empty(N, device=DEV)
+                nnz = torch.zeros(2, dtype=torch.int64, device=DEV)
+                ws = torch.empty(_lib.cnt_ws_words(N), dtype=torch.int32, device=DEV)
+                _lib.neuron_fwd_ex(xd, vd, sk_dense if skip_form == 'dense' else None, sk_packed if skip_form == 'packed' else None,
+                                   out, pk, None, v, nnz, ws, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0)
+                assert np.array_equal(pk.cpu().numpy(), want), (use_skip, skip_form, with_dense)
+                assert bit_equal(v, ref['v_last'])
+                assert int(nnz[1]) == int((ref['out'] != 0).sum()) and int(nnz[0]) == int(((ref['h'] - 1.0) >= 0).sum())
+                if with_dense:
+                    assert np.array_equal(out.cpu().numpy(), ref['out'])
+                for dt in (torch.float32, torch.bfloat16, torch.float16):
+                    dense = torch.empty(T, N, dtype=dt, device=DEV)
+                    _lib.unpack_spikes(pk, dense, T * N)
+                    assert np.array_equal(dense.float().cpu().numpy(), ref['out'])
+    # the training pair: forward without h (packed only) + recompute backward == the saved-h pair
+    g = rng.standard_normal((T, N)).astype(np.float32)
+    rb = c_oracle.neuron_bwd(g, ref['h'], v_init=v0, surrogate='ATan', alpha=2.0, **kw)
+    gx, gvi = torch.empty(T, N, device=DEV), torch.empty(N, device=DEV)
+    gk = torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+    gws = torch.empty(_lib.gk_ws_floats(), device=DEV) if kind == 'PLIF' else None
+    _lib.neuron_bwd_rc(_dev(g), None, xd, vd, gx, gvi, gk, gws, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0, 0, 2.0, True)
+    assert bit_equal(gx, rb['g_x'])
+
+
+def test_packed_io_argument_validation():
+    from stereospike_amd import _lib
+    x = torch.zeros(3, 32, device=DEV)
+    v = torch.empty(32, device=DEV)
+    pk = torch.zeros(3, 2, dtype=torch.int32, device=DEV)
+    with pytest.raises(_lib.SSNeuronError):                                  # T = 3 is not a compile-time T
+        _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, 3, 32, 1.0, 0, 2.0, None, 1.0, 0.0)
+    x5 = torch.zeros(5, 32, device=DEV)
+    pk5 = torch.zeros(5, 2, dtype=torch.int32, device=DEV)
+    with pytest.raises(_lib.SSNeuronError):                                  # packed output together with a saved h
+        _lib.neuron_fwd_ex(x5, None, None, None, None, pk5, torch.empty(5, 32, device=DEV), v, None, None, 5, 32, 1.0, 0, 2.0, None, 1.0, 0.0)
+    with pytest.raises(_lib.SSNeuronError):                                  # neither output
+        _lib.neuron_fwd_ex(x5, None, None, None, None, None, None, v, None, None, 5, 32, 1.0, 0, 2.0, None, 1.0, 0.0)
+    with pytest.raises(_lib.SSNeuronError):                                  # N % 16 != 0
+        _lib.neuron_fwd_ex(torch.zeros(5, 24, device=DEV), None, None, None, None, torch.zeros(5, 1, dtype=torch.int32, device=DEV), None,
+                           torch.empty(24, device=DEV), None, None, 5, 24, 1.0, 0, 2.0, None, 1.0, 0.0)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_counter_partials_match_count_nonzero_at_full_size(dt):
+    """Config-3 bottom layer (2.3e8 updates): the per-workgroup-partials counters (full grid) == count_nonzero, twice (accumulating)."""
+    from stereospike_amd import _lib
+    T, N = 5, 16 * 32 * 260 * 346
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = (torch.randn(T, N, device=DEV, generator=g) * 0.15).to(dt)
+    out, v = torch.empty_like(x), torch.empty(N, device=DEV)
+    nnz = torch.zeros(2, dtype=torch.int64, device=DEV)
+    ws = torch.empty(_lib.cnt_ws_words(N), dtype=torch.int32, device=DEV)
+    for rep in (1, 2):
+        _lib.neuron_fwd_ex(x, None, None, None, out, None, None, v, nnz, ws, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        assert int(nnz[0]) == rep * int(out.count_nonzero()) == int(nnz[1])
+
+
+def test_unpack_copies_and_packed_im2col_vs_oracle():
+    from oracle import np_pack, np_operands
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(5)
+    rows, Cc = 37 * 16, 64
+    xs = rng.integers(0, 4, (rows, Cc)).astype(np.float32)
+    pk = torch.from_numpy(np_pack.pack(xs.reshape(-1)).view(np.int32)).to(DEV)
+    x3 = torch.empty(rows, 3 * Cc, dtype=torch.bfloat16, device=DEV)
+    _lib.unpack_spikes(pk, x3, rows * Cc, row_len=Cc, copies=3)
+    assert np.array_equal(x3.float().cpu().numpy(), np.concatenate([xs, xs, xs], 1))
+    for (NB, h, w, Cin, k, s, pad) in ((2, 9, 12, 128, 5, 2, 2), (1, 7, 8, 512, 3, 1, 1), (3, 6, 6, 16, 5, 1, 2)):
+        x = rng.integers(0, 4, (NB, h, w, Cin)).astype(np.float32)
+        ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        xp = torch.from_numpy(np_pack.pack(x.reshape(-1)).view(np.int32)).to(DEV)
+        A1 = torch.empty(NB * ho * wo, k * k * Cin, dtype=torch.bfloat16, device=DEV)
+        A2 = torch.empty_like(A1)
+        _lib.im2col_cl_bf16_packed(xp, A1, NB, h, w, Cin, k, s, pad, ho, wo)
+        _lib.im2col_cl_bf16(torch.from_numpy(x).to(DEV), A2, NB, h, w, Cin, k, s, pad, ho, wo)
+        assert torch.equal(A1.view(torch.int16), A2.view(torch.int16)), (NB, h, w, Cin, k, s, pad)
+        ref = np_operands.im2col_cl(x, k, s, pad)[0]
+        assert np.array_equal(A1.float().cpu().numpy(), ref.reshape(A1.shape))
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('kind', ['IF', 'PLIF'])
+@pytest.mark.parametrize('T,N', [(5, 4096 * 3), (5, 1003), (10, 8192), (1, 64)])
+def test_x16_backward_with_forked_output_gradients(dt, kind, T, N):
+    """ss_neuron_bwd_fork_x16 == oracle/np_x16.py with g2_bits: g_x, g_v_init, g_sum bit-exact (ATan)."""
+    from oracle import np_x16
+    from stereospike_amd import _lib
+    name = 'f16' if dt == torch.float16 else 'bf16'
+    g = torch.Generator().manual_seed(T * 13 + N)
+    x = (torch.randn(T, N, generator=g) * 0.2).to(dt)
+    g1, g2 = torch.randn(T, N, generator=g).to(dt), torch.randn(T, N, generator=g).to(dt)
+    bits = lambda t: t.view(torch.int16).numpy().view(np.uint16)
+    kw = dict(kind=kind, scale=10.0, tau=3.0, k=np.float32(1 / 3.) if kind == 'PLIF' else None, v_th=1.0, v_reset=0.0)
+    ref = np_x16.neuron_fwd(bits(x), name, **kw)
+    rb = np_x16.neuron_bwd(bits(g1), ref['h'], name, surrogate='ATan', alpha=2.0, g2_bits=bits(g2), **kw)
+    kd = None if kind != 'PLIF' else torch.tensor([1 / 3.], device=DEV)
+    gx, gs, gvi = torch.empty(T, N, dtype=dt, device=DEV), torch.empty(T, N, dtype=dt, device=DEV), torch.empty(N, device=DEV)
+    gk = torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+    ws = torch.empty(_lib.gk_ws_floats(), device=DEV) if kind == 'PLIF' else None
+    _lib.neuron_bwd_fork_x16(g1.to(DEV), g2.to(DEV), gs, None, x.to(DEV), None, gx, gvi, gk, ws, T, N, 10.0, KIND[kind], 3.0, kd, 1.0, 0.0, 0, 2.0, True)
+    assert np.array_equal(bits(gx.cpu()), rb['g_x']) and np.array_equal(bits(gs.cpu()), rb['g_sum'])
+    assert bit_equal(gvi, rb['g_v_init'])
+    if kind == 'PLIF':
+        assert abs(float(gk) - rb['g_k']) <= 1e-5 * abs(rb['g_k']) + 2e-7 * T * N
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('T,N', [(2, 4096), (3, 8 * 777), (4, 1024), (7, 2048 + 8), (8, 4104), (10, 8 * 12345)])
+def test_x16_forward_every_time_step_count(dt, T, N):
+    """Compile-time-T (1, 2, 4, 5, 8, 10) and run-time-T instantiations of the 16-bit forward, 8- and 4-neuron lanes == np_x16."""
+    from oracle import np_x16
+    from stereospike_amd import _lib
+    name = 'f16' if dt == torch.float16 else 'bf16'
+    g = torch.Generator().manual_seed(T * 3 + N)
+    x = (torch.randn(T, N, generator=g) * 0.2).to(dt)
+    skip = torch.randint(0, 3, (T, N), generator=g).to(dt)
+    bits = lambda t: t.view(torch.int16).numpy().view(np.uint16)
+    for sk in (None, skip):
+        ref = np_x16.neuron_fwd(bits(x), name, kind='LIF', scale=10.0, tau=3.0, v_th=1.0, v_reset=0.0, skip_bits=None if sk is None else bits(sk))
+        for save_h in (True, False):
+            out, v = torch.empty(T, N, dtype=dt, device=DEV), torch.empty(N, device=DEV)
+            h = torch.empty(T, N, device=DEV) if save_h else None
+            _lib.neuron_fwd_x16(x.to(DEV), None, None if sk is None else sk.to(DEV), out, h, v, None, T, N, 10.0, 1, 3.0, None, 1.0, 0.0)
+            assert np.array_equal(bits(out.cpu()), ref['out']) and bit_equal(v, ref['v_last'])
+            if save_h:
+                assert bit_equal(h, ref['h'])

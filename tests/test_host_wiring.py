@@ -98,7 +98,18 @@ def host_backend(monkeypatch):
     monkeypatch.setattr(_lib, 'upconv_cl_bwd', upconv_cl_bwd)
     monkeypatch.setattr(_lib, 'upconv1_fwd', upconv1_fwd)
     monkeypatch.setattr(_lib, 'upconv1_bwd', upconv1_bwd)
+    def neuron_fwd_ex(x_seq, v_init, skip_seq, skip_packed, out_seq, out_packed, h_seq, v_last, nnz, cnt_ws, T, N, scale, kind, tau, k, v_th, v_reset):
+        from oracle import np_pack
+        if skip_packed is not None:
+            skip_seq = torch.from_numpy(np_pack.unpack(skip_packed.numpy().view(np.uint32).reshape(T, N // 16)))
+        dense = out_seq if out_seq is not None else torch.empty(T, N)
+        neuron_fwd(x_seq, v_init, skip_seq, dense, h_seq, v_last, nnz, T, N, scale, kind, tau, k, v_th, v_reset)
+        if out_packed is not None:
+            out_packed.copy_(torch.from_numpy(np_pack.pack(dense.numpy().reshape(T, N)).view(np.int32)).view_as(out_packed))
+
     monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
+    monkeypatch.setattr(_lib, 'neuron_fwd_ex', neuron_fwd_ex)
+    monkeypatch.setattr(_lib, 'cnt_ws_words', lambda N: 1)
     monkeypatch.setattr(_lib, 'neuron_bwd', neuron_bwd)
     monkeypatch.setattr(_lib, 'neuron_bwd_rc', neuron_bwd_rc)
     monkeypatch.setattr(_lib, 'neuron_bwd_fork', neuron_bwd_fork)
