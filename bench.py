@@ -76,8 +76,9 @@ def parse():
                          '(BASELINE.json configs 2 / 5) — reported as a separate line, never as the headline value')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    ap.add_argument('--cpu-b16-seconds', type=float, default=10.0,
-                    help='time budget of the second CPU-port leg at the bench batch size (1 warm-up + >= 1 timed iteration); 0 disables')
+    ap.add_argument('--cpu-b16-seconds', type=float, default=0.0,
+                    help='> 0: also time the CPU port at the bench batch size (SURVEY.md §8(d): B = 16): eval + 1 warm-up + >= 1 timed iteration, '
+                         '~110 s each on the GPU box host (measured 0.145 frames/s, profiles/r02/) — off by default so that the default run stays within minutes')
     ap.add_argument('--miopen-find', type=int, default=1,
                     help='torch.backends.cudnn.benchmark = MIOpen find mode: picks the fastest solver per conv (measured '
                          '73.8 vs 87.3 ms/step); the search costs ~3.5 min on a cold box, ~75 s with the in-tree find-db')

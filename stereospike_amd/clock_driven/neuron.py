@@ -77,14 +77,19 @@ class BaseNode(nn.Module):
         return torch.full_like(like, float(v))
 
     def forward_sequence(self, x_seq: torch.Tensor, scale: float = 1., skip_seq: Optional[torch.Tensor] = None,
-                         nnz: Optional[torch.Tensor] = None, channels_last: bool = False, fork: bool = False):
+                         nnz: Optional[torch.Tensor] = None, channels_last: bool = False, fork: bool = False,
+                         pack: int = 0, skip_packed: Optional[torch.Tensor] = None):
         """x_seq [T, ...]: T steps from the current membrane; returns out_seq [T, ...] and carries v forward.
         The kernel is element-wise, so any memory layout works as long as x, skip and v share it; with
         channels_last=True x_seq is an NHWC array [T, B, H, W, C] and `self.v` keeps its logical [B, C, H, W] shape
         (a permuted view of the NHWC membrane).  fork=True returns (out_seq, out_seq') — two handles on the same spikes for an output
-        with two consumers (next synapse + skip / head); their gradients are summed inside the backward kernel."""
+        with two consumers (next synapse + skip / head); their gradients are summed inside the backward kernel.
+        pack (1: dense + packed, 2: packed only — the returned tensor is then a data-less anchor of the logical shape) also writes the
+        output as a 2-bit packed spike tensor, left in `self.last_packed` (None when the packed kernel form does not apply: the output
+        is then dense); skip_packed: the skip operand in that form."""
         res = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0], channels_last),
-                           skip_seq=skip_seq, k=self._k(), nnz=nnz, fork=fork)
+                           skip_seq=skip_seq, k=self._k(), nnz=nnz, fork=fork, pack=pack, skip_packed=skip_packed)
+        self.last_packed = res[-1] if pack else None
         v_last = res[1]
         self.v = v_last.permute(0, 3, 1, 2) if channels_last else v_last
         return (res[0], res[2]) if fork else res[0]

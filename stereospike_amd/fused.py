@@ -77,43 +77,75 @@ TIMER = KernelTimer()
 RECOMPUTE_H = True
 
 
+# 2-bit packed spike tensors on the edges whose consumers can read them: the im2col of the exact-split convs
+# (conv3, conv4, the bottleneck) and the skip / SEW-identity operand of a neuron launch.  A layer whose consumers are all of that kind
+# writes NO dense output (forward 4.25 instead of 8 B/update); its autograd output is then a zero-strided "anchor" of the logical shape
+# (4 bytes of storage) that only carries the graph edge — the data travels in the packed tensor next to it.
+PACK_SPIKES = True
+
+
+def spike_anchor(shape, dtype, device):
+    return torch.zeros(1, dtype=dtype, device=device).as_strided(tuple(shape), (0,) * len(shape))
+
+
+def unpack_dense(packed, shape, dtype=torch.float32):
+    """Packed int32 [T, N/16] -> dense tensor of `shape` (for a consumer that cannot read the packed form)."""
+    out = torch.empty(tuple(shape), dtype=dtype, device=packed.device)
+    _lib.unpack_spikes(packed.contiguous(), out, out.numel())
+    return out
+
+
 class _FusedNeuron(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False):
+    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False, pack=0, skip_packed=None):
+        """pack: 0 dense output; 1 dense + packed; 2 packed only (the returned out_seq is an anchor).  skip_packed: the skip operand as a
+        packed tensor (skip_seq then only carries the autograd edge and may be an anchor)."""
         T = x_seq.shape[0]
         N = x_seq.numel() // T
         x_seq = x_seq.contiguous()
-        if skip_seq is not None:
-            skip_seq = skip_seq.contiguous()
         if v_init is not None:
             v_init = v_init.contiguous()
         need_grad = any(ctx.needs_input_grad[:4])
         half = x_seq.dtype in (torch.float16, torch.bfloat16)       # 16-bit activations, fp32 membrane (configs 2 / 5)
-        if skip_seq is not None and skip_seq.dtype != x_seq.dtype:
-            skip_seq = skip_seq.to(x_seq.dtype)                      # spikes are small integers: exact in every format
-        out_seq = torch.empty_like(x_seq)
         recompute = need_grad and RECOMPUTE_H and _lib.neuron_bwd_rc_supported(T)
+        # the packed kernel form: fp32 activations, compile-time T, whole words, no saved h
+        can_pk = (not half) and N % 16 == 0 and _lib.neuron_bwd_rc_supported(T) and (recompute or not need_grad)
+        if skip_packed is not None and not can_pk:
+            skip_seq, skip_packed = unpack_dense(skip_packed, x_seq.shape, x_seq.dtype), None
+        if not can_pk:
+            pack = 0
+        has_skip = skip_seq is not None or skip_packed is not None
+        if skip_packed is not None:
+            skip_dense = None
+        else:
+            skip_dense = None if skip_seq is None else skip_seq.contiguous()
+            if skip_dense is not None and skip_dense.dtype != x_seq.dtype:
+                skip_dense = skip_dense.to(x_seq.dtype)              # spikes are small integers: exact in every format
+        skip_seq = skip_dense
+        out_seq = spike_anchor(x_seq.shape, x_seq.dtype, x_seq.device) if pack == 2 else torch.empty_like(x_seq)
+        packed = torch.empty((T, N // 16), dtype=torch.int32, device=x_seq.device) if pack else None
         h_seq = torch.empty(x_seq.shape, dtype=torch.float32, device=x_seq.device) if (need_grad and not recompute) else None
         v_last = torch.empty(x_seq.shape[1:], dtype=torch.float32, device=x_seq.device)
         if v_init is not None and v_init.dtype != torch.float32:
             v_init = v_init.float()
         e0 = TIMER.start()
-        if nnz is not None:
+        if nnz is not None or pack or skip_packed is not None:
             # firing-rate counters: per-workgroup partials + one fixed second pass (full grid, no same-address atomics)
-            cnt_ws = torch.empty(_lib.cnt_ws_words(N), dtype=torch.int32, device=x_seq.device)
-            _lib.neuron_fwd_ex(x_seq, v_init, skip_seq, None, out_seq, None, h_seq, v_last, nnz, cnt_ws, T, N,
+            cnt_ws = torch.empty(_lib.cnt_ws_words(N), dtype=torch.int32, device=x_seq.device) if nnz is not None else None
+            _lib.neuron_fwd_ex(x_seq, v_init, skip_seq, skip_packed, None if pack == 2 else out_seq, packed, h_seq, v_last, nnz, cnt_ws, T, N,
                                cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
         else:
             (_lib.neuron_fwd_x16 if half else _lib.neuron_fwd)(x_seq, v_init, skip_seq, out_seq, h_seq, v_last, nnz, T, N,
                                                               cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset)
         es = 2 if half else 4
-        per = es * (2 + (1 if skip_seq is not None else 0)) + (4 if h_seq is not None else 0)
-        TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if skip_seq is not None else ''),
-                   per * T * N, T * N)
+        per = es * (1 + (0 if pack == 2 else 1)) + (0.25 if pack else 0) + (0.25 if skip_packed is not None else (es if skip_seq is not None else 0)) \
+            + (4 if h_seq is not None else 0)
+        TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else ''),
+                   int(per * T * N), T * N)
         ctx.cfg = cfg
         ctx.T, ctx.N = T, N
         ctx.has_vinit = v_init is not None
-        ctx.has_skip = skip_seq is not None
+        ctx.has_skip = has_skip
         ctx.io_dtype = x_seq.dtype
         ctx.set_materialize_grads(False)
         ctx.recompute = recompute
@@ -125,14 +157,12 @@ class _FusedNeuron(torch.autograd.Function):
             # the reference mutates it in place (blocks.py:171).  v_init only feeds the PLIF dL/dk term at t = 0.
             keep_v = v_init if (cfg.kind == _lib.KIND_PLIF and ctx.needs_input_grad[3]) else None
             ctx.save_for_backward(h_seq, keep_v, k)
-        if fork:
-            # a second handle on the same memory for the second consumer: autograd then delivers the two gradients separately and the
-            # backward kernel adds them on load (ss_neuron_bwd_fork_f32) instead of a separate 12 B/element accumulation pass
-            return out_seq, v_last, out_seq.view_as(out_seq)
-        return out_seq, v_last
+        # fork: a second handle on the same memory for the second consumer: autograd then delivers the two gradients separately and the
+        # backward kernel adds them on load (ss_neuron_bwd_fork_f32) instead of a separate 12 B/element accumulation pass
+        return out_seq, v_last, (out_seq.view_as(out_seq) if fork else None), packed
 
     @staticmethod
-    def backward(ctx, g_out_seq, g_v_last, g_out2_seq=None):
+    def backward(ctx, g_out_seq, g_v_last, g_out2_seq=None, g_packed=None):
         h_seq, v_init, k = ctx.saved_tensors          # h_seq is x_seq (activation dtype) when ctx.recompute
         cfg, T, N = ctx.cfg, ctx.T, ctx.N
         half = ctx.io_dtype in (torch.float16, torch.bfloat16)
@@ -174,17 +204,20 @@ class _FusedNeuron(torch.autograd.Function):
                 T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
         TIMER.stop(e0, ('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd', (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
         g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
-        return g_x_seq, g_v_init, g_skip, g_k, None, None, None
+        return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
 
 
 def fused_neuron(x_seq: torch.Tensor, cfg: NeuronCfg, v_init: Optional[torch.Tensor] = None,
                  skip_seq: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None,
-                 nnz: Optional[torch.Tensor] = None, fork: bool = False):
+                 nnz: Optional[torch.Tensor] = None, fork: bool = False, pack: int = 0, skip_packed: Optional[torch.Tensor] = None):
     """x_seq: [T, ...] conv output (before the gain).  Returns (out_seq [T, ...], v_last [...]) — with fork=True a third value: a
-    second handle on out_seq for its second consumer (the two gradients are then added inside the backward kernel)."""
+    second handle on out_seq for its second consumer (the two gradients are then added inside the backward kernel); with pack != 0 a
+    last value: the 2-bit packed output (int32 [T, N/16]; None when the packed kernel form does not apply — the output is then dense)."""
     if cfg.kind == _lib.KIND_PLIF and k is None:
         raise _lib.SSNeuronError('PLIF needs k = sigmoid(w) as a 0-dim HIP tensor')
-    return _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz, fork)
+    out, v_last, out2, packed = _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz, fork, pack, skip_packed)
+    res = (out, v_last) + ((out2,) if fork else ())
+    return res + ((packed,) if pack else ())
 
 
 class _IPool(torch.autograd.Function):
@@ -591,16 +624,21 @@ class _SpikeConvCL(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x_cl, weight, stride, pad):
-        x_cl = x_cl.contiguous()
+    def forward(ctx, x_cl, weight, stride, pad, x_packed=None):
+        # x_packed: the same input as a 2-bit packed spike tensor (x_cl then only carries shape and autograd edge; it may be an anchor)
+        if x_packed is None:
+            x_cl = x_cl.contiguous()
         NB, h, w, Cin = x_cl.shape
         Cout, _, k, _ = weight.shape
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
         M, K = NB * ho * wo, k * k * Cin
-        if ASSERT_EXACT_SPLIT:
+        if ASSERT_EXACT_SPLIT and x_packed is None:
             assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
         A = torch.empty((M, K), dtype=torch.bfloat16, device=x_cl.device)
-        _lib.im2col_cl_bf16(x_cl, A, NB, h, w, Cin, k, stride, pad, ho, wo)
+        if x_packed is not None:
+            _lib.im2col_cl_bf16_packed(x_packed.contiguous(), A, NB, h, w, Cin, k, stride, pad, ho, wo)
+        else:
+            _lib.im2col_cl_bf16(x_cl, A, NB, h, w, Cin, k, stride, pad, ho, wo)
         Wt = weight.permute(2, 3, 1, 0).reshape(K, Cout)                          # row index = (ky, kx, c): the im2col column order
         Wh = Wt.to(torch.bfloat16)
         r = Wt - Wh.float()
@@ -637,24 +675,31 @@ class _SpikeConvCL(torch.autograd.Function):
             g_x = g_x.permute(0, 2, 3, 1)
             if not g_x.is_contiguous():
                 g_x = g_x.contiguous()
-        return g_x, g_w, None, None
+        return g_x, g_w, None, None, None
 
 
 SPIKE_CONV_WGRAD_SPLIT = 8         # profiles/r01/wgrad_splitk.log
 SPIKE_CONV_MIN_CIN = 128           # conv3 (128), conv4 (256), bottleneck (512); below: im2col traffic outweighs the MFMA gain
 
 
-def spike_conv_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
-    """conv (nn.Conv2d, square kernel, no bias / groups / dilation) on a spike NHWC array through _SpikeConvCL, or None when the
-    exact-split form does not apply (caller then uses the MIOpen convolution)."""
+def spike_conv_applies(conv, device, dtype=torch.float32) -> bool:
+    """True when `conv` (nn.Conv2d) on a spike NHWC array of `dtype` on `device` runs through _SpikeConvCL (exact bf16x3 GEMM form)."""
+    import torch.nn as nn
+    if not isinstance(conv, nn.Conv2d):
+        return False
     k = conv.kernel_size[0]
-    ok = (EXACT_SPLIT_GEMM and x_cl.is_cuda and x_cl.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
-          and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size == (k, k)
-          and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and not isinstance(conv.padding, str)
-          and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= SPIKE_CONV_MIN_CIN)
-    if not ok:
+    return bool(EXACT_SPLIT_GEMM and device.type == 'cuda' and dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
+                and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size == (k, k)
+                and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and not isinstance(conv.padding, str)
+                and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= SPIKE_CONV_MIN_CIN)
+
+
+def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """conv (nn.Conv2d, square kernel, no bias / groups / dilation) on a spike NHWC array through _SpikeConvCL, or None when the
+    exact-split form does not apply (caller then uses the MIOpen convolution).  x_packed: the input as a packed spike tensor."""
+    if not spike_conv_applies(conv, x_cl.device, x_cl.dtype):
         return None
-    return _SpikeConvCL.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0])
+    return _SpikeConvCL.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0], x_packed)
 
 
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False):

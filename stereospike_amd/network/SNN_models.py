@@ -133,15 +133,34 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
 
             def two(r):
                 return r if fork else (r, r)
-            a, b = two(self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'), fork=fork))
-            enc, enc_skip = [a], [b]
+            # 2-bit packed spike tensors (fused.PACK_SPIKES) next to / instead of the dense fp32 ones, per edge: the skip operands of
+            # the decoder are read packed; a layer whose next synapse is an exact-split conv (reads packed through its im2col) writes
+            # no dense output at all.  dense=1, packed-only=2, off=0.
+            from .. import fused as _fused
+            pk_on = _fused.PACK_SPIKES and x_seq.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and x_seq.is_cuda
+
+            def mode(next_conv):
+                if not pk_on:
+                    return 0
+                return 2 if _fused.spike_conv_applies(next_conv, x_seq.device) else 1
+
+            def packed_in(conv, packed):      # hand the packed form only to a synapse that reads it
+                return packed if (packed is not None and _fused.spike_conv_applies(conv, x_seq.device)) else None
+            a, b = two(self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'), fork=fork,
+                                                            pack=mode(self.conv1[0])))
+            enc, enc_skip, enc_pk = [a], [b], [self.bottom[2].last_packed]
             for i in range(1, 4):
-                a, b = two(getattr(self, f'conv{i}').forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True, fork=fork))
+                st, nxt = getattr(self, f'conv{i}'), getattr(self, f'conv{i + 1}')
+                a, b = two(st.forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True, fork=fork,
+                                                       x_packed=packed_in(st[0], enc_pk[-1]), pack=mode(nxt[0])))
                 enc.append(a)
                 enc_skip.append(b)
-            enc.append(self.conv4.forward_sequence_conv_cl(enc[-1], nnz('conv4'), spikes_in=True))
-            cur = self.bottleneck[0].forward_sequence_cl(enc[4], spikes_in=True)          # enc[*], cur: spike tensors
-            cur = self.bottleneck[1].forward_sequence_cl(cur, nnz('rconv'), spikes_in=True)
+                enc_pk.append(st[2].last_packed)
+            bn0, bn1 = self.bottleneck[0], self.bottleneck[1]
+            enc.append(self.conv4.forward_sequence_conv_cl(enc[-1], nnz('conv4'), spikes_in=True, x_packed=packed_in(self.conv4[0], enc_pk[-1]),
+                                                           pack=mode(bn0.conv1[0])))
+            cur = bn0.forward_sequence_cl(enc[4], spikes_in=True, x_packed=self.conv4[2].last_packed, pack_out=mode(bn1.conv1[0]))   # enc[*], cur: spike tensors
+            cur = bn1.forward_sequence_cl(cur, nnz('rconv'), spikes_in=True, x_packed=bn0.sn2.last_packed)
             spikes, heads = [cur.permute(0, 1, 4, 2, 3)], []
         else:
             enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]
@@ -160,7 +179,8 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             if cl:
                 skip = enc_skip[lvl - 1] if enc_cl else enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
                 # the stage output feeds the next stage and its prediction head: forked handles again
-                r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_blocks.FORK_OUTPUTS)
+                r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_blocks.FORK_OUTPUTS,
+                                              skip_packed=enc_pk[lvl - 1] if enc_cl else None)
                 cur, cur_head = r if _blocks.FORK_OUTPUTS else (r, r)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
                 pd = head[0].forward_projected_cl(cur_head.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW

@@ -129,23 +129,28 @@ class SpikingStage(nn.Sequential):
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
 
 
-    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False, fork: bool = False):
+    def forward_sequence_conv_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False, fork: bool = False,
+                                 x_packed: Optional[torch.Tensor] = None, pack: int = 0):
         """Encoder stage on NHWC arrays: x_seq [T, B, h, w, C] -> [T, B, h', w', C'].  The Conv2d sees a logical-NCHW
         view with channels_last strides (no copy) and returns channels_last memory, i.e. again an NHWC array.
-        spikes_in: x_seq is the output of a spiking layer."""
+        spikes_in: x_seq is the output of a spiking layer.  x_packed: the same input as a 2-bit packed spike tensor (read by the
+        exact-split conv's im2col; x_seq may then be a data-less anchor).  pack: see BaseNode.forward_sequence — the packed output is
+        left in `self[2].last_packed`."""
         T, B = x_seq.shape[:2]
-        y = _conv_cl(self[0], x_seq.flatten(0, 1), spikes_in)
+        y = _conv_cl(self[0], x_seq.flatten(0, 1), spikes_in, x_packed)
         y, scale = _fold_gain(self[1], y)
-        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True, fork=fork)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True, fork=fork, pack=pack)
 
     def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None, spikes_in: bool = False,
-                            fork: bool = False):
+                            fork: bool = False, skip_packed: Optional[torch.Tensor] = None):
         """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
-        NNConvUpsampling.  spikes_in: x_seq is the output of a spiking layer (+ spike skip adds)."""
+        NNConvUpsampling.  spikes_in: x_seq is the output of a spiking layer (+ spike skip adds).  skip_packed: the skip operand as a
+        packed spike tensor (skip_seq then carries the autograd edge only)."""
         T, B = x_seq.shape[:2]
         y = self[0].forward_projected_cl(x_seq.flatten(0, 1), spikes_in)
         y, scale = _fold_gain(self[1], y)
-        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True, fork=fork)
+        return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True, fork=fork,
+                                        skip_packed=skip_packed)
 
 
 class ResBlock(nn.Module):
@@ -166,7 +171,7 @@ class ResBlock(nn.Module):
         return _connect(self.connect_function, self.conv2(self.conv1(x)), x, spiking=False)
 
 
-def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False) -> torch.Tensor:
+def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False, x_packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x_arr [NB, h, w, C] (NHWC array) -> conv -> [NB, h', w', C'] NHWC array, without layout copies when MIOpen returns
     channels_last memory (it does for channels_last inputs).  The filter is handed to MIOpen as a channels_last copy
     (72 MB for the whole network, ~0.03 ms per step); the Parameter itself keeps its standard layout, so optimisers,
@@ -175,9 +180,11 @@ def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False) -> t
     (fused.spike_conv_cl) instead of MIOpen's fp32 convolution."""
     if spikes_in and isinstance(conv, nn.Conv2d):
         from ..fused import spike_conv_cl
-        y = spike_conv_cl(x_arr, conv)
+        y = spike_conv_cl(x_arr, conv, x_packed)
         if y is not None:
             return y
+    if x_packed is not None and x_arr.stride(-1) == 0:
+        raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
     if isinstance(conv, nn.Conv2d):
         w = conv.weight.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x_arr.permute(0, 3, 1, 2), w, conv.bias, conv.stride, conv.padding,
@@ -241,19 +248,24 @@ class SEWResBlock(nn.Module):
         out = half(self.conv2, self.sn2, out, None, nnz)
         return _connect(self.connect_function, out, x_seq, spiking=True)
 
-    def forward_sequence_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False) -> torch.Tensor:
+    def forward_sequence_cl(self, x_seq: torch.Tensor, nnz=None, spikes_in: bool = False, x_packed: Optional[torch.Tensor] = None,
+                            pack_out: int = 0) -> torch.Tensor:
         """NHWC-array form of forward_sequence ('ADD' connect function only).  spikes_in: x_seq is a spike tensor (the inner
-        activation always is)."""
+        activation always is).  x_packed: x_seq as a 2-bit packed spike tensor; pack_out: pack mode of the block output (left in
+        `self.sn2.last_packed`).  The inner activation travels packed-only whenever conv2 is an exact-split conv."""
         if self.connect_function != 'ADD':
             raise NotImplementedError('channels-last SEW block supports the ADD connect function only')
+        from .. import fused
         T, B = x_seq.shape[:2]
 
-        def half(conv, sn, inp, skip, cnt, spk):
-            y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1), spk))
-            return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt, channels_last=True)
+        def half(conv, sn, inp, skip, cnt, spk, inp_packed, skip_packed, pack):
+            y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1), spk, inp_packed))
+            return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt, channels_last=True, pack=pack, skip_packed=skip_packed)
 
-        out = half(self.conv1, self.sn1, x_seq, None, None, spikes_in)
-        return half(self.conv2, self.sn2, out, x_seq, nnz, True)
+        exact1 = fused.spike_conv_applies(self.conv1[0], x_seq.device, x_seq.dtype)
+        exact2 = fused.PACK_SPIKES and fused.spike_conv_applies(self.conv2[0], x_seq.device, x_seq.dtype)
+        out = half(self.conv1, self.sn1, x_seq, None, None, spikes_in, x_packed if (exact1 and spikes_in) else None, None, 2 if exact2 else 0)
+        return half(self.conv2, self.sn2, out, x_seq, nnz, True, self.sn1.last_packed, x_packed, pack_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_sequence(x.unsqueeze(0))[0]

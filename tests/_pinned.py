@@ -37,10 +37,18 @@ def record_product_spikes(net):
     rec = {}
     orig = neuron.BaseNode.forward_sequence
 
-    def wrapped(self, x_seq, scale=1., skip_seq=None, nnz=None, channels_last=False, fork=False):
-        res = orig(self, x_seq, scale, skip_seq, nnz, channels_last, fork)
-        out = (res[0] if fork else res).detach().float()
-        z = out if skip_seq is None else out - skip_seq.detach().float()
+    def wrapped(self, x_seq, scale=1., skip_seq=None, nnz=None, channels_last=False, fork=False, pack=0, skip_packed=None):
+        from stereospike_amd import fused
+        res = orig(self, x_seq, scale, skip_seq, nnz, channels_last, fork, pack, skip_packed)
+        out = (res[0] if fork else res).detach()
+        if pack and self.last_packed is not None:          # packed(-only) output: the data lives in the packed tensor (out may be an anchor)
+            out = fused.unpack_dense(self.last_packed, x_seq.shape)
+        out = out.float()
+        if skip_packed is not None:
+            skip = fused.unpack_dense(skip_packed, x_seq.shape)
+        else:
+            skip = None if skip_seq is None else skip_seq.detach().float()
+        z = out if skip is None else out - skip
         if channels_last:
             z = z.permute(0, 1, 4, 2, 3)
         rec.setdefault(names[id(self)], []).append(z.to(torch.uint8).cpu())

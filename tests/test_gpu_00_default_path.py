@@ -67,16 +67,18 @@ def test_pinned_parity_small_default(name, C):
     _check(f'pinned_small_{name}', rep, MARGIN_DEFAULT, depth_bar=1e-4 if name == 'ANN' else 1e-5)
 
 
-@pytest.mark.parametrize('layout', ['all_nhwc_exact_split', 'all_nhwc', 'decoder_nhwc', 'nchw', 'two_op_miopen', 'saved_h_no_fork'])
+@pytest.mark.parametrize('layout', ['all_nhwc_exact_split', 'exact_split_dense_spikes', 'all_nhwc', 'decoder_nhwc', 'nchw', 'two_op_miopen', 'saved_h_no_fork'])
 def test_pinned_parity_every_execution_layout(layout, monkeypatch):
     """The same network through every execution variant of the synapses / neuron kernels: the shipped default; NHWC with plain fp32
     GEMMs; NHWC decoder only; projected NCHW; the reference's two-op up-convs on MIOpen; saved-h backward without forked gradients."""
     from stereospike_amd import fused
     from stereospike_amd.network import blocks
     monkeypatch.setattr(blocks, 'FUSE_UPCONV', layout != 'two_op_miopen')
-    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', layout in ('decoder_nhwc', 'all_nhwc', 'all_nhwc_exact_split', 'saved_h_no_fork'))
-    monkeypatch.setattr(blocks, 'ENCODER_CHANNELS_LAST', layout in ('all_nhwc', 'all_nhwc_exact_split', 'saved_h_no_fork'))
-    monkeypatch.setattr(fused, 'EXACT_SPLIT_GEMM', layout in ('all_nhwc_exact_split', 'saved_h_no_fork'))
+    exact = ('all_nhwc_exact_split', 'exact_split_dense_spikes', 'saved_h_no_fork')
+    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', layout in ('decoder_nhwc', 'all_nhwc') + exact)
+    monkeypatch.setattr(blocks, 'ENCODER_CHANNELS_LAST', layout in ('all_nhwc',) + exact)
+    monkeypatch.setattr(fused, 'EXACT_SPLIT_GEMM', layout in exact)
+    monkeypatch.setattr(fused, 'PACK_SPIKES', layout != 'exact_split_dense_spikes')
     monkeypatch.setattr(fused, 'ASSERT_EXACT_SPLIT', True)
     if layout == 'saved_h_no_fork':
         monkeypatch.setattr(fused, 'RECOMPUTE_H', False)
@@ -86,7 +88,47 @@ def test_pinned_parity_every_execution_layout(layout, monkeypatch):
     x = synth_input(2, 3, 4, 77, H, W, lam=0.08)
     gt = synth_label(2, 78, H, W)
     rep = pinned_parity(orc, net, x, gt)
-    _check(f'pinned_layout_{layout}', rep, MARGIN_DEFAULT if 'exact' in layout or layout == 'saved_h_no_fork' else MARGIN_MIOPEN)
+    _check(f'pinned_layout_{layout}', rep, MARGIN_DEFAULT if layout in exact else MARGIN_MIOPEN)
+
+
+def test_packed_spike_tensors_are_in_effect():
+    """fused.PACK_SPIKES (default on; every pinned test above runs with it): 2-bit packed spike tensors between conv2 .. bottleneck and
+    their consumers (packed-only: the autograd output is a data-less anchor), packed skip operands for the decoder.  Here: the packed
+    form really is in effect, and within ONE launch that writes both forms (bottom, conv1) unpack(packed) == the dense tensor bit for bit;
+    with PACK_SPIKES off no packed tensor exists.  (Bit-equality of the consumers on packed vs dense input: tests/test_gpu_kernels.py.)"""
+    from stereospike_amd import fused
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    H, W = 64, 80
+    _, net = pair('StereoSpike', H, W)
+    x = synth_input(2, 5, 4, 7, H, W, lam=0.08).to(DEV)
+    gt = synth_label(2, 8, H, W).to(DEV)
+    rec = {}
+    orig = net.bottom[2].forward_sequence
+
+    def spy(x_seq, *a, **kw):
+        r = orig(x_seq, *a, **kw)
+        rec['bottom_out'], rec['shape'] = (r[0] if isinstance(r, tuple) else r).detach().clone(), x_seq.shape
+        return r
+    net.bottom[2].forward_sequence = spy
+    functional.reset_net(net)
+    d, s = net.forward_sequence(x)
+    Total_Loss()(d, gt, s).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    for st in (net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
+        assert st.last_packed is not None and st.last_packed.dtype == torch.int32
+    assert net.bottom[2].last_packed is not None and net.conv1[2].last_packed is not None       # dense + packed (MIOpen reads the dense form)
+    assert net.deconv1[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    assert torch.equal(fused.unpack_dense(net.bottom[2].last_packed, rec['shape']), rec['bottom_out'])
+    assert 0.02 < float(rec['bottom_out'].mean()) < 0.9
+    fused.PACK_SPIKES = False
+    try:
+        functional.reset_net(net)
+        with torch.no_grad():
+            net.forward_sequence(x)
+        assert net.conv3[2].last_packed is None and net.bottom[2].last_packed is None
+    finally:
+        fused.PACK_SPIKES = True
 
 
 def test_pinned_parity_odd_sizes_runtime_T():
@@ -179,21 +221,22 @@ def test_fixture_stages_teacher_forced(tag, name):
 
 def test_fixture_ann_T1():
     """BASELINE config 1 network (equivalent ANN: no thresholds, hence no chaos) at 260x346 on the reference's fixture input / weights:
-    (a) trajectory-free pinned comparison with the float64-conv oracle (forward, loss, every gradient); (b) free-running against the
-    numbers the reference's own ANN_models.py produced on oneDNN.  BatchNorm runs on the statistics of ONE sample (training mode, B = 1,
-    as the reference); its 1/std amplifies the fp32 conv rounding difference between MIOpen and oneDNN, hence the wider bars of (b)
-    (measured: depth 7.4e-4, loss 4.7e-5, gradient norms 4.5e-3)."""
+    (a) with BatchNorm in eval mode, against the float64-conv oracle (forward, loss, every gradient) at fp32 tolerance; (b) in training
+    mode (BatchNorm on the statistics of ONE sample, B = 1, as the reference ran it) free-running against the numbers the reference's
+    own ANN_models.py produced on oneDNN.  The single-sample 1/std amplifies ANY fp32 conv rounding difference (MIOpen vs oneDNN vs
+    float64: measured depth 7.4e-4, loss 4.7e-5, gradient norms 4.5e-3 — the same vs the float64 oracle), hence the wider bars of (b)."""
     from stereospike_amd.clock_driven import functional
     from stereospike_amd.network.loss import Total_Loss
     z = load_npz('model_ann_T1.npz')
     orc, net = pair('ANN', 260, 346, seed=int(z['seed']))
     assert state_sha(orc) == str(z['state_sha'])
     xc, gtc = torch.tensor(z['x'].astype(np.float32)), torch.tensor(z['gt'])
-    sd0 = {k: v.clone() for k, v in net.state_dict().items()}                     # BatchNorm running stats move with every forward
+    # (a) BatchNorm in eval mode (running statistics: the well-conditioned form of the same graph) against the float64-conv oracle
+    orc.eval(), net.eval()
     rep_p = pinned_parity(orc, net, xc, gtc, returns_spikes=False, is_ann=True)
-    REPORT['pinned_full_ann_T1'] = rep_p
-    assert rep_p['depth_max_abs_rel'] <= 1e-4 and rep_p['loss_rel'] <= 1e-5 and rep_p['grad_rel_l2_max'] <= 2e-3, rep_p
-    net.load_state_dict(sd0)
+    REPORT['pinned_full_ann_T1_bn_eval'] = rep_p
+    assert rep_p['depth_max_abs_rel'] <= 1e-5 and rep_p['loss_rel'] <= 1e-5 and rep_p['grad_rel_l2_max'] <= 2e-3, rep_p
+    net.train()
     net.zero_grad()
     x, gt = xc.to(DEV), gtc.to(DEV)
     functional.reset_net(net)

@@ -422,11 +422,9 @@ def test_graphed_trainer_matches_the_eager_trainer():
         p0 = {k: p.detach().clone() for k, p in nets[0].named_parameters()}
         batches = [(synth_input(2, T, 4, 70 + i, H, W, lam=0.1).to(DEV), synth_label(2, 90 + i, H, W).to(DEV)) for i in range(4)]
         eager_a, eager_b = Trainer(nets[0], lr=1e-5), Trainer(nets[1], lr=1e-5)
+        # the graphed trainer's first call runs `warmup` eager iterations on batch 0 before capturing; they leave no trace (parameters,
+        # buffers restored, optimiser state zeroed), so its first replay is training step 1 like the eager trainers' first step
         graphed = GraphedTrainer(nets[2], lr=1e-5, warmup=2)
-        # the graphed trainer's first call runs `warmup` eager iterations on batch 0 before its first replay: mirror that
-        for tr in (eager_a, eager_b):
-            for _ in range(2):
-                tr.step(*batches[0])
         la, lb, lg = [], [], []
         for x, gt in batches:
             la.append(float(eager_a.step(x, gt)[0]))
