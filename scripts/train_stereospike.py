@@ -21,11 +21,14 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def set_random_seed(seed):                       # train.py:35-53
+def set_random_seed(seed, deterministic=False):   # train.py:35-53
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
+    if deterministic:                            # train.py:41-50 (cudnn.deterministic, benchmark off, use_deterministic_algorithms)
+        from stereospike_amd.engine import set_deterministic
+        set_deterministic(True)
 
 
 def main():
@@ -43,16 +46,20 @@ def main():
     ap.add_argument('--graph', type=int, default=-1,
                     help='replay each training iteration as one HIP graph (engine.GraphedTrainer): 1 on, 0 off, -1 (default) on for '
                          'single-GPU runs with batch * T <= 16, where an iteration is host-bound (the reference trains at batch 1)')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='the reference\'s reproducibility switch (train.py:35-50): deterministic MIOpen solvers, no find mode, no TunableOp '
+                         'record; two runs are bit-identical (slower)')
     a = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', 1), ('RANK', 0), ('LOCAL_RANK', 0)))
     torch.cuda.set_device(local)
     from stereospike_amd import gemm_tuning
-    gemm_tuning.enable(local)                                  # tracked GEMM-algorithm record, read-only
+    if not a.deterministic:
+        gemm_tuning.enable(local)                              # tracked GEMM-algorithm record, read-only
     device = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group('nccl', device_id=device)
-    set_random_seed(2021)
+    set_random_seed(2021, a.deterministic)
 
     from stereospike_amd.clock_driven import surrogate
     from stereospike_amd.dp import GradientAllReducer

@@ -18,6 +18,22 @@ def synthetic_batch(B, T, C=4, H=260, W=346, seed=2021, device='cpu', lam=0.05, 
     return x.to(device), gt.to(device)
 
 
+def set_deterministic(on: bool = True):
+    """The reference's reproducibility switch (/root/reference/train.py:35-50: cudnn.deterministic = True, cudnn.benchmark = False,
+    torch.use_deterministic_algorithms(True)) for the MI355X engine.  With it on, MIOpen is asked for deterministic solvers (no atomic
+    split-K weight gradients) and runs without its timing-based find mode, the GEMM algorithm record (TunableOp) is not consulted, and
+    torch refuses non-deterministic kernels; the engine's own kernels are deterministic by construction (integer counters, fixed-order
+    reductions for dL/dk, loss sums and split-K weight gradients).  Two runs of a training step from the same state are then
+    bit-identical (tests/test_gpu_model.py::test_deterministic_mode); slower than the default (measured in profiles/)."""
+    torch.backends.cudnn.deterministic = bool(on)
+    if on:
+        torch.backends.cudnn.benchmark = False
+    torch.use_deterministic_algorithms(bool(on), warn_only=False)
+    if torch.cuda.is_available() and hasattr(torch.cuda, 'tunable'):
+        if on:
+            torch.cuda.tunable.enable(False)
+
+
 class _null:
     def __enter__(self):
         return self

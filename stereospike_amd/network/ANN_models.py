@@ -1,6 +1,7 @@
 """The analog twin of StereoSpike (/root/reference/network/ANN_models.py:9-152): identical topology with biased
 encoder convs, an activation and BatchNorm after every conv, and the same non-firing I-neuron read-out pool
-(:111,:130-146).  Only that pool touches the neuron engine (one fused launch for the 4 heads)."""
+(:111,:130-146).  Only that pool touches the neuron engine (one fused launch for the 4 heads); on CPU tensors (BASELINE config 1) the
+whole model is plain torch."""
 import torch
 from torch import nn
 
@@ -61,11 +62,23 @@ class StereoSpike_equivalentANN(AnalogNet):
         for i in range(1, 5):
             enc.append(getattr(self, f'conv{i}')(enc[-1]))
         cur = self.bottleneck(enc[4])
+        pool = self.Ineurons
+        if not frame.is_cuda:
+            # BASELINE.json config 1 ("CPU PyTorch ... plumbing, no GPU, no LIF state"): the analog twin has no spiking state and no
+            # fused-kernel work — its read-out pool is four fp32 additions — so on CPU tensors it runs as plain torch ops in the
+            # reference's own order (ANN_models.py:130-146: two-op up-convs, v = v + head for heads 4, 3, 2, 1).  This is NOT a fallback
+            # of the HIP hot path (the spiking models still refuse CPU tensors).
+            v, depths = pool.v, []
+            for lvl in (4, 3, 2, 1):
+                cur = getattr(self, f'deconv{lvl}')(cur) + enc[lvl - 1]
+                v = v + getattr(self, f'predict_depth{lvl}')(cur)
+                depths.append(v)
+            pool.v = v
+            return depths[::-1]
         heads = []
         for lvl in (4, 3, 2, 1):
             cur = getattr(self, f'deconv{lvl}')(cur) + enc[lvl - 1]
             heads.append(getattr(self, f'predict_depth{lvl}')[0].forward_projected(cur))
-        pool = self.Ineurons
         depth = ipool(torch.stack(heads).unsqueeze(1), 1.0, pool.v_reset, pool._v_init(heads[0]))[0]
         pool.v = depth[3]
         return [depth[3], depth[2], depth[1], depth[0]]

@@ -440,3 +440,34 @@ def test_graphed_trainer_matches_the_eager_trainer():
         assert dev_loss <= 4 * floor_loss + 2e-2, (T, la, lb, lg)
         assert 1 - dev_cos <= 4 * (1 - floor_cos) + 5e-2, (T, dev_cos, floor_cos)
         assert abs(float(ua.norm() / ug.norm()) - 1) <= 0.05, (T, float(ua.norm()), float(ug.norm()))
+
+
+def test_deterministic_mode():
+    """engine.set_deterministic (the reference's train.py:35-50 switch): two training steps from identical state on identical data
+    give bit-identical losses, gradients and updated weights, at T = 5 with every fused kernel on the path (forked gradients, dL/dk
+    reduction, exact-split weight gradients with split-K, fused loss)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+from stereospike_amd import miopen_cache; miopen_cache.enable_hermetic()
+from stereospike_amd.engine import Trainer, set_deterministic, synthetic_batch
+from _models import product
+set_deterministic(True)
+x, gt = synthetic_batch(2, 5, H=64, W=80, seed=5, device='cuda:0', lam=0.08)
+out = []
+for rep in range(2):
+    torch.manual_seed(7)
+    net = product('PLIFNet', input_size=(64, 80)).to('cuda:0')
+    tr = Trainer(net, lr=1e-3)
+    losses = [tr.step(x, gt)[0].clone() for _ in range(3)]
+    out.append((losses, [p.detach().clone() for p in net.parameters()]))
+(l0, p0), (l1, p1) = out
+assert all(torch.equal(a, b) for a, b in zip(l0, l1)), (l0, l1)
+assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+print('DETERMINISTIC_OK', [float(v) for v in l0])
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    # own process: torch.use_deterministic_algorithms / TunableOp state must not leak into the other tests
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'DETERMINISTIC_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -186,3 +186,31 @@ def test_graph_helpers_refuse_cpu_loudly():
         GraphedInference(net, torch.zeros(1, 1, 4, 8, 8))
     with pytest.raises(AssertionError, match='MI355X'):
         GraphedTrainer(net)
+
+
+def test_config1_equivalent_ann_runs_on_cpu_and_equals_the_oracle():
+    """BASELINE.json configs[0]: StereoSpike_equivalentANN, monocular-sized plumbing case, batch 1, 64x64 synthetic voxels, CPU
+    PyTorch.  The analog twin has no spiking state: on CPU tensors the product model is plain torch ops in the reference's order and
+    must equal the oracle network (itself pinned to the reference's ANN_models.py by model_ann_T1.npz) bit for bit, forward and backward."""
+    import torch
+    from _util import ref_network as rn, sj, synth_input, synth_label
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.ANN_models import StereoSpike_equivalentANN
+    from stereospike_amd.network.loss import Total_Loss
+    torch.manual_seed(2021)
+    orc = rn.build('ANN', input_size=(64, 64))
+    net = StereoSpike_equivalentANN(input_size=(64, 64))
+    net.load_state_dict(orc.state_dict())
+    x, gt = synth_input(1, 1, 4, 3, 64, 64, lam=0.1), synth_label(1, 4, 64, 64)
+    sj.reset_net(orc)
+    functional.reset_net(net)
+    d0, d1 = orc(x), net(x)
+    assert all(torch.equal(a, b) for a, b in zip(d0, d1))
+    rn.total_loss(d0, gt).backward()
+    Total_Loss()(d1, gt, None).backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), orc.named_parameters()):
+        # the product's Total_Loss evaluates the same sums without boolean-index gathers (another fp32 order)
+        assert float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)) <= 1e-4, k
+    # stateful second call (membrane of the read-out pool carried) and reset
+    d0b, d1b = orc(x), net(x)
+    assert all(torch.equal(a, b) for a, b in zip(d0b, d1b)) and not torch.equal(d1b[0], d1[0])
