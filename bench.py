@@ -103,6 +103,8 @@ def parse():
                     help='1: replay the whole training iteration as one HIP graph (engine.GraphedTrainer; single GPU, for small host-bound '
                          'steps such as config 2: --T 1 --batch 8); the per-kernel roofline legs are not available in this mode')
     ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
+    ap.add_argument('--fused-mfma', type=int, default=1, help='1 (default): deconv1 / deconv2 forward as ONE hand-written MFMA kernel (projection + gather, P only in LDS); 0: GEMM + gather kernel')
+    ap.add_argument('--pack-spikes', type=int, default=1, help='1 (default): 2-bit packed spike tensors on the edges whose consumers read them')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
     return ap.parse_args()
@@ -203,6 +205,8 @@ def main():
     from stereospike_amd import fused as _fused_cfg
     _fused_cfg.RECOMPUTE_H = bool(a.recompute_h)
     _fused_cfg.EXACT_SPLIT_GEMM = bool(a.exact_split)
+    _fused_cfg.FUSED_UPCONV_MFMA = bool(a.fused_mfma)
+    _fused_cfg.PACK_SPIKES = bool(a.pack_spikes)
     if a.split_wgrad_min_k is not None:
         _fused_cfg.EXACT_SPLIT_WGRAD_MIN_K = a.split_wgrad_min_k
     if a.spike_wgrad_split is not None:
@@ -344,6 +348,9 @@ def main():
                                               / max(1, sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_bwd'))), 1)},
             'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
+            # the up-conv stages one by one (projection GEMM + gather, resp. adjoint + dgrad / wgrad GEMMs), keyed by output elements
+            'upconv_by_stage_ms_per_step': {f'{k[0]}:{k[1]}': round(v['ms'] / a.steps, 3) for k, v in sorted(shapes.items(), key=lambda kv: -kv[0][1])
+                                            if k[0].startswith('upconv')},
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }

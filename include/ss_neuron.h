@@ -224,6 +224,26 @@ int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB
                              int ho, int wo, void* stream);
 
 /*
+ * FUSED projection + gather of NNConvUpsampling (forward) on the bf16 matrix cores — the hand-written MFMA kernel of the decoder
+ * stages (/root/reference/network/blocks.py:110-132; SNN_models.py:110-129).  Same map as a projection GEMM followed by
+ * ss_upconv_cl_fwd_f32, but the per-tap projection tensor P (25 * C_out floats per SOURCE pixel) lives only in LDS: a workgroup owns a
+ * 16 x 16 tile of output pixels, builds P for the tile's source window (<= 128 low-resolution pixels) with v_mfma_f32_32x32x16_bf16 —
+ * x is a spike tensor (values 0..3, exact in bf16; fp32 NHWC array `x` or the 2-bit packed form `x_packed`), the fp32 weight is split
+ * exactly into three bf16 terms, fp32 accumulation — and gathers the 25 taps from LDS.  Value: fp32-GEMM accuracy (exact products,
+ * fp32 accumulation order: channels within a split, splits hi/mid/lo, then taps in (ky, kx) order).
+ *   ss_upconv_fused_supported(C_in, C_out, k): the compiled stage shapes ((64, 32) and (128, 64), k = 5 — deconv1 / deconv2).
+ *   ss_upconv_fused_prep_w: W [C_out][C_in][5][5] fp32 -> Wf, the 3-way-split weights in MFMA B-fragment order
+ *                           (ss_upconv_fused_wf_elems(C_in, C_out) bf16 elements; redo after every weight update).
+ *   ss_upconv_fused_fwd_f32: out [NB][H][W][C_out] fp32.  max_window = the largest (source rows x source columns) window any 16 x 16 tile
+ *                           needs, computed by the caller from the tables; SS_EINVAL if it exceeds 128 (use the unfused form then).
+ */
+int ss_upconv_fused_supported(int Cin, int Cout, int k);
+long long ss_upconv_fused_wf_elems(int Cin, int Cout);
+int ss_upconv_fused_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream);
+int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
+                            long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
+
+/*
  * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing
  * IF membrane that the K predict_depth heads charge in the order K-1..0 of the reference's forward
  * (predict_depth4 first), every time step.  pd_seq element (t,k,m) is at pd_seq[t*stride_t + k*stride_k + m],

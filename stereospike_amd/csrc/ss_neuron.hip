@@ -1227,13 +1227,161 @@ __global__ __launch_bounds__(kBlock) void split3_bf16_kernel(const float* __rest
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 2-bit packed spike tensors (SURVEY.md §8(f) rank 2): readers for the consumers of a packed neuron output
-// ---------------------------------------------------------------------------------------------------
-// code (0..3) -> bf16 bit pattern of the same small integer: 0x0000, 0x3F80, 0x4000, 0x4040
+// code (0..3) of a 2-bit packed spike -> bf16 bit pattern of the same small integer: 0x0000, 0x3F80, 0x4000, 0x4040
 #define SS_CODE_LUT 0x404040003F800000ull
 __device__ __forceinline__ unsigned short code_to_bf16(unsigned c) { return (unsigned short)((SS_CODE_LUT >> (16 * c)) & 0xFFFFu); }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused projection + gather of NNConvUpsampling (forward) on the bf16 matrix cores — the per-tap projection tensor P never reaches HBM.
+// ---------------------------------------------------------------------------------------------------
+// Reference: /root/reference/network/blocks.py:110-132 (UpsamplingNearest2d(size = up + k - 1) -> Conv2d(k = 5, stride 1, pad 0)),
+// call sites SNN_models.py:110-129 (deconv4..1).  Math as in ss_upconv_cl_fwd_f32: out[y][x][co] = sum_{ky,kx} P[src_y[y+ky]][src_x[x+kx]][ky,kx][co],
+// P[s][tap][co] = sum_ci x[s][ci] W[co][ci][tap].  One workgroup (4 wavefronts) owns a 16 x 16 tile of OUTPUT pixels of one frame:
+//   1. its source window (<= 128 low-resolution pixels, all C_in channels) is loaded straight into MFMA A fragments (spikes are exact in bf16);
+//   2. per pass over 8 output channels: P_tile[128 sources][25 taps x 8 channels] = A (bf16) x W (fp32 split EXACTLY into 3 bf16 terms,
+//      fragment-ordered by ss_upconv_fused_prep_w, streamed from L2) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: every product is
+//      exact, so P has fp32-GEMM accuracy (sum of exact products, fp32 accumulate) at the bf16 MFMA rate;
+//   3. the accumulators go to LDS (100 KiB), every lane gathers its pixel's 25 taps x 8 channels from LDS in the tap order of the unfused
+//      kernel and stores 32 B of the NHWC output.
+// HBM traffic: x once (+ halo), weights from L2, out once — instead of writing and re-reading P (25 x C_out floats per source pixel:
+// 5.76 GB per step for deconv1 at config 3).  MFMA work: ~1.6x the minimal projection (source-window halo + tile padding), still
+// ~2.5x less than the direct 25-tap convolution.
+constexpr int kFusT = 16;                     // output tile edge
+constexpr int kFusS = 128;                    // max source pixels per tile (4 M-tiles of 32)
+constexpr int kFusCC = 8;                     // output channels per pass
+constexpr int kFusNP = 25 * kFusCC;           // P columns per pass (200)
+constexpr int kFusNT = (kFusNP + 31) / 32;    // N tiles of 32 (7; the last one is a quarter full)
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// W [C_out][C_in][5][5] fp32 -> MFMA B fragments: Wf[pass][kstep][ntile][lane][8] bf16, pass = 8 output channels, kstep over K = 3 * C_in
+// (split-major: all of hi, then mid, then lo), element e of lane l = B[k = 16 kstep + 8 (l >> 5) + e][n = 32 ntile + (l & 31)], n = tap * 8 + c.
+__global__ __launch_bounds__(kBlock) void upconv_fused_prep_w_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wf, int Cin, int Cout)
+{
+    const int ksteps = 3 * Cin / 16, passes = Cout / kFusCC;
+    const long long total = (long long)passes * ksteps * kFusNT * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int nt = (int)(r % kFusNT); r /= kFusNT;
+        const int ks = (int)(r % ksteps); const int pass = (int)(r / ksteps);
+        const int n = 32 * nt + (lane & 31);
+        u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < kFusNP) {
+            const int tap = n / kFusCC, co = pass * kFusCC + (n % kFusCC);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * ks + 8 * (lane >> 5) + e;
+                const int split = k / Cin, ci = k - split * Cin;
+                const float wv = Wt[((long long)co * Cin + ci) * 25 + tap];
+                const unsigned short bh = narrow<SS_DT_BF16>(wv);
+                const float r1 = wv - widen<SS_DT_BF16>(bh);
+                const unsigned short bm = narrow<SS_DT_BF16>(r1);
+                const float r2 = r1 - widen<SS_DT_BF16>(bm);
+                o[e] = split == 0 ? bh : (split == 1 ? bm : narrow<SS_DT_BF16>(r2));
+            }
+        }
+        *reinterpret_cast<u16x8*>(Wf + i * 8) = o;
+    }
+}
+
+template <int CIN, int COUT, bool PACKED>
+__global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wf,
+                                                                  const int* __restrict__ src_y, const int* __restrict__ src_x,
+                                                                  float* __restrict__ out, int h, int w, int H, int W, int tiles_x, int tiles_y)
+{
+    constexpr int KC = CIN / 16;                      // ci chunks of 16
+    constexpr int KSTEPS = 3 * KC;
+    constexpr int PASSES = COUT / kFusCC;
+    __shared__ float Pt[kFusS * kFusNP];             // 102 400 B
+    const int tile = blockIdx.x % (tiles_x * tiles_y), img = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = (tile / tiles_x) * kFusT, x0 = (tile % tiles_x) * kFusT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // source window of the tile (tables are monotone): rows src_y[y0] .. src_y[last window row], same for columns
+    const int sy0 = src_y[y0], sx0 = src_x[x0];
+    const int SH = src_y[min(y0 + kFusT - 1, H - 1) + 4] - sy0 + 1, SW = src_x[min(x0 + kFusT - 1, W - 1) + 4] - sx0 + 1;
+    // ---- 1. A fragments of this wavefront's 32 source pixels: row i = lane & 31, channels 16 j + 8 (lane >> 5) .. + 7
+    const int srow = 32 * wave + (lane & 31);
+    s16x8 afrag[KC];
+    {
+        const bool valid = srow < SH * SW;
+        const int ly = valid ? srow / SW : 0, lx = valid ? srow - ly * SW : 0;
+        const long long pix = ((long long)img * h + (sy0 + ly)) * w + (sx0 + lx);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            s16x8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid) {
+                const long long e = pix * CIN + 16 * j + 8 * (lane >> 5);
+                if constexpr (PACKED) {
+                    const unsigned bits = (static_cast<const unsigned*>(xin)[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = (short)code_to_bf16((bits >> (2 * q)) & 3u);
+                } else {
+                    const float* xp = static_cast<const float*>(xin) + e;
+                    const f4 lo = *reinterpret_cast<const f4*>(xp), hi = *reinterpret_cast<const f4*>(xp + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a[q] = (short)(__float_as_uint(lo[q]) >> 16); a[4 + q] = (short)(__float_as_uint(hi[q]) >> 16); }   // spikes: exact
+                }
+            }
+            afrag[j] = a;
+        }
+    }
+    const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+    const int y = y0 + py, x = x0 + px;
+    const bool inside = y < H && x < W;
+    int soff[25];                                                       // LDS row offset of every tap's source pixel
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        const int ly = inside ? src_y[y + ky] - sy0 : 0;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) soff[ky * 5 + kx] = (ly * SW + (inside ? src_x[x + kx] - sx0 : 0)) * kFusNP + (ky * 5 + kx) * kFusCC;
+    }
+    for (int pass = 0; pass < PASSES; ++pass) {
+        // ---- 2. P_tile rows 32 wave .. + 31, all 200 columns of this pass
+        f32x16 acc[kFusNT];
+#pragma unroll
+        for (int t = 0; t < kFusNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const s16x8* bp = reinterpret_cast<const s16x8*>(Wf) + ((long long)pass * KSTEPS * kFusNT) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < kFusNT; ++t) {
+                const s16x8 b = bp[(ks * kFusNT + t) * 64];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks % KC], b, acc[t], 0, 0, 0);
+            }
+        }
+        if (pass) __syncthreads();                                       // the previous pass's gather is done with Pt
+        // ---- 3a. accumulators -> LDS: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+        for (int t = 0; t < kFusNT; ++t) {
+            const int col = 32 * t + (lane & 31);
+            if (col < kFusNP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Pt[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kFusNP + col] = acc[t][r];
+            }
+        }
+        __syncthreads();
+        // ---- 3b. gather: taps in (ky, kx) order — the unfused kernel's summation order
+        if (inside) {
+            f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tp = 0; tp < 25; ++tp) {
+                s0 += *reinterpret_cast<const f4*>(&Pt[soff[tp]]);
+                s1 += *reinterpret_cast<const f4*>(&Pt[soff[tp] + 4]);
+            }
+            float* op = out + (((long long)img * H + y) * W + x) * COUT + pass * kFusCC;
+            *reinterpret_cast<f4*>(op) = s0;
+            *reinterpret_cast<f4*>(op + 4) = s1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2-bit packed spike tensors (SURVEY.md §8(f) rank 2): readers for the consumers of a packed neuron output
+// ---------------------------------------------------------------------------------------------------
 // packed [n_words] -> dense values.  OUT: 0 = fp32, SS_DT_F16, SS_DT_BF16.  A lane expands one byte (4 neurons); `copies` > 1 writes the
 // same 4 values `copies` times with stride `copy_stride` elements: the [X X X] operand of the K-concatenated exact bf16x3 GEMM, where
 // a row of C values is followed by its two repetitions (row length C, copies = 3, copy_stride = C, rows become 3*C long).
@@ -1931,6 +2079,47 @@ int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB
     if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
     hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), x_packed, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_fused_supported(int Cin, int Cout, int k)
+{
+    return k == 5 && ((Cin == 64 && Cout == 32) || (Cin == 128 && Cout == 64));
+}
+
+long long ss_upconv_fused_wf_elems(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % kFusCC) return 0;
+    return (long long)(Cout / kFusCC) * (3 * Cin / 16) * kFusNT * 64 * 8;
+}
+
+int ss_upconv_fused_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream)
+{
+    if (!W || !Wf || !ss_upconv_fused_wf_elems(Cin, Cout) || !aligned16(Wf)) return SS_EINVAL;
+    hipLaunchKernelGGL(upconv_fused_prep_w_kernel, dim3(grid_for(ss_upconv_fused_wf_elems(Cin, Cout) / 8, 4096)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), W, static_cast<unsigned short*>(Wf), Cin, Cout);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
+                            long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream)
+{
+    if ((!x && !x_packed) || !Wf || !src_y || !src_x || !out || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (!ss_upconv_fused_supported(Cin, Cout, 5) || max_window <= 0 || max_window > kFusS) return SS_EINVAL;
+    if (!aligned16(Wf) || !aligned16(out) || (x && !aligned16(x))) return SS_EINVAL;
+    if (x_packed && (NB * h * w * Cin) % 16 != 0) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    const int tx = (W + kFusT - 1) / kFusT, ty = (H + kFusT - 1) / kFusT;
+    const long long blocks = NB * tx * ty;
+    if (blocks > 0x7fffffffLL || NB * H * W * (long long)Cout > 0x7fffffffffLL) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned short* wf = static_cast<const unsigned short*>(Wf);
+#define SS_FUS(CI, CO) do { if (x_packed) hipLaunchKernelGGL((upconv_fused_fwd_kernel<CI, CO, true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, \
+                                                             static_cast<const void*>(x_packed), wf, src_y, src_x, out, h, w, H, W, tx, ty); \
+                            else hipLaunchKernelGGL((upconv_fused_fwd_kernel<CI, CO, false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, \
+                                                    static_cast<const void*>(x), wf, src_y, src_x, out, h, w, H, W, tx, ty); } while (0)
+    if (Cin == 64) SS_FUS(64, 32); else SS_FUS(128, 64);
+#undef SS_FUS
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

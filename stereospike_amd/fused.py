@@ -466,6 +466,7 @@ WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient G
 # path with fp32 accumulation.  Every product is exact, so the result has the error profile of the fp32 GEMM (same 1e-6 relative
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
 EXACT_SPLIT_GEMM = True
+FUSED_UPCONV_MFMA = True          # decoder stages with a compiled shape (deconv1, deconv2): projection + gather in ONE hand-written MFMA kernel, P never in HBM
 ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
@@ -491,7 +492,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None):
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0):
         # lowp (only under bf16 autocast): the three GEMMs take bf16 operands with fp32 accumulation / output, exactly what
         # autocast does to the MIOpen convs of the encoder (spike inputs are exact in bf16; W and g_P are rounded).
         # P, the gather, its adjoint and every output stay fp32.
@@ -512,6 +513,24 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
         n = max(1, min(NB, P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
         exact = spikes_in and not lowp and EXACT_SPLIT_GEMM and Cin >= EXACT_SPLIT_MIN_K
+        # fused projection + gather on the bf16 matrix cores (P only in LDS): spike inputs, fp32 activations, the compiled stage shapes
+        fused_mfma = (FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and EXACT_SPLIT_GEMM and not half_in
+                      and 0 < max_window <= 128 and _lib.upconv_fused_supported(Cin, Cout, k))
+        if fused_mfma:
+            if ASSERT_EXACT_SPLIT:
+                assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
+            Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=x_cl.device)
+            e0 = TIMER.start()
+            _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout)
+            _lib.upconv_fused_fwd(x_cl, None, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
+            TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
+            ctx.save_for_backward(x_cl, Wt)
+            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+            ctx.exact = True
+            ctx.tables, ctx.k, ctx.n = tables, k, n
+            ctx.wshape = weight.shape
+            ctx.has_bias = False
+            return out
         if lowp:
             xg = x_cl if x_cl.dtype == torch.bfloat16 else x_cl.to(torch.bfloat16)
         elif exact or not half_in:
@@ -611,7 +630,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if g_x is not None and g_x.dtype != ctx.x_dtype:
             g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -702,9 +721,12 @@ def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = N
     return _SpikeConvCL.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0], x_packed)
 
 
-def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False):
+def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False,
+                        max_window: int = 0):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
-    spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection."""
+    spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection.
+    max_window: largest source window (rows x columns) of any 16 x 16 output tile (NNConvUpsampling.max_tile_window); > 0 enables the
+    fused MFMA kernel for the stage shapes it is compiled for."""
     amp = x_cl.is_cuda and torch.is_autocast_enabled('cuda')
     adt = torch.get_autocast_dtype('cuda') if amp else None
     lowp = amp and adt == torch.bfloat16
@@ -712,4 +734,4 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
     # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
     act_dtype = adt if (lowp_bwd and k == 5 and ACT16_GATHER) else None
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
-        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window)

@@ -28,5 +28,13 @@ def enable(device_index: int = 0, tuning: bool = False, filename: str = None):
     tn.tuning_enable(bool(tuning))
     tn.set_filename(filename)
     if os.path.exists(filename):
-        tn.read_file(filename)
+        ok = tn.read_file(filename)
+        n = len(tn.get_results()) if hasattr(tn, 'get_results') else -1
+        if ok is False or n == 0:
+            # TunableOp validates the record against the installed hipBLASLt / rocBLAS / ROCm versions and silently ignores it otherwise:
+            # the decoder GEMMs then run on the library heuristic (measured 217 instead of 291 frames/s at config 3)
+            import warnings
+            warnings.warn(f'stereospike_amd.gemm_tuning: the tracked GEMM-algorithm record {SEED} was REJECTED by TunableOp (made with '
+                          f'other library versions?): GEMMs fall back to the library defaults; re-tune with tools/tune_gemms.sh '
+                          f'(bench.py --gemm-tuning 2)', RuntimeWarning)
     return filename

@@ -26,7 +26,8 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
                                   # ABI 2
                                   'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes',
-                                  'ss_im2col_cl_bf16_packed'])
+                                  'ss_im2col_cl_bf16_packed',
+                                  'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():

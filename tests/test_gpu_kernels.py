@@ -847,3 +847,71 @@ def test_x16_forward_every_time_step_count(dt, T, N):
             assert np.array_equal(bits(out.cpu()), ref['out']) and bit_equal(v, ref['v_last'])
             if save_h:
                 assert bit_equal(h, ref['h'])
+
+
+# ======================================================================================================
+# fused projection + gather on the bf16 matrix cores (ss_upconv_fused_fwd_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 3),
+                                                (64, 32, (32, 40), (64, 80), 2), (128, 64, (13, 18), (25, 35), 5), (64, 32, (9, 11), (17, 19), 1)])
+def test_upconv_fused_mfma_forward(Cin, Cout, hw, HW, NB):
+    """The hand-written MFMA kernel == NNConvUpsampling (reference blocks.py:110-132) evaluated in float64, at fp32-GEMM accuracy;
+    == the unfused product path (exact bf16x3 GEMM + gather kernel) to fp32 rounding; packed input == dense input bit for bit;
+    deterministic."""
+    from oracle import np_pack
+    from stereospike_amd import _lib, fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    torch.manual_seed(Cin + hw[0])
+    (h, w), (H, W) = hw, HW
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W))
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(NB, Cin, h, w, generator=g) < 0.35).float() + (torch.rand(NB, Cin, h, w, generator=g) < 0.1).float()   # values 0, 1, 2
+    with torch.no_grad():
+        ref64 = up.double()(x.double())                                                    # [NB, Cout, H, W] float64
+    up = up.float().to(DEV)
+    x_cl = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    win = up.max_tile_window(h, w)
+    assert 0 < win <= 128
+    tables = up._tables(h, w, torch.device(DEV))
+    Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=DEV)
+    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf, Cin, Cout)
+    out = torch.full((NB, H, W, Cout), float('nan'), device=DEV)
+    _lib.upconv_fused_fwd(x_cl, None, Wf, tables[0], tables[3], out, NB, Cin, Cout, h, w, H, W, win)
+    got = out.permute(0, 3, 1, 2).double().cpu()
+    scale = float(ref64.abs().max())
+    err = float((got - ref64).abs().max()) / scale
+    assert err <= 2e-6, err                                                                # fp32 accumulation of exact products
+    # unfused product path on the same operands
+    prev = fused.FUSED_UPCONV_MFMA
+    fused.FUSED_UPCONV_MFMA = False
+    try:
+        with torch.no_grad():
+            unf = up.forward_projected_cl(x_cl, spikes_in=True)
+    finally:
+        fused.FUSED_UPCONV_MFMA = prev
+    assert float((unf - out).abs().max()) / scale <= 2e-6
+    with torch.no_grad():                                                                  # and through the module (fused on by default)
+        via = up.forward_projected_cl(x_cl, spikes_in=True)
+    assert torch.equal(via, out)
+    # packed spike input
+    xp = torch.from_numpy(np_pack.pack(x_cl.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
+    out2 = torch.empty_like(out)
+    _lib.upconv_fused_fwd(None, xp, Wf, tables[0], tables[3], out2, NB, Cin, Cout, h, w, H, W, win)
+    assert torch.equal(out2, out)
+    out3 = torch.empty_like(out)
+    _lib.upconv_fused_fwd(x_cl, None, Wf, tables[0], tables[3], out3, NB, Cin, Cout, h, w, H, W, win)
+    assert torch.equal(out3, out)
+
+
+def test_upconv_fused_mfma_argument_validation():
+    from stereospike_amd import _lib
+    assert _lib.upconv_fused_supported(64, 32, 5) and _lib.upconv_fused_supported(128, 64, 5)
+    assert not _lib.upconv_fused_supported(256, 128, 5) and not _lib.upconv_fused_supported(64, 32, 3)
+    x = torch.zeros(1, 4, 4, 64, device=DEV)
+    Wf = torch.zeros(_lib.upconv_fused_wf_elems(64, 32), dtype=torch.bfloat16, device=DEV)
+    t = torch.zeros(64, dtype=torch.int32, device=DEV)
+    out = torch.empty(1, 8, 8, 32, device=DEV)
+    with pytest.raises(_lib.SSNeuronError):                                  # window larger than the LDS tile
+        _lib.upconv_fused_fwd(x, None, Wf, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 129)
+    with pytest.raises(_lib.SSNeuronError):                                  # not a compiled stage shape
+        _lib.upconv_fused_fwd(torch.zeros(1, 4, 4, 32, device=DEV), None, Wf, t[:12], t[:12], out, 1, 32, 32, 4, 4, 8, 8, 64)
