@@ -490,8 +490,7 @@ def im2col_cl_bf16_packed(x_packed, A, NB, h, w, C_, k, stride, pad, ho, wo):
         rc = lib().ss_im2col_cl_bf16_packed(_ptr(x_packed, 'x_packed', NB * h * w * C_ // 16),
                                             _x16(A, 'A', NB * ho * wo * k * k * C_, torch.bfloat16), NB, h, w, C_, k, stride, pad, ho, wo,
                                             _stream(x_packed))
-    _check(rc, 'ss_im2col_cl_bf16_packed',
-           'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32')
+    _check(rc, 'ss_im2col_cl_bf16_packed')
 
 
 def upconv_fused_supported(Cin, Cout, k):
