@@ -1285,25 +1285,31 @@ __global__ __launch_bounds__(kBlock) void upconv_fused_prep_w_kernel(const float
     }
 }
 
+constexpr int kFusPS = 204;                   // LDS row stride of the P tile in floats: conflict-free 16-B writes (8-lane groups) and reads
+
+// Work split inside the workgroup: wavefront w owns the P COLUMN tiles {w, w + 4} (weights stationary in its registers for a
+// (pass, split) chunk, prefetched one chunk ahead) and runs them against all four 32-pixel source tiles; the product is taken as
+// P^T = W^T x^T (weights as the MFMA A operand) so that a lane ends up with 4 CONSECUTIVE columns of one source pixel -> 16-B LDS stores.
 template <int CIN, int COUT, bool PACKED>
 __global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wf,
                                                                   const int* __restrict__ src_y, const int* __restrict__ src_x,
                                                                   float* __restrict__ out, int h, int w, int H, int W, int tiles_x, int tiles_y)
 {
-    constexpr int KC = CIN / 16;                      // ci chunks of 16
+    constexpr int KC = CIN / 16;                      // ci chunks of 16 = MFMA k-steps per split
     constexpr int KSTEPS = 3 * KC;
     constexpr int PASSES = COUT / kFusCC;
-    __shared__ float Pt[kFusS * kFusNP];             // 102 400 B
+    constexpr int MT = kFusS / 32;                    // 4 source tiles
+    __shared__ float Pt[kFusS * kFusPS];             // 104 448 B
     const int tile = blockIdx.x % (tiles_x * tiles_y), img = blockIdx.x / (tiles_x * tiles_y);
     const int y0 = (tile / tiles_x) * kFusT, x0 = (tile % tiles_x) * kFusT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // source window of the tile (tables are monotone): rows src_y[y0] .. src_y[last window row], same for columns
     const int sy0 = src_y[y0], sx0 = src_x[x0];
     const int SH = src_y[min(y0 + kFusT - 1, H - 1) + 4] - sy0 + 1, SW = src_x[min(x0 + kFusT - 1, W - 1) + 4] - sx0 + 1;
-    // ---- 1. A fragments of this wavefront's 32 source pixels: row i = lane & 31, channels 16 j + 8 (lane >> 5) .. + 7
-    const int srow = 32 * wave + (lane & 31);
-    s16x8 afrag[KC];
-    {
+    // ---- 1. x fragments (MFMA B operand: column = source pixel 32 m + (lane & 31), k = channels 16 j + 8 (lane >> 5) .. + 7), all 4 source tiles
+    s16x8 xf[MT][KC];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int srow = 32 * m + (lane & 31);
         const bool valid = srow < SH * SW;
         const int ly = valid ? srow / SW : 0, lx = valid ? srow - ly * SW : 0;
         const long long pix = ((long long)img * h + (sy0 + ly)) * w + (sx0 + lx);
@@ -1323,44 +1329,72 @@ __global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __
                     for (int q = 0; q < 4; ++q) { a[q] = (short)(__float_as_uint(lo[q]) >> 16); a[4 + q] = (short)(__float_as_uint(hi[q]) >> 16); }   // spikes: exact
                 }
             }
-            afrag[j] = a;
+            xf[m][j] = a;
         }
     }
     const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
     const int y = y0 + py, x = x0 + px;
     const bool inside = y < H && x < W;
-    int soff[25];                                                       // LDS row offset of every tap's source pixel
+    int soff[25];                                                       // LDS offset of every tap's (source pixel, first channel of the tap)
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
         const int ly = inside ? src_y[y + ky] - sy0 : 0;
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) soff[ky * 5 + kx] = (ly * SW + (inside ? src_x[x + kx] - sx0 : 0)) * kFusNP + (ky * 5 + kx) * kFusCC;
+        for (int kx = 0; kx < 5; ++kx) soff[ky * 5 + kx] = (ly * SW + (inside ? src_x[x + kx] - sx0 : 0)) * kFusPS + (ky * 5 + kx) * kFusCC;
     }
-    for (int pass = 0; pass < PASSES; ++pass) {
-        // ---- 2. P_tile rows 32 wave .. + 31, all 200 columns of this pass
-        f32x16 acc[kFusNT];
+    const bool two = wave + 4 < kFusNT;                                  // wave 3 owns one column tile only (7 tiles)
+    const s16x8* wbase = reinterpret_cast<const s16x8*>(Wf) + lane;
+    // weight fragments of one (pass, split) chunk: [column tile 0 / 1][k-step]
+    auto load_chunk = [&](s16x8 (&dst)[2][KC], int pass, int split) {
 #pragma unroll
-        for (int t = 0; t < kFusNT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        const s16x8* bp = reinterpret_cast<const s16x8*>(Wf) + ((long long)pass * KSTEPS * kFusNT) * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-            for (int t = 0; t < kFusNT; ++t) {
-                const s16x8 b = bp[(ks * kFusNT + t) * 64];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks % KC], b, acc[t], 0, 0, 0);
-            }
+        for (int j = 0; j < KC; ++j) {
+            const long long ks = (long long)pass * KSTEPS + split * KC + j;
+            dst[0][j] = wbase[(ks * kFusNT + wave) * 64];
+            dst[1][j] = two ? wbase[(ks * kFusNT + wave + 4) * 64] : (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
+    };
+    s16x8 wA[2][KC], wB[2][KC];
+    load_chunk(wA, 0, 0);
+    for (int pass = 0; pass < PASSES; ++pass) {
+        // ---- 2. P^T tiles: rows = columns n of P (this wave's tiles), columns = source pixels
+        f32x16 acc[2][MT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+        auto mma = [&](const s16x8 (&wf)[2][KC]) {
+#pragma unroll
+            for (int j = 0; j < KC; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][j], xf[m][j], acc[0][m], 0, 0, 0);
+                    if (two) acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][j], xf[m][j], acc[1][m], 0, 0, 0);
+                }
+        };
+        load_chunk(wB, pass, 1);
+        mma(wA);                                                         // split hi
+        load_chunk(wA, pass, 2);
+        mma(wB);                                                         // split mid
+        if (pass + 1 < PASSES) load_chunk(wB, pass + 1, 0);              // lands during the LDS phases below
+        mma(wA);                                                         // split lo
         if (pass) __syncthreads();                                       // the previous pass's gather is done with Pt
-        // ---- 3a. accumulators -> LDS: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        // ---- 3a. accumulators -> LDS.  C layout of P^T: column (source) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5):
+        //          registers 4 q .. 4 q + 3 are 4 consecutive n of one source pixel
 #pragma unroll
-        for (int t = 0; t < kFusNT; ++t) {
-            const int col = 32 * t + (lane & 31);
-            if (col < kFusNP) {
+        for (int t = 0; t < 2; ++t) {
+            if (t == 0 || two) {
+                const int nt = wave + 4 * t;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Pt[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kFusNP + col] = acc[t][r];
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = 32 * nt + 8 * q + 4 * (lane >> 5);
+                        if (n < kFusNP)
+                            *reinterpret_cast<f4*>(&Pt[(32 * m + (lane & 31)) * kFusPS + n]) =
+                                (f4){acc[t][m][4 * q], acc[t][m][4 * q + 1], acc[t][m][4 * q + 2], acc[t][m][4 * q + 3]};
+                    }
             }
         }
         __syncthreads();
@@ -1376,6 +1410,10 @@ __global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __
             *reinterpret_cast<f4*>(op) = s0;
             *reinterpret_cast<f4*>(op + 4) = s1;
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) wA[t][j] = wB[t][j];
     }
 }
 
