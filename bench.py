@@ -103,6 +103,8 @@ def parse():
                     help='1: replay the whole training iteration as one HIP graph (engine.GraphedTrainer; single GPU, for small host-bound '
                          'steps such as config 2: --T 1 --batch 8); the per-kernel roofline legs are not available in this mode')
     ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
+    ap.add_argument('--count-rates', type=int, default=0,
+                    help='1: firing-rate counters of all 14 layers inside the training step (BASELINE.json config 5), from the fused kernels')
     ap.add_argument('--fused-mfma', type=int, default=1, help='1 (default): deconv1 / deconv2 forward as ONE hand-written MFMA kernel (projection + gather, P only in LDS); 0: GEMM + gather kernel')
     ap.add_argument('--pack-spikes', type=int, default=1, help='1 (default): 2-bit packed spike tensors on the edges whose consumers read them')
     ap.add_argument('--fuse-upconv', type=int, default=1,
@@ -221,19 +223,13 @@ def main():
     if a.channels_last:
         net = net.to(memory_format=torch.channels_last)
     reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20)), reduce_single_rank=a.force_dp) if use_dp else None
-    trainer = Trainer(net, reducer=reducer)
+    amp_dtype = {'bf16': torch.bfloat16, 'f16': torch.float16}.get(a.dtype)
+    # 16-bit modes: autocast inside Trainer.step; fp16 also scales the loss (torch.amp.GradScaler: fp16 activation gradients would underflow)
+    trainer = Trainer(net, reducer=reducer, amp_dtype=amp_dtype, count_rates=bool(a.count_rates))
     if a.graph:
         assert not use_dp, '--graph is single-GPU'
         from stereospike_amd.engine import GraphedTrainer
-        trainer = GraphedTrainer(net, amp_dtype={'bf16': torch.bfloat16, 'f16': torch.float16}.get(a.dtype))
-    elif a.dtype != 'f32':
-        amp_dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
-        plain_step = trainer.step
-
-        def amp_step(x_, gt_):
-            with torch.autocast('cuda', dtype=amp_dtype):
-                return plain_step(x_, gt_)
-        trainer.step = amp_step
+        trainer = GraphedTrainer(net, amp_dtype=amp_dtype)
     x, gt = synthetic_batch(a.batch, a.T, seed=2021 + rank, device=dev)     # resident in HBM before timing
 
     def sync():
@@ -351,6 +347,7 @@ def main():
             # the up-conv stages one by one (projection GEMM + gather, resp. adjoint + dgrad / wgrad GEMMs), keyed by output elements
             'upconv_by_stage_ms_per_step': {f'{k[0]}:{k[1]}': round(v['ms'] / a.steps, 3) for k, v in sorted(shapes.items(), key=lambda kv: -kv[0][1])
                                             if k[0].startswith('upconv')},
+            'roofline_upconv': _roof_upconv(shapes, a),
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
@@ -379,6 +376,35 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dp:
         dist.destroy_process_group()
+
+
+def _roof_upconv(shapes, a):
+    """The hand-written MFMA kernel of the decoder (ss_upconv_fused_fwd_f32: projection + gather of deconv1, the largest stage) on the
+    HBM roofline by its algorithmic bytes (input spikes + output + weights; P never leaves LDS) and on the bf16 MFMA roofline by the
+    useful FLOPs of the minimal projection (3 exact bf16 terms); HIP-event time of its launches in the timed region (incl. the tiny
+    weight-preparation launch)."""
+    key = [k for k in shapes if k[0] == 'upconv_cl_fwd']
+    if not key:
+        return None
+    k = max(key, key=lambda kk: kk[1])
+    d = shapes[k]
+    if not d['launches']:
+        return None
+    out_elems = k[1]                                   # NB * H * W * C_out of deconv1
+    cout, cin = 32, 64
+    src_px = a.batch * a.T * 130 * 173 if out_elems == a.batch * a.T * 260 * 346 * cout else None
+    if src_px is None:
+        return None
+    nbytes = 4 * (src_px * cin + out_elems) + 2 * 3 * 25 * cin * cout
+    flops = 2.0 * src_px * cin * 25 * cout * 3
+    us = 1e3 * d['ms'] / d['launches']
+    return dict(kernel='upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
+                bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=None,
+                mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
+                          note='useful FLOPs of the minimal projection x 3 exact bf16 terms; the kernel issues ~1.9x that (source-window halo, tile padding)'),
+                note='LDS / latency bound at one 4-wave workgroup per CU (100 KiB P tile); replaces GEMM + P round trip (11.5 GB) + gather',
+                fused=bool(a.fused_mfma))
 
 
 def _pmc_traffic(which='neuron_fwd'):

@@ -14,7 +14,11 @@ mode = sys.argv[2] if len(sys.argv) > 2 else 'rc'
 
 
 def key_of(name):
-    return 'neuron_fwd' if 'neuron_fwd_kernel' in name else 'neuron_bwd' if 'neuron_bwd_kernel' in name else None
+    if 'neuron_fwd_kernel' in name:
+        return 'neuron_fwd_packed' if name.rstrip().rstrip(')').split('(')[0].rstrip().endswith('true>') else 'neuron_fwd'
+    if 'upconv_fused_fwd_kernel' in name:
+        return 'upconv_fused'
+    return 'neuron_bwd' if 'neuron_bwd_kernel' in name else None
 
 
 def mean_counter(sub, counter):
@@ -45,12 +49,16 @@ res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, to
        'o_n_terms_bytes': {'neuron_fwd': 4 * N, 'neuron_bwd': 0},
        'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported; '
                'separate --pmc passes; the forward also writes v_last (4 B x N, an O(N) term outside the per-update figure)'}
-for k in ('neuron_fwd', 'neuron_bwd'):
+alg = {k: v * T * N for k, v in per_update.items()}
+alg['neuron_fwd_packed'] = int(4.25 * T * N)                        # x 4 B + 2-bit packed output 0.25 B per update (no dense output)
+alg['upconv_fused'] = 4 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 3 * 25 * 64 * 32      # deconv1: spikes in + out + split weights
+res['algorithmic_bytes_per_launch'] = alg
+for k in ('neuron_fwd', 'neuron_bwd', 'neuron_fwd_packed', 'upconv_fused'):
     if k in fetch and k in write:
         hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],
                   'hbm_read_bytes': int(2 * fetch[k] * 1024), 'hbm_write_bytes': int(write[k] * 1024),
-                  'hbm_bytes_per_launch': int(hbm), 'ratio_to_algorithmic': round(hbm / (per_update[k] * T * N), 4)}
+                  'hbm_bytes_per_launch': int(hbm), 'ratio_to_algorithmic': round(hbm / alg[k], 4)}
 if 'neuron_fwd' in res:
     res['neuron_fwd_train_bytes_per_launch'] = res['neuron_fwd']['hbm_bytes_per_launch']
 print(json.dumps(res, indent=1))

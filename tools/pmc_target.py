@@ -23,5 +23,20 @@ for _ in range(5):
     else:
         _lib.neuron_fwd(x, None, None, out, h, v, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
         _lib.neuron_bwd(g, None, h, None, gx, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+if mode == 'rc':
+    # round 2: (a) the packed-only forward (x 4 B + packed 0.25 B per update), (b) the fused projection + gather MFMA kernel at the
+    # deconv1 geometry of config 3 (80 frames, 130x173x64 -> 260x346x32)
+    pk = torch.empty(T, N // 16, dtype=torch.int32, device=dev)
+    NB, h, w, H, W, Cin, Cout = 80, 130, 173, 260, 346, 64, 32
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(dev)
+    xs = (torch.rand(NB, h, w, Cin, device=dev) < 0.4).float()
+    tabs = up._tables(h, w, torch.device(dev))
+    Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=dev)
+    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf, Cin, Cout)
+    o = torch.empty(NB, H, W, Cout, device=dev)
+    for _ in range(5):
+        _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.upconv_fused_fwd(xs, None, Wf, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, up.max_tile_window(h, w))
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
