@@ -352,6 +352,10 @@ def main():
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
         # `roofline` = the dominant kernel of the path: whichever of the two fused neuron kernels took more of the timed region
+        if 'fork' in bwd_tag and bwd['ms'] > 0:
+            # SURVEY.md §8(d) prices the backward at 12 B/update (g_out, x, g_x); the forked form also reads the second consumer's gradient
+            # (4 B/update that autograd's accumulation pass would otherwise move 3x): the same launches by that stricter definition
+            out['roofline_bwd']['frac_by_12B_per_update_definition'] = round(12 * bwd['updates'] / 1e9 / (bwd['ms'] / 1e3) / HBM_PEAK_GBS, 4)
         dom_key = 'roofline_bwd' if out['roofline_bwd']['ms_per_step_all_launches_of_this_kernel'] >= \
             out['roofline_fwd']['ms_per_step_all_launches_of_this_kernel'] else 'roofline_fwd'
         out = {**{k: v for k, v in out.items() if k not in ('roofline_fwd', 'roofline_bwd')}, 'roofline': out[dom_key],
@@ -373,9 +377,12 @@ def main():
             out['eval_mde_rel_diff_vs_cpu'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m'])
                                                     / out['cpu_baseline']['eval_mde_m'], 6)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dp:
-        dist.destroy_process_group()
+        dist.destroy_process_group()          # RCCL prints its version banner to stdout around here: keep the JSON line the LAST line
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 def _roof_upconv(shapes, a):

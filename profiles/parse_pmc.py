@@ -15,7 +15,10 @@ mode = sys.argv[2] if len(sys.argv) > 2 else 'rc'
 
 def key_of(name):
     if 'neuron_fwd_kernel' in name:
-        return 'neuron_fwd_packed' if name.rstrip().rstrip(')').split('(')[0].rstrip().endswith('true>') else 'neuron_fwd'
+        import re
+        m = re.search(r'neuron_fwd_kernel<([^>]*)>', name)
+        args = [a.strip() for a in m.group(1).split(',')] if m else []
+        return 'neuron_fwd_packed' if (len(args) >= 6 and args[5] == 'true') else 'neuron_fwd'      # 6th template argument = PK
     if 'upconv_fused_fwd_kernel' in name:
         return 'upconv_fused'
     return 'neuron_bwd' if 'neuron_bwd_kernel' in name else None
