@@ -305,6 +305,7 @@ def main():
         def bpu(d):
             return round(d['bytes'] / d['updates'], 1) if d['updates'] else 0
         recompute_h = bool(_fused.RECOMPUTE_H)
+        packed_on = bool(_fused.PACK_SPIKES) and a.dtype == 'f32' and recompute_h      # the PK instantiations run (2-bit packed outputs / skips)
         out = {
             'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if use_dp else 1, 'steps': a.steps, 'warmup': a.warmup,
@@ -319,7 +320,9 @@ def main():
                                         f'{bpu(fwd)} B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
                                  **roof(fwd),
                                  all_launches_of_this_instantiation=inst(
-                                     ['neuron_fwd_train'], f'neuron_fwd_kernel<0, {a.T}, false, {"false" if recompute_h else "true"}, 4>')),
+                                     ['neuron_fwd_train', 'neuron_fwd_train+packed'],
+                                     f'neuron_fwd_kernel<0, {a.T}, false, false, 4, true>' if packed_on
+                                     else f'neuron_fwd_kernel<0, {a.T}, false, {"false" if recompute_h else "true"}, 4, false>')),
             'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
                                         f'{", h recomputed from the layer input" if recompute_h else ""}'
                                         f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}), largest launch shape',
@@ -336,12 +339,12 @@ def main():
             # HIP-event averages over ALL launches of each kernel instantiation, for comparison with the AverageNs column of
             # the committed `rocprofv3 --kernel-trace --stats` CSV (profiles/): events add a few us per launch
             'rocprof_check_avg_us': {
-                'neuron_fwd_kernel<0, 5, false, %s, 4>' % ('false' if recompute_h else 'true'): round(1e3 * summ['neuron_fwd_train']['ms'] / summ['neuron_fwd_train']['launches'], 1)
-                if 'neuron_fwd_train' in summ else None,
-                'neuron_fwd_kernel<0, 5, true, %s, 4>' % ('false' if recompute_h else 'true'): round(1e3 * summ['neuron_fwd_train+skip']['ms'] / summ['neuron_fwd_train+skip']['launches'], 1)
-                if 'neuron_fwd_train+skip' in summ else None,
-                'neuron_bwd_kernel<*>': round(1e3 * sum(v['ms'] for k, v in summ.items() if k.startswith('neuron_bwd'))
-                                              / max(1, sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_bwd'))), 1)},
+                name: (round(1e3 * sum(summ[t]['ms'] for t in tags if t in summ) / max(1, sum(summ[t]['launches'] for t in tags if t in summ)), 1)
+                       if any(t in summ for t in tags) else None)
+                for name, tags in (
+                    (f'neuron_fwd_kernel<0, {a.T}, false, false, 4, {"true" if packed_on else "false"}>', ['neuron_fwd_train', 'neuron_fwd_train+packed']),
+                    (f'neuron_fwd_kernel<0, {a.T}, true, false, 4, {"true" if packed_on else "false"}>', ['neuron_fwd_train+skip', 'neuron_fwd_train+skip+packed']),
+                    ('neuron_bwd_kernel<*>', [k for k in summ if k.startswith('neuron_bwd')]))},
             'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
             # the up-conv stages one by one (projection GEMM + gather, resp. adjoint + dgrad / wgrad GEMMs), keyed by output elements
