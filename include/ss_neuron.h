@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 2
+#define SS_ABI_VERSION 3
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` to ss_neuron_bwd_f32 when g_k != NULL. */
@@ -242,6 +242,21 @@ long long ss_upconv_fused_wf_elems(int Cin, int Cout);
 int ss_upconv_fused_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream);
 int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
+
+/*
+ * The same map (blocks.py:110-132) and the SAME VALUE bit for bit, second kernel form (ABI 3): persistent workgroups of 8 wavefronts,
+ * four of which run the MFMAs while the other four gather the previous pass of P from a double-buffered LDS pass buffer; the source
+ * window goes once, coalesced, from HBM to LDS as bf16; P is produced in passes of four 32-column tiles (column = tap * C_out + co:
+ * no padding columns); the output pixel's 25-tap sum stays in registers and is written once; workgroups walk XCD-contiguous bands of
+ * tiles.  Own weight layout: ss_upconv_fused2_prep_w -> ss_upconv_fused2_wf_elems(C_in, C_out) = 75 * C_in * C_out bf16 elements.
+ * ss_upconv_fused2_supported(C_in, C_out, k, max_window): the compiled stage shapes with max_window <= 124 source pixels per tile
+ * (the first form covers 125..128).
+ */
+int ss_upconv_fused2_supported(int Cin, int Cout, int k, int max_window);
+long long ss_upconv_fused2_wf_elems(int Cin, int Cout);
+int ss_upconv_fused2_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream);
+int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
+                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
 
 /*
  * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing

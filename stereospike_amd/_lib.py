@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1
@@ -98,6 +98,14 @@ def lib():
     L.ss_upconv_fused_prep_w.restype = i32
     L.ss_upconv_fused_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_fused_fwd_f32.restype = i32
+    L.ss_upconv_fused2_supported.argtypes = [i32, i32, i32, i32]
+    L.ss_upconv_fused2_supported.restype = i32
+    L.ss_upconv_fused2_wf_elems.argtypes = [i32, i32]
+    L.ss_upconv_fused2_wf_elems.restype = i64
+    L.ss_upconv_fused2_prep_w.argtypes = [p, p, i32, i32, p]
+    L.ss_upconv_fused2_prep_w.restype = i32
+    L.ss_upconv_fused2_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_fused2_fwd_f32.restype = i32
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
               L.ss_upconv1_fwd_f32, L.ss_upconv1_bwd_f32, L.ss_upconv_cl_fwd_f32, L.ss_upconv_cl_bwd_f32):
         f.restype = i32
@@ -112,7 +120,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
            'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
            'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed',
-           'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32')
+           'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
+           'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -497,28 +506,42 @@ def upconv_fused_supported(Cin, Cout, k):
     return bool(lib().ss_upconv_fused_supported(int(Cin), int(Cout), int(k)))
 
 
-def upconv_fused_prep_w(weight, Wf, Cin, Cout):
-    """weight [Cout, Cin, 5, 5] fp32 -> Wf (bf16, ss_upconv_fused_wf_elems elements): 3-way split, MFMA B-fragment order."""
+def upconv_fused_form(Cin, Cout, k, max_window):
+    """Which fused MFMA kernel serves this stage: 2 = wavefront-specialised persistent form (max_window <= 124), 1 = first form
+    (max_window <= 128), 0 = none (caller uses GEMM + gather)."""
+    if max_window <= 0:
+        return 0
+    if lib().ss_upconv_fused2_supported(int(Cin), int(Cout), int(k), int(max_window)):
+        return 2
+    return 1 if (max_window <= 128 and upconv_fused_supported(Cin, Cout, k)) else 0
+
+
+def upconv_fused_wf_elems(Cin, Cout, form=1):
+    L = lib()
+    return int((L.ss_upconv_fused2_wf_elems if form == 2 else L.ss_upconv_fused_wf_elems)(int(Cin), int(Cout)))
+
+
+def upconv_fused_prep_w(weight, Wf, Cin, Cout, form=1):
+    """weight [Cout, Cin, 5, 5] fp32 -> Wf (bf16, upconv_fused_wf_elems(form) elements): 3-way split, MFMA fragment order of `form`."""
     _require_hip(weight, 'weight')
-    n = int(lib().ss_upconv_fused_wf_elems(Cin, Cout))
+    n = upconv_fused_wf_elems(Cin, Cout, form)
+    fn = lib().ss_upconv_fused2_prep_w if form == 2 else lib().ss_upconv_fused_prep_w
     with torch.cuda.device(weight.device):
-        rc = lib().ss_upconv_fused_prep_w(_f32(weight, 'weight', Cout * Cin * 25), _x16(Wf, 'Wf', n, torch.bfloat16), Cin, Cout, _stream(weight))
+        rc = fn(_f32(weight, 'weight', Cout * Cin * 25), _x16(Wf, 'Wf', n, torch.bfloat16), Cin, Cout, _stream(weight))
     _check(rc, 'ss_upconv_fused_prep_w')
 
 
-def upconv_fused_wf_elems(Cin, Cout):
-    return int(lib().ss_upconv_fused_wf_elems(int(Cin), int(Cout)))
-
-
-def upconv_fused_fwd(x, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window):
-    """Fused projection + gather (bf16 MFMA, P in LDS only).  x: fp32 NHWC spikes or None; x_packed: int32 packed form or None."""
+def upconv_fused_fwd(x, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form=1):
+    """Fused projection + gather (bf16 MFMA, P in LDS only).  x: fp32 NHWC spikes or None; x_packed: int32 packed form or None.
+    form: kernel form the weights were prepared for (upconv_fused_form)."""
     ref = x if x is not None else x_packed
     _require_hip(ref, 'x')
     if x_packed is not None and x_packed.dtype != torch.int32:
         raise SSNeuronError('x_packed: expected int32')
+    fn = lib().ss_upconv_fused2_fwd_f32 if form == 2 else lib().ss_upconv_fused_fwd_f32
     with torch.cuda.device(ref.device):
-        rc = lib().ss_upconv_fused_fwd_f32(_f32(x, 'x', NB * h * w * Cin), _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
-                                           _x16(Wf, 'Wf', upconv_fused_wf_elems(Cin, Cout), torch.bfloat16), _i32(src_y, 'src_y', H + 4),
-                                           _i32(src_x, 'src_x', W + 4), _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W,
-                                           int(max_window), _stream(ref))
+        rc = fn(_f32(x, 'x', NB * h * w * Cin), _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                _x16(Wf, 'Wf', upconv_fused_wf_elems(Cin, Cout, form), torch.bfloat16), _i32(src_y, 'src_y', H + 4),
+                _i32(src_x, 'src_x', W + 4), _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W,
+                int(max_window), _stream(ref))
     _check(rc, 'ss_upconv_fused_fwd_f32')

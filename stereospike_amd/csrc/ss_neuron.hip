@@ -1418,6 +1418,292 @@ __global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Fused projection + gather, second form: wavefront-specialised persistent workgroups (same value as upconv_fused_fwd_kernel, bit for bit)
+// ---------------------------------------------------------------------------------------------------
+// What bounded the first form (profiles/r02/fused_upconv_ab.log: 22 us per tile against 5 us of MFMA time): (1) every wavefront
+// fetched the whole source window itself, 16 B out of each 128-B line (4x redundant, ~8k L1 line look-ups per tile); (2) MFMA, LDS store
+// and LDS gather phases ran one after the other behind barriers with ONE workgroup per CU (104 KiB LDS, 342 - 508 registers);
+// (3) one workgroup per tile: dispatch, table look-ups and the first loads were exposed 30 000 times per launch.
+// This form:
+//   * persistent workgroups of 8 wavefronts, two per SIMD: 4 PRODUCERS (MFMA) and 4 CONSUMERS (gather); a workgroup walks a contiguous
+//     band of tiles of one XCD (neighbouring tiles share their window halo through that XCD's L2);
+//   * the source window goes ONCE, coalesced, from HBM to LDS as bf16 (row-swizzled 16-B chunks, conflict-free fragment reads);
+//   * P is produced in PASSES of four 32-column tiles (column = tap * C_out + co: no padding columns), one tile per producer wavefront,
+//     weights streamed from L2 straight into that wavefront's registers (each weight fragment is fetched once per tile per CU, three
+//     (pass, split) chunks in flight), product taken transposed (weights as the A operand) so a lane holds 4 consecutive P columns of
+//     one source pixel -> 16-B LDS stores into a double-buffered, swizzled pass buffer;
+//   * while the producers compute pass p + 1 the consumers gather pass p from the other buffer into per-pixel accumulators held in
+//     registers (taps in (ky, kx) order — the summation order of the unfused gather kernel and of the first form), write the tile's
+//     output once, and fetch the NEXT tile's window (loads issued before the last gather, committed to LDS after it).
+// LDS: 2 x 124 x 512 B pass buffers + 124 x C_in x 2 B window = 139.5 KiB (C_in 64) / 155 KiB (C_in 128).
+constexpr int kF2Threads = 512;
+constexpr int kF2Rows = 124;                  // source pixels of a tile held on chip (max_window <= 124, else the first form)
+constexpr int kF2PRowB = 512;                 // bytes of one source pixel's row in a pass buffer: 4 column tiles x 32 channels fp32
+
+// W [C_out][C_in][5][5] fp32 -> Wf2[column tile nt][split][k-step j][lane][8] bf16; column n = 32 nt + (lane & 31) = tap * C_out + co,
+// element e = split term of W[co][ci = 16 j + 8 (lane >> 5) + e][tap]
+__global__ __launch_bounds__(kBlock) void upconv_fused2_prep_w_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wf, int Cin, int Cout)
+{
+    const int KC = Cin / 16, NTL = 25 * Cout / 32;
+    const long long total = (long long)NTL * 3 * KC * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int j = (int)(r % KC); r /= KC;
+        const int split = (int)(r % 3); const int nt = (int)(r / 3);
+        const int n = 32 * nt + (lane & 31);
+        const int tap = n / Cout, co = n - tap * Cout;
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 16 * j + 8 * (lane >> 5) + e;
+            const float wv = Wt[((long long)co * Cin + ci) * 25 + tap];
+            const unsigned short bh = narrow<SS_DT_BF16>(wv);
+            const float r1 = wv - widen<SS_DT_BF16>(bh);
+            const unsigned short bm = narrow<SS_DT_BF16>(r1);
+            const float r2 = r1 - widen<SS_DT_BF16>(bm);
+            o[e] = split == 0 ? bh : (split == 1 ? bm : narrow<SS_DT_BF16>(r2));
+        }
+        *reinterpret_cast<u16x8*>(Wf + i * 8) = o;
+    }
+}
+
+template <int CIN, int COUT, bool PACKED>
+__global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wf,
+                                                                      const int* __restrict__ src_y, const int* __restrict__ src_x,
+                                                                      float* __restrict__ out, int h, int w, int H, int W,
+                                                                      int tiles_x, int tiles_y, int n_tiles)
+{
+    constexpr int KC = CIN / 16;                      // MFMA k-steps per split
+    constexpr int NPT = COUT / 32;                    // column tiles per tap
+    constexpr int NTL = 25 * NPT;                     // column tiles in all (25 / 50: no padding)
+    constexpr int NPASS = (NTL + 3) / 4;              // 7 / 13
+    constexpr int TPP = 4 / NPT;                      // taps per pass (4 / 2)
+    constexpr int XROWB = CIN * 2;                    // bytes of one source pixel in the bf16 window
+    constexpr int XCH = CIN / 8;                      // 16-B chunks per source pixel
+    constexpr int XU = (kF2Rows * XCH + 255) / 256;   // window chunks per consumer lane (4 / 8)
+    constexpr bool XREG = CIN <= 64;                  // producers keep the window fragments in registers across the three splits
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kF2Rows * kF2PRowB + kF2Rows * XROWB];
+    unsigned char* const Xs = smem + 2 * kF2Rows * kF2PRowB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool producer = wave < 4;
+    const int cw = wave & 3;
+    const int tiles_img = tiles_x * tiles_y;
+    // XCD-aware walk: workgroup b runs on XCD b % 8; XCD k owns the contiguous band of tiles [k * per_xcd, (k + 1) * per_xcd)
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int band0 = (int)(blockIdx.x & 7) * per_xcd, slot0 = (int)(blockIdx.x >> 3), slots = (int)(gridDim.x >> 3);
+    const int band_end = min(band0 + per_xcd, n_tiles);
+
+    auto xswz = [](int row) { return CIN <= 64 ? ((row >> 1) & 7) : (row & 15); };
+
+    if (producer) {
+        __builtin_amdgcn_s_setprio(3);
+        // ---- weight stream: chunk (pass, split) of this wavefront's column tile nt = 4 pass + cw sits in buffer `split`; three in flight
+        const s16x8* const wbase = reinterpret_cast<const s16x8*>(Wf) + lane;
+        s16x8 wq[3][KC];
+        auto load_chunk = [&](s16x8 (&dst)[KC], int pass, int split) {
+            const long long c0 = ((long long)(4 * pass + cw) * 3 + split) * KC;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) dst[j] = wbase[(c0 + j) * 64];
+        };
+        const bool any = cw < NTL;                                        // always true (NTL >= 4)
+        if (any) { load_chunk(wq[0], 0, 0); load_chunk(wq[1], 0, 1); load_chunk(wq[2], 0, 2); }
+        __syncthreads();                                                  // first window is in LDS
+        for (int tile = band0 + slot0; tile < band_end; tile += slots) {
+            s16x8 xf[XREG ? 4 : 1][XREG ? KC : 1];
+            auto xfrag = [&](int m, int j) -> s16x8 {
+                const int row = min(32 * m + (lane & 31), kF2Rows - 1);
+                return *reinterpret_cast<const s16x8*>(Xs + row * XROWB + (((2 * j + (lane >> 5)) ^ xswz(row)) << 4));
+            };
+            if constexpr (XREG) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < KC; ++j) xf[m][j] = xfrag(m, j);
+            }
+#pragma unroll 1
+            for (int pass = 0; pass < NPASS; ++pass) {
+                if (4 * pass + cw < NTL) {
+                    const int npass = (4 * (pass + 1) + cw < NTL) ? pass + 1 : 0;     // this wavefront's next pass (wraps into the next tile)
+                    f32x16 acc[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        if constexpr (XREG) {
+#pragma unroll
+                            for (int j = 0; j < KC; ++j)
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s][j], xf[m][j], acc[m], 0, 0, 0);
+                        } else {
+                            // the window fragments are re-read from LDS for every split (32 ds_read_b128, hidden under 32 MFMAs); the
+                            // clobber keeps the compiler from merging the three reads into 128 live registers
+                            asm volatile("" ::: "memory");
+                            s16x8 xc[4], xn[4];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) xc[m] = xfrag(m, 0);
+#pragma unroll
+                            for (int j = 0; j < KC; ++j) {
+                                if (j + 1 < KC) {
+#pragma unroll
+                                    for (int m = 0; m < 4; ++m) xn[m] = xfrag(m, j + 1);
+                                }
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s][j], xc[m], acc[m], 0, 0, 0);
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) xc[m] = xn[m];
+                            }
+                        }
+                        load_chunk(wq[s], npass, s);                              // lands two chunks of MFMA work later
+                    }
+                    // accumulators -> pass buffer.  C layout of P^T: column (source) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                    unsigned char* const Pp = smem + (pass & 1) * (kF2Rows * kF2PRowB);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int row = 32 * m + (lane & 31);
+                        if (row < kF2Rows) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int chunk = cw * 8 + 2 * q + (lane >> 5);
+                                *reinterpret_cast<f4*>(Pp + row * kF2PRowB + ((chunk ^ (row & 15)) << 4)) =
+                                    (f4){acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            __syncthreads();                                              // consumers: last gather, output, next window
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------- consumers
+    const int ct = cw * 64 + lane;                                        // 0..255: pixel (ct >> 4, ct & 15) of the tile
+    const int py = ct >> 4, px = ct & 15;
+    f4 xr[XU][PACKED ? 1 : 2];
+    unsigned xrp[XU];
+    struct Geo { int img, y0, x0, sy0, sx0, SH, SW; };
+    auto geom = [&](int tile) {
+        Geo g;
+        const int t2 = tile % tiles_img;
+        g.img = tile / tiles_img;
+        g.y0 = (t2 / tiles_x) * kFusT; g.x0 = (t2 % tiles_x) * kFusT;
+        g.sy0 = src_y[g.y0]; g.sx0 = src_x[g.x0];
+        g.SH = src_y[min(g.y0 + kFusT - 1, H - 1) + 4] - g.sy0 + 1;
+        g.SW = src_x[min(g.x0 + kFusT - 1, W - 1) + 4] - g.sx0 + 1;
+        return g;
+    };
+    auto window_issue = [&](const Geo& g) {                                // HBM -> registers
+        const int total = g.SH * g.SW * XCH;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int c = ct + 256 * u;
+            if (c < total) {
+                const int row = c / XCH, ch = c - row * XCH;
+                const int ly = row / g.SW, lx = row - ly * g.SW;
+                const long long e = ((((long long)g.img * h + (g.sy0 + ly)) * w) + (g.sx0 + lx)) * CIN + 8 * ch;
+                if constexpr (PACKED) {
+                    xrp[u] = (static_cast<const unsigned*>(xin)[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu;
+                } else {
+                    const float* xp = static_cast<const float*>(xin) + e;
+                    xr[u][0] = *reinterpret_cast<const f4*>(xp);
+                    xr[u][1] = *reinterpret_cast<const f4*>(xp + 4);
+                }
+            }
+        }
+    };
+    auto window_commit = [&](const Geo& g) {                               // registers -> bf16 window in LDS
+        const int total = g.SH * g.SW * XCH;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int c = ct + 256 * u;
+            if (c < total) {
+                const int row = c / XCH, ch = c - row * XCH;
+                s16x8 a;
+                if constexpr (PACKED) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = (short)code_to_bf16((xrp[u] >> (2 * q)) & 3u);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {                          // spikes: exact in bf16
+                        a[q] = (short)(__float_as_uint(xr[u][0][q]) >> 16);
+                        a[4 + q] = (short)(__float_as_uint(xr[u][1][q]) >> 16);
+                    }
+                }
+                *reinterpret_cast<s16x8*>(Xs + row * XROWB + ((ch ^ xswz(row)) << 4)) = a;
+            }
+        }
+    };
+    int tile = band0 + slot0;
+    Geo g = geom(min(tile, n_tiles - 1));
+    if (tile < band_end) { window_issue(g); window_commit(g); }
+    __syncthreads();
+    for (; tile < band_end; tile += slots) {
+        // ---- step 0 (producers compute pass 0): per-pixel tables.  tab: source row (ly * SW + lx) of every tap, one byte each, tap 0 in
+        //      the low byte of tab[0]; consumed from the bottom, TPP bytes per pass
+        const int y = g.y0 + py, x = g.x0 + px;
+        const bool inside = y < H && x < W;
+        unsigned tab[7] = {0, 0, 0, 0, 0, 0, 0};
+        {
+            int ly[5], lx[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                ly[k] = inside ? src_y[y + k] - g.sy0 : 0;
+                lx[k] = inside ? src_x[x + k] - g.sx0 : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < 25; ++t) tab[t >> 2] |= (unsigned)(ly[t / 5] * g.SW + lx[t % 5]) << (8 * (t & 3));
+        }
+        f4 acc[COUT / 4];
+#pragma unroll
+        for (int c = 0; c < COUT / 4; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+        const int ntile = tile + slots;
+        const bool has_next = ntile < band_end;
+        Geo gn = g;
+        __syncthreads();
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {                         // gather pass `pass` while the producers compute pass + 1
+            const bool last = pass == NPASS - 1;
+            if (last && has_next) { gn = geom(ntile); window_issue(gn); }
+            const unsigned char* const Pp = smem + (pass & 1) * (kF2Rows * kF2PRowB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (4 * pass + i < NTL) {
+                    const unsigned row = (tab[0] >> (8 * (i / NPT))) & 0xFFu;
+                    const unsigned char* const base = Pp + row * kF2PRowB;
+                    const unsigned swb = (row & 15u) << 4;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc)
+                        acc[(i % NPT) * 8 + cc] += *reinterpret_cast<const f4*>(base + ((unsigned)((i * 8 + cc) << 4) ^ swb));
+                }
+            }
+            // consume TPP bytes of the table
+            if constexpr (TPP == 4) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) tab[k] = tab[k + 1];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) tab[k] = (tab[k] >> 16) | (tab[k + 1] << 16);
+                tab[6] >>= 16;
+            }
+            if (last) {
+                if (inside) {
+                    float* op = out + ((((long long)g.img * H + y) * W) + x) * COUT;
+#pragma unroll
+                    for (int c = 0; c < COUT / 4; ++c) *reinterpret_cast<f4*>(op + 4 * c) = acc[c];
+                }
+                if (has_next) window_commit(gn);                           // the producers are done with this tile's window
+            }
+            __syncthreads();
+        }
+        g = gn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 2-bit packed spike tensors: readers for the consumers of a packed neuron output
 // ---------------------------------------------------------------------------------------------------
 // packed [n_words] -> dense values.  OUT: 0 = fp32, SS_DT_F16, SS_DT_BF16.  A lane expands one byte (4 neurons); `copies` > 1 writes the
@@ -2158,6 +2444,53 @@ int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const 
                                                     static_cast<const void*>(x), wf, src_y, src_x, out, h, w, H, W, tx, ty); } while (0)
     if (Cin == 64) SS_FUS(64, 32); else SS_FUS(128, 64);
 #undef SS_FUS
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_fused2_supported(int Cin, int Cout, int k, int max_window)
+{
+    return ss_upconv_fused_supported(Cin, Cout, k) && max_window > 0 && max_window <= kF2Rows;
+}
+
+long long ss_upconv_fused2_wf_elems(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 32) return 0;
+    return 25LL * Cout * 3 * Cin;
+}
+
+int ss_upconv_fused2_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream)
+{
+    if (!W || !Wf || !ss_upconv_fused2_wf_elems(Cin, Cout) || !aligned16(Wf)) return SS_EINVAL;
+    hipLaunchKernelGGL(upconv_fused2_prep_w_kernel, dim3(grid_for(ss_upconv_fused2_wf_elems(Cin, Cout) / 8, 4096)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), W, static_cast<unsigned short*>(Wf), Cin, Cout);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
+                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream)
+{
+    if ((!x && !x_packed) || !Wf || !src_y || !src_x || !out || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (!ss_upconv_fused2_supported(Cin, Cout, 5, max_window)) return SS_EINVAL;
+    if (!aligned16(Wf) || !aligned16(out) || (x && !aligned16(x))) return SS_EINVAL;
+    if (x_packed && (NB * h * w * Cin) % 16 != 0) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    const int tx = (W + kFusT - 1) / kFusT, ty = (H + kFusT - 1) / kFusT;
+    const long long tiles = NB * tx * ty;
+    if (tiles > 0x7fffffffLL || NB * H * W * (long long)Cout > 0x7fffffffffLL) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+        return SS_ELAUNCH;
+    // persistent workgroups: one per CU (the LDS footprint admits no more), a multiple of 8 so that workgroup b stays on XCD b % 8
+    const long long per_xcd = (tiles + 7) / 8;
+    const unsigned grid = 8u * (unsigned)(per_xcd < cus / 8 ? per_xcd : cus / 8);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned short* wf = static_cast<const unsigned short*>(Wf);
+#define SS_FUS2(CI, CO) do { if (x_packed) hipLaunchKernelGGL((upconv_fused2_fwd_kernel<CI, CO, true>), dim3(grid), dim3(kF2Threads), 0, s, \
+                                                              static_cast<const void*>(x_packed), wf, src_y, src_x, out, h, w, H, W, tx, ty, (int)tiles); \
+                             else hipLaunchKernelGGL((upconv_fused2_fwd_kernel<CI, CO, false>), dim3(grid), dim3(kF2Threads), 0, s, \
+                                                     static_cast<const void*>(x), wf, src_y, src_x, out, h, w, H, W, tx, ty, (int)tiles); } while (0)
+    if (Cin == 64) SS_FUS2(64, 32); else SS_FUS2(128, 64);
+#undef SS_FUS2
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

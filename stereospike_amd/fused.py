@@ -467,6 +467,7 @@ WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient G
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
 EXACT_SPLIT_GEMM = True
 FUSED_UPCONV_MFMA = True          # decoder stages with a compiled shape (deconv1, deconv2): projection + gather in ONE hand-written MFMA kernel, P never in HBM
+FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 124); 1: always the first form (A/B)
 ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
@@ -514,15 +515,18 @@ class _UpConvProjectedCL(torch.autograd.Function):
         n = max(1, min(NB, P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
         exact = spikes_in and not lowp and EXACT_SPLIT_GEMM and Cin >= EXACT_SPLIT_MIN_K
         # fused projection + gather on the bf16 matrix cores (P only in LDS): spike inputs, fp32 activations, the compiled stage shapes
-        fused_mfma = (FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and EXACT_SPLIT_GEMM and not half_in
-                      and 0 < max_window <= 128 and _lib.upconv_fused_supported(Cin, Cout, k))
-        if fused_mfma:
+        form = 0
+        if (FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and EXACT_SPLIT_GEMM and not half_in):
+            form = _lib.upconv_fused_form(Cin, Cout, k, max_window)           # 2: wavefront-specialised persistent kernel; 1: first form
+            if form == 2 and FUSED_UPCONV_FORM == 1 and max_window <= 128:
+                form = 1
+        if form:
             if ASSERT_EXACT_SPLIT:
                 assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
-            Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=x_cl.device)
+            Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, form), dtype=torch.bfloat16, device=x_cl.device)
             e0 = TIMER.start()
-            _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout)
-            _lib.upconv_fused_fwd(x_cl, None, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
+            _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout, form)
+            _lib.upconv_fused_fwd(x_cl, None, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
             TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
             ctx.save_for_backward(x_cl, Wt)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd

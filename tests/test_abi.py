@@ -27,7 +27,10 @@ def test_header_declares_the_expected_entry_points():
                                   # ABI 2
                                   'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes',
                                   'ss_im2col_cl_bf16_packed',
-                                  'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32'])
+                                  'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
+                                  # ABI 3
+                                  'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w',
+                                  'ss_upconv_fused2_fwd_f32'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -38,7 +41,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == 2
+    assert L.ss_abi_version() == 3
     assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()

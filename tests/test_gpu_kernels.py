@@ -901,6 +901,22 @@ def test_upconv_fused_mfma_forward(Cin, Cout, hw, HW, NB):
     out3 = torch.empty_like(out)
     _lib.upconv_fused_fwd(x_cl, None, Wf, tables[0], tables[3], out3, NB, Cin, Cout, h, w, H, W, win)
     assert torch.equal(out3, out)
+    # second kernel form (wavefront-specialised, persistent): the same value BIT FOR BIT, dense and packed input, run to run
+    assert _lib.upconv_fused_form(Cin, Cout, 5, win) == 2, win
+    Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=DEV)
+    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf2, Cin, Cout, 2)
+    for xd, xpk in ((x_cl, None), (None, xp), (x_cl, None)):
+        o2 = torch.full((NB, H, W, Cout), float('nan'), device=DEV)
+        _lib.upconv_fused_fwd(xd, xpk, Wf2, tables[0], tables[3], o2, NB, Cin, Cout, h, w, H, W, win, 2)
+        assert torch.equal(o2, out), float((o2 - out).abs().max())
+    prev = fused.FUSED_UPCONV_FORM
+    try:
+        for form in (1, 2):
+            fused.FUSED_UPCONV_FORM = form
+            with torch.no_grad():
+                assert torch.equal(up.forward_projected_cl(x_cl, spikes_in=True), out)
+    finally:
+        fused.FUSED_UPCONV_FORM = prev
 
 
 def test_upconv_fused_mfma_argument_validation():
@@ -915,3 +931,10 @@ def test_upconv_fused_mfma_argument_validation():
         _lib.upconv_fused_fwd(x, None, Wf, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 129)
     with pytest.raises(_lib.SSNeuronError):                                  # not a compiled stage shape
         _lib.upconv_fused_fwd(torch.zeros(1, 4, 4, 32, device=DEV), None, Wf, t[:12], t[:12], out, 1, 32, 32, 4, 4, 8, 8, 64)
+    assert _lib.upconv_fused_form(64, 32, 5, 121) == 2 and _lib.upconv_fused_form(64, 32, 5, 124) == 2
+    assert _lib.upconv_fused_form(64, 32, 5, 125) == 1 and _lib.upconv_fused_form(64, 32, 5, 129) == 0
+    assert _lib.upconv_fused_form(256, 128, 5, 100) == 0 and _lib.upconv_fused_form(64, 32, 5, 0) == 0
+    Wf2 = torch.zeros(_lib.upconv_fused_wf_elems(64, 32, 2), dtype=torch.bfloat16, device=DEV)
+    assert Wf2.numel() == 75 * 64 * 32
+    with pytest.raises(_lib.SSNeuronError):                                  # window larger than the second form's LDS tile
+        _lib.upconv_fused_fwd(x, None, Wf2, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 125, 2)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark of the fused projection + gather MFMA kernels (ss_upconv_fused_fwd_f32 / ss_upconv_fused2_fwd_f32) at the
+config-3 geometries of deconv1 / deconv2 (80 frames): interleaved rounds of both forms, HIP-event time per launch, equality check,
+roofline figures (algorithmic bytes = x + out; useful bf16 FLOPs = 3 exact products per MAC of the minimal projection).
+FORMS=1,2 (default) selects the forms; ROUNDS / REPS control the timing; ONLY=deconv1 restricts the geometry (for rocprofv3 passes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stereospike_amd import _lib
+from stereospike_amd.network.blocks import NNConvUpsampling
+dev = 'cuda:0'
+NB = int(os.environ.get('NB', 80))
+forms = [int(f) for f in os.environ.get('FORMS', '1,2').split(',')]
+rounds, reps = int(os.environ.get('ROUNDS', 5)), int(os.environ.get('REPS', 5))
+geoms = [('deconv1', 64, 32, (130, 173), (260, 346)), ('deconv2', 128, 64, (65, 87), (130, 173))]
+only = os.environ.get('ONLY')
+for name, Cin, Cout, (h, w), (H, W) in geoms:
+    if only and name not in only.split(','):
+        continue
+    torch.manual_seed(0)
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(dev)
+    x = ((torch.rand(NB, h, w, Cin, device=dev) < 0.35).float() + (torch.rand(NB, h, w, Cin, device=dev) < 0.1).float()).contiguous()
+    tabs = up._tables(h, w, torch.device(dev))
+    win = up.max_tile_window(h, w)
+    wt = up.up[1].weight.detach().contiguous()
+    outs, Wfs = {}, {}
+    for f in forms:
+        Wfs[f] = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, f), dtype=torch.bfloat16, device=dev)
+        _lib.upconv_fused_prep_w(wt, Wfs[f], Cin, Cout, f)
+        outs[f] = torch.full((NB, H, W, Cout), float('nan'), device=dev)
+
+    def run(f):
+        _lib.upconv_fused_fwd(x, None, Wfs[f], tabs[0], tabs[3], outs[f], NB, Cin, Cout, h, w, H, W, win, f)
+    for f in forms:
+        run(f)
+    torch.cuda.synchronize()
+    if len(forms) > 1:
+        print(name, 'forms equal bit for bit:', bool(torch.equal(outs[forms[0]], outs[forms[1]])),
+              'max |diff|', float((outs[forms[0]] - outs[forms[1]]).abs().max()), flush=True)
+    best = {f: 1e9 for f in forms}
+    for _ in range(rounds):
+        for f in forms:
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(reps):
+                run(f)
+            e1.record(); torch.cuda.synchronize()
+            best[f] = min(best[f], e0.elapsed_time(e1) / reps)
+    alg = 4 * (x.numel() + outs[forms[0]].numel())
+    flops = 2 * 3 * NB * h * w * Cin * 25 * Cout
+    for f in forms:
+        ms = best[f]
+        print(f'{name} form {f}: {ms:7.3f} ms/launch   {alg / ms / 1e6:7.1f} GB/s algorithmic ({alg / ms / 1e6 / 8000:.3f} of HBM peak)   '
+              f'{flops / ms / 1e9:7.1f} TFLOP/s useful bf16 ({flops / ms / 1e9 / 2500:.3f} of MFMA peak)   window {win}', flush=True)
