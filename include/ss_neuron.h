@@ -249,8 +249,8 @@ int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const 
  * window goes once, coalesced, from HBM to LDS as bf16; P is produced in passes of four 32-column tiles (column = tap * C_out + co:
  * no padding columns); the output pixel's 25-tap sum stays in registers and is written once; workgroups walk XCD-contiguous bands of
  * tiles.  Own weight layout: ss_upconv_fused2_prep_w -> ss_upconv_fused2_wf_elems(C_in, C_out) = 75 * C_in * C_out bf16 elements.
- * ss_upconv_fused2_supported(C_in, C_out, k, max_window): the compiled stage shapes with max_window <= 124 source pixels per tile
- * (the first form covers 125..128).
+ * ss_upconv_fused2_supported(C_in, C_out, k, max_window): the compiled stage shapes with max_window <= 122 source pixels per tile
+ * (the first form covers 123..128).
  */
 int ss_upconv_fused2_supported(int Cin, int Cout, int k, int max_window);
 long long ss_upconv_fused2_wf_elems(int Cin, int Cout);

@@ -507,7 +507,7 @@ def upconv_fused_supported(Cin, Cout, k):
 
 
 def upconv_fused_form(Cin, Cout, k, max_window):
-    """Which fused MFMA kernel serves this stage: 2 = wavefront-specialised persistent form (max_window <= 124), 1 = first form
+    """Which fused MFMA kernel serves this stage: 2 = wavefront-specialised persistent form (max_window <= 122), 1 = first form
     (max_window <= 128), 0 = none (caller uses GEMM + gather)."""
     if max_window <= 0:
         return 0

@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __
 // This form:
 //   * persistent workgroups of 8 wavefronts, two per SIMD: 4 PRODUCERS (MFMA) and 4 CONSUMERS (gather); a workgroup walks a contiguous
 //     band of tiles of one XCD (neighbouring tiles share their window halo through that XCD's L2);
-//   * the source window goes ONCE, coalesced, from HBM to LDS as bf16 (row-swizzled 16-B chunks, conflict-free fragment reads);
+//   * the source window goes ONCE, coalesced, from HBM to LDS as bf16 (rows padded by 16 B: conflict-free fragment reads);
 //   * P is produced in PASSES of four 32-column tiles (column = tap * C_out + co: no padding columns), one tile per producer wavefront,
 //     weights streamed from L2 straight into that wavefront's registers (each weight fragment is fetched once per tile per CU, three
 //     (pass, split) chunks in flight), product taken transposed (weights as the A operand) so a lane holds 4 consecutive P columns of
@@ -1435,10 +1435,39 @@ __global__ __launch_bounds__(kBlock) void upconv_fused_fwd_kernel(const void* __
 //   * while the producers compute pass p + 1 the consumers gather pass p from the other buffer into per-pixel accumulators held in
 //     registers (taps in (ky, kx) order — the summation order of the unfused gather kernel and of the first form), write the tile's
 //     output once, and fetch the NEXT tile's window (loads issued before the last gather, committed to LDS after it).
-// LDS: 2 x 124 x 512 B pass buffers + 124 x C_in x 2 B window = 139.5 KiB (C_in 64) / 155 KiB (C_in 128).
+// LDS: 2 x 122 x 528 B pass buffers + 122 x (2 C_in + 16) B window (+ 9 KiB output transposition scratch for C_in 64) = 152.0 / 158.2 KiB.
+#ifndef SS_F2_PRIO
+#define SS_F2_PRIO 2                          // wave priority: 0 none, 1 producers 3, 2 consumers 1, 3 consumers 3
+#endif
+#ifndef SS_F2_ABLATE
+#define SS_F2_ABLATE 0                        // development aid (make variant DEFS=-DSS_F2_ABLATE=mask; tools/bench_fused_upconv.py SS_LIB=...): skip
+#endif                                        // 1 gather, 2 pass-buffer stores, 4 weight stream, 8 MFMAs, 16 next-window fetch — wrong results, timing only
 constexpr int kF2Threads = 512;
-constexpr int kF2Rows = 124;                  // source pixels of a tile held on chip (max_window <= 124, else the first form)
-constexpr int kF2PRowB = 512;                 // bytes of one source pixel's row in a pass buffer: 4 column tiles x 32 channels fp32
+#ifndef SS_F2_TRACE
+#define SS_F2_TRACE 0                         // development aid: workgroup 0 records s_memtime stamps of its first steps (ss_debug_f2_trace)
+#endif
+#if SS_F2_TRACE
+__device__ unsigned long long f2_trace[2][64][4];
+#define F2_STAMP(role, slot) do { if (blockIdx.x == 0 && lane == 0 && cw == 0 && tstep < 64) f2_trace[role][tstep][slot] = clock64(); } while (0)
+#else
+#define F2_STAMP(role, slot) do { } while (0)
+#endif
+#ifndef SS_F2_BAR
+#define SS_F2_BAR 1
+#endif
+// Workgroup barrier of the wavefront-specialised kernel: orders LDS traffic only (lgkmcnt), so the weight / window loads a wavefront has
+// in flight (vmcnt) stay in flight across it — __syncthreads() would drain them at every pass
+__device__ __forceinline__ void f2_barrier()
+{
+#if SS_F2_BAR
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+constexpr int kF2Rows = 122;                  // source pixels of a tile held on chip (max_window <= 122, else the first form)
+constexpr int kF2PRowB = 528;                 // bytes of one source pixel's row in a pass buffer: 4 column tiles x 32 channels fp32 + 16 B of
+                                              // padding (consecutive rows start 4 banks apart: conflict-free 16-B stores and gathers, immediate offsets)
 
 // W [C_out][C_in][5][5] fp32 -> Wf2[column tile nt][split][k-step j][lane][8] bf16; column n = 32 nt + (lane & 31) = tap * C_out + co,
 // element e = split term of W[co][ci = 16 j + 8 (lane >> 5) + e][tap]
@@ -1479,12 +1508,25 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
     constexpr int NTL = 25 * NPT;                     // column tiles in all (25 / 50: no padding)
     constexpr int NPASS = (NTL + 3) / 4;              // 7 / 13
     constexpr int TPP = 4 / NPT;                      // taps per pass (4 / 2)
-    constexpr int XROWB = CIN * 2;                    // bytes of one source pixel in the bf16 window
+    constexpr int XROWB = CIN * 2 + 16;               // bytes of one source pixel in the bf16 window + 16 B of padding (rows start 4 banks
+                                                      // apart modulo 64: conflict-free fragment reads at immediate offsets)
     constexpr int XCH = CIN / 8;                      // 16-B chunks per source pixel
     constexpr int XU = (kF2Rows * XCH + 255) / 256;   // window chunks per consumer lane (4 / 8)
-    constexpr bool XREG = CIN <= 64;                  // producers keep the window fragments in registers across the three splits
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kF2Rows * kF2PRowB + kF2Rows * XROWB];
+    constexpr bool XREG = CIN <= 64;                  // producers keep the window fragments in registers for the whole tile
+    // CONT: the window buffer is free as soon as the producers hold their fragments, so the next tile's window is committed in the
+    // middle of this tile and the pipeline runs through tile boundaries (pass buffer = global step parity).  Otherwise the producers
+    // read the window in every pass and idle for one step per tile while the consumers commit the next one.
+    constexpr bool CONT = XREG;
+    constexpr int WC = NPASS - 2 < 3 ? NPASS - 2 : 3; // CONT: pass in which the next window is committed (issued in pass 0)
+    const int cw_ = (threadIdx.x >> 6) & 3;
+    // output transposition scratch: 16 pixels x (C_out floats + 16 B) per consumer wavefront.  CONT: its own region; otherwise the window
+    // region, which is free between the producers' last pass of a tile and the commit of the next window
+    constexpr int OROWB = COUT * 4 + 16;
+    constexpr int OSCR = 16 * OROWB;
+    static_assert(CONT || 4 * OSCR <= kF2Rows * XROWB, "transposition scratch must fit the window region");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kF2Rows * kF2PRowB + kF2Rows * XROWB + (CONT ? 4 * OSCR : 0)];
     unsigned char* const Xs = smem + 2 * kF2Rows * kF2PRowB;
+    unsigned char* const Os = (CONT ? Xs + kF2Rows * XROWB : Xs) + cw_ * OSCR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool producer = wave < 4;
     const int cw = wave & 3;
@@ -1493,11 +1535,11 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
     const int per_xcd = (n_tiles + 7) / 8;
     const int band0 = (int)(blockIdx.x & 7) * per_xcd, slot0 = (int)(blockIdx.x >> 3), slots = (int)(gridDim.x >> 3);
     const int band_end = min(band0 + per_xcd, n_tiles);
+    [[maybe_unused]] int tstep = 0;
 
-    auto xswz = [](int row) { return CIN <= 64 ? ((row >> 1) & 7) : (row & 15); };
 
     if (producer) {
-        __builtin_amdgcn_s_setprio(3);
+        if (SS_F2_PRIO == 1) __builtin_amdgcn_s_setprio(3);
         // ---- weight stream: chunk (pass, split) of this wavefront's column tile nt = 4 pass + cw sits in buffer `split`; three in flight
         const s16x8* const wbase = reinterpret_cast<const s16x8*>(Wf) + lane;
         s16x8 wq[3][KC];
@@ -1506,14 +1548,14 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
 #pragma unroll
             for (int j = 0; j < KC; ++j) dst[j] = wbase[(c0 + j) * 64];
         };
-        const bool any = cw < NTL;                                        // always true (NTL >= 4)
-        if (any) { load_chunk(wq[0], 0, 0); load_chunk(wq[1], 0, 1); load_chunk(wq[2], 0, 2); }
-        __syncthreads();                                                  // first window is in LDS
+        load_chunk(wq[0], 0, 0); load_chunk(wq[1], 0, 1); load_chunk(wq[2], 0, 2);
+        f2_barrier();                                                     // first window is in LDS
+        int gstep = 0;
         for (int tile = band0 + slot0; tile < band_end; tile += slots) {
             s16x8 xf[XREG ? 4 : 1][XREG ? KC : 1];
             auto xfrag = [&](int m, int j) -> s16x8 {
                 const int row = min(32 * m + (lane & 31), kF2Rows - 1);
-                return *reinterpret_cast<const s16x8*>(Xs + row * XROWB + (((2 * j + (lane >> 5)) ^ xswz(row)) << 4));
+                return *reinterpret_cast<const s16x8*>(Xs + row * XROWB + ((2 * j + (lane >> 5)) << 4));
             };
             if constexpr (XREG) {
 #pragma unroll
@@ -1522,65 +1564,103 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                     for (int j = 0; j < KC; ++j) xf[m][j] = xfrag(m, j);
             }
 #pragma unroll 1
-            for (int pass = 0; pass < NPASS; ++pass) {
+            for (int pass = 0; pass < NPASS; ++pass, ++gstep) {
+                F2_STAMP(0, 0);
                 if (4 * pass + cw < NTL) {
                     const int npass = (4 * (pass + 1) + cw < NTL) ? pass + 1 : 0;     // this wavefront's next pass (wraps into the next tile)
+                    unsigned char* const Pp = smem + ((CONT ? gstep : pass) & 1) * (kF2Rows * kF2PRowB);
                     f32x16 acc[4];
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+                    // The MFMA builtin has no side effects, so hipcc re-orders these freely (it had moved every pass-buffer store behind the
+                    // last MFMA and the weight loads of all three splits to the end of the pass); sched_barrier(0) pins the phases:
+                    //   hi | load hi' | mid | load mid' | lo of source tiles 0, 1 | lo of tiles 2, 3 interleaved with the stores of tiles 0, 1 |
+                    //   stores of tiles 2, 3 | load lo'            (x' = the same split of this wavefront's next pass)
+                    // Per accumulator the order stays hi, mid, lo with k ascending (bit-identical to the first kernel form).
+                    auto xop = [&](int m, int jj) -> s16x8 { if constexpr (XREG) return xf[m][jj]; else return xfrag(m, jj); };
+                    auto mma = [&](f32x16& a, const s16x8& wv, const s16x8& xv, int m, int jj) {
+                        if (!(SS_F2_ABLATE & 8)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, a, 0, 0, 0);
+                        else a[jj] += (float)wv[m] + (float)xv[0];
+                    };
+                    // splits hi, mid: k-step outer, the four source tiles inner (4 independent accumulators)
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) {
+                    for (int s = 0; s < 2; ++s) {
                         if constexpr (XREG) {
 #pragma unroll
-                            for (int j = 0; j < KC; ++j)
+                            for (int jj = 0; jj < KC; ++jj)
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s][j], xf[m][j], acc[m], 0, 0, 0);
+                                for (int m = 0; m < 4; ++m) mma(acc[m], wq[s][jj], xf[m][jj], m, jj);
                         } else {
-                            // the window fragments are re-read from LDS for every split (32 ds_read_b128, hidden under 32 MFMAs); the
+                            // the window fragments are re-read from LDS for every split (ds_read_b128, two k-steps ahead of their MFMAs); the
                             // clobber keeps the compiler from merging the three reads into 128 live registers
                             asm volatile("" ::: "memory");
-                            s16x8 xc[4], xn[4];
+                            s16x8 xa[4], xb[4], xc[4];
 #pragma unroll
-                            for (int m = 0; m < 4; ++m) xc[m] = xfrag(m, 0);
+                            for (int m = 0; m < 4; ++m) { xa[m] = xfrag(m, 0); xb[m] = xfrag(m, 1); }
 #pragma unroll
-                            for (int j = 0; j < KC; ++j) {
-                                if (j + 1 < KC) {
+                            for (int jj = 0; jj < KC; ++jj) {
+                                if (jj + 2 < KC) {
 #pragma unroll
-                                    for (int m = 0; m < 4; ++m) xn[m] = xfrag(m, j + 1);
+                                    for (int m = 0; m < 4; ++m) xc[m] = xfrag(m, jj + 2);
                                 }
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s][j], xc[m], acc[m], 0, 0, 0);
+                                for (int m = 0; m < 4; ++m) mma(acc[m], wq[s][jj], xa[m], m, jj);
 #pragma unroll
-                                for (int m = 0; m < 4; ++m) xc[m] = xn[m];
+                                for (int m = 0; m < 4; ++m) { xa[m] = xb[m]; xb[m] = xc[m]; }
                             }
                         }
-                        load_chunk(wq[s], npass, s);                              // lands two chunks of MFMA work later
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(SS_F2_ABLATE & 4)) load_chunk(wq[s], npass, s);     // lands two chunks of MFMA work later
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    // accumulators -> pass buffer.  C layout of P^T: column (source) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-                    unsigned char* const Pp = smem + (pass & 1) * (kF2Rows * kF2PRowB);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                    // C layout of P^T: column (source) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                    if constexpr (!XREG) asm volatile("" ::: "memory");
+                    auto store_q = [&](int m, int q) {
                         const int row = 32 * m + (lane & 31);
-                        if (row < kF2Rows) {
+                        if (row < kF2Rows && (!(SS_F2_ABLATE & 2) || acc[m][0] == 12345.f))
+                            *reinterpret_cast<f4*>(Pp + row * kF2PRowB + ((cw * 8 + 2 * q + (lane >> 5)) << 4)) =
+                                (f4){acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
+                    };
+                    // split lo, source tiles 0 and 1 (two interleaved accumulator chains)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int chunk = cw * 8 + 2 * q + (lane >> 5);
-                                *reinterpret_cast<f4*>(Pp + row * kF2PRowB + ((chunk ^ (row & 15)) << 4)) =
-                                    (f4){acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
-                            }
-                        }
+                    for (int jj = 0; jj < KC; ++jj) { mma(acc[0], wq[2][jj], xop(0, jj), 0, jj); mma(acc[1], wq[2][jj], xop(1, jj), 1, jj); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // split lo, tiles 2 and 3; the finished tiles 0 and 1 go to the pass buffer under these MFMAs
+#pragma unroll
+                    for (int jj = 0; jj < KC; ++jj) {
+                        mma(acc[2], wq[2][jj], xop(2, jj), 2, jj);
+                        if (2 * jj < 8) store_q(jj * 2 / 4, (jj * 2) % 4);
+                        if (2 * jj + 1 < 8) store_q((jj * 2 + 1) / 4, (jj * 2 + 1) % 4);
+                        mma(acc[3], wq[2][jj], xop(3, jj), 3, jj);
                     }
+                    static_assert(KC >= 4, "the store interleave above expects >= 4 k-steps");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(SS_F2_ABLATE & 4)) load_chunk(wq[2], npass, 2);
+#if SS_F2_TRACE
+                    if (acc[0][0] == 12345.f && acc[1][1] == 1.f && acc[2][2] == 2.f && acc[3][3] == 3.f) f2_trace[0][63][3] = 1;   // waits for the MFMAs
+                    F2_STAMP(0, 1);
+#endif
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { store_q(2, q); store_q(3, q); }
                 }
-                __syncthreads();
+#if SS_F2_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                F2_STAMP(0, 2);
+#endif
+                f2_barrier();
+                F2_STAMP(0, 3);
+                ++tstep;
             }
-            __syncthreads();                                              // consumers: last gather, output, next window
+            if constexpr (!CONT) { f2_barrier(); f2_barrier(); ++tstep; }  // consumers: last gather + output | next window
         }
         return;
     }
 
     // ------------------------------------------------------------- consumers
+    if (SS_F2_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    if (SS_F2_PRIO == 3) __builtin_amdgcn_s_setprio(3);
     const int ct = cw * 64 + lane;                                        // 0..255: pixel (ct >> 4, ct & 15) of the tile
     const int py = ct >> 4, px = ct & 15;
     f4 xr[XU][PACKED ? 1 : 2];
@@ -1633,73 +1713,170 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                         a[4 + q] = (short)(__float_as_uint(xr[u][1][q]) >> 16);
                     }
                 }
-                *reinterpret_cast<s16x8*>(Xs + row * XROWB + ((ch ^ xswz(row)) << 4)) = a;
+                *reinterpret_cast<s16x8*>(Xs + row * XROWB + (ch << 4)) = a;
             }
         }
     };
+    // per-pixel table: source row (ly * SW + lx) of every tap, one byte each, tap 0 in the low byte of tab[0]; consumed from the bottom,
+    // TPP bytes per pass
+    struct Pix { int y, x; bool inside; int ly[5], lx[5]; };
+    auto pix_issue = [&](const Geo& g) {
+        Pix p;
+        p.y = g.y0 + py; p.x = g.x0 + px;
+        p.inside = p.y < H && p.x < W;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            p.ly[k] = p.inside ? src_y[p.y + k] - g.sy0 : 0;
+            p.lx[k] = p.inside ? src_x[p.x + k] - g.sx0 : 0;
+        }
+        return p;
+    };
+    auto build_tab = [&](const Pix& p, const Geo& g, unsigned (&tab)[7]) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tab[k] = 0;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) tab[t >> 2] |= (unsigned)(p.ly[t / 5] * g.SW + p.lx[t % 5]) << (8 * (t & 3));
+    };
+    f4 acc[COUT / 4];
+    auto gather = [&](const unsigned char* Pp, int pass, unsigned (&tab)[7]) {
+        constexpr int NB_ = COUT <= 32 ? 2 : 1;                            // column tiles per batch of reads issued before their adds (16 / 8 reads)
+#pragma unroll
+        for (int b = 0; b < 4 / NB_; ++b) {
+            f4 v[NB_][8];
+#pragma unroll
+            for (int ii = 0; ii < NB_; ++ii) {
+                const int i = NB_ * b + ii;
+                if (4 * pass + i < NTL && !(SS_F2_ABLATE & 1)) {
+                    const unsigned row = (tab[0] >> (8 * (i / NPT))) & 0xFFu;
+                    const unsigned char* const base = Pp + row * kF2PRowB + i * 128;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) v[ii][cc] = *reinterpret_cast<const f4*>(base + 16 * cc);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < NB_; ++ii) {
+                const int i = NB_ * b + ii;
+                if (4 * pass + i < NTL && !(SS_F2_ABLATE & 1)) {
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) acc[(i % NPT) * 8 + cc] += v[ii][cc];
+                }
+            }
+        }
+        // consume TPP bytes of the table
+        if constexpr (TPP == 4) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tab[k] = tab[k + 1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) tab[k] = (tab[k] >> 16) | (tab[k + 1] << 16);
+            tab[6] >>= 16;
+        }
+    };
+    // tile output: a lane holds all C_out channels of ONE pixel; written directly that is 64 partial lines per store instruction.  Instead
+    // the wavefront's four pixel rows go through its LDS scratch one after the other and leave as 1-KiB contiguous stores
+    // (lane -> 16-B chunk t = lane + 64 u of the row's 16 pixels x C_out floats).  LDS executes a wavefront's operations in order.
+    auto store_out = [&](const Geo& g) {
+        constexpr int NCH = COUT / 4;                                      // 16-B chunks per pixel
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if ((lane >> 4) == r) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) *reinterpret_cast<f4*>(Os + (lane & 15) * OROWB + 16 * c) = acc[c];
+            }
+            asm volatile("" ::: "memory");        // hipcc 7.2 otherwise sinks the first scratch read INTO the lane-masked store region above
+            const int yy = g.y0 + 4 * cw + r;
+            float* const orow = out + (((long long)g.img * H + yy) * W + g.x0) * COUT;
+#pragma unroll
+            for (int u = 0; u < NCH / 4; ++u) {
+                const int t = lane + 64 * u;
+                const int pxl = t / NCH, c = t - pxl * NCH;
+                const f4 v = *reinterpret_cast<const f4*>(Os + pxl * OROWB + 16 * c);
+                if (yy < H && g.x0 + pxl < W) *reinterpret_cast<f4*>(orow + (long long)pxl * COUT + 4 * c) = v;
+            }
+            asm volatile("" ::: "memory");
+        }
+    };
+
     int tile = band0 + slot0;
     Geo g = geom(min(tile, n_tiles - 1));
     if (tile < band_end) { window_issue(g); window_commit(g); }
-    __syncthreads();
-    for (; tile < band_end; tile += slots) {
-        // ---- step 0 (producers compute pass 0): per-pixel tables.  tab: source row (ly * SW + lx) of every tap, one byte each, tap 0 in
-        //      the low byte of tab[0]; consumed from the bottom, TPP bytes per pass
-        const int y = g.y0 + py, x = g.x0 + px;
-        const bool inside = y < H && x < W;
-        unsigned tab[7] = {0, 0, 0, 0, 0, 0, 0};
-        {
-            int ly[5], lx[5];
+    f2_barrier();
+    if (tile >= band_end) return;
+
+    if constexpr (CONT) {
+        // ---- producers compute step 0: tables of the first tile
+        Pix p = pix_issue(g);
+        unsigned tab[7];
+        build_tab(p, g, tab);
+        f2_barrier();
+        ++tstep;
+        int gstep = 0;
+        for (; tile < band_end; tile += slots) {
+            const int ntile = tile + slots;
+            const bool has_next = ntile < band_end && !(SS_F2_ABLATE & 16);
+            Geo gn = g;
+            if (has_next) gn = geom(ntile);
+            Pix pn = p;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                ly[k] = inside ? src_y[y + k] - g.sy0 : 0;
-                lx[k] = inside ? src_x[x + k] - g.sx0 : 0;
-            }
-#pragma unroll
-            for (int t = 0; t < 25; ++t) tab[t >> 2] |= (unsigned)(ly[t / 5] * g.SW + lx[t % 5]) << (8 * (t & 3));
-        }
-        f4 acc[COUT / 4];
-#pragma unroll
-        for (int c = 0; c < COUT / 4; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
-        const int ntile = tile + slots;
-        const bool has_next = ntile < band_end;
-        Geo gn = g;
-        __syncthreads();
+            for (int c = 0; c < COUT / 4; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int pass = 0; pass < NPASS; ++pass) {                         // gather pass `pass` while the producers compute pass + 1
-            const bool last = pass == NPASS - 1;
-            if (last && has_next) { gn = geom(ntile); window_issue(gn); }
-            const unsigned char* const Pp = smem + (pass & 1) * (kF2Rows * kF2PRowB);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (4 * pass + i < NTL) {
-                    const unsigned row = (tab[0] >> (8 * (i / NPT))) & 0xFFu;
-                    const unsigned char* const base = Pp + row * kF2PRowB;
-                    const unsigned swb = (row & 15u) << 4;
-#pragma unroll
-                    for (int cc = 0; cc < 8; ++cc)
-                        acc[(i % NPT) * 8 + cc] += *reinterpret_cast<const f4*>(base + ((unsigned)((i * 8 + cc) << 4) ^ swb));
+            for (int pass = 0; pass < NPASS; ++pass, ++gstep) {            // gather step g while the producers compute step g + 1
+                F2_STAMP(1, 0);
+                if (pass == 0 && has_next) window_issue(gn);               // next window: HBM -> registers, in flight over WC steps
+                if (pass == 1 && has_next) pn = pix_issue(gn);             // next tile's table look-ups, used after the last pass
+                gather(smem + (gstep & 1) * (kF2Rows * kF2PRowB), pass, tab);
+#if SS_F2_TRACE
+                if (acc[0][0] == 12345.f && acc[7][1] == 1.f) f2_trace[1][63][3] = 1;               // waits for the gather
+                F2_STAMP(1, 1);
+#endif
+                if (pass == WC && has_next) window_commit(gn);             // the producers hold this tile's fragments in registers
+                if (pass == NPASS - 1) {
+                    store_out(g);
+                    if (has_next) build_tab(pn, gn, tab);
                 }
+                F2_STAMP(1, 2);
+                if (pass < NPASS - 1 || has_next) f2_barrier();
+                F2_STAMP(1, 3);
+                ++tstep;
             }
-            // consume TPP bytes of the table
-            if constexpr (TPP == 4) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) tab[k] = tab[k + 1];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) tab[k] = (tab[k] >> 16) | (tab[k + 1] << 16);
-                tab[6] >>= 16;
-            }
-            if (last) {
-                if (inside) {
-                    float* op = out + ((((long long)g.img * H + y) * W) + x) * COUT;
-#pragma unroll
-                    for (int c = 0; c < COUT / 4; ++c) *reinterpret_cast<f4*>(op + 4 * c) = acc[c];
-                }
-                if (has_next) window_commit(gn);                           // the producers are done with this tile's window
-            }
-            __syncthreads();
+            g = gn; p = pn;
         }
-        g = gn;
+    } else {
+        for (; tile < band_end; tile += slots) {
+            // ---- step 0 (producers compute pass 0): per-pixel tables
+            Pix p = pix_issue(g);
+            unsigned tab[7];
+            build_tab(p, g, tab);
+#pragma unroll
+            for (int c = 0; c < COUT / 4; ++c) acc[c] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int ntile = tile + slots;
+            const bool has_next = ntile < band_end && !(SS_F2_ABLATE & 16);
+            Geo gn = g;
+            if (has_next) gn = geom(ntile);                                // scalar table look-ups of the next tile: under the producers' pass 0
+            f2_barrier();
+            ++tstep;
+#pragma unroll 1
+            for (int pass = 0; pass < NPASS; ++pass) {                     // gather pass `pass` while the producers compute pass + 1
+                const bool last = pass == NPASS - 1;
+                F2_STAMP(1, 0);
+                if (pass == (NPASS > 3 ? NPASS - 3 : 0) && has_next) window_issue(gn);   // next window: in flight over the last gathers
+                gather(smem + (pass & 1) * (kF2Rows * kF2PRowB), pass, tab);
+#if SS_F2_TRACE
+                if (acc[0][0] == 12345.f && acc[7][1] == 1.f) f2_trace[1][63][3] = 1;               // waits for the gather
+                F2_STAMP(1, 1);
+#endif
+                if (last) {
+                    store_out(g);                                          // through the (idle) window region
+                    f2_barrier();
+                    if (has_next) window_commit(gn);                       // the producers are done with this tile's window
+                }
+                F2_STAMP(1, 2);
+                f2_barrier();
+                F2_STAMP(1, 3);
+                ++tstep;
+            }
+            g = gn;
+        }
     }
 }
 
@@ -2446,6 +2623,13 @@ int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const 
 #undef SS_FUS
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
+
+#if SS_F2_TRACE
+int ss_debug_f2_trace(unsigned long long* host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(f2_trace), sizeof(unsigned long long) * 2 * 64 * 4) == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+#endif
 
 int ss_upconv_fused2_supported(int Cin, int Cout, int k, int max_window)
 {

@@ -467,7 +467,7 @@ WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient G
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
 EXACT_SPLIT_GEMM = True
 FUSED_UPCONV_MFMA = True          # decoder stages with a compiled shape (deconv1, deconv2): projection + gather in ONE hand-written MFMA kernel, P never in HBM
-FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 124); 1: always the first form (A/B)
+FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 122); 1: always the first form (A/B)
 ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough

@@ -931,10 +931,10 @@ def test_upconv_fused_mfma_argument_validation():
         _lib.upconv_fused_fwd(x, None, Wf, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 129)
     with pytest.raises(_lib.SSNeuronError):                                  # not a compiled stage shape
         _lib.upconv_fused_fwd(torch.zeros(1, 4, 4, 32, device=DEV), None, Wf, t[:12], t[:12], out, 1, 32, 32, 4, 4, 8, 8, 64)
-    assert _lib.upconv_fused_form(64, 32, 5, 121) == 2 and _lib.upconv_fused_form(64, 32, 5, 124) == 2
-    assert _lib.upconv_fused_form(64, 32, 5, 125) == 1 and _lib.upconv_fused_form(64, 32, 5, 129) == 0
+    assert _lib.upconv_fused_form(64, 32, 5, 121) == 2 and _lib.upconv_fused_form(64, 32, 5, 122) == 2
+    assert _lib.upconv_fused_form(64, 32, 5, 123) == 1 and _lib.upconv_fused_form(64, 32, 5, 129) == 0
     assert _lib.upconv_fused_form(256, 128, 5, 100) == 0 and _lib.upconv_fused_form(64, 32, 5, 0) == 0
     Wf2 = torch.zeros(_lib.upconv_fused_wf_elems(64, 32, 2), dtype=torch.bfloat16, device=DEV)
     assert Wf2.numel() == 75 * 64 * 32
     with pytest.raises(_lib.SSNeuronError):                                  # window larger than the second form's LDS tile
-        _lib.upconv_fused_fwd(x, None, Wf2, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 125, 2)
+        _lib.upconv_fused_fwd(x, None, Wf2, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 123, 2)

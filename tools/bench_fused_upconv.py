@@ -7,6 +7,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stereospike_amd import _lib
+if os.environ.get('SS_LIB'):                       # a `make variant` build (timing experiments)
+    _lib.LIB_PATH = os.path.abspath(os.environ['SS_LIB'])
 from stereospike_amd.network.blocks import NNConvUpsampling
 dev = 'cuda:0'
 NB = int(os.environ.get('NB', 80))
@@ -52,3 +54,16 @@ for name, Cin, Cout, (h, w), (H, W) in geoms:
         ms = best[f]
         print(f'{name} form {f}: {ms:7.3f} ms/launch   {alg / ms / 1e6:7.1f} GB/s algorithmic ({alg / ms / 1e6 / 8000:.3f} of HBM peak)   '
               f'{flops / ms / 1e9:7.1f} TFLOP/s useful bf16 ({flops / ms / 1e9 / 2500:.3f} of MFMA peak)   window {win}', flush=True)
+    if os.environ.get('TRACE') and 2 in forms:      # a -DSS_F2_TRACE=1 build: s_memtime stamps of workgroup 0's first 64 steps
+        import ctypes, numpy as np
+        run(2); torch.cuda.synchronize()
+        buf = np.zeros((2, 64, 4), dtype=np.uint64)
+        L = _lib.lib()
+        L.ss_debug_f2_trace.argtypes = [ctypes.c_void_p]
+        assert L.ss_debug_f2_trace(buf.ctypes.data) == 0
+        t0 = int(buf[0, 0, 0])
+        print(name, 'trace (cycles rel. to producer step 0): step | producer start, mfma done, stores done, barrier out | consumer start, gather done, step done, barrier out')
+        for st in range(0, 34):
+            pr = [int(v) - t0 if v else -1 for v in buf[0, st]]
+            co = [int(v) - t0 if v else -1 for v in buf[1, st]]
+            print(f'  {st:3d} | {pr[0]:7d} {pr[1]:7d} {pr[2]:7d} {pr[3]:7d} | {co[0]:7d} {co[1]:7d} {co[2]:7d} {co[3]:7d}')
