@@ -105,6 +105,7 @@ def parse():
     ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
     ap.add_argument('--count-rates', type=int, default=0,
                     help='1: firing-rate counters of all 14 layers inside the training step (BASELINE.json config 5), from the fused kernels')
+    ap.add_argument('--fused-form', type=int, default=2, choices=[1, 2], help='kernel form of the fused up-conv: 2 (default) wavefront-specialised persistent workgroups, 1 the first form (A/B)')
     ap.add_argument('--fused-mfma', type=int, default=1, help='1 (default): deconv1 / deconv2 forward as ONE hand-written MFMA kernel (projection + gather, P only in LDS); 0: GEMM + gather kernel')
     ap.add_argument('--pack-spikes', type=int, default=1, help='1 (default): 2-bit packed spike tensors on the edges whose consumers read them')
     ap.add_argument('--fuse-upconv', type=int, default=1,
@@ -208,6 +209,7 @@ def main():
     _fused_cfg.RECOMPUTE_H = bool(a.recompute_h)
     _fused_cfg.EXACT_SPLIT_GEMM = bool(a.exact_split)
     _fused_cfg.FUSED_UPCONV_MFMA = bool(a.fused_mfma)
+    _fused_cfg.FUSED_UPCONV_FORM = int(a.fused_form)
     _fused_cfg.PACK_SPIKES = bool(a.pack_spikes)
     if a.split_wgrad_min_k is not None:
         _fused_cfg.EXACT_SPLIT_WGRAD_MIN_K = a.split_wgrad_min_k
@@ -408,12 +410,18 @@ def _roof_upconv(shapes, a):
     nbytes = 4 * (src_px * cin + out_elems) + 2 * 3 * 25 * cin * cout
     flops = 2.0 * src_px * cin * 25 * cout * 3
     us = 1e3 * d['ms'] / d['launches']
-    return dict(kernel='upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
+    from stereospike_amd import fused as _fused
+    form2 = getattr(_fused, 'FUSED_UPCONV_FORM', 1) == 2
+    return dict(kernel=('upconv_fused2_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only; wavefront-specialised '
+                        'persistent form)') if form2 else
+                       'upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
                 bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
                 avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=None,
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
-                          note='useful FLOPs of the minimal projection x 3 exact bf16 terms; the kernel issues ~1.9x that (source-window halo, tile padding)'),
-                note='LDS / latency bound at one 4-wave workgroup per CU (100 KiB P tile); replaces GEMM + P round trip (11.5 GB) + gather',
+                          note='useful FLOPs of the minimal projection x 3 exact bf16 terms; the kernel issues ~1.9x that (source-window halo)'),
+                note=('issue bound: the MFMAs of the 4 producer wavefronts and the LDS / VALU instructions of the 4 gathering wavefronts share each '
+                      "SIMD's issue slots (per-step trace in DESIGN.md 3.5); replaces GEMM + P round trip (11.5 GB) + gather") if form2 else
+                     'LDS / latency bound at one 4-wave workgroup per CU (100 KiB P tile); replaces GEMM + P round trip (11.5 GB) + gather',
                 fused=bool(a.fused_mfma))
 
 

@@ -259,6 +259,21 @@ int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const
                              long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
 
 /*
+ * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
+ * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
+ *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]
+ * in three hand-written transform kernels around ONE batched fp32 GEMM that the caller runs on the library:
+ *   ss_wino_dgrad_weights_f32: W [C_out][C_in][3][3] -> U [16][C_out][C_in]          (U_k = G Wf G^T, redo after every weight update)
+ *   ss_wino_dgrad_input_f32  : g [NB][H][W][C_out]   -> V [16][T][C_out]             (V = B^T d B; T = NB * ceil(H/2) * ceil(W/2) tiles)
+ *   caller                   : M[k] = V[k] @ U[k]      [16][T][C_in]
+ *   ss_wino_dgrad_output_f32 : M [16][T][C_in]       -> g_in [NB][H][W][C_in]        (Y = A^T M A)
+ * 2.25x fewer multiplications than the direct contraction; fp32, every op rounds once; C % 4 == 0, 16-byte aligned buffers.
+ */
+int ss_wino_dgrad_weights_f32(const float* W, float* U, int Cout, int Cin, void* stream);
+int ss_wino_dgrad_input_f32(const float* g, float* V, long long NB, int H, int W, int C, void* stream);
+int ss_wino_dgrad_output_f32(const float* M, float* g_in, long long NB, int H, int W, int C, void* stream);
+
+/*
  * I-neuron read-out pool (SNN_models.py:150,172-188; ANN_models.py:111,130-146): one shared non-firing
  * IF membrane that the K predict_depth heads charge in the order K-1..0 of the reference's forward
  * (predict_depth4 first), every time step.  pd_seq element (t,k,m) is at pd_seq[t*stride_t + k*stride_k + m],

@@ -106,6 +106,10 @@ def lib():
     L.ss_upconv_fused2_prep_w.restype = i32
     L.ss_upconv_fused2_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_fused2_fwd_f32.restype = i32
+    L.ss_wino_dgrad_weights_f32.argtypes = [p, p, i32, i32, p]
+    L.ss_wino_dgrad_input_f32.argtypes = [p, p, i64, i32, i32, i32, p]
+    L.ss_wino_dgrad_output_f32.argtypes = [p, p, i64, i32, i32, i32, p]
+    L.ss_wino_dgrad_weights_f32.restype = L.ss_wino_dgrad_input_f32.restype = L.ss_wino_dgrad_output_f32.restype = i32
     for f in (L.ss_neuron_fwd_f32, L.ss_neuron_bwd_f32, L.ss_ipool_fwd_f32, L.ss_ipool_bwd_f32,
               L.ss_upconv1_fwd_f32, L.ss_upconv1_bwd_f32, L.ss_upconv_cl_fwd_f32, L.ss_upconv_cl_bwd_f32):
         f.restype = i32
@@ -121,7 +125,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
            'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed',
            'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
-           'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32')
+           'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32',
+           'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -396,6 +401,34 @@ def split3_bf16(g, g3, M, N):
     with torch.cuda.device(g.device):
         rc = lib().ss_split3_bf16(_f32(g, 'g', M * N), _x16(g3, 'g3', 3 * M * N, torch.bfloat16), M, N, _stream(g))
     _check(rc, 'ss_split3_bf16')
+
+
+def wino_dgrad_weights(weight, U, Cout, Cin):
+    """weight [Cout, Cin, 3, 3] fp32 (contiguous) -> U [16, Cout, Cin]: the transformed, flipped filters of the Winograd data gradient."""
+    _require_hip(weight, 'weight')
+    with torch.cuda.device(weight.device):
+        rc = lib().ss_wino_dgrad_weights_f32(_f32(weight, 'weight', Cout * Cin * 9), _f32(U, 'U', 16 * Cout * Cin), Cout, Cin, _stream(weight))
+    _check(rc, 'ss_wino_dgrad_weights_f32')
+
+
+def wino_tiles(NB, H, W):
+    return NB * ((H + 1) // 2) * ((W + 1) // 2)
+
+
+def wino_dgrad_input(g, V, NB, H, W, C_):
+    """g [NB, H, W, C] (NHWC array) -> V [16, T, C], T = wino_tiles(NB, H, W)."""
+    _require_hip(g, 'g')
+    with torch.cuda.device(g.device):
+        rc = lib().ss_wino_dgrad_input_f32(_f32(g, 'g', NB * H * W * C_), _f32(V, 'V', 16 * wino_tiles(NB, H, W) * C_), NB, H, W, C_, _stream(g))
+    _check(rc, 'ss_wino_dgrad_input_f32')
+
+
+def wino_dgrad_output(M, g_in, NB, H, W, C_):
+    """M [16, T, C] -> g_in [NB, H, W, C]."""
+    _require_hip(M, 'M')
+    with torch.cuda.device(M.device):
+        rc = lib().ss_wino_dgrad_output_f32(_f32(M, 'M', 16 * wino_tiles(NB, H, W) * C_), _f32(g_in, 'g_in', NB * H * W * C_), NB, H, W, C_, _stream(M))
+    _check(rc, 'ss_wino_dgrad_output_f32')
 
 
 def loss_ws_doubles():

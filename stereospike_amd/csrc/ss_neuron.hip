@@ -1932,6 +1932,125 @@ __global__ __launch_bounds__(kBlock) void im2col_cl_bf16_packed_kernel(const uns
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) DATA GRADIENT of a 3x3 / stride 1 / pad 1 convolution, NHWC (the four bottleneck convs)
+// ---------------------------------------------------------------------------------------------------
+// Reference: the autograd backward of SEWResBlock's conv1 / conv2 (/root/reference/network/blocks.py:146-159) w.r.t. their input:
+//   g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * Wf[a][b][co][ci],      Wf[a][b][co][ci] = W[co][ci][2 - a][2 - b]
+// — a dense x dense contraction (no spike operand, so no exact bf16 split).  As 2 x 2 output tiles on 4 x 4 input tiles (Lavin & Gray):
+//   V = B^T d B (input transform), U = G Wf G^T (weights), M_k = V_k U_k for the 16 transform positions k (ONE batched fp32 GEMM
+//   [16][tiles x C_out] @ [16][C_out x C_in] on the library), Y = A^T M A (output transform): 2.25x fewer multiplications than the
+//   direct form.  fp32 throughout; the transforms only add / subtract (weights: x 0.5), every op rounds once (-ffp-contract=off), so the
+//   three kernels are bit-exact against oracle/np_winograd.py.
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+__global__ __launch_bounds__(kBlock) void wino_dgrad_weights_kernel(const float* __restrict__ Wt, float* __restrict__ U, int Co, int Ci)
+{
+    const long long n = (long long)Co * Ci;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const int co = (int)(i / Ci), ci = (int)(i - (long long)co * Ci);
+        const float* wp = Wt + i * 9;                                   // W[co][ci][ky][kx]
+        float f[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) f[a][b] = wp[(2 - a) * 3 + (2 - b)];
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = f[0][b];
+            t[1][b] = 0.5f * ((f[0][b] + f[1][b]) + f[2][b]);
+            t[2][b] = 0.5f * ((f[0][b] - f[1][b]) + f[2][b]);
+            t[3][b] = f[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u0 = t[a][0], u1 = 0.5f * ((t[a][0] + t[a][1]) + t[a][2]), u2 = 0.5f * ((t[a][0] - t[a][1]) + t[a][2]), u3 = t[a][2];
+            U[((long long)(4 * a + 0) * Co + co) * Ci + ci] = u0;
+            U[((long long)(4 * a + 1) * Co + co) * Ci + ci] = u1;
+            U[((long long)(4 * a + 2) * Co + co) * Ci + ci] = u2;
+            U[((long long)(4 * a + 3) * Co + co) * Ci + ci] = u3;
+        }
+    }
+}
+
+// g [NB][H][W][C] -> V[16][T][C], T = NB * th * tw tiles (th = ceil(H / 2), tw = ceil(W / 2)); a lane owns 4 consecutive channels of a tile
+__global__ __launch_bounds__(kBlock) void wino_dgrad_input_kernel(const float* __restrict__ g, float* __restrict__ V, long long T, int H, int W,
+                                                                  int C, int th, int tw)
+{
+    const int C4 = C / 4;
+    const long long n = T * C4;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const long long tile = i / C4;
+        const int c = (int)(i - tile * C4) * 4;
+        const int tx = (int)(tile % tw);
+        const long long r = tile / tw;
+        const int ty = (int)(r % th);
+        const long long nb = r / th;
+        f4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int y = 2 * ty - 1 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = 2 * tx - 1 + b;
+                d[a][b] = (y >= 0 && y < H && x >= 0 && x < W) ? *reinterpret_cast<const f4*>(g + ((nb * H + y) * W + x) * C + c)
+                                                               : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 t[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = d[0][b] - d[2][b];
+            t[1][b] = d[1][b] + d[2][b];
+            t[2][b] = d[2][b] - d[1][b];
+            t[3][b] = d[1][b] - d[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float* vp = V + ((long long)(4 * a) * T + tile) * C + c;
+            *reinterpret_cast<f4*>(vp) = t[a][0] - t[a][2];
+            *reinterpret_cast<f4*>(vp + T * C) = t[a][1] + t[a][2];
+            *reinterpret_cast<f4*>(vp + 2 * T * C) = t[a][2] - t[a][1];
+            *reinterpret_cast<f4*>(vp + 3 * T * C) = t[a][1] - t[a][3];
+        }
+    }
+}
+
+// M[16][T][C] -> g_in [NB][H][W][C]
+__global__ __launch_bounds__(kBlock) void wino_dgrad_output_kernel(const float* __restrict__ M, float* __restrict__ gin, long long T, int H, int W,
+                                                                   int C, int th, int tw)
+{
+    const int C4 = C / 4;
+    const long long n = T * C4;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const long long tile = i / C4;
+        const int c = (int)(i - tile * C4) * 4;
+        const int tx = (int)(tile % tw);
+        const long long r = tile / tw;
+        const int ty = (int)(r % th);
+        const long long nb = r / th;
+        f4 m[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[a][b] = *reinterpret_cast<const f4*>(M + ((long long)(4 * a + b) * T + tile) * C + c);
+        f4 t[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            t[0][b] = (m[0][b] + m[1][b]) + m[2][b];
+            t[1][b] = (m[1][b] - m[2][b]) - m[3][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int y = 2 * ty + a;
+            if (y >= H) continue;
+            float* op = gin + ((nb * H + y) * W + 2 * tx) * C + c;
+            *reinterpret_cast<f4*>(op) = (t[a][0] + t[a][1]) + t[a][2];
+            if (2 * tx + 1 < W) *reinterpret_cast<f4*>(op + C) = (t[a][1] - t[a][2]) - t[a][3];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // voxeliser: events -> two-polarity count frames (datasets/MVSEC/utils.py:215-281)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void voxelize_kernel(const double* __restrict__ ev, long long E, const double* __restrict__ start,
@@ -2825,6 +2944,36 @@ int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream)
     if (!g || !g3 || M <= 0 || N <= 0 || N % 4 != 0 || !aligned16(g) || !aligned16(g3)) return SS_EINVAL;
     hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(M * (N / 4), kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        g, static_cast<unsigned short*>(g3), M, N);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_wino_dgrad_weights_f32(const float* W, float* U, int Cout, int Cin, void* stream)
+{
+    if (!W || !U || Cout <= 0 || Cin <= 0) return SS_EINVAL;
+    hipLaunchKernelGGL(wino_dgrad_weights_kernel, dim3(grid_for((long long)Cout * Cin, 4096)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       W, U, Cout, Cin);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_wino_dgrad_input_f32(const float* g, float* V, long long NB, int H, int W, int C, void* stream)
+{
+    if (!g || !V || NB < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || !aligned16(g) || !aligned16(V)) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long long T = NB * th * tw;
+    hipLaunchKernelGGL(wino_dgrad_input_kernel, dim3(grid_for(T * (C / 4), kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       g, V, T, H, W, C, th, tw);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_wino_dgrad_output_f32(const float* M, float* g_in, long long NB, int H, int W, int C, void* stream)
+{
+    if (!M || !g_in || NB < 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || !aligned16(M) || !aligned16(g_in)) return SS_EINVAL;
+    if (NB == 0) return SS_OK;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long long T = NB * th * tw;
+    hipLaunchKernelGGL(wino_dgrad_output_kernel, dim3(grid_for(T * (C / 4), kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       M, g_in, T, H, W, C, th, tw);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -938,3 +938,73 @@ def test_upconv_fused_mfma_argument_validation():
     assert Wf2.numel() == 75 * 64 * 32
     with pytest.raises(_lib.SSNeuronError):                                  # window larger than the second form's LDS tile
         _lib.upconv_fused_fwd(x, None, Wf2, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 123, 2)
+
+
+# ======================================================================================================
+# Winograd F(2x2, 3x3) data gradient of the bottleneck convs (ss_wino_dgrad_*_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('NB,H,W,Co,Ci', [(3, 17, 22, 64, 32), (2, 5, 7, 8, 12), (1, 4, 4, 4, 4), (2, 1, 3, 8, 4), (80, 17, 22, 512, 512)])
+def test_winograd_dgrad_kernels(NB, H, W, Co, Ci):
+    """The three transform kernels are BIT-EXACT against oracle/np_winograd.py; the composed data gradient (transforms + torch.bmm) matches the
+    float64 gradient of the 3x3 / pad 1 convolution (reference blocks.py:146-159 under autograd) at fp32-GEMM accuracy, and MIOpen's own
+    data gradient to the same tolerance; deterministic."""
+    from oracle import np_winograd as nw
+    from stereospike_amd import _lib, fused
+    rng = np.random.default_rng(NB * 100 + H)
+    big = NB * H * W * Co > 4e6
+    g = rng.standard_normal((NB, H, W, Co)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 3, 3)) * 0.05).astype(np.float32)
+    gd, wd = torch.tensor(g, device=DEV), torch.tensor(w, device=DEV)
+    T = _lib.wino_tiles(NB, H, W)
+    U = torch.full((16, Co, Ci), float('nan'), device=DEV)
+    V = torch.full((16, T, Co), float('nan'), device=DEV)
+    _lib.wino_dgrad_weights(wd, U, Co, Ci)
+    _lib.wino_dgrad_input(gd, V, NB, H, W, Co)
+    assert np.array_equal(U.cpu().numpy().view(np.int32), nw.weights(w).view(np.int32))
+    if not big:
+        assert np.array_equal(V.cpu().numpy().view(np.int32), nw.input_tiles(g).view(np.int32))
+        m = rng.standard_normal((16, T, Ci)).astype(np.float32)
+        out = torch.full((NB, H, W, Ci), float('nan'), device=DEV)
+        _lib.wino_dgrad_output(torch.tensor(m, device=DEV), out, NB, H, W, Ci)
+        assert np.array_equal(out.cpu().numpy().view(np.int32), nw.output_tiles(m, NB, H, W).view(np.int32))
+    else:                                                  # config-3 size: a sub-range against the oracle
+        sub = nw.input_tiles(g[:2])
+        Vv = V.view(16, NB, -1, Co)[:, :2].reshape(16, -1, Co)
+        assert np.array_equal(Vv.cpu().numpy().view(np.int32), sub.view(np.int32))
+    got = fused.winograd_dgrad_cl(gd, wd)
+    assert torch.equal(got, fused.winograd_dgrad_cl(gd, wd))
+    if big:
+        gx64 = torch.ops.aten.convolution_backward(gd.double().permute(0, 3, 1, 2), torch.empty(NB, Ci, H, W, dtype=torch.float64, device=DEV),
+                                                   wd.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        ref = gx64.permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) / scale <= 3e-6
+    else:
+        ref = nw.dgrad_direct64(g, w)
+        assert np.abs(got.cpu().numpy() - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max())
+    mi = torch.ops.aten.convolution_backward(gd.permute(0, 3, 1, 2), torch.empty(NB, Ci, H, W, device=DEV), wd, None,
+                                             [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
+    assert float((got - mi).abs().max()) <= 2e-5 * max(1.0, float(mi.abs().max()))
+
+
+def test_winograd_dgrad_inside_the_spike_conv():
+    """_SpikeConvCL with WINOGRAD_DGRAD on / off: same input gradient to fp32-GEMM accuracy, identical forward and weight gradient."""
+    from stereospike_amd import fused
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(128, 128, 3, 1, 1, bias=False).to(DEV)
+    x = (torch.rand(4, 9, 11, 128, device=DEV) < 0.3).float().requires_grad_()
+    gy = torch.randn(4, 9, 11, 128, device=DEV)
+    res = {}
+    prev = fused.WINOGRAD_DGRAD
+    try:
+        for flag in (True, False):
+            fused.WINOGRAD_DGRAD = flag
+            x.grad = None; conv.weight.grad = None
+            y = fused.spike_conv_cl(x, conv)
+            assert y is not None
+            y.backward(gy)
+            res[flag] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone())
+    finally:
+        fused.WINOGRAD_DGRAD = prev
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-5 * float(res[False][1].abs().max())

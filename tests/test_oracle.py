@@ -284,3 +284,19 @@ def test_exact_split_operand_oracle_identities():
         y = (A.astype(np.float64) @ Wh + A.astype(np.float64) @ Wm + A.astype(np.float64) @ Wl).reshape(2, ho, wo, Cout)
         ref = torch.nn.functional.conv2d(torch.tensor(x).permute(0, 3, 1, 2).double(), torch.tensor(W).double(), None, s, p)
         assert np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-12      # exact products, float64 accumulation on both sides
+
+
+def test_winograd_dgrad_oracle_matches_autograd():
+    """oracle/np_winograd.py: the float64 direct form == torch autograd's conv data gradient; the fp32 Winograd restatement is within fp32
+    accumulation error of it (odd sizes, ragged last tile)."""
+    import torch.nn.functional as F
+    from oracle import np_winograd as nw
+    rng = np.random.default_rng(5)
+    for NB, H, W, Co, Ci in ((2, 17, 22, 8, 12), (1, 4, 4, 4, 4), (3, 5, 7, 8, 4), (1, 1, 1, 4, 4)):
+        g = rng.standard_normal((NB, H, W, Co)).astype(np.float32)
+        w = (rng.standard_normal((Co, Ci, 3, 3)) * 0.1).astype(np.float32)
+        x = torch.zeros(NB, Ci, H, W, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x, torch.tensor(w, dtype=torch.float64), padding=1).backward(torch.tensor(g, dtype=torch.float64).permute(0, 3, 1, 2))
+        ref = x.grad.permute(0, 2, 3, 1).numpy()
+        assert np.abs(nw.dgrad_direct64(g, w) - ref).max() <= 1e-12
+        assert np.abs(nw.dgrad(g, w) - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
