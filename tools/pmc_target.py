@@ -32,11 +32,15 @@ if mode == 'rc':
     up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(dev)
     xs = (torch.rand(NB, h, w, Cin, device=dev) < 0.4).float()
     tabs = up._tables(h, w, torch.device(dev))
+    win = up.max_tile_window(h, w)
     Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=dev)
     _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf, Cin, Cout)
+    Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=dev)       # the shipped (second) kernel form
+    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf2, Cin, Cout, 2)
     o = torch.empty(NB, H, W, Cout, device=dev)
     for _ in range(5):
         _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
-        _lib.upconv_fused_fwd(xs, None, Wf, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, up.max_tile_window(h, w))
+        _lib.upconv_fused_fwd(xs, None, Wf, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win)
+        _lib.upconv_fused_fwd(xs, None, Wf2, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win, 2)
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
