@@ -259,6 +259,19 @@ int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const
                              long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
 
 /*
+ * Weight gradient of a synapse on spike inputs as an exact bf16x3 MFMA contraction over the rows (ABI 3) — the decoder's
+ * g_W = x^T @ g_P (autograd of NNConvUpsampling, /root/reference/network/blocks.py:110-132; call sites SNN_models.py:110-129):
+ *     g_w[ci][n] (+)= sum_r x[r][ci] * g[r][n]        x [R][C_in] fp32 spike counts (exact in bf16), g [R][N] fp32, g_w [C_in][N]
+ * g is split exactly into three bf16 terms in registers, products are exact, accumulation fp32 (v_mfma_f32_32x32x16_bf16); split-K over
+ * the rows with a fixed-order second pass (deterministic).  ss_spike_wgrad_supported(C_in, N): C_in in {64, 128}, N % 32 == 0.
+ * ws: caller workspace of ss_spike_wgrad_ws_floats(C_in, N, R) floats (16-byte aligned: split-K partials + the spike operand transposed into
+ * MFMA fragment order as bf16).  accumulate != 0 adds to g_w.
+ */
+int ss_spike_wgrad_supported(int Cin, int N);
+long long ss_spike_wgrad_ws_floats(int Cin, int N, long long R);
+int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long R, int Cin, int N, int accumulate, void* stream);
+
+/*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
  * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
  *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]

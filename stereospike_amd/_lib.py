@@ -106,6 +106,12 @@ def lib():
     L.ss_upconv_fused2_prep_w.restype = i32
     L.ss_upconv_fused2_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_fused2_fwd_f32.restype = i32
+    L.ss_spike_wgrad_supported.argtypes = [i32, i32]
+    L.ss_spike_wgrad_supported.restype = i32
+    L.ss_spike_wgrad_ws_floats.argtypes = [i32, i32, i64]
+    L.ss_spike_wgrad_ws_floats.restype = i64
+    L.ss_spike_wgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, p]
+    L.ss_spike_wgrad_f32.restype = i32
     L.ss_wino_dgrad_weights_f32.argtypes = [p, p, i32, i32, p]
     L.ss_wino_dgrad_input_f32.argtypes = [p, p, i64, i32, i32, i32, p]
     L.ss_wino_dgrad_output_f32.argtypes = [p, p, i64, i32, i32, i32, p]
@@ -126,7 +132,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed',
            'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
            'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32',
-           'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32')
+           'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32',
+           'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -401,6 +408,20 @@ def split3_bf16(g, g3, M, N):
     with torch.cuda.device(g.device):
         rc = lib().ss_split3_bf16(_f32(g, 'g', M * N), _x16(g3, 'g3', 3 * M * N, torch.bfloat16), M, N, _stream(g))
     _check(rc, 'ss_split3_bf16')
+
+
+def spike_wgrad_supported(Cin, N):
+    return bool(lib().ss_spike_wgrad_supported(int(Cin), int(N)))
+
+
+def spike_wgrad(g, x, g_w, R, Cin, N, accumulate=False):
+    """g_w [Cin, N] (+)= x^T @ g with x [R, Cin] fp32 spike counts (exact in bf16) and g [R, N] fp32: exact bf16x3 MFMA contraction."""
+    _require_hip(g, 'g')
+    ws = torch.empty(int(lib().ss_spike_wgrad_ws_floats(int(Cin), int(N), int(R))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_spike_wgrad_f32(_f32(g, 'g', R * N), _f32(x, 'x', R * Cin), _f32(g_w, 'g_w', Cin * N), _f32(ws, 'ws'), R, Cin, N,
+                                      int(bool(accumulate)), _stream(g))
+    _check(rc, 'ss_spike_wgrad_f32')
 
 
 def wino_dgrad_weights(weight, U, Cout, Cin):

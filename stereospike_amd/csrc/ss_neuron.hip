@@ -1932,6 +1932,154 @@ __global__ __launch_bounds__(kBlock) void im2col_cl_bf16_packed_kernel(const uns
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Weight gradient of a synapse on spike inputs as an EXACT bf16x3 MFMA contraction over the rows:  G_W[ci][n] = sum_r x[r][ci] * g[r][n]
+// ---------------------------------------------------------------------------------------------------
+// The decoder's weight gradient (fused.py::_UpConvProjectedCL.backward: g_Wt = x^T @ g_P; /root/reference/network/blocks.py:110-132 under
+// autograd): x [R][C_in] is a spike tensor (values 0..3: exact in bf16), g [R][N] dense fp32 (N = 25 * C_out columns, row-major).  The
+// library's fp32 GEMM runs it at the fp32-MFMA rate (1.4 ms for deconv1 / deconv2 at config 3: compute-bound); here g is split EXACTLY
+// into three bf16 terms in registers (truncation split: each residual is exactly representable), every product x * g_s is exact, the
+// accumulation is fp32 on v_mfma_f32_32x32x16_bf16 — fp32-GEMM accuracy at the bf16 rate, bound by reading g once from HBM.
+//   * the contraction index is the ROW, and an MFMA operand wants 8 consecutive k per lane: a lane loads g[r0 + 8 (lane >> 5) + e][n0 + (lane & 31)],
+//     e = 0..7, as 8 dwords (a wavefront instruction covers two full 128-B lines) — the registers ARE the fragment, no LDS, no
+//     transposition; the small spike operand is transposed once into fragment order by spike_wgrad_xprep_kernel (2 B/element);
+//   * the N / 32 column tiles are dealt to Q workgroup kinds x 8 wavefronts (<= NTW tiles per wavefront), accumulators
+//     [NTW][C_in / 32] x 16 registers stay resident while the workgroup walks its slice of the rows (split-K over gridDim.x / Q slices);
+//   * partial sums go to ws[slice][n][ci] (coalesced), spike_wgrad_reduce_kernel adds the slices in a fixed order and transposes into
+//     G_W[ci][n]: deterministic, no atomics.
+constexpr int kSwThreads = 512;
+// x [R][C_in] fp32 spike counts -> xT[k-step][ci][16 rows] bf16 (exact): the MFMA operand of a k-step is then ONE 16-B load per lane and
+// C_in tile (lane -> 8 consecutive rows of one ci) instead of 8 dword loads
+__global__ __launch_bounds__(kBlock) void spike_wgrad_xprep_kernel(const float* __restrict__ x, unsigned short* __restrict__ xT, long long R, int CIN)
+{
+    const long long KS = (R + 15) / 16, total = KS * CIN;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const long long ks = i / CIN;
+        const int ci = (int)(i - ks * CIN);
+        u16x8 a, b;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const long long r = 16 * ks + rr;
+            const unsigned short v = r < R ? (unsigned short)(__float_as_uint(x[r * CIN + ci]) >> 16) : (unsigned short)0;
+            if (rr < 8) a[rr] = v; else b[rr - 8] = v;
+        }
+        *reinterpret_cast<u16x8*>(xT + i * 16) = a;
+        *reinterpret_cast<u16x8*>(xT + i * 16 + 8) = b;
+    }
+}
+
+template <int CIT, int NTW, int PF>
+__global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __restrict__ g, const unsigned short* __restrict__ xT,
+                                                                float* __restrict__ ws, long long R, int N, int Q)
+{
+    constexpr int CIN = 32 * CIT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // wave-uniform: keeps the operand base addresses in SGPRs
+    const int q = (int)(blockIdx.x % Q), slice = (int)(blockIdx.x / Q), slices = (int)(gridDim.x / Q);
+    const int NT = N / 32;
+    // kind q owns the CONTIGUOUS column tiles [q tpk, (q + 1) tpk): a workgroup then reads one contiguous piece of every row of g
+    const int tpk = (NT + Q - 1) / Q, kt = min(tpk, NT - q * tpk);
+    const int tile0 = q * tpk + wave;                                            // this wavefront's column tiles: tile0 + 8 j, j < NTW
+    if (wave >= kt) return;
+    bool own[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) own[j] = wave + 8 * j < kt;
+    f32x16 acc[NTW][CIT];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int t = 0; t < CIT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+    const long long KS = (R + 15) / 16, KSF = R / 16;                            // k-steps in all / complete ones
+    const long long per = (KS + slices - 1) / slices;
+    const long long ks0 = slice * per, ks1 = min(ks0 + per, KS);
+    // Addressing: one 32-bit lane offset for all loads; the row e of the k-step and the column tile j are folded into wave-uniform bases
+    const unsigned goff = (unsigned)((lane >> 5) * 8) * (unsigned)N + (unsigned)(lane & 31);          // elements
+    const unsigned xoff = (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * 8u;                  // bf16 elements
+    float gv[PF][NTW][8];
+    s16x8 xn[PF][CIT];
+    auto load_step = [&](float (&gd)[NTW][8], s16x8 (&xd)[CIT], long long ks) {
+        const unsigned short* xb = xT + ks * CIN * 16;
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) xd[t] = *reinterpret_cast<const s16x8*>(xb + 32 * 16 * t + xoff);
+        if (ks < KSF) {                                                          // all 16 rows exist: uniform bases
+            const float* gb = g + ks * 16 * N + 32 * tile0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) gd[j][e] = own[j] ? load_stream(gb + (long long)e * N + 32 * 8 * j + goff) : 0.f;
+        } else {                                                                 // the ragged last k-step: rows beyond R read row R - 1
+#pragma unroll                                                                   // (finite) and meet the zero rows of xT
+            for (int e = 0; e < 8; ++e) {
+                const long long r = min(16 * ks + 8 * (lane >> 5) + e, R - 1);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) gd[j][e] = own[j] ? g[r * N + 32 * (tile0 + 8 * j) + (lane & 31)] : 0.f;
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u)
+        if (ks0 + u < ks1) load_step(gv[u], xn[u], ks0 + u);
+#pragma unroll 1
+    for (long long ks = ks0; ks < ks1; ks += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (ks + u < ks1) {
+                if (ks + u + PF - 1 < ks1) load_step(gv[(u + PF - 1) % PF], xn[(u + PF - 1) % PF], ks + u + PF - 1);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (own[j]) {
+                        s16x8 gs[3];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = gv[u][j][e];
+                            const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
+                            const float r1 = v - __uint_as_float(uh);                                          // exact
+                            const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+                            const float r2 = r1 - __uint_as_float(um);                                         // exact, <= 8 significant bits
+                            gs[0][e] = (short)(uh >> 16); gs[1][e] = (short)(um >> 16); gs[2][e] = (short)(__float_as_uint(r2) >> 16);
+                        }
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                            for (int t = 0; t < CIT; ++t)
+                                acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs[sp], xn[u][t], acc[j][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D[n][ci]: column (ci) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* const wsl = ws + (long long)slice * N * CIN;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        if (own[j]) {
+#pragma unroll
+            for (int t = 0; t < CIT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * (tile0 + 8 * j) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    wsl[(long long)n * CIN + 32 * t + (lane & 31)] = acc[j][t][r];
+                }
+        }
+    }
+}
+
+// G_W[ci][n] (+)= sum over slices of ws[slice][n][ci], slices in ascending order
+__global__ __launch_bounds__(kBlock) void spike_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int slices, int N, int CIN,
+                                                                   int accumulate)
+{
+    const long long total = (long long)N * CIN;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int n = (int)(i / CIN), ci = (int)(i - (long long)n * CIN);
+        float a = 0.f;
+        for (int sIdx = 0; sIdx < slices; ++sIdx) a += ws[(long long)sIdx * total + i];
+        float* o = gw + (long long)ci * N + n;
+        *o = accumulate ? *o + a : a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) DATA GRADIENT of a 3x3 / stride 1 / pad 1 convolution, NHWC (the four bottleneck convs)
 // ---------------------------------------------------------------------------------------------------
 // Reference: the autograd backward of SEWResBlock's conv1 / conv2 (/root/reference/network/blocks.py:146-159) w.r.t. their input:
@@ -2944,6 +3092,47 @@ int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream)
     if (!g || !g3 || M <= 0 || N <= 0 || N % 4 != 0 || !aligned16(g) || !aligned16(g3)) return SS_EINVAL;
     hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(M * (N / 4), kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        g, static_cast<unsigned short*>(g3), M, N);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_spike_wgrad_supported(int Cin, int N)
+{
+    return (Cin == 64 || Cin == 128) && N > 0 && N % 32 == 0 && N / 32 <= 128;
+}
+
+static int spike_wgrad_plan(int Cin, int N, int* Q, int* slices)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
+    // accumulators per wavefront: NTW x (Cin / 32) x 16 registers = 64 (with the prefetched operands of the next k-step the kernel
+    // stays inside the 256 registers of two wavefronts per SIMD): Cin 64 -> 2 column tiles per wavefront, 128 -> 1
+    const int ntw = Cin == 64 ? 2 : 1;
+    const int nt = N / 32;
+    *Q = (nt + 8 * ntw - 1) / (8 * ntw);
+    *slices = cus / *Q > 0 ? cus / *Q : 1;
+    return 1;
+}
+
+long long ss_spike_wgrad_ws_floats(int Cin, int N, long long R)
+{
+    int Q = 0, slices = 0;
+    if (R <= 0 || !ss_spike_wgrad_supported(Cin, N) || !spike_wgrad_plan(Cin, N, &Q, &slices)) return 0;
+    return (long long)slices * N * Cin + ((R + 15) / 16) * Cin * 8;           // split-K partials + the bf16 fragment-order copy of x
+}
+
+int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long R, int Cin, int N, int accumulate, void* stream)
+{
+    if (!g || !x || !g_w || !ws || R <= 0 || !ss_spike_wgrad_supported(Cin, N) || !aligned16(ws)) return SS_EINVAL;
+    int Q = 0, slices = 0;
+    if (!spike_wgrad_plan(Cin, N, &Q, &slices)) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* xT = reinterpret_cast<unsigned short*>(ws + (long long)slices * N * Cin);
+    hipLaunchKernelGGL(spike_wgrad_xprep_kernel, dim3(grid_for(((R + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s, x, xT, R, Cin);
+    const unsigned grid = (unsigned)(Q * slices);
+    if (Cin == 64) hipLaunchKernelGGL((spike_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q);
+    else hipLaunchKernelGGL((spike_wgrad_kernel<4, 1, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    hipLaunchKernelGGL(spike_wgrad_reduce_kernel, dim3(grid_for((long long)N * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, N, Cin, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -470,6 +470,10 @@ FUSED_UPCONV_MFMA = True          # decoder stages with a compiled shape (deconv
 FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 122); 1: always the first form (A/B)
 ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
+EXACT_WGRAD_MFMA = True            # weight gradient of the decoder stages with C_in 64 / 128 (deconv1, deconv2) as the hand-written exact bf16x3 MFMA
+                                   # contraction ss_spike_wgrad_f32 (was the library's fp32 GEMM at the fp32-MFMA rate)
+import os as _os
+EXACT_WGRAD_MFMA_CIN = tuple(int(c) for c in _os.environ.get('SS_WGRAD_MFMA_CIN', '64,128').split(',') if c)   # A/B knob (tools/)
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
                                    # to pay for the extra 10 B/element split pass over g_P (profiles/r01/split_wgrad_sweep.log)
 ASSERT_EXACT_SPLIT = False         # tests: verify (with a host sync) that the input really is bf16-exact
@@ -604,7 +608,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
             if need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
-            if need_w and ctx.exact and not lowp and Cin >= EXACT_SPLIT_WGRAD_MIN_K:
+            if (need_w and ctx.exact and not lowp and EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
+                    and Cin in EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
+                # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
+                _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)
+            elif need_w and ctx.exact and not lowp and Cin >= EXACT_SPLIT_WGRAD_MIN_K:
                 # x is a spike tensor: g_Wt = x^T @ (gh + gm + gl) with exact products on the bf16 MFMA path (one extra 10 B/element pass
                 # over g_P for the split — pays only where the GEMM is compute-bound, i.e. the widest stage)
                 g3 = torch.empty((rows, 3 * kk * Cout), dtype=torch.bfloat16, device=x_cl.device)

@@ -1008,3 +1008,30 @@ def test_winograd_dgrad_inside_the_spike_conv():
         fused.WINOGRAD_DGRAD = prev
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
     assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-5 * float(res[False][1].abs().max())
+
+
+# ======================================================================================================
+# exact bf16x3 MFMA weight gradient of a synapse on spike inputs (ss_spike_wgrad_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('R,Cin,N', [(1000, 64, 800), (4099, 128, 1600), (37, 64, 96), (16 * 130 * 173, 64, 800), (5 * 65 * 87, 128, 1600)])
+def test_spike_wgrad_mfma(R, Cin, N):
+    """g_w[ci][n] = sum_r x[r][ci] g[r][n] for spike x: products exact, fp32 accumulation -> within fp32 summation error of the float64
+    contraction (far inside it: the error of an fp32 GEMM); ragged row counts; accumulate flag; run-to-run bit-identical."""
+    from stereospike_amd import _lib
+    gen = torch.Generator(device=DEV).manual_seed(R + N)
+    x = ((torch.rand(R, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(R, Cin, device=DEV, generator=gen) < 0.1).float())
+    g = torch.randn(R, N, device=DEV, generator=gen) * torch.exp(torch.randn(R, 1, device=DEV, generator=gen))       # wide dynamic range
+    assert _lib.spike_wgrad_supported(Cin, N)
+    out = torch.full((Cin, N), float('nan'), device=DEV)
+    _lib.spike_wgrad(g, x, out, R, Cin, N)
+    ref = x.double().t() @ g.double()
+    bound = (x.double().t().abs() @ g.double().abs()) * 2.0 ** -22 + 1e-30          # a few ulp of the magnitude sum (fp32 accumulation)
+    assert bool(((out.double() - ref).abs() <= bound).all()), float(((out.double() - ref).abs() / bound).max())
+    lib32 = x.t() @ g
+    assert float((out - ref.float()).abs().max()) <= 2.0 * float((lib32 - ref.float()).abs().max()) + 1e-6 * float(ref.abs().max())
+    out2 = torch.empty_like(out)
+    _lib.spike_wgrad(g, x, out2, R, Cin, N)
+    assert torch.equal(out, out2)
+    _lib.spike_wgrad(g, x, out2, R, Cin, N, accumulate=True)
+    assert torch.equal(out2, out + out)
+    assert not _lib.spike_wgrad_supported(32, 800) and not _lib.spike_wgrad_supported(64, 100)

@@ -67,3 +67,29 @@ for name, Cin, Cout, (h, w), (H, W) in geoms:
             pr = [int(v) - t0 if v else -1 for v in buf[0, st]]
             co = [int(v) - t0 if v else -1 for v in buf[1, st]]
             print(f'  {st:3d} | {pr[0]:7d} {pr[1]:7d} {pr[2]:7d} {pr[3]:7d} | {co[0]:7d} {co[1]:7d} {co[2]:7d} {co[3]:7d}')
+
+if os.environ.get('WGRAD', '1') == '1':       # exact bf16x3 MFMA weight gradient vs the library's fp32 GEMM (split-K as in fused.py)
+    from stereospike_amd import fused
+    for name, Cin, Cout, (h, w), _ in geoms:
+        R, N = NB * h * w, 25 * Cout
+        x = (torch.rand(R, Cin, device=dev) < 0.35).float()
+        g = torch.randn(R, N, device=dev)
+        out = torch.empty(Cin, N, device=dev)
+        S = max(1, R // fused.WGRAD_SPLIT_ROWS); L = R // S
+
+        def lib():
+            return torch.bmm(x[:S * L].view(S, L, Cin).transpose(1, 2), g[:S * L].view(S, L, N)).sum(0)
+
+        def own():
+            _lib.spike_wgrad(g, x, out, R, Cin, N)
+        res = {}
+        for tag, fn in (('library fp32 split-K bmm', lib), ('ss_spike_wgrad_f32', own)):
+            fn(); fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            res[tag] = e0.elapsed_time(e1) / 5
+        print(f'{name} wgrad [{Cin} x {R}] @ [{R} x {N}]: ' + ', '.join(f'{k} {v:.3f} ms' for k, v in res.items()) +
+              f'  (g read once at HBM rate: {4 * R * N / 5.5e9:.3f} ms)', flush=True)
