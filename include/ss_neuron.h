@@ -257,6 +257,13 @@ long long ss_upconv_fused2_wf_elems(int Cin, int Cout);
 int ss_upconv_fused2_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream);
 int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
                              long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
+/* The same kernel for 16-bit activation modes (BASELINE.json configs 2 / 5; decoder stages under torch.autocast): x and out are fp16 / bf16
+ * arrays (dtype = SS_DT_F16 / SS_DT_BF16; spikes are exact in both), the sums are fp32 and narrowed (nearest even) on store.
+ * nsplit = 3: exact fp32 weights (compiled for fp16: the forward of the fp16 mode stays exact); nsplit = 1: weights rounded once to bf16, what
+ * bf16 autocast does to every synapse (compiled for bf16).  ss_upconv_fused2_prep_w_x16 writes nsplit terms (same buffer size as _prep_w). */
+int ss_upconv_fused2_prep_w_x16(const float* W, void* Wf, int Cin, int Cout, int nsplit, void* stream);
+int ss_upconv_fused2_fwd_x16(const void* x, int dtype, const void* Wf, int nsplit, const int* src_y, const int* src_x, void* out,
+                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
 
 /*
  * Weight gradient of a synapse on spike inputs as an exact bf16x3 MFMA contraction over the rows (ABI 3) — the decoder's

@@ -106,6 +106,10 @@ def lib():
     L.ss_upconv_fused2_prep_w.restype = i32
     L.ss_upconv_fused2_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_fused2_fwd_f32.restype = i32
+    L.ss_upconv_fused2_prep_w_x16.argtypes = [p, p, i32, i32, i32, p]
+    L.ss_upconv_fused2_prep_w_x16.restype = i32
+    L.ss_upconv_fused2_fwd_x16.argtypes = [p, i32, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_fused2_fwd_x16.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
     L.ss_spike_wgrad_supported.restype = i32
     L.ss_spike_wgrad_ws_floats.argtypes = [i32, i32, i64]
@@ -133,7 +137,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
            'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32',
            'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32',
-           'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32')
+           'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
+           'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16')
 
 
 def _ptr(t, name, numel=None):
@@ -408,6 +413,24 @@ def split3_bf16(g, g3, M, N):
     with torch.cuda.device(g.device):
         rc = lib().ss_split3_bf16(_f32(g, 'g', M * N), _x16(g3, 'g3', 3 * M * N, torch.bfloat16), M, N, _stream(g))
     _check(rc, 'ss_split3_bf16')
+
+
+def upconv_fused2_x16(x, weight, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window):
+    """Fused projection + gather (form 2) on 16-bit activations: x [NB, h, w, Cin] and out [NB, H, W, Cout] fp16 or bf16 (same dtype), weight
+    [Cout, Cin, 5, 5] fp32.  fp16: exact fp32 weights (3 bf16 terms); bf16: weights rounded once to bf16 (autocast semantics)."""
+    _require_hip(x, 'x')
+    if x.dtype not in (torch.float16, torch.bfloat16) or out.dtype != x.dtype:
+        raise SSNeuronError('upconv_fused2_x16: x and out must both be fp16 or both bf16')
+    nsplit = 3 if x.dtype == torch.float16 else 1
+    Wf = torch.empty(upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().ss_upconv_fused2_prep_w_x16(_f32(weight, 'weight', Cout * Cin * 25), _x16(Wf, 'Wf', Wf.numel(), torch.bfloat16), Cin, Cout, nsplit,
+                                               _stream(x))
+        _check(rc, 'ss_upconv_fused2_prep_w_x16')
+        rc = lib().ss_upconv_fused2_fwd_x16(_x16(x, 'x', NB * h * w * Cin, x.dtype), DT_CODE[x.dtype], _x16(Wf, 'Wf', Wf.numel(), torch.bfloat16), nsplit,
+                                            _i32(src_y, 'src_y', H + 4), _i32(src_x, 'src_x', W + 4), _x16(out, 'out', NB * H * W * Cout, out.dtype),
+                                            NB, Cin, Cout, h, w, H, W, int(max_window), _stream(x))
+    _check(rc, 'ss_upconv_fused2_fwd_x16')
 
 
 def spike_wgrad_supported(Cin, N):

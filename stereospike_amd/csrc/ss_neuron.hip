@@ -1471,15 +1471,16 @@ constexpr int kF2PRowB = 528;                 // bytes of one source pixel's row
 
 // W [C_out][C_in][5][5] fp32 -> Wf2[column tile nt][split][k-step j][lane][8] bf16; column n = 32 nt + (lane & 31) = tap * C_out + co,
 // element e = split term of W[co][ci = 16 j + 8 (lane >> 5) + e][tap]
-__global__ __launch_bounds__(kBlock) void upconv_fused2_prep_w_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wf, int Cin, int Cout)
+__global__ __launch_bounds__(kBlock) void upconv_fused2_prep_w_kernel(const float* __restrict__ Wt, unsigned short* __restrict__ Wf, int Cin, int Cout,
+                                                                      int nsplit)
 {
     const int KC = Cin / 16, NTL = 25 * Cout / 32;
-    const long long total = (long long)NTL * 3 * KC * 64;
+    const long long total = (long long)NTL * nsplit * KC * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
         long long r = i >> 6;
         const int j = (int)(r % KC); r /= KC;
-        const int split = (int)(r % 3); const int nt = (int)(r / 3);
+        const int split = (int)(r % nsplit); const int nt = (int)(r / nsplit);
         const int n = 32 * nt + (lane & 31);
         const int tap = n / Cout, co = n - tap * Cout;
         u16x8 o;
@@ -1497,12 +1498,19 @@ __global__ __launch_bounds__(kBlock) void upconv_fused2_prep_w_kernel(const floa
     }
 }
 
-template <int CIN, int COUT, bool PACKED>
+// XIN: input spikes as 0 fp32, kF2Packed 2-bit packed, SS_DT_F16 / SS_DT_BF16 16-bit activations (all exact in bf16);  ODT: output fp32 (0) or
+// 16-bit activations (the fp32 sums narrowed on store: decoder stages under 16-bit autocast);  NSPLIT: 3 = exact fp32 weights (hi, mid, lo),
+// 1 = weights rounded once to bf16 (what bf16 autocast does to every synapse; Wf then holds the hi terms only)
+constexpr int kF2Packed = 3;
+template <int CIN, int COUT, int XIN, int ODT, int NSPLIT>
 __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wf,
                                                                       const int* __restrict__ src_y, const int* __restrict__ src_x,
-                                                                      float* __restrict__ out, int h, int w, int H, int W,
+                                                                      void* __restrict__ outv, int h, int w, int H, int W,
                                                                       int tiles_x, int tiles_y, int n_tiles)
 {
+    constexpr bool PACKED = XIN == kF2Packed;
+    constexpr bool X16 = XIN == SS_DT_F16 || XIN == SS_DT_BF16;
+    static_assert(NSPLIT == 3 || NSPLIT == 1, "three exact terms or one rounded term");
     constexpr int KC = CIN / 16;                      // MFMA k-steps per split
     constexpr int NPT = COUT / 32;                    // column tiles per tap
     constexpr int NTL = 25 * NPT;                     // column tiles in all (25 / 50: no padding)
@@ -1521,7 +1529,7 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
     const int cw_ = (threadIdx.x >> 6) & 3;
     // output transposition scratch: 16 pixels x (C_out floats + 16 B) per consumer wavefront.  CONT: its own region; otherwise the window
     // region, which is free between the producers' last pass of a tile and the commit of the next window
-    constexpr int OROWB = COUT * 4 + 16;
+    constexpr int OROWB = COUT * 4 + 16;              // (fp32 in the scratch; narrowed when it leaves)
     constexpr int OSCR = 16 * OROWB;
     static_assert(CONT || 4 * OSCR <= kF2Rows * XROWB, "transposition scratch must fit the window region");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kF2Rows * kF2PRowB + kF2Rows * XROWB + (CONT ? 4 * OSCR : 0)];
@@ -1540,15 +1548,18 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
 
     if (producer) {
         if (SS_F2_PRIO == 1) __builtin_amdgcn_s_setprio(3);
-        // ---- weight stream: chunk (pass, split) of this wavefront's column tile nt = 4 pass + cw sits in buffer `split`; three in flight
+        // ---- weight stream: chunk (pass, split) of this wavefront's column tile nt = 4 pass + cw sits in buffer `split`; NSPLIT in flight
+        //      (NSPLIT == 1: the next pass's chunk is loaded into wnx during this pass and copied over)
         const s16x8* const wbase = reinterpret_cast<const s16x8*>(Wf) + lane;
         s16x8 wq[3][KC];
+        [[maybe_unused]] s16x8 wnx[KC];
         auto load_chunk = [&](s16x8 (&dst)[KC], int pass, int split) {
-            const long long c0 = ((long long)(4 * pass + cw) * 3 + split) * KC;
+            const long long c0 = ((long long)(4 * pass + cw) * NSPLIT + split) * KC;
 #pragma unroll
             for (int j = 0; j < KC; ++j) dst[j] = wbase[(c0 + j) * 64];
         };
-        load_chunk(wq[0], 0, 0); load_chunk(wq[1], 0, 1); load_chunk(wq[2], 0, 2);
+        if constexpr (NSPLIT == 3) { load_chunk(wq[0], 0, 0); load_chunk(wq[1], 0, 1); load_chunk(wq[2], 0, 2); }
+        else load_chunk(wq[2], 0, 0);                                     // the single term plays the role of the last split
         f2_barrier();                                                     // first window is in LDS
         int gstep = 0;
         for (int tile = band0 + slot0; tile < band_end; tile += slots) {
@@ -1586,7 +1597,7 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                     };
                     // splits hi, mid: k-step outer, the four source tiles inner (4 independent accumulators)
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
+                    for (int s = 0; s < NSPLIT - 1; ++s) {
                         if constexpr (XREG) {
 #pragma unroll
                             for (int jj = 0; jj < KC; ++jj)
@@ -1623,6 +1634,7 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                             *reinterpret_cast<f4*>(Pp + row * kF2PRowB + ((cw * 8 + 2 * q + (lane >> 5)) << 4)) =
                                 (f4){acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]};
                     };
+                    if constexpr (NSPLIT == 1) { if (!(SS_F2_ABLATE & 4)) load_chunk(wnx, npass, 0); }
                     // split lo, source tiles 0 and 1 (two interleaved accumulator chains)
 #pragma unroll
                     for (int jj = 0; jj < KC; ++jj) { mma(acc[0], wq[2][jj], xop(0, jj), 0, jj); mma(acc[1], wq[2][jj], xop(1, jj), 1, jj); }
@@ -1637,7 +1649,11 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                     }
                     static_assert(KC >= 4, "the store interleave above expects >= 4 k-steps");
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!(SS_F2_ABLATE & 4)) load_chunk(wq[2], npass, 2);
+                    if constexpr (NSPLIT == 3) { if (!(SS_F2_ABLATE & 4)) load_chunk(wq[2], npass, 2); }
+                    else {
+#pragma unroll
+                        for (int jj = 0; jj < KC; ++jj) wq[2][jj] = wnx[jj];
+                    }
 #if SS_F2_TRACE
                     if (acc[0][0] == 12345.f && acc[1][1] == 1.f && acc[2][2] == 2.f && acc[3][3] == 3.f) f2_trace[0][63][3] = 1;   // waits for the MFMAs
                     F2_STAMP(0, 1);
@@ -1663,7 +1679,7 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
     if (SS_F2_PRIO == 3) __builtin_amdgcn_s_setprio(3);
     const int ct = cw * 64 + lane;                                        // 0..255: pixel (ct >> 4, ct & 15) of the tile
     const int py = ct >> 4, px = ct & 15;
-    f4 xr[XU][PACKED ? 1 : 2];
+    f4 xr[XU][(PACKED || X16) ? 1 : 2];
     unsigned xrp[XU];
     struct Geo { int img, y0, x0, sy0, sx0, SH, SW; };
     auto geom = [&](int tile) {
@@ -1687,6 +1703,8 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                 const long long e = ((((long long)g.img * h + (g.sy0 + ly)) * w) + (g.sx0 + lx)) * CIN + 8 * ch;
                 if constexpr (PACKED) {
                     xrp[u] = (static_cast<const unsigned*>(xin)[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu;
+                } else if constexpr (X16) {
+                    xr[u][0] = *reinterpret_cast<const f4*>(static_cast<const unsigned short*>(xin) + e);     // 8 channels x 16 bit
                 } else {
                     const float* xp = static_cast<const float*>(xin) + e;
                     xr[u][0] = *reinterpret_cast<const f4*>(xp);
@@ -1706,6 +1724,12 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
                 if constexpr (PACKED) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) a[q] = (short)code_to_bf16((xrp[u] >> (2 * q)) & 3u);
+                } else if constexpr (XIN == SS_DT_BF16) {
+                    a = __builtin_bit_cast(s16x8, xr[u][0]);
+                } else if constexpr (XIN == SS_DT_F16) {
+                    const u16x8 hv = __builtin_bit_cast(u16x8, xr[u][0]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = (short)(__float_as_uint(widen<SS_DT_F16>(hv[q])) >> 16);   // small integers: exact
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {                          // spikes: exact in bf16
@@ -1776,7 +1800,7 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
     // the wavefront's four pixel rows go through its LDS scratch one after the other and leave as 1-KiB contiguous stores
     // (lane -> 16-B chunk t = lane + 64 u of the row's 16 pixels x C_out floats).  LDS executes a wavefront's operations in order.
     auto store_out = [&](const Geo& g) {
-        constexpr int NCH = COUT / 4;                                      // 16-B chunks per pixel
+        constexpr int NCH = COUT / 4;                                      // 16-B chunks (4 channels) per pixel in the scratch
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if ((lane >> 4) == r) {
@@ -1785,13 +1809,22 @@ __global__ __launch_bounds__(kF2Threads) void upconv_fused2_fwd_kernel(const voi
             }
             asm volatile("" ::: "memory");        // hipcc 7.2 otherwise sinks the first scratch read INTO the lane-masked store region above
             const int yy = g.y0 + 4 * cw + r;
-            float* const orow = out + (((long long)g.img * H + yy) * W + g.x0) * COUT;
+            const long long orow = (((long long)g.img * H + yy) * W + g.x0) * COUT;
 #pragma unroll
             for (int u = 0; u < NCH / 4; ++u) {
                 const int t = lane + 64 * u;
                 const int pxl = t / NCH, c = t - pxl * NCH;
                 const f4 v = *reinterpret_cast<const f4*>(Os + pxl * OROWB + 16 * c);
-                if (yy < H && g.x0 + pxl < W) *reinterpret_cast<f4*>(orow + (long long)pxl * COUT + 4 * c) = v;
+                if (yy < H && g.x0 + pxl < W) {
+                    if constexpr (ODT == 0) {
+                        *reinterpret_cast<f4*>(static_cast<float*>(outv) + orow + (long long)pxl * COUT + 4 * c) = v;
+                    } else {
+                        u16x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = narrow<ODT>(v[q]);
+                        *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(outv) + orow + (long long)pxl * COUT + 4 * c) = o;
+                    }
+                }
             }
             asm volatile("" ::: "memory");
         }
@@ -2909,21 +2942,25 @@ long long ss_upconv_fused2_wf_elems(int Cin, int Cout)
     return 25LL * Cout * 3 * Cin;
 }
 
-int ss_upconv_fused2_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream)
+static int fused2_prep(const float* W, void* Wf, int Cin, int Cout, int nsplit, void* stream)
 {
-    if (!W || !Wf || !ss_upconv_fused2_wf_elems(Cin, Cout) || !aligned16(Wf)) return SS_EINVAL;
-    hipLaunchKernelGGL(upconv_fused2_prep_w_kernel, dim3(grid_for(ss_upconv_fused2_wf_elems(Cin, Cout) / 8, 4096)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), W, static_cast<unsigned short*>(Wf), Cin, Cout);
+    if (!W || !Wf || !ss_upconv_fused2_wf_elems(Cin, Cout) || !aligned16(Wf) || (nsplit != 1 && nsplit != 3)) return SS_EINVAL;
+    hipLaunchKernelGGL(upconv_fused2_prep_w_kernel, dim3(grid_for(ss_upconv_fused2_wf_elems(Cin, Cout) / 24 * nsplit, 4096)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), W, static_cast<unsigned short*>(Wf), Cin, Cout, nsplit);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
-int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
-                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream)
+int ss_upconv_fused2_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream) { return fused2_prep(W, Wf, Cin, Cout, 3, stream); }
+int ss_upconv_fused2_prep_w_x16(const float* W, void* Wf, int Cin, int Cout, int nsplit, void* stream) { return fused2_prep(W, Wf, Cin, Cout, nsplit, stream); }
+
+// xin_kind: 0 fp32, kF2Packed packed, SS_DT_F16 / SS_DT_BF16;  out_dt: 0 fp32, SS_DT_F16 / SS_DT_BF16;  nsplit 3 / 1
+static int fused2_launch(const void* xin, int xin_kind, const void* Wf, const int* src_y, const int* src_x, void* out, int out_dt, int nsplit,
+                         long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream)
 {
-    if ((!x && !x_packed) || !Wf || !src_y || !src_x || !out || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (!xin || !Wf || !src_y || !src_x || !out || NB < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
     if (!ss_upconv_fused2_supported(Cin, Cout, 5, max_window)) return SS_EINVAL;
-    if (!aligned16(Wf) || !aligned16(out) || (x && !aligned16(x))) return SS_EINVAL;
-    if (x_packed && (NB * h * w * Cin) % 16 != 0) return SS_EINVAL;
+    if (!aligned16(Wf) || !aligned16(out) || (xin_kind != kF2Packed && !aligned16(xin))) return SS_EINVAL;
+    if (xin_kind == kF2Packed && (NB * h * w * Cin) % 16 != 0) return SS_EINVAL;
     if (NB == 0) return SS_OK;
     const int tx = (W + kFusT - 1) / kFusT, ty = (H + kFusT - 1) / kFusT;
     const long long tiles = NB * tx * ty;
@@ -2936,13 +2973,32 @@ int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const
     const unsigned grid = 8u * (unsigned)(per_xcd < cus / 8 ? per_xcd : cus / 8);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned short* wf = static_cast<const unsigned short*>(Wf);
-#define SS_FUS2(CI, CO) do { if (x_packed) hipLaunchKernelGGL((upconv_fused2_fwd_kernel<CI, CO, true>), dim3(grid), dim3(kF2Threads), 0, s, \
-                                                              static_cast<const void*>(x_packed), wf, src_y, src_x, out, h, w, H, W, tx, ty, (int)tiles); \
-                             else hipLaunchKernelGGL((upconv_fused2_fwd_kernel<CI, CO, false>), dim3(grid), dim3(kF2Threads), 0, s, \
-                                                     static_cast<const void*>(x), wf, src_y, src_x, out, h, w, H, W, tx, ty, (int)tiles); } while (0)
-    if (Cin == 64) SS_FUS2(64, 32); else SS_FUS2(128, 64);
+#define SS_FUS2(CI, CO, XI, OD, NS) hipLaunchKernelGGL((upconv_fused2_fwd_kernel<CI, CO, XI, OD, NS>), dim3(grid), dim3(kF2Threads), 0, s, \
+                                                       xin, wf, src_y, src_x, out, h, w, H, W, tx, ty, (int)tiles)
+#define SS_FUS2_SHAPES(XI, OD, NS) do { if (Cin == 64) SS_FUS2(64, 32, XI, OD, NS); else SS_FUS2(128, 64, XI, OD, NS); } while (0)
+    if (xin_kind == 0 && out_dt == 0 && nsplit == 3) SS_FUS2_SHAPES(0, 0, 3);
+    else if (xin_kind == kF2Packed && out_dt == 0 && nsplit == 3) SS_FUS2_SHAPES(kF2Packed, 0, 3);
+    else if (xin_kind == SS_DT_F16 && out_dt == SS_DT_F16 && nsplit == 3) SS_FUS2_SHAPES(SS_DT_F16, SS_DT_F16, 3);
+    else if (xin_kind == SS_DT_BF16 && out_dt == SS_DT_BF16 && nsplit == 1) SS_FUS2_SHAPES(SS_DT_BF16, SS_DT_BF16, 1);
+    else return SS_EINVAL;
+#undef SS_FUS2_SHAPES
 #undef SS_FUS2
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
+                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream)
+{
+    if (!x && !x_packed) return SS_EINVAL;
+    return fused2_launch(x_packed ? static_cast<const void*>(x_packed) : static_cast<const void*>(x), x_packed ? kF2Packed : 0, Wf, src_y, src_x, out, 0, 3,
+                         NB, Cin, Cout, h, w, H, W, max_window, stream);
+}
+
+int ss_upconv_fused2_fwd_x16(const void* x, int dtype, const void* Wf, int nsplit, const int* src_y, const int* src_x, void* out,
+                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream)
+{
+    if (dtype != SS_DT_F16 && dtype != SS_DT_BF16) return SS_EINVAL;
+    return fused2_launch(x, dtype, Wf, src_y, src_x, out, dtype, nsplit, NB, Cin, Cout, h, w, H, W, max_window, stream);
 }
 
 int ss_ipool_fwd_f32(const float* pd_seq, long long stride_t, long long stride_k, const float* v_init,

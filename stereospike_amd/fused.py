@@ -467,6 +467,7 @@ WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient G
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
 EXACT_SPLIT_GEMM = True
 FUSED_UPCONV_MFMA = True          # decoder stages with a compiled shape (deconv1, deconv2): projection + gather in ONE hand-written MFMA kernel, P never in HBM
+FUSED_UPCONV_X16 = True            # 16-bit autocast: deconv1 / deconv2 forward through the same fused kernel on 16-bit activations (was GEMM + gather)
 FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 122); 1: always the first form (A/B)
 ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
@@ -524,6 +525,22 @@ class _UpConvProjectedCL(torch.autograd.Function):
             form = _lib.upconv_fused_form(Cin, Cout, k, max_window)           # 2: wavefront-specialised persistent kernel; 1: first form
             if form == 2 and FUSED_UPCONV_FORM == 1 and max_window <= 128:
                 form = 1
+        # 16-bit autocast, decoder stage with 16-bit spike input and 16-bit activation output: the same kernel (form 2) on 16-bit I/O —
+        # fp16: exact fp32 weights like the fp32 mode; bf16: weights rounded once to bf16, autocast's own semantics for every synapse
+        x16_fused = (FUSED_UPCONV_MFMA and FUSED_UPCONV_X16 and spikes_in and act_dtype is not None and bias is None and half_in
+                     and x_cl.dtype == act_dtype and lowp == (act_dtype == torch.bfloat16) and (lowp or EXACT_SPLIT_GEMM)
+                     and _lib.upconv_fused_form(Cin, Cout, k, max_window) == 2)
+        if x16_fused:
+            e0 = TIMER.start()
+            _lib.upconv_fused2_x16(x_cl, weight.contiguous(), src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
+            TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
+            ctx.save_for_backward(x_cl, Wt)
+            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+            ctx.exact = not lowp
+            ctx.tables, ctx.k, ctx.n = tables, k, n
+            ctx.wshape = weight.shape
+            ctx.has_bias = False
+            return out
         if form:
             if ASSERT_EXACT_SPLIT:
                 assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'

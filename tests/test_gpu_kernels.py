@@ -1035,3 +1035,40 @@ def test_spike_wgrad_mfma(R, Cin, N):
     _lib.spike_wgrad(g, x, out2, R, Cin, N, accumulate=True)
     assert torch.equal(out2, out + out)
     assert not _lib.spike_wgrad_supported(32, 800) and not _lib.spike_wgrad_supported(64, 100)
+
+
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 2), (64, 32, (9, 11), (17, 19), 3)])
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_upconv_fused_mfma_x16(Cin, Cout, hw, HW, NB, dt):
+    """Form-2 kernel on 16-bit activations.  fp16: the fp32 kernel's sums narrowed on store — bit-identical to narrowing the fp32 output
+    (exact weights, exact spike inputs).  bf16: weights rounded once to bf16 (autocast semantics): against NNConvUpsampling in float64 with
+    bf16-rounded weights at fp32-accumulation accuracy + one bf16 rounding of the result."""
+    from stereospike_amd import _lib
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    torch.manual_seed(7)
+    (h, w), (H, W) = hw, HW
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
+    x = ((torch.rand(NB, h, w, Cin, device=DEV) < 0.35).float() + (torch.rand(NB, h, w, Cin, device=DEV) < 0.1).float())
+    tables = up._tables(h, w, torch.device(DEV))
+    win = up.max_tile_window(h, w)
+    wt = up.up[1].weight.detach().contiguous()
+    out16 = torch.full((NB, H, W, Cout), float('nan'), dtype=dt, device=DEV)
+    _lib.upconv_fused2_x16(x.to(dt), wt, tables[0], tables[3], out16, NB, Cin, Cout, h, w, H, W, win)
+    assert bool(torch.isfinite(out16.float()).all())
+    if dt == torch.float16:
+        Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=DEV)
+        _lib.upconv_fused_prep_w(wt, Wf2, Cin, Cout, 2)
+        o32 = torch.empty(NB, H, W, Cout, device=DEV)
+        _lib.upconv_fused_fwd(x, None, Wf2, tables[0], tables[3], o32, NB, Cin, Cout, h, w, H, W, win, 2)
+        assert torch.equal(out16, o32.to(torch.float16))
+    else:
+        up64 = NNConvUpsampling(Cin, Cout, 5, (H, W)).double()
+        up64.up[1].weight.data.copy_(wt.to(torch.bfloat16).double().cpu())
+        with torch.no_grad():
+            ref = up64(x.permute(0, 3, 1, 2).double().cpu()).permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        assert float((out16.double().cpu() - ref).abs().max()) <= 2.0 ** -8 * scale
+        assert float((out16.double().cpu() - ref).abs().mean()) <= 2.0 ** -10 * scale
+    again = torch.empty_like(out16)
+    _lib.upconv_fused2_x16(x.to(dt), wt, tables[0], tables[3], again, NB, Cin, Cout, h, w, H, W, win)
+    assert torch.equal(again, out16)
