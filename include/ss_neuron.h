@@ -279,6 +279,22 @@ long long ss_spike_wgrad_ws_floats(int Cin, int N, long long R);
 int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long R, int Cin, int N, int accumulate, void* stream);
 
 /*
+ * Decoder backward, fused (ABI 3): the adjoint gather of ss_upconv_cl_bwd_f32 (same g_P, same summation order) AND the exact bf16x3 MFMA
+ * weight gradient of ss_spike_wgrad_f32 in one pass — a lane computes g_P for 8 consecutive source pixels of one column, which IS the MFMA
+ * fragment of the contraction over sources; g_P is written once (for the data-gradient GEMM) and never read back for g_w.
+ *   g_out [NB][H][W][C_out] fp32 (gradient of the stage output), x [NB][h][w][C_in] fp32 spike counts, tables as for ss_upconv_cl_bwd_f32,
+ *   g_P [NB*h*w][25*C_out] (tap-major columns), g_w [C_in][25*C_out] (+= when accumulate), ws: ss_upconv_bwd_fused_ws_floats floats.
+ * ss_upconv_bwd_fused_supported: compiled stage shapes ((64,32), (128,64), k = 5) whose tables fit the on-chip window: max_rows4 / max_rows2 =
+ * largest output-row span incl. the 4 extra tap rows of 4 / 2 consecutive source rows, max_cols16 = the same for 16 consecutive source columns,
+ * max_span = most rows / columns a source pixel collects per tap (<= 3) — the caller derives them from the tables.
+ */
+int ss_upconv_bwd_fused_supported(int Cin, int Cout, int k, int max_rows4, int max_rows2, int max_cols16, int max_span);
+long long ss_upconv_bwd_fused_ws_floats(int Cin, int Cout, long long NB, int h, int w);
+int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                            float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
+                            int accumulate, void* stream);
+
+/*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
  * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
  *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]

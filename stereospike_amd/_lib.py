@@ -110,6 +110,12 @@ def lib():
     L.ss_upconv_fused2_prep_w_x16.restype = i32
     L.ss_upconv_fused2_fwd_x16.argtypes = [p, i32, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_fused2_fwd_x16.restype = i32
+    L.ss_upconv_bwd_fused_supported.argtypes = [i32, i32, i32, i32, i32, i32, i32]
+    L.ss_upconv_bwd_fused_supported.restype = i32
+    L.ss_upconv_bwd_fused_ws_floats.argtypes = [i32, i32, i64, i32, i32]
+    L.ss_upconv_bwd_fused_ws_floats.restype = i64
+    L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_bwd_fused_f32.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
     L.ss_spike_wgrad_supported.restype = i32
     L.ss_spike_wgrad_ws_floats.argtypes = [i32, i32, i64]
@@ -138,7 +144,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32',
            'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32',
            'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
-           'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16')
+           'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
+           'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -431,6 +438,23 @@ def upconv_fused2_x16(x, weight, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, m
                                             _i32(src_y, 'src_y', H + 4), _i32(src_x, 'src_x', W + 4), _x16(out, 'out', NB * H * W * Cout, out.dtype),
                                             NB, Cin, Cout, h, w, H, W, int(max_window), _stream(x))
     _check(rc, 'ss_upconv_fused2_fwd_x16')
+
+
+def upconv_bwd_fused_supported(Cin, Cout, k, extents):
+    """extents = (max_rows4, max_rows2, max_cols16, max_span) from fused.adjoint_extents(tables)."""
+    return bool(lib().ss_upconv_bwd_fused_supported(int(Cin), int(Cout), int(k), *[int(v) for v in extents]))
+
+
+def upconv_bwd_fused(g_out, x, y_lo, y_hi, x_lo, x_hi, g_P, g_w, NB, Cin, Cout, h, w, H, W, accumulate=False):
+    """Adjoint gather (g_P written) + exact bf16x3 MFMA weight gradient (g_w [Cin, 25 * Cout]) in one pass."""
+    _require_hip(g_out, 'g_out')
+    ws = torch.empty(int(lib().ss_upconv_bwd_fused_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g_out.device)
+    with torch.cuda.device(g_out.device):
+        rc = lib().ss_upconv_bwd_fused_f32(_f32(g_out, 'g_out', NB * H * W * Cout), _f32(x, 'x', NB * h * w * Cin), _i32(y_lo, 'y_lo', h),
+                                           _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
+                                           _f32(g_P, 'g_P', NB * h * w * 25 * Cout), _f32(g_w, 'g_w', Cin * 25 * Cout), _f32(ws, 'ws'),
+                                           NB, Cin, Cout, h, w, H, W, int(bool(accumulate)), _stream(g_out))
+    _check(rc, 'ss_upconv_bwd_fused_f32')
 
 
 def spike_wgrad_supported(Cin, N):

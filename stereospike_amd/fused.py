@@ -488,6 +488,34 @@ def _split3_bf16(Wt):
     return torch.cat((Wh, Wm, Wl), 0)                                 # [3K, N]
 
 
+FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather + exact MFMA weight gradient in one kernel (g_P written once, read only by dgrad)
+
+
+FUSED_UPCONV_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN', '64').split(',') if c)   # C_in 128 (deconv2): the fused form is slower
+                                   # than adjoint kernel + ss_spike_wgrad_f32 (4 workgroup kinds re-load every window; profiles/r02/fused_bwd.log)
+
+
+def adjoint_extents(tables):
+    """(max_rows4, max_rows2, max_cols16, max_span) of the inverse resize tables (y_lo, y_hi, x_lo, x_hi at indices 1, 2, 4, 5): the output
+    window that 4 / 2 consecutive source rows and 16 consecutive source columns need (incl. the 4 extra tap rows / columns), and the widest
+    per-source range — what ss_upconv_bwd_fused_supported checks against its on-chip window.  Host-side, cached on the tables tuple."""
+    key = id(tables)
+    hit = _EXTENTS.get(key)
+    if hit is not None and hit[0] is tables:
+        return hit[1]
+    y_lo, y_hi, x_lo, x_hi = (tables[i].cpu().tolist() for i in (1, 2, 4, 5))
+
+    def span(lo, hi, n):
+        return max(hi[min(i + n - 1, len(lo) - 1)] - lo[i] for i in range(0, len(lo), n)) + 4
+    ext = (span(y_lo, y_hi, 4), span(y_lo, y_hi, 2), span(x_lo, x_hi, 16),
+           max(max(b - a for a, b in zip(y_lo, y_hi)), max(b - a for a, b in zip(x_lo, x_hi))))
+    _EXTENTS[key] = (tables, ext)
+    return ext
+
+
+_EXTENTS = {}
+
+
 class _UpConvProjectedCL(torch.autograd.Function):
     """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
     forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
@@ -613,7 +641,12 @@ class _UpConvProjectedCL(torch.autograd.Function):
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
-            if lowp and k == 5:
+            fused_bwd = (FUSED_UPCONV_BWD and need_w and ctx.exact and not lowp and not g16 and k == 5 and x_cl.dtype == torch.float32
+                         and Cin in FUSED_UPCONV_BWD_CIN and _lib.upconv_bwd_fused_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
+            if fused_bwd:
+                g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
+                _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True)
+            elif lowp and k == 5:
                 # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
                 _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
@@ -625,7 +658,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
             if need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
-            if (need_w and ctx.exact and not lowp and EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
+            if fused_bwd:
+                pass                                                              # g_Wt accumulated by the fused kernel above
+            elif (need_w and ctx.exact and not lowp and EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
                     and Cin in EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
                 # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
                 _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)

@@ -1072,3 +1072,38 @@ def test_upconv_fused_mfma_x16(Cin, Cout, hw, HW, NB, dt):
     again = torch.empty_like(out16)
     _lib.upconv_fused2_x16(x.to(dt), wt, tables[0], tables[3], again, NB, Cin, Cout, h, w, H, W, win)
     assert torch.equal(again, out16)
+
+
+# ======================================================================================================
+# fused decoder backward: adjoint gather + exact MFMA weight gradient (ss_upconv_bwd_fused_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 3),
+                                                (64, 32, (32, 40), (64, 80), 2), (128, 64, (13, 18), (25, 35), 5), (64, 32, (9, 11), (17, 19), 1)])
+def test_upconv_bwd_fused(Cin, Cout, hw, HW, NB):
+    """g_P of the fused kernel == the adjoint gather kernel's (same summation order: equal values); its weight gradient == x^T @ g_P within
+    fp32 accumulation error of the float64 contraction, == ss_spike_wgrad_f32 to that accuracy; deterministic; ragged tiles."""
+    from stereospike_amd import _lib, fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    (h, w), (H, W) = hw, HW
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
+    tables = up._tables(h, w, torch.device(DEV))
+    ext = fused.adjoint_extents(tables)
+    assert _lib.upconv_bwd_fused_supported(Cin, Cout, 5, ext), ext
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen)
+    x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float())
+    R, N = NB * h * w, 25 * Cout
+    ref_P = torch.empty(R, N, device=DEV)
+    _lib.upconv_cl_bwd(g, tables[1], tables[2], tables[4], tables[5], ref_P, NB, 5, Cout, h, w, H, W)
+    g_P = torch.full((R, N), float('nan'), device=DEV)
+    g_w = torch.full((Cin, N), float('nan'), device=DEV)
+    _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P, g_w, NB, Cin, Cout, h, w, H, W)
+    assert torch.equal(g_P, ref_P), float((g_P - ref_P).abs().max())
+    ref = x.view(R, Cin).double().t() @ ref_P.double()
+    bound = (x.view(R, Cin).double().t().abs() @ ref_P.double().abs()) * 2.0 ** -22 + 1e-30
+    assert bool(((g_w.double() - ref).abs() <= bound).all()), float(((g_w.double() - ref).abs() / bound).max())
+    g_w2 = torch.empty_like(g_w); g_P2 = torch.empty_like(g_P)
+    _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P2, g_w2, NB, Cin, Cout, h, w, H, W)
+    assert torch.equal(g_w, g_w2) and torch.equal(g_P, g_P2)
+    _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P2, g_w2, NB, Cin, Cout, h, w, H, W, accumulate=True)
+    assert torch.equal(g_w2, g_w + g_w)

@@ -93,3 +93,31 @@ if os.environ.get('WGRAD', '1') == '1':       # exact bf16x3 MFMA weight gradien
             res[tag] = e0.elapsed_time(e1) / 5
         print(f'{name} wgrad [{Cin} x {R}] @ [{R} x {N}]: ' + ', '.join(f'{k} {v:.3f} ms' for k, v in res.items()) +
               f'  (g read once at HBM rate: {4 * R * N / 5.5e9:.3f} ms)', flush=True)
+
+if os.environ.get('BWD', '1') == '1':         # fused adjoint + weight gradient vs adjoint kernel + ss_spike_wgrad_f32
+    from stereospike_amd import fused
+    for name, Cin, Cout, (h, w), (H, W) in geoms:
+        up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(dev)
+        tabs = up._tables(h, w, torch.device(dev))
+        R, N = NB * h * w, 25 * Cout
+        g = torch.randn(NB, H, W, Cout, device=dev)
+        x = (torch.rand(NB, h, w, Cin, device=dev) < 0.35).float()
+        gP = torch.empty(R, N, device=dev); gw = torch.empty(Cin, N, device=dev)
+
+        def two():
+            _lib.upconv_cl_bwd(g, tabs[1], tabs[2], tabs[4], tabs[5], gP, NB, 5, Cout, h, w, H, W)
+            _lib.spike_wgrad(gP, x.view(R, Cin), gw, R, Cin, N)
+
+        def one():
+            _lib.upconv_bwd_fused(g, x, tabs[1], tabs[2], tabs[4], tabs[5], gP, gw, NB, Cin, Cout, h, w, H, W)
+        res = {}
+        for tag, fn in (('adjoint + wgrad kernels', two), ('fused', one)):
+            fn(); fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            res[tag] = e0.elapsed_time(e1) / 5
+        print(f'{name} backward (adjoint + weight gradient): ' + ', '.join(f'{k} {v:.3f} ms' for k, v in res.items()) +
+              f'  (g_P written once at HBM rate: {4 * R * N / 5.5e9:.3f} ms)', flush=True)
