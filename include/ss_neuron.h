@@ -295,6 +295,17 @@ int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo,
                             int accumulate, void* stream);
 
 /*
+ * Dense x dense fp32 GEMM on the bf16 matrix cores with six cross terms (ABI 3) — the decoder's data gradient g_x = g_P @ W2 (autograd of
+ * NNConvUpsampling, /root/reference/network/blocks.py:110-132): C [R][N] = A [R][K] @ B [K][N], all fp32 row-major.  Both operands are split
+ * exactly into three bf16 terms (round to nearest); the six products ah bh, ah bm, am bh, ah bl, am bm, al bh are kept (each exact), fp32
+ * accumulation: |C - exact| <= 2^-21 sum_k |a||b| (the dropped terms amount to one fp32 product rounding).  K % 16 == 0, N in {64, 128,
+ * 256, 512}; ws: ss_gemm6_ws_floats(K, N) floats (B's terms in fragment order), 16-byte aligned.
+ */
+int ss_gemm6_supported(int K, int N);
+long long ss_gemm6_ws_floats(int K, int N);
+int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long R, int K, int N, void* stream);
+
+/*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
  * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
  *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]

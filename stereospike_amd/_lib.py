@@ -116,6 +116,12 @@ def lib():
     L.ss_upconv_bwd_fused_ws_floats.restype = i64
     L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_bwd_fused_f32.restype = i32
+    L.ss_gemm6_supported.argtypes = [i32, i32]
+    L.ss_gemm6_supported.restype = i32
+    L.ss_gemm6_ws_floats.argtypes = [i32, i32]
+    L.ss_gemm6_ws_floats.restype = i64
+    L.ss_gemm6_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
+    L.ss_gemm6_f32.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
     L.ss_spike_wgrad_supported.restype = i32
     L.ss_spike_wgrad_ws_floats.argtypes = [i32, i32, i64]
@@ -145,7 +151,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32',
            'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
-           'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32')
+           'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
+           'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -455,6 +462,19 @@ def upconv_bwd_fused(g_out, x, y_lo, y_hi, x_lo, x_hi, g_P, g_w, NB, Cin, Cout, 
                                            _f32(g_P, 'g_P', NB * h * w * 25 * Cout), _f32(g_w, 'g_w', Cin * 25 * Cout), _f32(ws, 'ws'),
                                            NB, Cin, Cout, h, w, H, W, int(bool(accumulate)), _stream(g_out))
     _check(rc, 'ss_upconv_bwd_fused_f32')
+
+
+def gemm6_supported(K, N):
+    return bool(lib().ss_gemm6_supported(int(K), int(N)))
+
+
+def gemm6(A, B, C_, R, K, N):
+    """C [R, N] = A [R, K] @ B [K, N], dense fp32 operands, six bf16 cross terms on the matrix cores (fp32-product accuracy)."""
+    _require_hip(A, 'A')
+    ws = torch.empty(int(lib().ss_gemm6_ws_floats(int(K), int(N))), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        rc = lib().ss_gemm6_f32(_f32(A, 'A', R * K), _f32(B, 'B', K * N), _f32(C_, 'C', R * N), _f32(ws, 'ws'), R, K, N, _stream(A))
+    _check(rc, 'ss_gemm6_f32')
 
 
 def spike_wgrad_supported(Cin, N):

@@ -2287,6 +2287,153 @@ __global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Dense x dense fp32 GEMM on the bf16 matrix cores with SIX cross terms:  C[R][N] = A[R][K] @ B[K][N]   (decoder data gradient g_x = g_P @ W2)
+// ---------------------------------------------------------------------------------------------------
+// Both operands are dense fp32 (no spike operand), so the exact 3-term split of ONE operand is not enough.  a = ah + am + al and
+// b = bh + bm + bl exactly (round-to-nearest splits, |am| <= 2^-8 |a|, |al| <= 2^-16 |a|); of the nine products the six
+//   ah bh + ah bm + am bh + ah bl + am bm + al bh
+// are kept (each exact in fp32), the three dropped ones are <= (2 * 2^-24 + 2^-32) |a b|: the rounding of ONE fp32 product.  Accumulation is
+// fp32 in the MFMA.  Error bound asserted in tests/: |C - C_float64| <= 2^-21 sum_k |a||b| (measured worst element: 1.05 x 2^-22).  6 bf16 MFMAs per fp32-MFMA-equivalent at 16x the
+// rate: the library's fp32 GEMM is compute-bound at 110 - 133 TFLOP/s on these shapes (K = 800 .. 6400, N = 64 .. 512).
+//   * workgroup = 8 wavefronts x 32 rows; all N <= 256 columns per workgroup (N = 512: two column halves, A read twice);
+//   * A: a lane loads its row's 8 consecutive k (32 B) per k-step and splits them in registers — the registers are the fragments; a ring of
+//     KB k-steps keeps one LDS stage of loads in flight;
+//   * B: split once into fragment order by gemm6_prep_b_kernel, streamed through a double-buffered LDS stage of KB k-steps (all 8
+//     wavefronts read the same fragments), one barrier per stage.
+constexpr int kG6Threads = 512;
+template <int CIT, int KB>
+__global__ __launch_bounds__(kG6Threads) void gemm6_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Bf, float* __restrict__ C,
+                                                          long long R, int K, int N, int col_kinds)
+{
+    constexpr int STG = KB * 3 * CIT * 1024;                               // bytes of one B stage (KB k-steps x 3 splits x CIT tiles x 1 KiB)
+    constexpr int LPT = STG / 16 / kG6Threads;                             // 16-B pieces per thread per stage
+    static_assert(STG % (16 * kG6Threads) == 0, "stage must divide among the threads");
+    __shared__ __attribute__((aligned(16))) unsigned char bs[2 * STG];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kind = (int)(blockIdx.x % col_kinds);
+    const long long m0 = (long long)(blockIdx.x / col_kinds) * 256 + 32 * wave;
+    const int KS = K / 16, NST = (KS + KB - 1) / KB;
+    const int NTall = N / 32;                                              // column tiles of B in all; this workgroup: [kind * CIT, kind * CIT + CIT)
+    const long long row = min(m0 + (lane & 31), R - 1);
+    const float* const arow = A + row * K + 8 * (lane >> 5);
+    f32x16 acc[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // B stage addressing: the stage's pieces are [k-step][split][tile of this kind][lane][16 B]; global Bf is [k-step][split][all tiles][lane][8 bf16]
+    f4 st[LPT];
+    auto stage_issue = [&](int stg) {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int pidx = threadIdx.x + kG6Threads * u;                  // 16-B piece within the stage
+            const int ln = pidx & 63, tt = (pidx >> 6) % CIT, sp = ((pidx >> 6) / CIT) % 3, kk = (pidx >> 6) / (3 * CIT);
+            const int ks = min(stg * KB + kk, KS - 1);
+            st[u] = *reinterpret_cast<const f4*>(Bf + ((((long long)ks * 3 + sp) * NTall + kind * CIT + tt) * 64 + ln) * 8);
+        }
+    };
+    auto stage_commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) *reinterpret_cast<f4*>(bs + buf * STG + (threadIdx.x + kG6Threads * u) * 16) = st[u];
+    };
+    f4 av[KB][2];
+    auto a_load = [&](f4 (&d)[2], int ks) {
+        const float* p = arow + 16 * min(ks, KS - 1);
+        d[0] = load_stream(reinterpret_cast<const f4*>(p));
+        d[1] = load_stream(reinterpret_cast<const f4*>(p + 4));
+    };
+    stage_issue(0);
+#pragma unroll
+    for (int j = 0; j < KB; ++j) a_load(av[j], j);
+    stage_commit(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int stg = 0; stg < NST; ++stg) {
+        const bool more = stg + 1 < NST;
+        if (more) stage_issue(stg + 1);
+        const unsigned char* const bb = bs + (stg & 1) * STG + lane * 16;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            if (stg * KB + j < KS) {
+                // split this k-step's 8 values of A (round to nearest: residuals <= 2^-8, 2^-16)
+                s16x8 ah, am, al;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = av[j][e >> 2][e & 3];                   // (__bf16) casts: v_cvt_pk_bf16_f32 on gfx950 (round to nearest even)
+                    const __bf16 h1 = (__bf16)v;
+                    const float r1 = v - (float)h1;
+                    const __bf16 h2 = (__bf16)r1;
+                    const float r2 = r1 - (float)h2;
+                    const __bf16 h3 = (__bf16)r2;
+                    ah[e] = __builtin_bit_cast(short, h1); am[e] = __builtin_bit_cast(short, h2); al[e] = __builtin_bit_cast(short, h3);
+                }
+                if (more) a_load(av[j], (stg + 1) * KB + j);                // this slot's next occupant: one stage ahead
+                const unsigned char* const bk = bb + j * (3 * CIT * 1024);
+                // column tiles two at a time, term-major: consecutive MFMAs alternate between two accumulators (a back-to-back chain on ONE
+                // accumulator waits for the previous result: ~2x the issue time)
+#pragma unroll
+                for (int t = 0; t < CIT; t += 2) {
+                    s16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        bh[u] = *reinterpret_cast<const s16x8*>(bk + (0 * CIT + t + u) * 1024);
+                        bm[u] = *reinterpret_cast<const s16x8*>(bk + (1 * CIT + t + u) * 1024);
+                        bl[u] = *reinterpret_cast<const s16x8*>(bk + (2 * CIT + t + u) * 1024);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[u], acc[t + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[u], acc[t + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[u], acc[t + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[u], acc[t + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[u], acc[t + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[u], acc[t + u], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stage_commit((stg + 1) & 1);
+        __syncthreads();
+    }
+    // D[row][col]: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < CIT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (rr < R) store_out(C + rr * N + 32 * (kind * CIT + t) + (lane & 31), acc[t][r]);
+        }
+}
+
+// B [K][N] fp32 -> Bf[k-step][split][column tile][lane][8] bf16, element e = split term of B[16 ks + 8 (lane >> 5) + e][32 tile + (lane & 31)]
+__global__ __launch_bounds__(kBlock) void gemm6_prep_b_kernel(const float* __restrict__ B, unsigned short* __restrict__ Bf, int K, int N)
+{
+    const int KS = K / 16, NT = N / 32;
+    const long long total = (long long)KS * 3 * NT * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int tile = (int)(r % NT); r /= NT;
+        const int sp = (int)(r % 3); const int ks = (int)(r / 3);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = B[(long long)(16 * ks + 8 * (lane >> 5) + e) * N + 32 * tile + (lane & 31)];
+            const unsigned short h1 = narrow<SS_DT_BF16>(v);
+            const float r1 = v - widen<SS_DT_BF16>(h1);
+            const unsigned short h2 = narrow<SS_DT_BF16>(r1);
+            const float r2 = r1 - widen<SS_DT_BF16>(h2);
+            o[e] = sp == 0 ? h1 : (sp == 1 ? h2 : narrow<SS_DT_BF16>(r2));
+        }
+        *reinterpret_cast<u16x8*>(Bf + i * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) DATA GRADIENT of a 3x3 / stride 1 / pad 1 convolution, NHWC (the four bottleneck convs)
 // ---------------------------------------------------------------------------------------------------
 // Reference: the autograd backward of SEWResBlock's conv1 / conv2 (/root/reference/network/blocks.py:146-159) w.r.t. their input:
@@ -3421,6 +3568,32 @@ int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo,
                             g_P, ws, (int)NB, h, w, H, W, Q);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(spike_wgrad_reduce_kernel, dim3(grid_for((long long)N * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, N, Cin, accumulate);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_gemm6_supported(int K, int N)
+{
+    return K > 0 && K % 16 == 0 && (N == 64 || N == 128 || N == 256 || N == 512);
+}
+
+long long ss_gemm6_ws_floats(int K, int N)
+{
+    return ss_gemm6_supported(K, N) ? (long long)K * N * 3 / 2 : 0;       // the 3 bf16 terms of B in fragment order
+}
+
+int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long R, int K, int N, void* stream)
+{
+    if (!A || !B || !C || !ws || R <= 0 || !ss_gemm6_supported(K, N) || !aligned16(A) || !aligned16(ws) || (K % 4) != 0) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
+    hipLaunchKernelGGL(gemm6_prep_b_kernel, dim3(grid_for((long long)K / 16 * 3 * (N / 32) * 64, 4096)), dim3(kBlock), 0, s, B, Bf, K, N);
+    const long long mt = (R + 255) / 256;
+    const int kinds = N == 512 ? 2 : 1;
+    if (mt * kinds > 0x7fffffffLL) return SS_EINVAL;
+    const dim3 grid((unsigned)(mt * kinds));
+    if (N == 64) hipLaunchKernelGGL((gemm6_kernel<2, 8>), grid, dim3(kG6Threads), 0, s, A, Bf, C, R, K, N, kinds);
+    else if (N == 128) hipLaunchKernelGGL((gemm6_kernel<4, 4>), grid, dim3(kG6Threads), 0, s, A, Bf, C, R, K, N, kinds);
+    else hipLaunchKernelGGL((gemm6_kernel<8, 2>), grid, dim3(kG6Threads), 0, s, A, Bf, C, R, K, N, kinds);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -488,6 +488,9 @@ def _split3_bf16(Wt):
     return torch.cat((Wh, Wm, Wl), 0)                                 # [3K, N]
 
 
+GEMM6_DGRAD = True                 # decoder data gradient g_x = g_P @ W2 of the two wide stages as ss_gemm6_f32 (six bf16 cross terms, fp32-product accuracy)
+GEMM6_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_GEMM6_CIN', '256,512').split(',') if c)   # C_in 64 / 128: the library's fp32 GEMM is
+                                   # HBM-bound there and faster (profiles/r02/decoder_backward_kernels.log)
 FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather + exact MFMA weight gradient in one kernel (g_P written once, read only by dgrad)
 
 
@@ -655,7 +658,10 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
                 if lowp:
                     g_P = g_P.to(torch.bfloat16)
-            if need_x:
+            if need_x and not lowp and GEMM6_DGRAD and Cin in GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
+                # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy): the fp32 GEMM is compute-bound here
+                _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
+            elif need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
             if fused_bwd:

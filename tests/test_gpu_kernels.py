@@ -1107,3 +1107,28 @@ def test_upconv_bwd_fused(Cin, Cout, hw, HW, NB):
     assert torch.equal(g_w, g_w2) and torch.equal(g_P, g_P2)
     _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P2, g_w2, NB, Cin, Cout, h, w, H, W, accumulate=True)
     assert torch.equal(g_w2, g_w + g_w)
+
+
+# ======================================================================================================
+# dense x dense GEMM with six bf16 cross terms (ss_gemm6_f32): the decoder's data gradient
+# ======================================================================================================
+@pytest.mark.parametrize('R,K,N', [(1000, 800, 64), (5000, 1600, 128), (777, 3200, 256), (300, 6400, 512), (33, 16, 64),
+                                   (16 * 130 * 173, 800, 64), (8 * 65 * 87, 1600, 128)])
+def test_gemm6(R, K, N):
+    """|C - float64| <= 2^-21 sum_k |a||b| element-wise (six exact cross terms + fp32 accumulation: the dropped terms are one fp32 product
+    rounding); at least as accurate as the library's fp32 GEMM in max error (x 2 slack); ragged row counts; deterministic."""
+    from stereospike_amd import _lib
+    gen = torch.Generator(device=DEV).manual_seed(R + K)
+    A = torch.randn(R, K, device=DEV, generator=gen) * torch.exp(torch.randn(R, 1, device=DEV, generator=gen))
+    B = torch.randn(K, N, device=DEV, generator=gen) * 0.05
+    assert _lib.gemm6_supported(K, N) and not _lib.gemm6_supported(K + 1, N) and not _lib.gemm6_supported(K, 96)
+    C = torch.full((R, N), float('nan'), device=DEV)
+    _lib.gemm6(A, B, C, R, K, N)
+    ref = A.double() @ B.double()
+    bound = (A.double().abs() @ B.double().abs()) * 2.0 ** -21 + 1e-30
+    assert bool(((C.double() - ref).abs() <= bound).all()), float(((C.double() - ref).abs() / bound).max())
+    lib32 = A @ B
+    assert float((C.double() - ref).abs().max()) <= 2.0 * float((lib32.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
+    C2 = torch.empty_like(C)
+    _lib.gemm6(A, B, C2, R, K, N)
+    assert torch.equal(C, C2)

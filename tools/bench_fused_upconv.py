@@ -121,3 +121,19 @@ if os.environ.get('BWD', '1') == '1':         # fused adjoint + weight gradient 
             res[tag] = e0.elapsed_time(e1) / 5
         print(f'{name} backward (adjoint + weight gradient): ' + ', '.join(f'{k} {v:.3f} ms' for k, v in res.items()) +
               f'  (g_P written once at HBM rate: {4 * R * N / 5.5e9:.3f} ms)', flush=True)
+
+if os.environ.get('GEMM6', '1') == '1':       # decoder data gradient: library fp32 GEMM vs the six-term bf16 MFMA GEMM
+    for name, R, K, N in (('deconv1', 80 * 130 * 173, 800, 64), ('deconv2', 80 * 65 * 87, 1600, 128), ('deconv3', 80 * 33 * 44, 3200, 256),
+                          ('deconv4', 80 * 17 * 22, 6400, 512)):
+        A = torch.randn(R, K, device=dev); B = torch.randn(K, N, device=dev) * 0.05; C = torch.empty(R, N, device=dev)
+        res = {}
+        for tag, fn in (('library fp32', lambda: torch.mm(A, B, out=C)), ('ss_gemm6_f32', lambda: _lib.gemm6(A, B, C, R, K, N))):
+            fn(); fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            res[tag] = e0.elapsed_time(e1) / 5
+        print(f'{name} dgrad [{R} x {K}] @ [{K} x {N}]: ' + ', '.join(f'{k} {v:.3f} ms' for k, v in res.items()) +
+              f'  (A read once at HBM rate: {4 * R * K / 5.5e9:.3f} ms; 6 x bf16 MFMA at peak: {12.0 * R * K * N / 2.5e15 * 1e3:.3f} ms)', flush=True)
