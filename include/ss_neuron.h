@@ -304,6 +304,9 @@ int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo,
 int ss_gemm6_supported(int K, int N);
 long long ss_gemm6_ws_floats(int K, int N);
 int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long R, int K, int N, void* stream);
+/* batch independent products C[b] = A[b] @ B[b] (contiguous [batch][R][K], [batch][K][N], [batch][R][N]; ws: batch * ss_gemm6_ws_floats) — the 16
+ * transform-domain products of the Winograd data gradient. */
+int ss_gemm6_batched_f32(const float* A, const float* B, float* C, float* ws, int batch, long long R, int K, int N, void* stream);
 
 /*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2

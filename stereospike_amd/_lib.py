@@ -122,6 +122,8 @@ def lib():
     L.ss_gemm6_ws_floats.restype = i64
     L.ss_gemm6_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
     L.ss_gemm6_f32.restype = i32
+    L.ss_gemm6_batched_f32.argtypes = [p, p, p, p, i32, i64, i32, i32, p]
+    L.ss_gemm6_batched_f32.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
     L.ss_spike_wgrad_supported.restype = i32
     L.ss_spike_wgrad_ws_floats.argtypes = [i32, i32, i64]
@@ -152,7 +154,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
-           'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32')
+           'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -475,6 +477,16 @@ def gemm6(A, B, C_, R, K, N):
     with torch.cuda.device(A.device):
         rc = lib().ss_gemm6_f32(_f32(A, 'A', R * K), _f32(B, 'B', K * N), _f32(C_, 'C', R * N), _f32(ws, 'ws'), R, K, N, _stream(A))
     _check(rc, 'ss_gemm6_f32')
+
+
+def gemm6_batched(A, B, C_, batch, R, K, N):
+    """C [batch, R, N] = A [batch, R, K] @ B [batch, K, N] (contiguous), six bf16 cross terms per product."""
+    _require_hip(A, 'A')
+    ws = torch.empty(batch * int(lib().ss_gemm6_ws_floats(int(K), int(N))), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        rc = lib().ss_gemm6_batched_f32(_f32(A, 'A', batch * R * K), _f32(B, 'B', batch * K * N), _f32(C_, 'C', batch * R * N), _f32(ws, 'ws'),
+                                        batch, R, K, N, _stream(A))
+    _check(rc, 'ss_gemm6_batched_f32')
 
 
 def spike_wgrad_supported(Cin, N):

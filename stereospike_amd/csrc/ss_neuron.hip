@@ -2313,6 +2313,7 @@ __global__ __launch_bounds__(kG6Threads) void gemm6_kernel(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kind = (int)(blockIdx.x % col_kinds);
     const long long m0 = (long long)(blockIdx.x / col_kinds) * 256 + 32 * wave;
+    A += (long long)blockIdx.y * R * K; C += (long long)blockIdx.y * R * N; Bf += (long long)blockIdx.y * K * N * 3;    // batch (blockIdx.y)
     const int KS = K / 16, NST = (KS + KB - 1) / KB;
     const int NTall = N / 32;                                              // column tiles of B in all; this workgroup: [kind * CIT, kind * CIT + CIT)
     const long long row = min(m0 + (lane & 31), R - 1);
@@ -2370,29 +2371,37 @@ __global__ __launch_bounds__(kG6Threads) void gemm6_kernel(const float* __restri
                 }
                 if (more) a_load(av[j], (stg + 1) * KB + j);                // this slot's next occupant: one stage ahead
                 const unsigned char* const bk = bb + j * (3 * CIT * 1024);
-                // column tiles two at a time, term-major: consecutive MFMAs alternate between two accumulators (a back-to-back chain on ONE
-                // accumulator waits for the previous result: ~2x the issue time)
-#pragma unroll
-                for (int t = 0; t < CIT; t += 2) {
-                    s16x8 bh[2], bm[2], bl[2];
+                // column tiles two at a time, term-major (consecutive MFMAs alternate between two accumulators); the fragments of the NEXT
+                // pair are read from LDS before this pair's 12 MFMAs are issued (pinned: hipcc otherwise places each read right before its use)
+                s16x8 bq[2][6];
+                auto b_read = [&](s16x8 (&d)[6], int t) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        bh[u] = *reinterpret_cast<const s16x8*>(bk + (0 * CIT + t + u) * 1024);
-                        bm[u] = *reinterpret_cast<const s16x8*>(bk + (1 * CIT + t + u) * 1024);
-                        bl[u] = *reinterpret_cast<const s16x8*>(bk + (2 * CIT + t + u) * 1024);
+                        d[0 + u] = *reinterpret_cast<const s16x8*>(bk + (0 * CIT + t + u) * 1024);
+                        d[2 + u] = *reinterpret_cast<const s16x8*>(bk + (1 * CIT + t + u) * 1024);
+                        d[4 + u] = *reinterpret_cast<const s16x8*>(bk + (2 * CIT + t + u) * 1024);
                     }
+                };
+                b_read(bq[0], 0);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[u], acc[t + u], 0, 0, 0);
+                for (int t = 0; t < CIT; t += 2) {
+                    const int cur = (t >> 1) & 1;
+                    if (t + 2 < CIT) b_read(bq[cur ^ 1], t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const s16x8 (&b)[6] = bq[cur];                            // [0,1] hi, [2,3] mid, [4,5] lo of tiles t, t + 1
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[u], acc[t + u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[4 + u], acc[t + u], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[u], acc[t + u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[2 + u], acc[t + u], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[u], acc[t + u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0 + u], acc[t + u], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[u], acc[t + u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2 + u], acc[t + u], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[u], acc[t + u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0 + u], acc[t + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[t + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0 + u], acc[t + u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -2414,6 +2423,7 @@ __global__ __launch_bounds__(kBlock) void gemm6_prep_b_kernel(const float* __res
 {
     const int KS = K / 16, NT = N / 32;
     const long long total = (long long)KS * 3 * NT * 64;
+    B += (long long)blockIdx.y * K * N; Bf += (long long)blockIdx.y * K * N * 3;                                           // batch (blockIdx.y)
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
         long long r = i >> 6;
@@ -3578,23 +3588,29 @@ int ss_gemm6_supported(int K, int N)
 
 long long ss_gemm6_ws_floats(int K, int N)
 {
-    return ss_gemm6_supported(K, N) ? (long long)K * N * 3 / 2 : 0;       // the 3 bf16 terms of B in fragment order
+    return ss_gemm6_supported(K, N) ? (long long)K * N * 3 / 2 : 0;       // the 3 bf16 terms of B in fragment order (per batch entry)
 }
 
-int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long R, int K, int N, void* stream)
+int ss_gemm6_batched_f32(const float* A, const float* B, float* C, float* ws, int batch, long long R, int K, int N, void* stream)
 {
-    if (!A || !B || !C || !ws || R <= 0 || !ss_gemm6_supported(K, N) || !aligned16(A) || !aligned16(ws) || (K % 4) != 0) return SS_EINVAL;
+    if (!A || !B || !C || !ws || R <= 0 || batch <= 0 || batch > 65535 || !ss_gemm6_supported(K, N) || !aligned16(A) || !aligned16(ws) || (K % 4) != 0 ||
+        ((R * K) % 4) != 0) return SS_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
-    hipLaunchKernelGGL(gemm6_prep_b_kernel, dim3(grid_for((long long)K / 16 * 3 * (N / 32) * 64, 4096)), dim3(kBlock), 0, s, B, Bf, K, N);
+    hipLaunchKernelGGL(gemm6_prep_b_kernel, dim3(grid_for((long long)K / 16 * 3 * (N / 32) * 64, 4096), batch), dim3(kBlock), 0, s, B, Bf, K, N);
     const long long mt = (R + 255) / 256;
     const int kinds = N == 512 ? 2 : 1;
     if (mt * kinds > 0x7fffffffLL) return SS_EINVAL;
-    const dim3 grid((unsigned)(mt * kinds));
+    const dim3 grid((unsigned)(mt * kinds), batch);
     if (N == 64) hipLaunchKernelGGL((gemm6_kernel<2, 8>), grid, dim3(kG6Threads), 0, s, A, Bf, C, R, K, N, kinds);
     else if (N == 128) hipLaunchKernelGGL((gemm6_kernel<4, 4>), grid, dim3(kG6Threads), 0, s, A, Bf, C, R, K, N, kinds);
     else hipLaunchKernelGGL((gemm6_kernel<8, 2>), grid, dim3(kG6Threads), 0, s, A, Bf, C, R, K, N, kinds);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long R, int K, int N, void* stream)
+{
+    return ss_gemm6_batched_f32(A, B, C, ws, 1, R, K, N, stream);
 }
 
 int ss_wino_dgrad_weights_f32(const float* W, float* U, int Cout, int Cin, void* stream)

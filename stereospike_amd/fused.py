@@ -773,6 +773,9 @@ WINOGRAD_DGRAD = True              # data gradient of the 3x3 / stride 1 convs (
                                    # transforms around one batched fp32 GEMM, 2.25x fewer multiplications (1.14 -> 0.7 ms per layer at config 3)
 
 
+WINOGRAD_GEMM6 = True              # the transform-domain products as ss_gemm6_batched_f32 instead of the library's fp32 batched GEMM
+
+
 def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """Data gradient of conv2d(x, weight, stride 1, padding 1), weight [C_out, C_in, 3, 3]: g [NB, H, W, C_out] (contiguous NHWC array, fp32)
     -> g_x [NB, H, W, C_in].  The autograd backward of the reference's SEWResBlock convs (/root/reference/network/blocks.py:146-159) w.r.t.
@@ -784,7 +787,11 @@ def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     V = torch.empty((16, T, Cout), dtype=torch.float32, device=g.device)
     _lib.wino_dgrad_weights(weight.detach().float().contiguous(), U, Cout, Cin)
     _lib.wino_dgrad_input(g, V, NB, H, W, Cout)
-    M = torch.bmm(V, U)
+    if WINOGRAD_GEMM6 and _lib.gemm6_supported(Cout, Cin) and (T * Cout) % 4 == 0:
+        M = torch.empty((16, T, Cin), dtype=torch.float32, device=g.device)          # the 16 products on the bf16 matrix cores, six cross terms
+        _lib.gemm6_batched(V, U, M, 16, T, Cout, Cin)
+    else:
+        M = torch.bmm(V, U)
     del V
     g_x = torch.empty((NB, H, W, Cin), dtype=torch.float32, device=g.device)
     _lib.wino_dgrad_output(M, g_x, NB, H, W, Cin)

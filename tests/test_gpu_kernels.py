@@ -1132,3 +1132,18 @@ def test_gemm6(R, K, N):
     C2 = torch.empty_like(C)
     _lib.gemm6(A, B, C2, R, K, N)
     assert torch.equal(C, C2)
+
+
+def test_gemm6_batched():
+    from stereospike_amd import _lib
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    b, R, K, N = 16, 1000, 512, 512
+    A = torch.randn(b, R, K, device=DEV, generator=gen); B = torch.randn(b, K, N, device=DEV, generator=gen) * 0.05
+    C = torch.full((b, R, N), float('nan'), device=DEV)
+    _lib.gemm6_batched(A, B, C, b, R, K, N)
+    ref = torch.bmm(A.double(), B.double())
+    bound = torch.bmm(A.double().abs(), B.double().abs()) * 2.0 ** -21
+    assert bool(((C.double() - ref).abs() <= bound).all())
+    one = torch.empty(R, N, device=DEV)
+    _lib.gemm6(A[5], B[5], one, R, K, N)
+    assert torch.equal(one, C[5])
