@@ -2349,10 +2349,24 @@ __global__ __launch_bounds__(kG6Threads) void gemm6_kernel(const float* __restri
     for (int j = 0; j < KB; ++j) a_load(av[j], j);
     stage_commit(0);
     __syncthreads();
+    // The bf16 MFMA's fp32 accumulation is not exactly round-to-nearest: measured against float64 every accumulator drifts DOWN by ~2^-28 of the
+    // magnitude sum (tools/diag_gemm6_bias.py; the fp32 MFMA of the library shows 1e-11).  Harmless per element, but coherent over all elements:
+    // a cancelling reduction of the result (a PLIF node's scalar dL/dw) lost two digits.  So the sign of the running sum alternates every kFlip
+    // stages — acc = -acc and A enters negated — which turns the drift of the negative phases upward and cancels it in expectation.
+    constexpr int kFlip = 4;
+    bool neg = false;
 #pragma unroll 1
     for (int stg = 0; stg < NST; ++stg) {
         const bool more = stg + 1 < NST;
         if (more) stage_issue(stg + 1);
+        if (((stg / kFlip) & 1) != (int)neg) {
+            neg = !neg;
+#pragma unroll
+            for (int t = 0; t < CIT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = -acc[t][r];
+        }
+        const float sgn = neg ? -1.f : 1.f;
         const unsigned char* const bb = bs + (stg & 1) * STG + lane * 16;
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
@@ -2361,7 +2375,7 @@ __global__ __launch_bounds__(kG6Threads) void gemm6_kernel(const float* __restri
                 s16x8 ah, am, al;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = av[j][e >> 2][e & 3];                   // (__bf16) casts: v_cvt_pk_bf16_f32 on gfx950 (round to nearest even)
+                    const float v = av[j][e >> 2][e & 3] * sgn;             // (__bf16) casts: v_cvt_pk_bf16_f32 on gfx950 (round to nearest even)
                     const __bf16 h1 = (__bf16)v;
                     const float r1 = v - (float)h1;
                     const __bf16 h2 = (__bf16)r1;
@@ -2409,12 +2423,13 @@ __global__ __launch_bounds__(kG6Threads) void gemm6_kernel(const float* __restri
         __syncthreads();
     }
     // D[row][col]: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float fin = neg ? -1.f : 1.f;
 #pragma unroll
     for (int t = 0; t < CIT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long rr = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (rr < R) store_out(C + rr * N + 32 * (kind * CIT + t) + (lane & 31), acc[t][r]);
+            if (rr < R) store_out(C + rr * N + 32 * (kind * CIT + t) + (lane & 31), acc[t][r] * fin);
         }
 }
 

@@ -488,7 +488,7 @@ def _split3_bf16(Wt):
     return torch.cat((Wh, Wm, Wl), 0)                                 # [3K, N]
 
 
-GEMM6_DGRAD = True                 # decoder data gradient g_x = g_P @ W2 of the two wide stages as ss_gemm6_f32 (six bf16 cross terms, fp32-product accuracy)
+GEMM6_DGRAD = _os.environ.get('SS_GEMM6_DGRAD', '1') == '1'   # decoder data gradient g_x = g_P @ W2 of the two wide stages as ss_gemm6_f32 (six bf16 cross terms, fp32-product accuracy)
 GEMM6_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_GEMM6_CIN', '256,512').split(',') if c)   # C_in 64 / 128: the library's fp32 GEMM is
                                    # HBM-bound there and faster (profiles/r02/decoder_backward_kernels.log)
 FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather + exact MFMA weight gradient in one kernel (g_P written once, read only by dgrad)
@@ -773,7 +773,7 @@ WINOGRAD_DGRAD = True              # data gradient of the 3x3 / stride 1 convs (
                                    # transforms around one batched fp32 GEMM, 2.25x fewer multiplications (1.14 -> 0.7 ms per layer at config 3)
 
 
-WINOGRAD_GEMM6 = True              # the transform-domain products as ss_gemm6_batched_f32 instead of the library's fp32 batched GEMM
+WINOGRAD_GEMM6 = _os.environ.get('SS_WINOGRAD_GEMM6', '1') == '1'   # the transform-domain products as ss_gemm6_batched_f32 instead of the library's fp32 batched GEMM
 
 
 def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:

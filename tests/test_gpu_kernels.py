@@ -1129,6 +1129,10 @@ def test_gemm6(R, K, N):
     assert bool(((C.double() - ref).abs() <= bound).all()), float(((C.double() - ref).abs() / bound).max())
     lib32 = A @ B
     assert float((C.double() - ref).abs().max()) <= 2.0 * float((lib32.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
+    if R * N >= 50000 and K >= 800:
+        # no coherent drift: the bf16 MFMA's accumulation drifts down by ~5e-9 of the magnitude sum unless the running sum's sign alternates
+        # (ss_gemm6 does); a cancelling reduction over the result (a PLIF node's dL/dw) sees the mean, not the rms
+        assert abs(float(((C.double() - ref) / bound).mean())) * 2.0 ** -21 <= 1e-9
     C2 = torch.empty_like(C)
     _lib.gemm6(A, B, C2, R, K, N)
     assert torch.equal(C, C2)
