@@ -90,6 +90,7 @@ def host_backend(monkeypatch):
     from stereospike_amd.network import loss as loss_mod
     from stereospike_amd import fused as fused_mod
     monkeypatch.setattr(fused_mod, 'EXACT_SPLIT_GEMM', False)         # torch.mm(bf16, bf16, out_dtype=fp32) exists on the GPU only
+    monkeypatch.setattr(fused_mod, 'GEMM6_DGRAD', False)              # hand-written MFMA kernels: GPU only (the fp32 GEMM runs instead)
     monkeypatch.setattr(_lib, 'loss_stats', loss_stats)
     monkeypatch.setattr(_lib, 'loss_grad', loss_grad)
     monkeypatch.setattr(_lib, 'loss_ws_doubles', lambda: 1)
