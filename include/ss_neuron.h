@@ -270,7 +270,7 @@ int ss_upconv_fused2_fwd_x16(const void* x, int dtype, const void* Wf, int nspli
  * g_W = x^T @ g_P (autograd of NNConvUpsampling, /root/reference/network/blocks.py:110-132; call sites SNN_models.py:110-129):
  *     g_w[ci][n] (+)= sum_r x[r][ci] * g[r][n]        x [R][C_in] fp32 spike counts (exact in bf16), g [R][N] fp32, g_w [C_in][N]
  * g is split exactly into three bf16 terms in registers, products are exact, accumulation fp32 (v_mfma_f32_32x32x16_bf16); split-K over
- * the rows with a fixed-order second pass (deterministic).  ss_spike_wgrad_supported(C_in, N): C_in in {64, 128}, N % 32 == 0.
+ * the rows with a fixed-order second pass (deterministic).  ss_spike_wgrad_supported(C_in, N): C_in in {64, 128, 256, 512}, N % 32 == 0.
  * ws: caller workspace of ss_spike_wgrad_ws_floats(C_in, N, R) floats (16-byte aligned: split-K partials + the spike operand transposed into
  * MFMA fragment order as bf16).  accumulate != 0 adds to g_w.
  */

@@ -2002,12 +2002,15 @@ __global__ __launch_bounds__(kBlock) void spike_wgrad_xprep_kernel(const float* 
 
 template <int CIT, int NTW, int PF>
 __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __restrict__ g, const unsigned short* __restrict__ xT,
-                                                                float* __restrict__ ws, long long R, int N, int Q)
+                                                                float* __restrict__ ws, long long R, int N, int Q, int CIN)
 {
-    constexpr int CIN = 32 * CIT;
+    // CIN: all input channels (xT / ws strides); this workgroup handles the 32 CIT channels starting at ci0 (channel groups are a second
+    // kind dimension: blockIdx.x = (slice * CG + channel group) * Q + column kind)
+    const int CG = CIN / (32 * CIT);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);           // wave-uniform: keeps the operand base addresses in SGPRs
-    const int q = (int)(blockIdx.x % Q), slice = (int)(blockIdx.x / Q), slices = (int)(gridDim.x / Q);
+    const int q = (int)(blockIdx.x % Q), cgi = (int)((blockIdx.x / Q) % CG), slice = (int)(blockIdx.x / (Q * CG)), slices = (int)(gridDim.x / (Q * CG));
+    const int ci0 = 32 * CIT * cgi;
     const int NT = N / 32;
     // kind q owns the CONTIGUOUS column tiles [q tpk, (q + 1) tpk): a workgroup then reads one contiguous piece of every row of g
     const int tpk = (NT + Q - 1) / Q, kt = min(tpk, NT - q * tpk);
@@ -2032,7 +2035,7 @@ __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __
     float gv[PF][NTW][8];
     s16x8 xn[PF][CIT];
     auto load_step = [&](float (&gd)[NTW][8], s16x8 (&xd)[CIT], long long ks) {
-        const unsigned short* xb = xT + ks * CIN * 16;
+        const unsigned short* xb = xT + (ks * CIN + ci0) * 16;
 #pragma unroll
         for (int t = 0; t < CIT; ++t) xd[t] = *reinterpret_cast<const s16x8*>(xb + 32 * 16 * t + xoff);
         if (ks < KSF) {                                                          // all 16 rows exist: uniform bases
@@ -2092,7 +2095,7 @@ __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = 32 * (tile0 + 8 * j) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    wsl[(long long)n * CIN + 32 * t + (lane & 31)] = acc[j][t][r];
+                    wsl[(long long)n * CIN + ci0 + 32 * t + (lane & 31)] = acc[j][t][r];
                 }
         }
     }
@@ -3499,19 +3502,20 @@ int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream)
 
 int ss_spike_wgrad_supported(int Cin, int N)
 {
-    return (Cin == 64 || Cin == 128) && N > 0 && N % 32 == 0 && N / 32 <= 128;
+    return (Cin == 64 || Cin == 128 || Cin == 256 || Cin == 512) && N > 0 && N % 32 == 0 && N / 32 <= 256;
 }
 
 static int spike_wgrad_plan(int Cin, int N, int* Q, int* slices)
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
-    // accumulators per wavefront: NTW x (Cin / 32) x 16 registers = 64 (with the prefetched operands of the next k-step the kernel
-    // stays inside the 256 registers of two wavefronts per SIMD): Cin 64 -> 2 column tiles per wavefront, 128 -> 1
+    // accumulators per wavefront: NTW x CIT x 16 registers: C_in 64 -> 2 column tiles x 2 channel tiles, 128 -> 1 x 4, 256 -> 1 x 8,
+    // 512 -> 1 x 8 in two channel groups
     const int ntw = Cin == 64 ? 2 : 1;
+    const int cg = Cin == 512 ? 2 : 1;
     const int nt = N / 32;
     *Q = (nt + 8 * ntw - 1) / (8 * ntw);
-    *slices = cus / *Q > 0 ? cus / *Q : 1;
+    *slices = cus / (*Q * cg) > 0 ? cus / (*Q * cg) : 1;
     return 1;
 }
 
@@ -3530,9 +3534,10 @@ int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, lo
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* xT = reinterpret_cast<unsigned short*>(ws + (long long)slices * N * Cin);
     hipLaunchKernelGGL(spike_wgrad_xprep_kernel, dim3(grid_for(((R + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s, x, xT, R, Cin);
-    const unsigned grid = (unsigned)(Q * slices);
-    if (Cin == 64) hipLaunchKernelGGL((spike_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q);
-    else hipLaunchKernelGGL((spike_wgrad_kernel<4, 1, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q);
+    const unsigned grid = (unsigned)(Q * slices * (Cin == 512 ? 2 : 1));
+    if (Cin == 64) hipLaunchKernelGGL((spike_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
+    else if (Cin == 128) hipLaunchKernelGGL((spike_wgrad_kernel<4, 1, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
+    else hipLaunchKernelGGL((spike_wgrad_kernel<8, 1, 2>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(spike_wgrad_reduce_kernel, dim3(grid_for((long long)N * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, N, Cin, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;

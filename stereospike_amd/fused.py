@@ -471,10 +471,10 @@ FUSED_UPCONV_X16 = True            # 16-bit autocast: deconv1 / deconv2 forward 
 FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 122); 1: always the first form (A/B)
 ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
-EXACT_WGRAD_MFMA = True            # weight gradient of the decoder stages with C_in 64 / 128 (deconv1, deconv2) as the hand-written exact bf16x3 MFMA
+EXACT_WGRAD_MFMA = True            # weight gradient of the decoder stages (C_in 64 .. 512) as the hand-written exact bf16x3 MFMA
                                    # contraction ss_spike_wgrad_f32 (was the library's fp32 GEMM at the fp32-MFMA rate)
 import os as _os
-EXACT_WGRAD_MFMA_CIN = tuple(int(c) for c in _os.environ.get('SS_WGRAD_MFMA_CIN', '64,128').split(',') if c)   # A/B knob (tools/)
+EXACT_WGRAD_MFMA_CIN = tuple(int(c) for c in _os.environ.get('SS_WGRAD_MFMA_CIN', '64,128,256,512').split(',') if c)   # A/B knob (tools/)
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
                                    # to pay for the extra 10 B/element split pass over g_P (profiles/r01/split_wgrad_sweep.log)
 ASSERT_EXACT_SPLIT = False         # tests: verify (with a host sync) that the input really is bf16-exact

@@ -1013,7 +1013,8 @@ def test_winograd_dgrad_inside_the_spike_conv():
 # ======================================================================================================
 # exact bf16x3 MFMA weight gradient of a synapse on spike inputs (ss_spike_wgrad_f32)
 # ======================================================================================================
-@pytest.mark.parametrize('R,Cin,N', [(1000, 64, 800), (4099, 128, 1600), (37, 64, 96), (16 * 130 * 173, 64, 800), (5 * 65 * 87, 128, 1600)])
+@pytest.mark.parametrize('R,Cin,N', [(1000, 64, 800), (4099, 128, 1600), (37, 64, 96), (16 * 130 * 173, 64, 800), (5 * 65 * 87, 128, 1600),
+                                     (3001, 256, 3200), (777, 512, 6400), (80 * 33 * 44, 256, 3200)])
 def test_spike_wgrad_mfma(R, Cin, N):
     """g_w[ci][n] = sum_r x[r][ci] g[r][n] for spike x: products exact, fp32 accumulation -> within fp32 summation error of the float64
     contraction (far inside it: the error of an fp32 GEMM); ragged row counts; accumulate flag; run-to-run bit-identical."""

@@ -70,7 +70,7 @@ for name, Cin, Cout, (h, w), (H, W) in geoms:
 
 if os.environ.get('WGRAD', '1') == '1':       # exact bf16x3 MFMA weight gradient vs the library's fp32 GEMM (split-K as in fused.py)
     from stereospike_amd import fused
-    for name, Cin, Cout, (h, w), _ in geoms:
+    for name, Cin, Cout, (h, w), _ in geoms + [('deconv3', 256, 128, (33, 44), None), ('deconv4', 512, 256, (17, 22), None)]:
         R, N = NB * h * w, 25 * Cout
         x = (torch.rand(R, Cin, device=dev) < 0.35).float()
         g = torch.randn(R, N, device=dev)
