@@ -309,6 +309,19 @@ int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long 
 int ss_gemm6_batched_f32(const float* A, const float* B, float* C, float* ws, int batch, long long R, int K, int N, void* stream);
 
 /*
+ * Weight gradient of a 5x5 / stride 2 / pad 2 convolution on spike inputs (ABI 3) — autograd of the reference's conv1 / conv2
+ * (nn.Conv2d(32, 64, 5, 2, 2), nn.Conv2d(64, 128, 5, 2, 2): /root/reference/network/SNN_models.py:80-90) w.r.t. their weight:
+ *     g_w[co][ci][ky][kx] (+)= sum_{nb, oy, ox} g[nb][oy][ox][co] * x[nb][2 oy + ky - 2][2 ox + kx - 2][ci]
+ * g [NB][ho][wo][C_out] fp32 (NHWC), x [NB][h][w][C_in] fp32 spike counts (exact in bf16), g_w [C_out][C_in][5][5].  g is split exactly into
+ * three bf16 terms in registers; products exact; fp32 accumulation on v_mfma_f32_32x32x16_bf16; split-K with a fixed-order second pass.
+ * ws: ss_spike_conv_wgrad_ws_floats floats (partials + five column-decimated bf16 copies of x), 16-byte aligned.
+ */
+int ss_spike_conv_wgrad_supported(int Cin, int Cout, int k, int stride, int pad);
+long long ss_spike_conv_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w);
+int ss_spike_conv_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate,
+                            void* stream);
+
+/*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
  * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
  *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]

@@ -124,6 +124,12 @@ def lib():
     L.ss_gemm6_f32.restype = i32
     L.ss_gemm6_batched_f32.argtypes = [p, p, p, p, i32, i64, i32, i32, p]
     L.ss_gemm6_batched_f32.restype = i32
+    L.ss_spike_conv_wgrad_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_spike_conv_wgrad_supported.restype = i32
+    L.ss_spike_conv_wgrad_ws_floats.argtypes = [i32, i32, i64, i32, i32]
+    L.ss_spike_conv_wgrad_ws_floats.restype = i64
+    L.ss_spike_conv_wgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_spike_conv_wgrad_f32.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
     L.ss_spike_wgrad_supported.restype = i32
     L.ss_spike_wgrad_ws_floats.argtypes = [i32, i32, i64]
@@ -154,7 +160,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
-           'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32')
+           'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
+           'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -487,6 +494,21 @@ def gemm6_batched(A, B, C_, batch, R, K, N):
         rc = lib().ss_gemm6_batched_f32(_f32(A, 'A', batch * R * K), _f32(B, 'B', batch * K * N), _f32(C_, 'C', batch * R * N), _f32(ws, 'ws'),
                                         batch, R, K, N, _stream(A))
     _check(rc, 'ss_gemm6_batched_f32')
+
+
+def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):
+    return bool(lib().ss_spike_conv_wgrad_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def spike_conv_wgrad(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False):
+    """g_w [Cout, Cin, 5, 5] (+)= weight gradient of conv2d(x, ., stride 2, pad 2): g [NB, ho, wo, Cout] fp32 NHWC, x [NB, h, w, Cin] fp32 spikes."""
+    _require_hip(g, 'g')
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ws = torch.empty(int(lib().ss_spike_conv_wgrad_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_spike_conv_wgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), _f32(x, 'x', NB * h * w * Cin), _f32(g_w, 'g_w', Cout * Cin * 25),
+                                           _f32(ws, 'ws'), NB, Cin, Cout, h, w, int(bool(accumulate)), _stream(g))
+    _check(rc, 'ss_spike_conv_wgrad_f32')
 
 
 def spike_wgrad_supported(Cin, N):

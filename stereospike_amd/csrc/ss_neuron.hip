@@ -2116,6 +2116,161 @@ __global__ __launch_bounds__(kBlock) void spike_wgrad_reduce_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Weight gradient of a 5x5 / stride 2 / pad 2 convolution on SPIKE inputs as an exact bf16x3 MFMA contraction over the output pixels
+// ---------------------------------------------------------------------------------------------------
+// Reference: autograd of conv1 / conv2 (nn.Conv2d(32, 64, 5, 2, 2) / (64, 128, 5, 2, 2), /root/reference/network/SNN_models.py:80-90) w.r.t.
+// their weight:  g_w[co][ci][ky][kx] = sum_{nb, oy, ox} g[nb][oy][ox][co] * x[nb][2 oy + ky - 2][2 ox + kx - 2][ci],  x a spike tensor.
+// Same scheme as spike_wgrad_kernel — the contraction index (16 consecutive ox of one output row = one k-step) is what a lane holds 8
+// consecutive values of; g is split exactly into three bf16 terms in registers; products exact, fp32 accumulation — with the spike operand
+// of tap (ky, kx) read from five column-decimated bf16 copies of x (one per kx: xK[kx][nb][iy + 2][ox / 8][ci][ox % 8] =
+// x[nb][iy][2 ox + kx - 2][ci], zero padded), so that the fragment of 8 consecutive ox is ONE aligned 16-B load, coalesced over ci.  The 25 C_in / 32 "virtual
+// channel" tiles (tap, ci tile) are dealt to workgroup kinds x wavefronts; every wavefront keeps NVC x (C_out / 32) accumulator tiles.
+template <int CIT, int COT, int NVC>
+__global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const float* __restrict__ g, const unsigned short* __restrict__ xK,
+                                                                     float* __restrict__ ws, int NB, int h, int ho, int wo, int Q)
+{
+    constexpr int CIN = 32 * CIT, COUT = 32 * COT, NV = 25 * CIT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = (int)(blockIdx.x % Q), slice = (int)(blockIdx.x / Q), slices = (int)(gridDim.x / Q);
+    const int vpk = (NV + Q - 1) / Q, kv = min(vpk, NV - q * vpk);
+    const int v0 = q * vpk + wave;
+    if (wave >= kv) return;
+    bool own[NVC];
+    long long xbase[NVC];                                                  // element offset of (kx, ., ky, ci tile) inside xK, without (nb, oy, ox)
+    const int KSR = (wo + 15) / 16, OX8 = 2 * KSR, HP = h + 4;
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+        own[j] = wave + 8 * j < kv;
+        const int v = own[j] ? v0 + 8 * j : v0;
+        const int tap = v / CIT, cit = v - tap * CIT, ky = tap / 5, kx = tap - 5 * ky;
+        xbase[j] = (((((long long)kx * NB) * HP + ky) * OX8 + (lane >> 5)) * CIN + 32 * cit + (lane & 31)) * 8;
+    }
+    f32x16 acc[NVC][COT];
+#pragma unroll
+    for (int j = 0; j < NVC; ++j)
+#pragma unroll
+        for (int t = 0; t < COT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+    const long long KS = (long long)NB * ho * KSR;
+    const long long per = (KS + slices - 1) / slices;
+    const long long ks0 = slice * per, ks1 = min(ks0 + per, KS);
+    constexpr int PF = 2;
+    float gv[PF][COT][8];
+    s16x8 xn[PF][NVC];
+    auto load_step = [&](float (&gd)[COT][8], s16x8 (&xd)[NVC], long long ks) {
+        const int c = (int)(ks % KSR);
+        const long long ro = ks / KSR;                                     // nb * ho + oy
+        const int oy = (int)(ro % ho);
+        const long long nb = ro / ho;
+        const int ox0 = 16 * c + 8 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < NVC; ++j)
+            xd[j] = *reinterpret_cast<const s16x8*>(xK + xbase[j] + (((nb * HP + 2 * oy) * OX8 + 2 * c) * CIN) * 8LL);
+        const float* gb = g + (ro * wo + ox0) * COUT + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = ox0 + e < wo;                                   // the last k-step of a row is ragged (x is zero there as well)
+#pragma unroll
+            for (int t = 0; t < COT; ++t) gd[t][e] = ok ? load_stream(gb + (long long)e * COUT + 32 * t) : 0.f;
+        }
+    };
+    if (ks0 < ks1) load_step(gv[0], xn[0], ks0);
+#pragma unroll 1
+    for (long long ks = ks0; ks < ks1; ks += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (ks + u < ks1) {
+                if (ks + u + 1 < ks1) load_step(gv[(u + 1) % PF], xn[(u + 1) % PF], ks + u + 1);
+#pragma unroll
+                for (int t = 0; t < COT; ++t) {
+                    s16x8 gs[3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = gv[u][t][e];
+                        const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
+                        const float r1 = v - __uint_as_float(uh);
+                        const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+                        const float r2 = r1 - __uint_as_float(um);
+                        gs[0][e] = (short)(uh >> 16); gs[1][e] = (short)(um >> 16); gs[2][e] = (short)(__float_as_uint(r2) >> 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NVC; ++j) {
+                        if (own[j]) {
+#pragma unroll
+                            for (int sp = 0; sp < 3; ++sp) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs[sp], xn[u][j], acc[j][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // D[co][ci]: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);  ws[slice][virtual channel v * 32 + ci][co]
+    float* const wsl = ws + (long long)slice * NV * 32 * COUT;
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+        if (own[j]) {
+#pragma unroll
+            for (int t = 0; t < COT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    wsl[((long long)(v0 + 8 * j) * 32 + (lane & 31)) * COUT + co] = acc[j][t][r];
+                }
+        }
+    }
+}
+
+// g_w[co][ci][ky][kx] (+)= sum over slices of ws[slice][(tap * CIT + ci / 32) * 32 + ci % 32][co]
+__global__ __launch_bounds__(kBlock) void spike_conv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gw, int slices, int CIN, int COUT,
+                                                                        int accumulate)
+{
+    const int CIT = CIN / 32;
+    const long long per = 25LL * CIN * COUT;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < per; i += (long long)gridDim.x * kBlock) {
+        const int co = (int)(i % COUT);
+        const long long vc = i / COUT;                                     // (tap * CIT + cit) * 32 + cil
+        const int cil = (int)(vc & 31), v = (int)(vc >> 5);
+        const int tap = v / CIT, ci = 32 * (v - tap * CIT) + cil;
+        float a = 0.f;
+        for (int sIdx = 0; sIdx < slices; ++sIdx) a += ws[(long long)sIdx * per + i];
+        float* o = gw + ((long long)co * CIN + ci) * 25 + tap;
+        *o = accumulate ? *o + a : a;
+    }
+}
+
+// x [NB][h][w][C] fp32 spike counts -> xK[kx][nb][iy + 2][ox / 8][ci][ox % 8] bf16 = x[nb][iy][2 ox + kx - 2][ci] (zero outside), ox < 16 ceil(wo / 16).
+// A lane owns (nb, padded row, 8-ox chunk, ci): 19 input columns -> the five kx fragments; reads and 16-B writes coalesced over ci.
+__global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const float* __restrict__ x, unsigned short* __restrict__ xK, int NB, int h, int w, int C,
+                                                                  int wo)
+{
+    const int OX8 = 2 * ((wo + 15) / 16), HP = h + 4;
+    const long long total = (long long)NB * HP * OX8 * C;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int ci = (int)(i % C);
+        long long r = i / C;
+        const int o8 = (int)(r % OX8); r /= OX8;
+        const int iyp = (int)(r % HP); const int nb = (int)(r / HP);
+        const int iy = iyp - 2;
+        unsigned short v[19];
+#pragma unroll
+        for (int t = 0; t < 19; ++t) {
+            const int ix = 16 * o8 - 2 + t;
+            v[t] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? (unsigned short)(__float_as_uint(x[(((long long)nb * h + iy) * w + ix) * C + ci]) >> 16)
+                                                            : (unsigned short)0;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            u16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[2 * e + kx];
+            *reinterpret_cast<u16x8*>(xK + ((((((long long)kx * NB + nb) * HP + iyp) * OX8 + o8) * C + ci) * 8)) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Decoder backward, fused: adjoint gather (g_P) + exact bf16x3 MFMA weight gradient in ONE pass — g_P is written once for the data-gradient
 // GEMM and never read back for the weight gradient
 // ---------------------------------------------------------------------------------------------------
@@ -3631,6 +3786,50 @@ int ss_gemm6_batched_f32(const float* A, const float* B, float* C, float* ws, in
 int ss_gemm6_f32(const float* A, const float* B, float* C, float* ws, long long R, int K, int N, void* stream)
 {
     return ss_gemm6_batched_f32(A, B, C, ws, 1, R, K, N, stream);
+}
+
+int ss_spike_conv_wgrad_supported(int Cin, int Cout, int k, int stride, int pad)
+{
+    return k == 5 && stride == 2 && pad == 2 && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128));
+}
+
+static int spike_conv_wgrad_plan(int Cin, int* Q, int* slices)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
+    const int nv = 25 * Cin / 32, nvc = Cin == 32 ? 2 : 1;                 // virtual channel tiles; tiles per wavefront
+    *Q = (nv + 8 * nvc - 1) / (8 * nvc);
+    *slices = cus / *Q > 0 ? cus / *Q : 1;
+    return 1;
+}
+
+long long ss_spike_conv_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w)
+{
+    int Q = 0, slices = 0;
+    if (!ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || NB <= 0 || h <= 0 || w <= 0 || !spike_conv_wgrad_plan(Cin, &Q, &slices)) return 0;
+    const int wo = (w + 4 - 5) / 2 + 1;
+    const long long oxp = ((wo + 15) / 16) * 16;
+    return (long long)slices * 25 * Cin * Cout + (5LL * NB * (h + 4) * Cin * oxp + 1) / 2;
+}
+
+int ss_spike_conv_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate,
+                            void* stream)
+{
+    if (!g || !x || !g_w || !ws || NB <= 0 || NB > 0x7fffffff || h <= 0 || w <= 0 || !ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(ws))
+        return SS_EINVAL;
+    int Q = 0, slices = 0;
+    if (!spike_conv_wgrad_plan(Cin, &Q, &slices)) return SS_ELAUNCH;
+    const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* xK = reinterpret_cast<unsigned short*>(ws + (long long)slices * 25 * Cin * Cout);
+    const long long oxp = ((wo + 15) / 16) * 16;
+    hipLaunchKernelGGL(spike_conv_xprep_kernel, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s, x, xK, (int)NB, h, w, Cin, wo);
+    const unsigned grid = (unsigned)(Q * slices);
+    if (Cin == 32) hipLaunchKernelGGL((spike_conv_wgrad_kernel<1, 2, 2>), dim3(grid), dim3(kSwThreads), 0, s, g, xK, ws, (int)NB, h, ho, wo, Q);
+    else hipLaunchKernelGGL((spike_conv_wgrad_kernel<2, 4, 1>), dim3(grid), dim3(kSwThreads), 0, s, g, xK, ws, (int)NB, h, ho, wo, Q);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    hipLaunchKernelGGL(spike_conv_wgrad_reduce_kernel, dim3(grid_for(25LL * Cin * Cout, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cin, Cout, accumulate);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
 int ss_wino_dgrad_weights_f32(const float* W, float* U, int Cout, int Cin, void* stream)

@@ -1152,3 +1152,36 @@ def test_gemm6_batched():
     one = torch.empty(R, N, device=DEV)
     _lib.gemm6(A[5], B[5], one, R, K, N)
     assert torch.equal(one, C[5])
+
+
+# ======================================================================================================
+# exact MFMA weight gradient of the stride-2 5x5 encoder convs on spike inputs (ss_spike_conv_wgrad_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('NB,Cin,Cout,hw', [(2, 32, 64, (64, 80)), (3, 64, 128, (33, 45)), (1, 32, 64, (7, 9)), (5, 64, 128, (130, 173)), (4, 32, 64, (260, 346))])
+def test_spike_conv_wgrad_mfma(NB, Cin, Cout, hw):
+    """== the float64 weight gradient of conv2d(x, w, stride 2, padding 2) within fp32 accumulation error of exact products (bound 2^-22 of
+    the magnitude sum per element); at least as close as MIOpen's fp32 weight gradient (x 2); odd sizes / ragged row tails; deterministic."""
+    import torch.nn.functional as F
+    from stereospike_amd import _lib
+    h, w = hw
+    gen = torch.Generator(device=DEV).manual_seed(NB + h)
+    x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float())
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    g = torch.randn(NB, ho, wo, Cout, device=DEV, generator=gen) * torch.exp(torch.randn(NB, ho, wo, 1, device=DEV, generator=gen))
+    assert _lib.spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) and not _lib.spike_conv_wgrad_supported(Cin, Cout, 3, 1, 1)
+    gw = torch.full((Cout, Cin, 5, 5), float('nan'), device=DEV)
+    _lib.spike_conv_wgrad(g, x, gw, NB, Cin, Cout, h, w)
+
+    def wgrad(xx, gg):
+        return torch.ops.aten.convolution_backward(gg.permute(0, 3, 1, 2), xx.permute(0, 3, 1, 2), torch.empty(Cout, Cin, 5, 5, dtype=xx.dtype, device=DEV),
+                                                   None, [2, 2], [2, 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    ref = wgrad(x.double(), g.double())
+    mag = wgrad(x.double(), g.double().abs())
+    assert bool(((gw.double() - ref).abs() <= mag * 2.0 ** -22 + 1e-30).all()), float(((gw.double() - ref).abs() / (mag * 2.0 ** -22 + 1e-30)).max())
+    mi = wgrad(x, g)
+    assert float((gw.double() - ref).abs().max()) <= 2.0 * float((mi.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
+    gw2 = torch.empty_like(gw)
+    _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w)
+    assert torch.equal(gw, gw2)
+    _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w, accumulate=True)
+    assert torch.equal(gw2, gw + gw)
