@@ -2126,83 +2126,62 @@ __global__ __launch_bounds__(kBlock) void spike_wgrad_reduce_kernel(const float*
 // x[nb][iy][2 ox + kx - 2][ci], zero padded), so that the fragment of 8 consecutive ox is ONE aligned 16-B load, coalesced over ci.  The 25 C_in / 32 "virtual
 // channel" tiles (tap, ci tile) are dealt to workgroup kinds x wavefronts; every wavefront keeps NVC x (C_out / 32) accumulator tiles.
 template <int CIT, int COT, int NVC>
-__global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const float* __restrict__ g, const unsigned short* __restrict__ xK,
+__global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const unsigned short* __restrict__ gT, const unsigned short* __restrict__ xK,
                                                                      float* __restrict__ ws, int NB, int h, int ho, int wo, int Q)
 {
-    constexpr int CIN = 32 * CIT, COUT = 32 * COT, NV = 25 * CIT;
+    // wavefront = (C_out tile, group of virtual-channel tiles): a wavefront loads the three pre-split g fragments of ITS C_out tile (the first
+    // version split g in every wavefront: 56x redundant VALU work) and NVC spike fragments per k-step, and issues 3 NVC MFMAs
+    constexpr int CIN = 32 * CIT, COUT = 32 * COT, NV = 25 * CIT, NG = 8 / COT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cot = wave % COT, grp = wave / COT;
     const int q = (int)(blockIdx.x % Q), slice = (int)(blockIdx.x / Q), slices = (int)(gridDim.x / Q);
     const int vpk = (NV + Q - 1) / Q, kv = min(vpk, NV - q * vpk);
-    const int v0 = q * vpk + wave;
-    if (wave >= kv) return;
+    const int v0 = q * vpk + grp;                                          // this wavefront's virtual-channel tiles: v0 + NG j, j < NVC
+    if (grp >= kv) return;
     bool own[NVC];
-    long long xbase[NVC];                                                  // element offset of (kx, ., ky, ci tile) inside xK, without (nb, oy, ox)
+    long long xbase[NVC];
     const int KSR = (wo + 15) / 16, OX8 = 2 * KSR, HP = h + 4;
 #pragma unroll
     for (int j = 0; j < NVC; ++j) {
-        own[j] = wave + 8 * j < kv;
-        const int v = own[j] ? v0 + 8 * j : v0;
+        own[j] = grp + NG * j < kv;
+        const int v = own[j] ? v0 + NG * j : v0;
         const int tap = v / CIT, cit = v - tap * CIT, ky = tap / 5, kx = tap - 5 * ky;
         xbase[j] = (((((long long)kx * NB) * HP + ky) * OX8 + (lane >> 5)) * CIN + 32 * cit + (lane & 31)) * 8;
     }
-    f32x16 acc[NVC][COT];
+    f32x16 acc[NVC];
 #pragma unroll
     for (int j = 0; j < NVC; ++j)
 #pragma unroll
-        for (int t = 0; t < COT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const long long KS = (long long)NB * ho * KSR;
     const long long per = (KS + slices - 1) / slices;
     const long long ks0 = slice * per, ks1 = min(ks0 + per, KS);
     constexpr int PF = 2;
-    float gv[PF][COT][8];
-    s16x8 xn[PF][NVC];
-    auto load_step = [&](float (&gd)[COT][8], s16x8 (&xd)[NVC], long long ks) {
+    s16x8 gs[PF][3], xn[PF][NVC];
+    auto load_step = [&](s16x8 (&gd)[3], s16x8 (&xd)[NVC], long long ks) {
         const int c = (int)(ks % KSR);
         const long long ro = ks / KSR;                                     // nb * ho + oy
         const int oy = (int)(ro % ho);
         const long long nb = ro / ho;
-        const int ox0 = 16 * c + 8 * (lane >> 5);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) gd[sp] = *reinterpret_cast<const s16x8*>(gT + (((ks * 3 + sp) * COT + cot) * 64 + lane) * 8);
 #pragma unroll
         for (int j = 0; j < NVC; ++j)
             xd[j] = *reinterpret_cast<const s16x8*>(xK + xbase[j] + (((nb * HP + 2 * oy) * OX8 + 2 * c) * CIN) * 8LL);
-        const float* gb = g + (ro * wo + ox0) * COUT + (lane & 31);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ok = ox0 + e < wo;                                   // the last k-step of a row is ragged (x is zero there as well)
-#pragma unroll
-            for (int t = 0; t < COT; ++t) gd[t][e] = ok ? load_stream(gb + (long long)e * COUT + 32 * t) : 0.f;
-        }
     };
-    if (ks0 < ks1) load_step(gv[0], xn[0], ks0);
+    if (ks0 < ks1) load_step(gs[0], xn[0], ks0);
 #pragma unroll 1
     for (long long ks = ks0; ks < ks1; ks += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (ks + u < ks1) {
-                if (ks + u + 1 < ks1) load_step(gv[(u + 1) % PF], xn[(u + 1) % PF], ks + u + 1);
+                if (ks + u + 1 < ks1) load_step(gs[(u + 1) % PF], xn[(u + 1) % PF], ks + u + 1);
 #pragma unroll
-                for (int t = 0; t < COT; ++t) {
-                    s16x8 gs[3];
+                for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = gv[u][t][e];
-                        const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
-                        const float r1 = v - __uint_as_float(uh);
-                        const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
-                        const float r2 = r1 - __uint_as_float(um);
-                        gs[0][e] = (short)(uh >> 16); gs[1][e] = (short)(um >> 16); gs[2][e] = (short)(__float_as_uint(r2) >> 16);
-                    }
-#pragma unroll
-                    for (int j = 0; j < NVC; ++j) {
-                        if (own[j]) {
-#pragma unroll
-                            for (int sp = 0; sp < 3; ++sp) acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs[sp], xn[u][j], acc[j][t], 0, 0, 0);
-                        }
-                    }
-                }
+                    for (int j = 0; j < NVC; ++j)
+                        if (own[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs[u][sp], xn[u][j], acc[j], 0, 0, 0);
             }
         }
     }
@@ -2212,13 +2191,40 @@ __global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const floa
     for (int j = 0; j < NVC; ++j) {
         if (own[j]) {
 #pragma unroll
-            for (int t = 0; t < COT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    wsl[((long long)(v0 + 8 * j) * 32 + (lane & 31)) * COUT + co] = acc[j][t][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * cot + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wsl[((long long)(v0 + NG * j) * 32 + (lane & 31)) * COUT + co] = acc[j][r];
+            }
         }
+    }
+}
+
+// g [NB * ho][wo][C_out] fp32 -> gT[k-step][split][C_out tile][lane][8] bf16: the exact three-term split of g in MFMA fragment order (lane ->
+// co = 32 tile + (lane & 31), the 8 consecutive ox of its half of the k-step; zero beyond wo)
+__global__ __launch_bounds__(kBlock) void spike_conv_gprep_kernel(const float* __restrict__ g, unsigned short* __restrict__ gT, long long rows, int wo,
+                                                                  int COUT)
+{
+    const int KSR = (wo + 15) / 16, COT = COUT / 32;
+    const long long total = rows * KSR * COT * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int t = (int)(r % COT); r /= COT;
+        const int c = (int)(r % KSR); const long long ro = r / KSR;
+        const long long ks = ro * KSR + c;
+        u16x8 o[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ox = 16 * c + 8 * (lane >> 5) + e;
+            const float v = ox < wo ? g[(ro * wo + ox) * COUT + 32 * t + (lane & 31)] : 0.f;
+            const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
+            const float r1 = v - __uint_as_float(uh);
+            const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+            const float r2 = r1 - __uint_as_float(um);
+            o[0][e] = (unsigned short)(uh >> 16); o[1][e] = (unsigned short)(um >> 16); o[2][e] = (unsigned short)(__float_as_uint(r2) >> 16);
+        }
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<u16x8*>(gT + (((ks * 3 + sp) * COT + t) * 64 + lane) * 8) = o[sp];
     }
 }
 
@@ -3797,8 +3803,9 @@ static int spike_conv_wgrad_plan(int Cin, int* Q, int* slices)
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
-    const int nv = 25 * Cin / 32, nvc = Cin == 32 ? 2 : 1;                 // virtual channel tiles; tiles per wavefront
-    *Q = (nv + 8 * nvc - 1) / (8 * nvc);
+    // a workgroup covers (8 / C_out tiles) groups x 7 virtual-channel tiles: C_in 32 (25 tiles, 2 C_out tiles): 28 -> one kind; C_in 64 (50, 4): 14 -> 4 kinds
+    const int nv = 25 * Cin / 32, cov = Cin == 32 ? 28 : 14;
+    *Q = (nv + cov - 1) / cov;
     *slices = cus / *Q > 0 ? cus / *Q : 1;
     return 1;
 }
@@ -3807,9 +3814,9 @@ long long ss_spike_conv_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, 
 {
     int Q = 0, slices = 0;
     if (!ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || NB <= 0 || h <= 0 || w <= 0 || !spike_conv_wgrad_plan(Cin, &Q, &slices)) return 0;
-    const int wo = (w + 4 - 5) / 2 + 1;
-    const long long oxp = ((wo + 15) / 16) * 16;
-    return (long long)slices * 25 * Cin * Cout + (5LL * NB * (h + 4) * Cin * oxp + 1) / 2;
+    const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
+    const long long ksr = (wo + 15) / 16, oxp = ksr * 16;
+    return (long long)slices * 25 * Cin * Cout + (5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + NB * ho * ksr * (Cout / 32) * 768 + 8;
 }
 
 int ss_spike_conv_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate,
@@ -3821,12 +3828,15 @@ int ss_spike_conv_wgrad_f32(const float* g, const float* x, float* g_w, float* w
     if (!spike_conv_wgrad_plan(Cin, &Q, &slices)) return SS_ELAUNCH;
     const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    unsigned short* xK = reinterpret_cast<unsigned short*>(ws + (long long)slices * 25 * Cin * Cout);
-    const long long oxp = ((wo + 15) / 16) * 16;
+    const long long ksr = (wo + 15) / 16, oxp = ksr * 16;
+    const long long part = (long long)slices * 25 * Cin * Cout, xk = ((5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + 3) & ~3LL;
+    unsigned short* xK = reinterpret_cast<unsigned short*>(ws + part);
+    unsigned short* gT = reinterpret_cast<unsigned short*>(ws + part + xk);
     hipLaunchKernelGGL(spike_conv_xprep_kernel, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s, x, xK, (int)NB, h, w, Cin, wo);
+    hipLaunchKernelGGL(spike_conv_gprep_kernel, dim3(grid_for(NB * ho * ksr * (Cout / 32) * 64, kMaxGridBwd)), dim3(kBlock), 0, s, g, gT, NB * ho, wo, Cout);
     const unsigned grid = (unsigned)(Q * slices);
-    if (Cin == 32) hipLaunchKernelGGL((spike_conv_wgrad_kernel<1, 2, 2>), dim3(grid), dim3(kSwThreads), 0, s, g, xK, ws, (int)NB, h, ho, wo, Q);
-    else hipLaunchKernelGGL((spike_conv_wgrad_kernel<2, 4, 1>), dim3(grid), dim3(kSwThreads), 0, s, g, xK, ws, (int)NB, h, ho, wo, Q);
+    if (Cin == 32) hipLaunchKernelGGL((spike_conv_wgrad_kernel<1, 2, 7>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q);
+    else hipLaunchKernelGGL((spike_conv_wgrad_kernel<2, 4, 7>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(spike_conv_wgrad_reduce_kernel, dim3(grid_for(25LL * Cin * Cout, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cin, Cout, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;

@@ -800,6 +800,57 @@ def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return g_x
 
 
+SPIKE_CONV_WGRAD_MFMA = _os.environ.get('SS_CONV_WGRAD_MFMA', '1') == '1'   # conv1 / conv2 (5x5, stride 2, spike inputs): forward and data gradient on
+                                   # MIOpen, weight gradient as the hand-written exact bf16x3 MFMA contraction ss_spike_conv_wgrad_f32
+
+
+class _SpikeConvWgradCL(torch.autograd.Function):
+    """Conv2d(k 5, stride 2, pad 2) of conv1 / conv2 (/root/reference/network/SNN_models.py:80-90) on a spike NHWC array: forward and data gradient
+    are MIOpen's fp32 convolution (as before), the WEIGHT gradient — one operand is a spike tensor — is the exact bf16x3 MFMA contraction over the
+    output pixels (ss_spike_conv_wgrad_f32)."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x_cl, weight):
+        x_cl = x_cl.contiguous()
+        w_cl = weight.contiguous(memory_format=torch.channels_last)
+        y = torch.nn.functional.conv2d(x_cl.permute(0, 3, 1, 2), w_cl, None, 2, 2).permute(0, 2, 3, 1)
+        y = y if y.is_contiguous() else y.contiguous()
+        ctx.save_for_backward(x_cl, weight)
+        return y
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, g):
+        x_cl, weight = ctx.saved_tensors
+        NB, h, w, Cin = x_cl.shape
+        Cout = weight.shape[0]
+        g = g.float().contiguous()
+        g_x = g_w = None
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            _lib.spike_conv_wgrad(g, x_cl, g_w, NB, Cin, Cout, h, w)
+        if ctx.needs_input_grad[0]:
+            x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+            g_x = torch.ops.aten.convolution_backward(
+                g.permute(0, 3, 1, 2), x_meta, weight.contiguous(memory_format=torch.channels_last), None,
+                [2, 2], [2, 2], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
+            if not g_x.is_contiguous():
+                g_x = g_x.contiguous()
+        return g_x, g_w
+
+
+def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
+    """conv on a spike NHWC array through _SpikeConvWgradCL, or None when it does not apply (caller then uses the plain MIOpen convolution)."""
+    import torch.nn as nn
+    if not (SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
+            and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2) and x_cl.stride(-1) == 1
+            and _lib.spike_conv_wgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2)):
+        return None
+    return _SpikeConvWgradCL.apply(x_cl, conv.weight)
+
+
 SPIKE_CONV_WGRAD_SPLIT = 8         # profiles/r01/wgrad_splitk.log
 SPIKE_CONV_MIN_CIN = 128           # conv3 (128), conv4 (256), bottleneck (512); below: im2col traffic outweighs the MFMA gain
 
