@@ -128,7 +128,7 @@ def lib():
     L.ss_spike_conv_wgrad_supported.restype = i32
     L.ss_spike_conv_wgrad_ws_floats.argtypes = [i32, i32, i64, i32, i32]
     L.ss_spike_conv_wgrad_ws_floats.restype = i64
-    L.ss_spike_conv_wgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_spike_conv_wgrad_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     L.ss_spike_conv_wgrad_f32.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
     L.ss_spike_wgrad_supported.restype = i32
@@ -500,13 +500,15 @@ def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):
     return bool(lib().ss_spike_conv_wgrad_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
 
 
-def spike_conv_wgrad(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False):
+def spike_conv_wgrad(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False, x_packed=None):
     """g_w [Cout, Cin, 5, 5] (+)= weight gradient of conv2d(x, ., stride 2, pad 2): g [NB, ho, wo, Cout] fp32 NHWC, x [NB, h, w, Cin] fp32 spikes."""
     _require_hip(g, 'g')
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     ws = torch.empty(int(lib().ss_spike_conv_wgrad_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        rc = lib().ss_spike_conv_wgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), _f32(x, 'x', NB * h * w * Cin), _f32(g_w, 'g_w', Cout * Cin * 25),
+        rc = lib().ss_spike_conv_wgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
+                                           _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                                           _f32(g_w, 'g_w', Cout * Cin * 25),
                                            _f32(ws, 'ws'), NB, Cin, Cout, h, w, int(bool(accumulate)), _stream(g))
     _check(rc, 'ss_spike_conv_wgrad_f32')
 

@@ -2248,9 +2248,12 @@ __global__ __launch_bounds__(kBlock) void spike_conv_wgrad_reduce_kernel(const f
 
 // x [NB][h][w][C] fp32 spike counts -> xK[kx][nb][iy + 2][ox / 8][ci][ox % 8] bf16 = x[nb][iy][2 ox + kx - 2][ci] (zero outside), ox < 16 ceil(wo / 16).
 // A lane owns (nb, padded row, 8-ox chunk, ci): 19 input columns -> the five kx fragments; reads and 16-B writes coalesced over ci.
-__global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const float* __restrict__ x, unsigned short* __restrict__ xK, int NB, int h, int w, int C,
+template <bool PACKED>
+__global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const void* __restrict__ xv, unsigned short* __restrict__ xK, int NB, int h, int w, int C,
                                                                   int wo)
 {
+    const float* x = static_cast<const float*>(xv);
+    const unsigned* xp = static_cast<const unsigned*>(xv);                  // PACKED: the 2-bit packed spike tensor (16 neurons per word)
     const int OX8 = 2 * ((wo + 15) / 16), HP = h + 4;
     const long long total = (long long)NB * HP * OX8 * C;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
@@ -2263,8 +2266,10 @@ __global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const float* _
 #pragma unroll
         for (int t = 0; t < 19; ++t) {
             const int ix = 16 * o8 - 2 + t;
-            v[t] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? (unsigned short)(__float_as_uint(x[(((long long)nb * h + iy) * w + ix) * C + ci]) >> 16)
-                                                            : (unsigned short)0;
+            const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
+            const long long el = (((long long)nb * h + iy) * w + ix) * C + ci;
+            if constexpr (PACKED) v[t] = ok ? code_to_bf16((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u) : (unsigned short)0;
+            else v[t] = ok ? (unsigned short)(__float_as_uint(x[el]) >> 16) : (unsigned short)0;
         }
 #pragma unroll
         for (int kx = 0; kx < 5; ++kx) {
@@ -3819,10 +3824,11 @@ long long ss_spike_conv_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, 
     return (long long)slices * 25 * Cin * Cout + (5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + NB * ho * ksr * (Cout / 32) * 768 + 8;
 }
 
-int ss_spike_conv_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate,
-                            void* stream)
+int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* x_packed, float* g_w, float* ws, long long NB, int Cin, int Cout, int h,
+                            int w, int accumulate, void* stream)
 {
-    if (!g || !x || !g_w || !ws || NB <= 0 || NB > 0x7fffffff || h <= 0 || w <= 0 || !ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(ws))
+    if (x_packed && (NB * h * w * Cin) % 16 != 0) return SS_EINVAL;
+    if (!g || (!x && !x_packed) || !g_w || !ws || NB <= 0 || NB > 0x7fffffff || h <= 0 || w <= 0 || !ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(ws))
         return SS_EINVAL;
     int Q = 0, slices = 0;
     if (!spike_conv_wgrad_plan(Cin, &Q, &slices)) return SS_ELAUNCH;
@@ -3832,7 +3838,10 @@ int ss_spike_conv_wgrad_f32(const float* g, const float* x, float* g_w, float* w
     const long long part = (long long)slices * 25 * Cin * Cout, xk = ((5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + 3) & ~3LL;
     unsigned short* xK = reinterpret_cast<unsigned short*>(ws + part);
     unsigned short* gT = reinterpret_cast<unsigned short*>(ws + part + xk);
-    hipLaunchKernelGGL(spike_conv_xprep_kernel, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s, x, xK, (int)NB, h, w, Cin, wo);
+    if (x_packed) hipLaunchKernelGGL(spike_conv_xprep_kernel<true>, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
+                                     static_cast<const void*>(x_packed), xK, (int)NB, h, w, Cin, wo);
+    else hipLaunchKernelGGL(spike_conv_xprep_kernel<false>, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
+                            static_cast<const void*>(x), xK, (int)NB, h, w, Cin, wo);
     hipLaunchKernelGGL(spike_conv_gprep_kernel, dim3(grid_for(NB * ho * ksr * (Cout / 32) * 64, kMaxGridBwd)), dim3(kBlock), 0, s, g, gT, NB * ho, wo, Cout);
     const unsigned grid = (unsigned)(Q * slices);
     if (Cin == 32) hipLaunchKernelGGL((spike_conv_wgrad_kernel<1, 2, 7>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q);

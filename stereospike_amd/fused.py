@@ -811,25 +811,26 @@ class _SpikeConvWgradCL(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x_cl, weight):
+    def forward(ctx, x_cl, weight, x_packed=None):
         x_cl = x_cl.contiguous()
         w_cl = weight.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x_cl.permute(0, 3, 1, 2), w_cl, None, 2, 2).permute(0, 2, 3, 1)
         y = y if y.is_contiguous() else y.contiguous()
-        ctx.save_for_backward(x_cl, weight)
+        # the backward's operand copy reads the 2-bit packed form when the producer wrote one (16x less to read than the fp32 tensor)
+        ctx.save_for_backward(x_cl, weight, x_packed)
         return y
 
     @staticmethod
     @_bwd32
     def backward(ctx, g):
-        x_cl, weight = ctx.saved_tensors
+        x_cl, weight, x_packed = ctx.saved_tensors
         NB, h, w, Cin = x_cl.shape
         Cout = weight.shape[0]
         g = g.float().contiguous()
         g_x = g_w = None
         if ctx.needs_input_grad[1]:
             g_w = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
-            _lib.spike_conv_wgrad(g, x_cl, g_w, NB, Cin, Cout, h, w)
+            _lib.spike_conv_wgrad(g, x_cl, g_w, NB, Cin, Cout, h, w, x_packed=None if x_packed is None else x_packed.contiguous())
         if ctx.needs_input_grad[0]:
             x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
             g_x = torch.ops.aten.convolution_backward(
@@ -837,10 +838,10 @@ class _SpikeConvWgradCL(torch.autograd.Function):
                 [2, 2], [2, 2], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
             if not g_x.is_contiguous():
                 g_x = g_x.contiguous()
-        return g_x, g_w
+        return g_x, g_w, None
 
 
-def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
+def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """conv on a spike NHWC array through _SpikeConvWgradCL, or None when it does not apply (caller then uses the plain MIOpen convolution)."""
     import torch.nn as nn
     if not (SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
@@ -848,7 +849,7 @@ def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
             and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2) and x_cl.stride(-1) == 1
             and _lib.spike_conv_wgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2)):
         return None
-    return _SpikeConvWgradCL.apply(x_cl, conv.weight)
+    return _SpikeConvWgradCL.apply(x_cl, conv.weight, x_packed)
 
 
 SPIKE_CONV_WGRAD_SPLIT = 8         # profiles/r01/wgrad_splitk.log

@@ -144,8 +144,14 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                     return 0
                 return 2 if _fused.spike_conv_applies(next_conv, x_seq.device) else 1
 
-            def packed_in(conv, packed):      # hand the packed form only to a synapse that reads it
-                return packed if (packed is not None and _fused.spike_conv_applies(conv, x_seq.device)) else None
+            def packed_in(conv, packed):      # hand the packed form only to a synapse that reads it (exact-split im2col; the operand copy of
+                if packed is None:            # the MFMA weight gradient of conv1 / conv2, which still takes the dense form for MIOpen's forward)
+                    return None
+                if _fused.spike_conv_applies(conv, x_seq.device):
+                    return packed
+                wg = (_fused.SPIKE_CONV_WGRAD_MFMA and getattr(conv, 'kernel_size', None) == (5, 5) and conv.stride == (2, 2)
+                      and conv.in_channels in (32, 64))
+                return packed if wg else None
             a, b = two(self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'), fork=fork,
                                                             pack=mode(self.conv1[0])))
             enc, enc_skip, enc_pk = [a], [b], [self.bottom[2].last_packed]

@@ -203,7 +203,7 @@ def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False, x_pa
         raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
     if spikes_in and isinstance(conv, nn.Conv2d):
         from ..fused import spike_conv_wgrad_cl
-        y = spike_conv_wgrad_cl(x_arr, conv)              # conv1 / conv2: MIOpen forward / data gradient, exact MFMA weight gradient
+        y = spike_conv_wgrad_cl(x_arr, conv, x_packed)    # conv1 / conv2: MIOpen forward / data gradient, exact MFMA weight gradient
         if y is not None:
             return y
     if isinstance(conv, nn.Conv2d):

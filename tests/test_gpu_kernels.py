@@ -1183,5 +1183,11 @@ def test_spike_conv_wgrad_mfma(NB, Cin, Cout, hw):
     gw2 = torch.empty_like(gw)
     _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w)
     assert torch.equal(gw, gw2)
+    if (NB * h * w * Cin) % 16 == 0:                         # packed spike input: the same operand copy, bit for bit
+        from oracle import np_pack
+        xp = torch.from_numpy(np_pack.pack(x.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
+        gw3 = torch.empty_like(gw)
+        _lib.spike_conv_wgrad(g, None, gw3, NB, Cin, Cout, h, w, x_packed=xp)
+        assert torch.equal(gw, gw3)
     _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w, accumulate=True)
     assert torch.equal(gw2, gw + gw)
