@@ -271,7 +271,8 @@ def main():
         fwd = fwd_shapes.get(dom, zero)
         # backward: the launch group with the most updates; at equal size the forked form without the extra g_sum store (the bottom
         # layer: 16 B/update), which is also the variant the PMC passes measure (tools/pmc_target.py)
-        pref = {'neuron_bwd+fork': 2, 'neuron_bwd': 1, 'neuron_bwd+fork+sum': 0}
+        # (since the prediction heads hand over their gradient as a rank-9 pair: the '+lr' form, 13.1 B/update at 32 channels)
+        pref = {'neuron_bwd+lr': 3, 'neuron_bwd+fork': 2, 'neuron_bwd': 1, 'neuron_bwd+fork+sum': 0, 'neuron_bwd+lr+sum': 0, 'neuron_bwd+lronly': 0}
         bwd_shapes = {k: v for k, v in shapes.items() if k[0] in pref}
         bwd = bwd_shapes.get(max(bwd_shapes, key=lambda k: (k[1], pref[k[0]])), zero) if bwd_shapes else zero
         bwd_tag = max(bwd_shapes, key=lambda k: (k[1], pref[k[0]]))[0] if bwd_shapes else 'neuron_bwd'
@@ -288,9 +289,9 @@ def main():
                         achieved_GBps=round(by / 1e9 / (ms / 1e3), 1) if ms > 0 else 0.0,
                         frac=round(by / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else 0.0)
 
-        def roof(d, which='neuron_fwd'):
+        def roof(d, which='neuron_fwd', pmc_key=None):
             ach = (d['bytes'] / 1e9) / (d['ms'] / 1e3) if d['ms'] > 0 else 0.0
-            traffic = _pmc_traffic(which)
+            traffic = _pmc_traffic(pmc_key or which)
             avg_us = 1e3 * d['ms'] / max(1, d['launches'])
             return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
@@ -327,12 +328,15 @@ def main():
                                      else f'neuron_fwd_kernel<0, {a.T}, false, {"false" if recompute_h else "true"}, 4, false>')),
             'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
                                         f'{", h recomputed from the layer input" if recompute_h else ""}'
-                                        f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}), largest launch shape',
-                                 **roof(bwd, 'neuron_bwd'),
+                                        f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}'
+                                        f'{", second consumer (prediction head) gradient formed in registers from its rank-9 pair and added on load" if "+lr" in bwd_tag else ""}), largest launch shape',
+                                 **roof(bwd, 'neuron_bwd', 'neuron_bwd_lr' if '+lr' in bwd_tag else None),
                                  all_launches_of_this_instantiation=inst(
+                                     ['neuron_bwd+lr', 'neuron_bwd+lr+sum', 'neuron_bwd+lronly'] if '+lr' in bwd_tag else
                                      ['neuron_bwd+fork', 'neuron_bwd+fork+sum'] if 'fork' in bwd_tag else ['neuron_bwd'],
-                                     f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true>' if 'fork' in bwd_tag
-                                     else f'neuron_bwd_kernel<*, *, {a.T}, 4, {"true" if recompute_h else "false"}, false>')),
+                                     f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, true>' if '+lr' in bwd_tag else
+                                     f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, false>' if 'fork' in bwd_tag
+                                     else f'neuron_bwd_kernel<*, *, {a.T}, 4, {"true" if recompute_h else "false"}, false, false>')),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
                 ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
@@ -357,7 +361,7 @@ def main():
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
         # `roofline` = the dominant kernel of the path: whichever of the two fused neuron kernels took more of the timed region
-        if 'fork' in bwd_tag and bwd['ms'] > 0:
+        if ('fork' in bwd_tag or '+lr' in bwd_tag) and bwd['ms'] > 0:
             # SURVEY.md §8(d) prices the backward at 12 B/update (g_out, x, g_x); the forked form also reads the second consumer's gradient
             # (4 B/update that autograd's accumulation pass would otherwise move 3x): the same launches by that stricter definition
             out['roofline_bwd']['frac_by_12B_per_update_definition'] = round(12 * bwd['updates'] / 1e9 / (bwd['ms'] / 1e3) / HBM_PEAK_GBS, 4)

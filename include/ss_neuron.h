@@ -136,6 +136,25 @@ int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, floa
                            void* stream);
 
 /*
+ * ss_neuron_bwd_fork_f32 (recompute form) whose SECOND gradient arrives in low-rank form.  The second consumer of a decoder stage's
+ * output — and, through the fused skip add, of the full-resolution encoder layer's — is a prediction head: a 3 x 3 synapse with ONE output
+ * channel on the projected form (/root/reference/network/SNN_models.py:150-163, blocks.py:110-132), so its input gradient is
+ * g2[t][pixel][c] = sum_{j < 9} lr_p[t][pixel][j] * lr_w[j][c]: 9 floats per pixel instead of C.  The kernel forms g2 in registers
+ * (taps ascending; multiply and add rounded separately) and adds it on load: g = g_out + g2, or g = g2 when g_out_seq is NULL — the
+ * head's data-gradient GEMM and its C-channel output never exist, and this launch reads 36 / C B per update instead of 4 for it.
+ *   lr_p [T, N / C, lr_rank], lr_w [lr_rank, C] (16-B aligned), lr_rank == 9, C = channels of the NHWC layer ((256 * 4) % C == 0, N % C == 0);
+ *   g_sum_seq (nullable, needs g_out_seq): g written out, as in ss_neuron_bwd_fork_f32.
+ * SS_EINVAL when ss_neuron_bwd_fork_lr_supported(T, N, C, lr_rank) is 0 or a buffer is not 16-B aligned.
+ */
+int ss_neuron_bwd_fork_lr_supported(int T, long long N, int C, int lr_rank);
+int ss_neuron_bwd_fork_lr_f32(const float* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, float* g_sum_seq,
+                              const float* g_v_last, const float* x_seq, const float* v_init, float* g_x_seq, float* g_v_init,
+                              float* g_k, float* g_k_ws, int T, long long N,
+                              float scale, int kind, float tau, const float* k,
+                              float v_th, float v_reset, int surrogate, float alpha, int detach_reset,
+                              void* stream);
+
+/*
  * 16-bit activation I/O variants (BASELINE.json configs 2 and 5: bf16 / fp16 activations, fp32 membrane state).
  * x_seq, skip_seq, out_seq (and g_out_seq, g_x_seq) hold IEEE fp16 (dtype = SS_DT_F16) or bfloat16 (SS_DT_BF16) values;
  * every input is widened to fp32 on load, ALL arithmetic and the membrane (v_init, v_last, h_seq, g_v_*) stay fp32 exactly

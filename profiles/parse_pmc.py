@@ -23,7 +23,12 @@ def key_of(name):
         return 'upconv_fused2'
     if 'upconv_fused_fwd_kernel' in name:
         return 'upconv_fused'
-    return 'neuron_bwd' if 'neuron_bwd_kernel' in name else None
+    if 'neuron_bwd_kernel' in name:
+        import re
+        m = re.search(r'neuron_bwd_kernel<([^>]*)>', name)
+        args = [a.strip() for a in m.group(1).split(',')] if m else []
+        return 'neuron_bwd_lr' if (len(args) >= 7 and args[6] == 'true') else 'neuron_bwd'          # 7th template argument = LR (rank-9 second gradient)
+    return None
 
 
 def mean_counter(sub, counter):
@@ -56,10 +61,11 @@ res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, to
                'separate --pmc passes; the forward also writes v_last (4 B x N, an O(N) term outside the per-update figure)'}
 alg = {k: v * T * N for k, v in per_update.items()}
 alg['neuron_fwd_packed'] = int(4.25 * T * N)                        # x 4 B + 2-bit packed output 0.25 B per update (no dense output)
+alg['neuron_bwd_lr'] = int((12 + 4 + 36 / 32) * T * N)               # g_out, x, g_x + the head's rank-9 pair: 9 floats per 32-channel pixel
 alg['upconv_fused'] = 4 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 3 * 25 * 64 * 32      # deconv1: spikes in + out + split weights
 alg['upconv_fused2'] = alg['upconv_fused']                          # the shipped form: wavefront-specialised persistent workgroups
 res['algorithmic_bytes_per_launch'] = alg
-for k in ('neuron_fwd', 'neuron_bwd', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2'):
+for k in ('neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2'):
     if k in fetch and k in write:
         hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],

@@ -49,6 +49,10 @@ def lib():
     L.ss_neuron_bwd_rc_f32.restype = i32
     L.ss_neuron_bwd_fork_f32.argtypes = [p, p, p, p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
     L.ss_neuron_bwd_fork_f32.restype = i32
+    L.ss_neuron_bwd_fork_lr_f32.argtypes = [p, p, p, i32, i32, p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
+    L.ss_neuron_bwd_fork_lr_f32.restype = i32
+    L.ss_neuron_bwd_fork_lr_supported.argtypes = [i32, i64, i32, i32]
+    L.ss_neuron_bwd_fork_lr_supported.restype = i32
     L.ss_neuron_bwd_rc_supported.argtypes = [i32]
     L.ss_neuron_bwd_rc_supported.restype = i32
     L.ss_ipool_fwd_f32.argtypes = [p, i64, i64, p, p, i32, i32, i64, f32, f32, p]
@@ -161,7 +165,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
-           'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32')
+           'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
+           'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
 
 
 def _ptr(t, name, numel=None):
@@ -240,6 +245,27 @@ def neuron_bwd_fork(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, h_seq, x_seq, v_
                                           T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
                                           int(bool(detach_reset)), _stream(g_out_seq))
     _check(rc, 'ss_neuron_bwd_fork_f32')
+
+
+def neuron_bwd_fork_lr_supported(T, N, C, rank):
+    return bool(lib().ss_neuron_bwd_fork_lr_supported(int(T), int(N), int(C), int(rank)))
+
+
+def neuron_bwd_fork_lr(g_out_seq, lr_p, lr_w, g_sum_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                       v_th, v_reset, surrogate, alpha, detach_reset):
+    """Recompute-form backward whose second output gradient is the low-rank pair (lr_p [T, N / C, rank], lr_w [rank, C]) of a prediction
+    head, formed in registers and added on load; g_out_seq (the dense first gradient) may be None."""
+    _require_hip(x_seq, 'x_seq')
+    rank, C = int(lr_w.shape[0]), int(lr_w.shape[1])
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_bwd_fork_lr_f32(_f32(g_out_seq, 'g_out_seq', T * N), _f32(lr_p, 'lr_p', T * (N // C) * rank),
+                                             _f32(lr_w, 'lr_w', rank * C), rank, C, _f32(g_sum_seq, 'g_sum_seq', T * N),
+                                             _f32(g_v_last, 'g_v_last', N), _f32(x_seq, 'x_seq', T * N),
+                                             _f32(v_init, 'v_init', N), _f32(g_x_seq, 'g_x_seq', T * N), _f32(g_v_init, 'g_v_init', N),
+                                             _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'),
+                                             T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
+                                             int(bool(detach_reset)), _stream(x_seq))
+    _check(rc, 'ss_neuron_bwd_fork_lr_f32')
 
 
 def neuron_bwd_rc_supported(T):

@@ -326,11 +326,15 @@ struct BwdArgs {
     const float* x_seq;   // non-null (templated T only): h_seq is not read, h is recomputed from the layer input (ss_neuron_bwd_rc_f32)
     const float* g_out2_seq;  // nullable: gradient from a second consumer of out_seq, added on load (ss_neuron_bwd_fork_f32)
     float* g_sum_seq;         // nullable (with g_out2_seq): g_out + g_out2 written out = dL/dskip_seq of a stage that has both
+    // low-rank second gradient (ss_neuron_bwd_fork_lr_f32): g2[t][n] = sum_j lr_p[(t * N / lr_C + n / lr_C) * kLrRank + j] * lr_w[j * lr_C + n % lr_C]
+    const float* lr_p; const float* lr_w; int lr_C;
 };
+constexpr int kLrRank = 9;    // the prediction heads: 3 x 3 taps, one output channel (SNN_models.py:150-163 of the reference)
 
-template <int KIND, int SG, int TS, int VEC, bool RC = false, bool G2 = false>
+template <int KIND, int SG, int TS, int VEC, bool RC = false, bool G2 = false, bool LR = false>
 __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
 {
+    static_assert(!LR || (RC && G2 && VEC == 4 && TS > 0), "low-rank second gradient: recompute form, float4 lanes");
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
     const int T = (TS > 0) ? TS : a.T;
     const long long NV = a.N / VEC;
@@ -341,6 +345,13 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
     const bool detach = a.detach_reset != 0;
     const bool want_gk = (KIND == SS_KIND_PLIF) && a.g_k_partials != nullptr;
     float acc_k = 0.f;
+    // LR: the lane's 4 channels are the same in every trip of the grid-stride loop (kBlock * 4 is a multiple of C: checked by the host)
+    f4 lr_wl[LR ? kLrRank : 1];
+    if constexpr (LR) {
+        const int c0 = (int)((threadIdx.x * 4u) % (unsigned)a.lr_C);
+#pragma unroll
+        for (int j = 0; j < kLrRank; ++j) lr_wl[j] = *reinterpret_cast<const f4*>(a.lr_w + (long long)j * a.lr_C + c0);
+    }
 
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
         const vec_t* gp = reinterpret_cast<const vec_t*>(a.g_out_seq) + i;
@@ -393,9 +404,36 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
                 // issue order = consumption order: x ascending (forward recurrence), then g descending (reverse loop)
 #pragma unroll
                 for (int t = 0; t < TS; ++t) hs[t] = load_stream(xq + (long long)t * NV);
+                if constexpr (LR) {   // second consumer's gradient in low-rank form: kLrRank floats per pixel and step instead of C
+                    const long long rows = a.N / a.lr_C;
+                    const float* pp = a.lr_p + ((i * 4) / a.lr_C) * kLrRank;
+                    float pj[TS][kLrRank];
+#pragma unroll
+                    for (int t = TS - 1; t >= 0; --t)
+#pragma unroll
+                        for (int j = 0; j < kLrRank; ++j) pj[t][j] = pp[(long long)t * rows * kLrRank + j];
+                    const bool has_g1 = a.g_out_seq != nullptr;   // wave-uniform
+                    if (has_g1) {
+#pragma unroll
+                        for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(gp + (long long)t * NV);
+                    }
+#pragma unroll
+                    for (int t = TS - 1; t >= 0; --t) {
+                        f4 acc = pj[t][0] * lr_wl[0];              // taps in ascending order, multiply and add rounded separately
+#pragma unroll
+                        for (int j = 1; j < kLrRank; ++j) acc = acc + pj[t][j] * lr_wl[j];
+                        gs[t] = has_g1 ? gs[t] + acc : acc;
+                    }
+                    if (a.g_sum_seq) {   // wave-uniform
+                        vec_t* sp = reinterpret_cast<vec_t*>(a.g_sum_seq) + i;
+#pragma unroll
+                        for (int t = TS - 1; t >= 0; --t) sp[(long long)t * NV] = gs[t];
+                    }
+                } else {
 #pragma unroll
                 for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(gp + (long long)t * NV);
-                if constexpr (G2) {   // second consumer's gradient, added on load
+                }
+                if constexpr (G2 && !LR) {   // second consumer's gradient, added on load
                     const vec_t* gp2 = reinterpret_cast<const vec_t*>(a.g_out2_seq) + i;
                     vec_t g2[TS];
 #pragma unroll
@@ -2983,7 +3021,10 @@ int launch_bwd(const BwdArgs& a, hipStream_t s, int* grid_out)
             int grid = vec ? grid_for(a.N / 4, kMaxGridBwd) : grid_for(a.N, kMaxGridBwd);
             if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
             *grid_out = grid;
-            if (a.g_out2_seq) {
+            if (a.lr_p) {
+                if (!vec || !aligned16(a.lr_w)) return SS_EINVAL;
+                hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4, true, true, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            } else if (a.g_out2_seq) {
                 if (vec) hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 4, true, true>), dim3(grid), dim3(kBlock), 0, s, a);
                 else     hipLaunchKernelGGL((neuron_bwd_kernel<KIND, SG, TS, 1, true, true>), dim3(grid), dim3(kBlock), 0, s, a);
             } else {
@@ -3168,9 +3209,10 @@ int ss_neuron_fwd_f32(const float* x_seq, const float* v_init, const float* skip
 static int neuron_bwd_f32_impl(const float* g_out_seq, const float* g_out2_seq, float* g_sum_seq, const float* g_v_last, const float* h_seq, const float* x_seq,
                                const float* v_init, float* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
                                int T, long long N, float scale, int kind, float tau, const float* k,
-                               float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+                               float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream,
+                               const float* lr_p = nullptr, const float* lr_w = nullptr, int lr_C = 0)
 {
-    if (!g_out_seq || (!h_seq && !x_seq) || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
+    if ((!g_out_seq && !lr_p) || (!h_seq && !x_seq) || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
     if (kind < SS_KIND_IF || kind > SS_KIND_PLIF) return SS_EINVAL;
     if (surrogate != SS_SG_ATAN && surrogate != SS_SG_SIGMOID) return SS_EINVAL;
     if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
@@ -3183,7 +3225,8 @@ static int neuron_bwd_f32_impl(const float* g_out_seq, const float* g_out2_seq, 
         return SS_OK;
     }
     BwdArgs a{g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, want_gk ? g_k_ws : nullptr,
-              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset, x_seq, g_out2_seq, g_out2_seq ? g_sum_seq : nullptr};
+              T, N, scale, tau, v_th, v_reset, alpha, k, detach_reset, x_seq, g_out2_seq, (g_out2_seq || lr_p) ? g_sum_seq : nullptr,
+              lr_p, lr_w, lr_C};
     int grid = 0, rc;
     switch (kind) {
         case SS_KIND_IF: rc = dispatch_bwd_sg<SS_KIND_IF>(a, surrogate, s, &grid); break;
@@ -3235,6 +3278,23 @@ int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, floa
     if (g_sum_seq && (!g_out2_seq || g_sum_seq == g_x_seq)) return SS_EINVAL;
     return neuron_bwd_f32_impl(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, h_seq, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind,
                                tau, k, v_th, v_reset, surrogate, alpha, detach_reset, stream);
+}
+
+int ss_neuron_bwd_fork_lr_supported(int T, long long N, int C, int lr_rank)
+{
+    return ss_neuron_bwd_rc_supported(T) && lr_rank == kLrRank && C >= 4 && C % 4 == 0 && (kBlock * 4) % C == 0 && N > 0 && N % C == 0;
+}
+
+int ss_neuron_bwd_fork_lr_f32(const float* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, float* g_sum_seq,
+                              const float* g_v_last, const float* x_seq, const float* v_init, float* g_x_seq, float* g_v_init,
+                              float* g_k, float* g_k_ws, int T, long long N, float scale, int kind, float tau, const float* k,
+                              float v_th, float v_reset, int surrogate, float alpha, int detach_reset, void* stream)
+{
+    if (!lr_p || !lr_w || !x_seq) return SS_EINVAL;
+    if (!ss_neuron_bwd_fork_lr_supported(T, N, C, lr_rank)) return SS_EINVAL;
+    if (g_sum_seq && (!g_out_seq || g_sum_seq == g_x_seq)) return SS_EINVAL;   // without a dense first gradient the "sum" IS the low-rank pair
+    return neuron_bwd_f32_impl(g_out_seq, nullptr, g_sum_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind,
+                               tau, k, v_th, v_reset, surrogate, alpha, detach_reset, stream, lr_p, lr_w, C);
 }
 
 int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_seq,

@@ -9,6 +9,8 @@ blocks.py:171) and, in backward, the autograd chain through surrogate.ATan / sur
 
 Everything here needs the HIP library and HIP tensors; there is no eager fallback.
 """
+import collections as _collections
+import os as _os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -95,6 +97,37 @@ def unpack_dense(packed, shape, dtype=torch.float32):
     return out
 
 
+# Low-rank gradient of a prediction head (3 x 3 taps, ONE output channel): d loss / d input = g_P [rows, 9] @ W2 [9, C].  Instead of running
+# that GEMM and writing the C-channel result (which the neuron backward of the stage — and, through the fused skip add, of the full-resolution
+# encoder layer — would then read at 4 B/update), the head's backward hands the PAIR to the consumer: autograd carries a NaN-filled zero-stride
+# anchor (any consumer that does not know about the pair fails loudly), the pair travels in this registry keyed by the anchor's storage, and
+# ss_neuron_bwd_fork_lr_f32 forms the gradient in registers from 36 / C B/update.
+LOWRANK_HEAD_GRAD = _os.environ.get('SS_LOWRANK_HEAD_GRAD', '1') == '1'
+_LOWRANK = _collections.OrderedDict()       # anchor storage pointer -> (anchor base tensor: keeps the pointer unique, lr_p, lr_w)
+_LOWRANK_KEEP = 8                           # two backward passes' worth of heads; older pairs are dropped (bounded memory)
+
+
+def lowrank_anchor(shape, lr_p, lr_w):
+    base = torch.full((1,), float('nan'), dtype=torch.float32, device=lr_p.device)
+    _LOWRANK[base.untyped_storage().data_ptr()] = (base, lr_p, lr_w)
+    while len(_LOWRANK) > _LOWRANK_KEEP:
+        _LOWRANK.popitem(last=False)
+    return base.as_strided(tuple(shape), (0,) * len(shape))
+
+
+def lowrank_of(g):
+    """(lr_p, lr_w) when g is (a view of) a low-rank anchor, else None."""
+    if g is None or not _LOWRANK or g.dtype != torch.float32 or any(g.stride()):
+        return None
+    ent = _LOWRANK.get(g.untyped_storage().data_ptr())
+    return None if ent is None else ent[1:]
+
+
+def lowrank_dense(lr, shape):
+    """The dense gradient a low-rank pair stands for (consumers without the fused form)."""
+    return torch.mm(lr[0], lr[1]).view(tuple(shape))
+
+
 class _FusedNeuron(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False, pack=0, skip_packed=None):
@@ -166,11 +199,25 @@ class _FusedNeuron(torch.autograd.Function):
         h_seq, v_init, k = ctx.saved_tensors          # h_seq is x_seq (activation dtype) when ctx.recompute
         cfg, T, N = ctx.cfg, ctx.T, ctx.N
         half = ctx.io_dtype in (torch.float16, torch.bfloat16)
-        if g_out_seq is None:
+        lr = lr_anchor = None
+        if _LOWRANK:                                   # a prediction head's gradient as a low-rank pair (see lowrank_anchor)
+            l1, l2 = lowrank_of(g_out_seq), lowrank_of(g_out2_seq)
+            if l1 is not None and l2 is not None:      # two pairs: one stays low-rank
+                g_out_seq, l1 = lowrank_dense(l1, h_seq.shape), None
+            if l1 is not None:
+                g_out_seq, g_out2_seq, l2 = g_out2_seq, g_out_seq, l1
+            if l2 is not None:
+                C = int(l2[1].shape[1])
+                if ctx.recompute and not half and h_seq.shape[-1] == C and _lib.neuron_bwd_fork_lr_supported(T, N, C, l2[1].shape[0]):
+                    lr, lr_anchor, g_out2_seq = l2, g_out2_seq, None
+                else:
+                    g_out2_seq = lowrank_dense(l2, h_seq.shape)
+        if g_out_seq is None and lr is None:
             g_out_seq, g_out2_seq = g_out2_seq, None
-        if g_out_seq is None:
+        if g_out_seq is None and lr is None:
             g_out_seq = torch.zeros(h_seq.shape, dtype=ctx.io_dtype, device=h_seq.device)
-        g_out_seq = g_out_seq.to(ctx.io_dtype).contiguous()
+        if g_out_seq is not None:
+            g_out_seq = g_out_seq.to(ctx.io_dtype).contiguous()
         fuse2 = g_out2_seq is not None and ctx.recompute
         if g_out2_seq is not None:
             g_out2_seq = g_out2_seq.to(ctx.io_dtype).contiguous()
@@ -188,7 +235,15 @@ class _FusedNeuron(torch.autograd.Function):
             g_k_ws = torch.empty(_lib.gk_ws_floats(), dtype=torch.float32, device=h_seq.device)
         e0 = TIMER.start()
         want_gskip = ctx.has_skip and ctx.needs_input_grad[2]
-        g_sum = torch.empty_like(g_out_seq) if (fuse2 and want_gskip) else None
+        g_sum = torch.empty_like(g_out_seq) if ((fuse2 or lr is not None) and want_gskip and g_out_seq is not None) else None
+        if lr is not None:
+            _lib.neuron_bwd_fork_lr(g_out_seq, lr[0], lr[1], g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+                                    T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
+            per = 8 + 4 * lr[1].shape[0] / lr[1].shape[1] + (4 if g_out_seq is not None else 0) + (4 if g_sum is not None else 0)
+            TIMER.stop(e0, 'neuron_bwd+lr' + ('+sum' if g_sum is not None else '') if g_out_seq is not None else 'neuron_bwd+lronly', int(per * T * N), T * N)
+            # dL/dskip: the dense sum when there was a dense first gradient, else the low-rank pair itself travels on (identity)
+            g_skip = (g_sum if g_out_seq is not None else lr_anchor.view(h_seq.shape)) if want_gskip else None
+            return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
         if fuse2 and half:
             _lib.neuron_bwd_fork_x16(g_out_seq, g_out2_seq, g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                                      T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
@@ -473,7 +528,6 @@ ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / rea
 EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
 EXACT_WGRAD_MFMA = True            # weight gradient of the decoder stages (C_in 64 .. 512) as the hand-written exact bf16x3 MFMA
                                    # contraction ss_spike_wgrad_f32 (was the library's fp32 GEMM at the fp32-MFMA rate)
-import os as _os
 EXACT_WGRAD_MFMA_CIN = tuple(int(c) for c in _os.environ.get('SS_WGRAD_MFMA_CIN', '64,128,256,512').split(',') if c)   # A/B knob (tools/)
 EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
                                    # to pay for the extra 10 B/element split pass over g_P (profiles/r01/split_wgrad_sweep.log)
@@ -529,7 +583,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0):
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0,
+                lowrank_grad=False):
+        # lowrank_grad: the caller guarantees x_cl is consumed by nothing else and produced by a fused neuron layer (a forked handle), so
+        # the input gradient of a one-channel 3 x 3 head may be handed over as the pair (g_P, W2) instead of their product (lowrank_anchor)
+        ctx.lowrank_grad = bool(lowrank_grad)
         # lowp (only under bf16 autocast): the three GEMMs take bf16 operands with fp32 accumulation / output, exactly what
         # autocast does to the MIOpen convs of the encoder (spike inputs are exact in bf16; W and g_P are rounded).
         # P, the gather, its adjoint and every output stay fp32.
@@ -634,7 +692,10 @@ class _UpConvProjectedCL(torch.autograd.Function):
         g_out = g_out.contiguous() if g16 else g_out.float().contiguous()
         lowp = ctx.lowp
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if need_x else None
+        # one-channel 3 x 3 head on a forked neuron output: g_x = g_P [rows, 9] @ W2 [9, C_in] is left to the consumer's backward kernel
+        lowrank = (need_x and ctx.lowrank_grad and LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
+                   and ctx.x_dtype == torch.float32 and Cin % 4 == 0 and 1024 % Cin == 0)
+        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
         if lowp:
@@ -658,7 +719,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
                 if lowp:
                     g_P = g_P.to(torch.bfloat16)
-            if need_x and not lowp and GEMM6_DGRAD and Cin in GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
+            if lowrank:
+                g_x = lowrank_anchor(x_cl.shape, g_P, W2)
+            elif need_x and not lowp and GEMM6_DGRAD and Cin in GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
                 # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy): the fp32 GEMM is compute-bound here
                 _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
             elif need_x:
@@ -700,7 +763,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if g_x is not None and g_x.dtype != ctx.x_dtype:
             g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -877,7 +940,7 @@ def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = N
 
 
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False,
-                        max_window: int = 0):
+                        max_window: int = 0, lowrank_grad: bool = False):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
     spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection.
     max_window: largest source window (rows x columns) of any 16 x 16 output tile (NNConvUpsampling.max_tile_window); > 0 enables the
@@ -889,4 +952,4 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
     # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
     act_dtype = adt if (lowp_bwd and k == 5 and ACT16_GATHER) else None
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
-        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad)

@@ -189,7 +189,11 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                                               skip_packed=enc_pk[lvl - 1] if enc_cl else None)
                 cur, cur_head = r if _blocks.FORK_OUTPUTS else (r, r)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
-                pd = head[0].forward_projected_cl(cur_head.flatten(0, 1))  # [T*B, H, W, 1]: one channel, NHWC == NCHW
+                # the head is the only consumer of its forked handle: its input gradient travels as a rank-9 pair into the stage's neuron backward.
+                # The full-resolution stage has no other gradient, so there the pair itself travels on as dL/dskip — which only another fused
+                # neuron layer (the forked NHWC encoder output) can take
+                lr_ok = bool(_blocks.FORK_OUTPUTS) and (enc_cl or lvl != 1)
+                pd = head[0].forward_projected_cl(cur_head.flatten(0, 1), lowrank_grad=lr_ok)  # [T*B, H, W, 1]: one channel, NHWC == NCHW
             else:
                 cur = stage.forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
                 spikes.append(cur)

@@ -110,14 +110,16 @@ class NNConvUpsampling(_UpConv):
             cache[(h, w, tile)] = extent(h, Hu) * extent(w, Wu)
         return cache[(h, w, tile)]
 
-    def forward_projected_cl(self, x_cl: torch.Tensor, spikes_in: bool = False) -> torch.Tensor:
-        """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array).  spikes_in: x_cl is a spike tensor."""
+    def forward_projected_cl(self, x_cl: torch.Tensor, spikes_in: bool = False, lowrank_grad: bool = False) -> torch.Tensor:
+        """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array).  spikes_in: x_cl is a spike tensor.
+        lowrank_grad: x_cl is a forked handle of a fused neuron layer's output with no other consumer — a one-channel 3 x 3 head may then
+        hand its input gradient over as the pair (g_P, W2) for ss_neuron_bwd_fork_lr_f32 (fused.lowrank_anchor)."""
         conv = self.up[1]
         k = conv.kernel_size[0]
         Hu, Wu = self.up[0].size
         win = self.max_tile_window(x_cl.shape[1], x_cl.shape[2]) if (spikes_in and k == 5) else 0
         return upconv_projected_cl(x_cl, conv.weight, conv.bias, self._tables(x_cl.shape[1], x_cl.shape[2], x_cl.device),
-                                   k, Hu - k + 1, Wu - k + 1, spikes_in, win)
+                                   k, Hu - k + 1, Wu - k + 1, spikes_in, win, lowrank_grad)
 
 
 class BilinConvUpsampling(_UpConv):

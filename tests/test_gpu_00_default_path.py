@@ -131,6 +131,49 @@ def test_packed_spike_tensors_are_in_effect():
         fused.PACK_SPIKES = True
 
 
+@pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
+def test_low_rank_head_gradients_are_in_effect_and_equal_the_dense_form(name):
+    """fused.LOWRANK_HEAD_GRAD (default on; every pinned test above runs with it): the four prediction heads hand their input gradient to the
+    stage's neuron backward as the rank-9 pair (g_P, W2) — the full-resolution pair travels on through the fused skip add into the first
+    encoder layer's backward — instead of a GEMM + a C-channel tensor.  Here: the low-rank launches really happen (4 + 1 per backward), and
+    every parameter gradient equals the dense form's up to the rounding of a 9-term sum done in another order."""
+    from stereospike_amd import fused
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    H, W = 64, 80
+    _, net = pair(name, H, W)
+    x = synth_input(2, 5, 4, 7, H, W, lam=0.08).to(DEV)
+    gt = synth_label(2, 8, H, W).to(DEV)
+
+    def grads(on):
+        fused.LOWRANK_HEAD_GRAD = on
+        fused.TIMER.clear()
+        fused.TIMER.enabled = True
+        try:
+            functional.reset_net(net)
+            for p in net.parameters():
+                p.grad = None
+            out = net.forward_sequence(x)
+            d, s = out if isinstance(out, tuple) else (out, None)
+            Total_Loss()(d, gt, s).backward()
+            torch.cuda.synchronize()
+            tags = {k: v['launches'] for k, v in fused.TIMER.summary().items() if k.startswith('neuron_bwd')}
+        finally:
+            fused.LOWRANK_HEAD_GRAD = True
+            fused.TIMER.enabled = False
+        return {n: p.grad.detach().double().clone() for n, p in net.named_parameters()}, tags
+    g_on, t_on = grads(True)
+    g_off, t_off = grads(False)
+    assert t_on.get('neuron_bwd+lronly', 0) == 1 and t_on.get('neuron_bwd+lr', 0) + t_on.get('neuron_bwd+lr+sum', 0) == 4, t_on
+    assert not any('lr' in k for k in t_off), t_off
+    for n in g_on:
+        den = float(g_off[n].norm())
+        # a PLIF layer's scalar dL/dw is ONE sum over all its neurons and steps with heavy cancellation: rounding differences of the
+        # incoming gradient show up amplified there (measured 2.1e-5); the weight tensors agree to ~1e-6
+        bar = 1e-4 if g_off[n].numel() == 1 else 2e-5
+        assert float((g_on[n] - g_off[n]).norm()) <= bar * den + 1e-12, (n, float((g_on[n] - g_off[n]).norm()) / max(den, 1e-30))
+
+
 def test_pinned_parity_odd_sizes_runtime_T():
     """Frame size with odd pyramid levels (50x70 -> 25x35 -> 13x18 -> 7x9 -> 4x5), T = 7 (run-time-T kernels, saved h), B = 3."""
     orc, net = pair('PLIFNet', 50, 70)

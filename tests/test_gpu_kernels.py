@@ -640,6 +640,50 @@ def test_backward_with_forked_output_gradients(kind, T, N):
         _lib.neuron_bwd_fork(g1, g2, None, None, x, None, v0, gx_c, None, None, None, *args)      # saved-h form + second gradient
 
 
+@pytest.mark.parametrize('kind', ['IF', 'PLIF'])
+@pytest.mark.parametrize('T,rows,C', [(5, 96, 32), (5, 17, 64), (10, 8, 128), (1, 3, 256), (4, 5, 512), (2, 7, 4)])
+def test_backward_with_low_rank_second_gradient(kind, T, rows, C):
+    """ss_neuron_bwd_fork_lr_f32: the second gradient as the rank-9 pair of a prediction head (lr_p [T, rows, 9], lr_w [9, C]), formed in
+    registers == the recompute backward fed g1 + oracle.np_lowrank.head_input_gradient(lr_p, lr_w), bit for bit (g_x, g_v_init, g_sum, dL/dk);
+    without a dense first gradient == the backward fed the expansion alone; unsupported shapes are refused."""
+    from stereospike_amd import _lib
+    from oracle import np_lowrank
+    N = rows * C
+    rng = np.random.default_rng(N + T)
+    x = _dev((rng.standard_normal((T, N)) * 0.25).astype(np.float32))
+    g1 = _dev(rng.standard_normal((T, N)).astype(np.float32))
+    lr_p = (rng.standard_normal((T, rows, 9)) * 2).astype(np.float32)
+    lr_w = rng.standard_normal((9, C)).astype(np.float32)
+    g2 = _dev(np_lowrank.head_input_gradient(lr_p, lr_w).reshape(T, N))
+    assert float(np.abs(g2.cpu().numpy().reshape(T, rows, C) - np_lowrank.head_input_gradient64(lr_p, lr_w)).max()) < 1e-4
+    P, Wl = _dev(lr_p), _dev(lr_w)
+    v0 = _dev((rng.standard_normal(N) * 0.5).astype(np.float32))
+    k = torch.tensor([0.3], device=DEV) if kind == 'PLIF' else None
+    args = (T, N, 7.5, KIND[kind], 2.0, k, 1.0, 0.0, SG['ATan'], 2.0, True)
+    ws = torch.empty(_lib.gk_ws_floats(), device=DEV) if kind == 'PLIF' else None
+
+    def gk():
+        return torch.zeros(1, device=DEV) if kind == 'PLIF' else None
+    assert _lib.neuron_bwd_fork_lr_supported(T, N, C, 9)
+    gx_a, gv_a, gk_a = torch.empty_like(x), torch.empty(N, device=DEV), gk()
+    _lib.neuron_bwd_rc(g1 + g2, None, x, v0, gx_a, gv_a, gk_a, ws, *args)
+    gx_b, gv_b, gk_b = torch.empty_like(x), torch.empty(N, device=DEV), gk()
+    gsum = torch.full_like(x, float('nan'))
+    _lib.neuron_bwd_fork_lr(g1, P, Wl, gsum, None, x, v0, gx_b, gv_b, gk_b, ws, *args)
+    assert torch.equal(gx_a, gx_b) and torch.equal(gv_a, gv_b) and torch.equal(gsum, g1 + g2)
+    if kind == 'PLIF':
+        assert float(gk_a) == float(gk_b)
+    # the pair alone (the full-resolution stage: its only consumer is the head)
+    gx_c, gx_d = torch.empty_like(x), torch.empty_like(x)
+    _lib.neuron_bwd_rc(g2, None, x, v0, gx_c, None, gk(), ws, *args)
+    _lib.neuron_bwd_fork_lr(None, P, Wl, None, None, x, v0, gx_d, None, gk(), ws, *args)
+    assert torch.equal(gx_c, gx_d)
+    with pytest.raises(_lib.SSNeuronError):
+        _lib.neuron_bwd_fork_lr(None, P, Wl, gsum, None, x, v0, gx_d, None, gk(), ws, *args)     # a "sum" needs a dense first gradient
+    assert not _lib.neuron_bwd_fork_lr_supported(T, N, C, 25) and not _lib.neuron_bwd_fork_lr_supported(3, N, C, 9)
+    assert not _lib.neuron_bwd_fork_lr_supported(T, 96 * 48, 48, 9)                                 # 1024 % C != 0
+
+
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
 def test_upconv_cl_x16_equals_fp32_gather_with_narrowed_io(dt):
     """ss_upconv_cl_fwd_x16 == nearest-even narrowing of ss_upconv_cl_fwd_f32's output; ss_upconv_cl_bwd_x16 on a 16-bit gradient ==

@@ -60,6 +60,16 @@ def host_backend(monkeypatch):
         neuron_bwd_rc(g, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k, v_th, v_reset,
                       surrogate, alpha, detach_reset)
 
+    def neuron_bwd_fork_lr(g_out_seq, lr_p, lr_w, g_sum_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale,
+                           kind, tau, k, v_th, v_reset, surrogate, alpha, detach_reset):
+        # stand-in for the in-register expansion of a head's rank-9 gradient pair: the numpy restatement, then the forked form
+        from oracle import np_lowrank
+        g2 = torch.from_numpy(np_lowrank.head_input_gradient(lr_p.numpy(), lr_w.numpy())).view(x_seq.shape)
+        assert g_sum_seq is None or g_out_seq is not None
+        g1 = g2 if g_out_seq is None else g_out_seq
+        neuron_bwd_fork(g1, None if g_out_seq is None else g2, g_sum_seq, g_v_last, None, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+                        T, N, scale, kind, tau, k, v_th, v_reset, surrogate, alpha, detach_reset)
+
     def ipool_fwd(pd_seq, st, sk, v_init, depth_seq, T, K, M, scale, v_reset):
         assert L.ss_ref_ipool_fwd_f32(_p(pd_seq), st, sk, _p(v_init), _p(depth_seq), T, K, M, scale, v_reset) == 0
 
@@ -114,6 +124,9 @@ def host_backend(monkeypatch):
     monkeypatch.setattr(_lib, 'neuron_bwd', neuron_bwd)
     monkeypatch.setattr(_lib, 'neuron_bwd_rc', neuron_bwd_rc)
     monkeypatch.setattr(_lib, 'neuron_bwd_fork', neuron_bwd_fork)
+    monkeypatch.setattr(_lib, 'neuron_bwd_fork_lr', neuron_bwd_fork_lr)
+    monkeypatch.setattr(_lib, 'neuron_bwd_fork_lr_supported',
+                        lambda T, N, C, rank: T in (1, 2, 4, 5, 8, 10) and rank == 9 and C % 4 == 0 and 1024 % C == 0 and N % C == 0)
     monkeypatch.setattr(_lib, 'neuron_bwd_rc_supported', lambda T: T in (1, 2, 4, 5, 8, 10))
     monkeypatch.setattr(_lib, 'ipool_fwd', ipool_fwd)
     monkeypatch.setattr(_lib, 'ipool_bwd', ipool_bwd)

@@ -38,6 +38,10 @@ if mode == 'rc':
     Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=dev)       # the shipped (second) kernel form
     _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf2, Cin, Cout, 2)
     o = torch.empty(NB, H, W, Cout, device=dev)
+    # round 2, last: the backward whose second gradient is a prediction head's rank-9 pair (ss_neuron_bwd_fork_lr_f32; 13.125 B/update at C = 32)
+    lr_p, lr_w = torch.randn(T, N // 32, 9, device=dev), torch.randn(9, 32, device=dev)
+    for _ in range(5):
+        _lib.neuron_bwd_fork_lr(g, lr_p, lr_w, None, None, x, None, gx, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
     for _ in range(5):
         _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
         _lib.upconv_fused_fwd(xs, None, Wf, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win)
