@@ -142,7 +142,7 @@ int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, floa
  * g2[t][pixel][c] = sum_{j < 9} lr_p[t][pixel][j] * lr_w[j][c]: 9 floats per pixel instead of C.  The kernel forms g2 in registers
  * (taps ascending; multiply and add rounded separately) and adds it on load: g = g_out + g2, or g = g2 when g_out_seq is NULL — the
  * head's data-gradient GEMM and its C-channel output never exist, and this launch reads 36 / C B per update instead of 4 for it.
- *   lr_p [T, N / C, lr_rank], lr_w [lr_rank, C] (16-B aligned), lr_rank == 9, C = channels of the NHWC layer ((256 * 4) % C == 0, N % C == 0);
+ *   lr_p [T, N / C, lr_rank], lr_w [lr_rank, C] (16-B aligned), lr_rank == 9, C = channels of the NHWC layer (C <= 512, (256 * 4) % C == 0, N % C == 0);
  *   g_sum_seq (nullable, needs g_out_seq): g written out, as in ss_neuron_bwd_fork_f32.
  * SS_EINVAL when ss_neuron_bwd_fork_lr_supported(T, N, C, lr_rank) is 0 or a buffer is not 16-B aligned.
  */

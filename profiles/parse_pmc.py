@@ -61,7 +61,7 @@ res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, to
                'separate --pmc passes; the forward also writes v_last (4 B x N, an O(N) term outside the per-update figure)'}
 alg = {k: v * T * N for k, v in per_update.items()}
 alg['neuron_fwd_packed'] = int(4.25 * T * N)                        # x 4 B + 2-bit packed output 0.25 B per update (no dense output)
-alg['neuron_bwd_lr'] = int((12 + 4 + 36 / 32) * T * N)               # g_out, x, g_x + the head's rank-9 pair: 9 floats per 32-channel pixel
+alg['neuron_bwd_lr'] = int((12 + 36 / 32) * T * N)                   # g_out, x, g_x + the head's rank-9 pair: 9 floats per 32-channel pixel
 alg['upconv_fused'] = 4 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 3 * 25 * 64 * 32      # deconv1: spikes in + out + split weights
 alg['upconv_fused2'] = alg['upconv_fused']                          # the shipped form: wavefront-specialised persistent workgroups
 res['algorithmic_bytes_per_launch'] = alg

@@ -329,10 +329,16 @@ struct BwdArgs {
     // low-rank second gradient (ss_neuron_bwd_fork_lr_f32): g2[t][n] = sum_j lr_p[(t * N / lr_C + n / lr_C) * kLrRank + j] * lr_w[j * lr_C + n % lr_C]
     const float* lr_p; const float* lr_w; int lr_C;
 };
+constexpr int kLrMaxC = 512;  // widest layer that feeds a head (deconv4's output has 256 channels)
 constexpr int kLrRank = 9;    // the prediction heads: 3 x 3 taps, one output channel (SNN_models.py:150-163 of the reference)
 
+#ifndef SS_LR_WAVES
+#define SS_LR_WAVES 4    // LR form, T = 5: 132 registers as compiled freely — 4 over the 4-waves-per-SIMD budget; asking for it spills 4 and
+#endif                   // measures 486 vs 494 - 498 us on the 32 x 260 x 346 layer for IF / LIF; PLIF (division-heavy dL/dk term) is faster
+                         // left alone: 544 vs 564 us (profiles/r02/bench_lr_variants.log)
 template <int KIND, int SG, int TS, int VEC, bool RC = false, bool G2 = false, bool LR = false>
-__global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((LR && TS == 5 && KIND != SS_KIND_PLIF) ? SS_LR_WAVES : 1)))
+void neuron_bwd_kernel(BwdArgs a)
 {
     static_assert(!LR || (RC && G2 && VEC == 4 && TS > 0), "low-rank second gradient: recompute form, float4 lanes");
     typedef typename std::conditional<VEC == 4, f4, float>::type vec_t;
@@ -345,12 +351,14 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
     const bool detach = a.detach_reset != 0;
     const bool want_gk = (KIND == SS_KIND_PLIF) && a.g_k_partials != nullptr;
     float acc_k = 0.f;
-    // LR: the lane's 4 channels are the same in every trip of the grid-stride loop (kBlock * 4 is a multiple of C: checked by the host)
-    f4 lr_wl[LR ? kLrRank : 1];
+    // LR: the head's 9 x C weight matrix sits in LDS (<= 18 KB); the lane's 4 channels are the same in every trip of the grid-stride loop
+    // (kBlock * 4 is a multiple of C: checked by the host), so a lane always reads the same nine 16-B slices
+    __shared__ __attribute__((aligned(16))) float lr_ws[LR ? kLrRank * kLrMaxC : 4];
+    int lr_c0 = 0;
     if constexpr (LR) {
-        const int c0 = (int)((threadIdx.x * 4u) % (unsigned)a.lr_C);
-#pragma unroll
-        for (int j = 0; j < kLrRank; ++j) lr_wl[j] = *reinterpret_cast<const f4*>(a.lr_w + (long long)j * a.lr_C + c0);
+        for (int q = threadIdx.x; q < kLrRank * a.lr_C; q += kBlock) lr_ws[q] = a.lr_w[q];
+        lr_c0 = (int)((threadIdx.x * 4u) % (unsigned)a.lr_C);
+        __syncthreads();
     }
 
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < NV; i += (long long)gridDim.x * kBlock) {
@@ -417,13 +425,17 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd_kernel(BwdArgs a)
 #pragma unroll
                         for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(gp + (long long)t * NV);
                     }
+                    f4 acc[TS];                                    // per step: taps in ascending order, multiply and add rounded separately
+                    int c0v = lr_c0;
+                    asm volatile("" : "+v"(c0v));                  // keep the nine LDS reads inside the loop (hoisted they would pin 36 registers)
 #pragma unroll
-                    for (int t = TS - 1; t >= 0; --t) {
-                        f4 acc = pj[t][0] * lr_wl[0];              // taps in ascending order, multiply and add rounded separately
+                    for (int j = 0; j < kLrRank; ++j) {
+                        const f4 wj = *reinterpret_cast<const f4*>(&lr_ws[j * a.lr_C + c0v]);
 #pragma unroll
-                        for (int j = 1; j < kLrRank; ++j) acc = acc + pj[t][j] * lr_wl[j];
-                        gs[t] = has_g1 ? gs[t] + acc : acc;
+                        for (int t = TS - 1; t >= 0; --t) acc[t] = (j == 0) ? pj[t][0] * wj : acc[t] + pj[t][j] * wj;
                     }
+#pragma unroll
+                    for (int t = TS - 1; t >= 0; --t) gs[t] = has_g1 ? gs[t] + acc[t] : acc[t];
                     if (a.g_sum_seq) {   // wave-uniform
                         vec_t* sp = reinterpret_cast<vec_t*>(a.g_sum_seq) + i;
 #pragma unroll
@@ -3282,7 +3294,7 @@ int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, floa
 
 int ss_neuron_bwd_fork_lr_supported(int T, long long N, int C, int lr_rank)
 {
-    return ss_neuron_bwd_rc_supported(T) && lr_rank == kLrRank && C >= 4 && C % 4 == 0 && (kBlock * 4) % C == 0 && N > 0 && N % C == 0;
+    return ss_neuron_bwd_rc_supported(T) && lr_rank == kLrRank && C >= 4 && C <= kLrMaxC && C % 4 == 0 && (kBlock * 4) % C == 0 && N > 0 && N % C == 0;
 }
 
 int ss_neuron_bwd_fork_lr_f32(const float* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, float* g_sum_seq,
