@@ -361,7 +361,7 @@ def main():
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
         # `roofline` = the dominant kernel of the path: whichever of the two fused neuron kernels took more of the timed region
-        if ('fork' in bwd_tag or '+lr' in bwd_tag) and bwd['ms'] > 0:
+        if ('fork' in bwd_tag or '+lr' in bwd_tag) and bwd['ms'] > 0 and a.dtype == 'f32':
             # SURVEY.md §8(d) prices the backward at 12 B/update (g_out, x, g_x); the forked form also reads the second consumer's gradient
             # (4 B/update that autograd's accumulation pass would otherwise move 3x): the same launches by that stricter definition
             out['roofline_bwd']['frac_by_12B_per_update_definition'] = round(12 * bwd['updates'] / 1e9 / (bwd['ms'] / 1e3) / HBM_PEAK_GBS, 4)
