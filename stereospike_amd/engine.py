@@ -34,6 +34,12 @@ def set_deterministic(on: bool = True):
             torch.cuda.tunable.enable(False)
 
 
+def _release_lowrank_pairs():
+    """Drop the prediction heads' gradient pairs of the backward that just ran (fused.lowrank_anchor keeps the last few alive)."""
+    from . import fused
+    fused._LOWRANK.clear()
+
+
 class _null:
     def __enter__(self):
         return self
@@ -75,6 +81,7 @@ class Trainer:
         self.last_rates = rates
         with torch.autocast('cuda', enabled=False) if loss.is_cuda else _null():
             (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
+        _release_lowrank_pairs()
         if self.reducer is not None:
             self.reducer.finish()
         if self.scaler is not None:
@@ -166,10 +173,12 @@ class GraphedTrainer:
             loss = self.loss_module(pred, self.static_gt, spks)
         if self.scaler is not None:
             self.scaler.scale(loss).backward()
+            _release_lowrank_pairs()
             self.scaler.step(self.opt)
             self.scaler.update()
         else:
             loss.backward()
+            _release_lowrank_pairs()
             self.opt.step()
         return loss.detach(), pred[0].detach()
 

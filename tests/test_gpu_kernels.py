@@ -640,8 +640,8 @@ def test_backward_with_forked_output_gradients(kind, T, N):
         _lib.neuron_bwd_fork(g1, g2, None, None, x, None, v0, gx_c, None, None, None, *args)      # saved-h form + second gradient
 
 
-@pytest.mark.parametrize('kind', ['IF', 'PLIF'])
-@pytest.mark.parametrize('T,rows,C', [(5, 96, 32), (5, 17, 64), (10, 8, 128), (1, 3, 256), (4, 5, 512), (2, 7, 4)])
+@pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
+@pytest.mark.parametrize('T,rows,C', [(5, 96, 32), (5, 17, 64), (10, 8, 128), (1, 3, 256), (4, 5, 512), (2, 7, 4), (5, 40000, 32), (8, 33, 16)])
 def test_backward_with_low_rank_second_gradient(kind, T, rows, C):
     """ss_neuron_bwd_fork_lr_f32: the second gradient as the rank-9 pair of a prediction head (lr_p [T, rows, 9], lr_w [9, C]), formed in
     registers == the recompute backward fed g1 + oracle.np_lowrank.head_input_gradient(lr_p, lr_w), bit for bit (g_x, g_v_init, g_sum, dL/dk);
@@ -682,6 +682,7 @@ def test_backward_with_low_rank_second_gradient(kind, T, rows, C):
         _lib.neuron_bwd_fork_lr(None, P, Wl, gsum, None, x, v0, gx_d, None, gk(), ws, *args)     # a "sum" needs a dense first gradient
     assert not _lib.neuron_bwd_fork_lr_supported(T, N, C, 25) and not _lib.neuron_bwd_fork_lr_supported(3, N, C, 9)
     assert not _lib.neuron_bwd_fork_lr_supported(T, 96 * 48, 48, 9)                                 # 1024 % C != 0
+    assert not _lib.neuron_bwd_fork_lr_supported(T, 4 * 1024, 1024, 9)                              # the weight matrix must fit the LDS budget (C <= 512)
 
 
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])

@@ -214,3 +214,24 @@ def test_config1_equivalent_ann_runs_on_cpu_and_equals_the_oracle():
     # stateful second call (membrane of the read-out pool carried) and reset
     d0b, d1b = orc(x), net(x)
     assert all(torch.equal(a, b) for a, b in zip(d0b, d1b)) and not torch.equal(d1b[0], d1[0])
+
+
+def test_low_rank_gradient_registry():
+    """fused.lowrank_anchor / lowrank_of: the pair is found through any view of the anchor, plain tensors (also zero-stride ones) are not
+    mistaken for anchors, an unknowing consumer sees NaNs (loud), the registry is bounded, and lowrank_dense is the product it stands for."""
+    import torch
+    from stereospike_amd import fused
+    fused._LOWRANK.clear()
+    p, w = torch.randn(6, 9), torch.randn(9, 8)
+    a = fused.lowrank_anchor((2, 3, 8), p, w)
+    assert a.shape == (2, 3, 8) and not any(a.stride()) and bool(torch.isnan(a).all())
+    for v in (a, a.view(6, 8), a.reshape(1, 2, 3, 8), a[1]):
+        got = fused.lowrank_of(v)
+        assert got is not None and got[0] is p and got[1] is w
+    assert fused.lowrank_of(torch.zeros(2, 3, 8)) is None and fused.lowrank_of(None) is None
+    assert fused.lowrank_of(torch.zeros(1).expand(2, 3, 8)) is None            # a zero-stride tensor that is not an anchor
+    assert torch.equal(fused.lowrank_dense((p, w), (2, 3, 8)), (p @ w).view(2, 3, 8))
+    for _ in range(3 * fused._LOWRANK_KEEP):
+        fused.lowrank_anchor((1, 8), p[:1], w)
+    assert len(fused._LOWRANK) == fused._LOWRANK_KEEP and fused.lowrank_of(a) is None    # evicted: the oldest pairs are dropped
+    fused._LOWRANK.clear()
