@@ -534,12 +534,24 @@ EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3
 ASSERT_EXACT_SPLIT = False         # tests: verify (with a host sync) that the input really is bf16-exact
 
 
-def _split3_bf16(Wt):
+def _split3_cols(Wt):
+    """Wt [K, N] fp32 -> [K, 3N] bf16 = [Wh | Wm | Wl] with Wh + Wm + Wl == Wt exactly (8 + 8 + 8 mantissa bits), in ONE launch of the
+    kernel that splits the gradients (ss_split3_bf16) — was 2 subtractions, 5 casts and a concatenation, ~9 small launches per layer and step."""
+    K, N = Wt.shape
+    if Wt.is_cuda and N % 4 == 0:
+        W3 = torch.empty((K, 3 * N), dtype=torch.bfloat16, device=Wt.device)
+        _lib.split3_bf16(Wt.contiguous(), W3, K, N)
+        return W3
     Wh = Wt.to(torch.bfloat16)
     r = Wt - Wh.float()
     Wm = r.to(torch.bfloat16)
     Wl = (r - Wm.float()).to(torch.bfloat16)
-    return torch.cat((Wh, Wm, Wl), 0)                                 # [3K, N]
+    return torch.cat((Wh, Wm, Wl), 1)
+
+
+def _split3_bf16(Wt):
+    K, N = Wt.shape
+    return _split3_cols(Wt).view(K, 3, N).permute(1, 0, 2).reshape(3 * K, N)      # [3K, N]: rows = (term, k)
 
 
 GEMM6_DGRAD = _os.environ.get('SS_GEMM6_DGRAD', '1') == '1'   # decoder data gradient g_x = g_P @ W2 of the two wide stages as ss_gemm6_f32 (six bf16 cross terms, fp32-product accuracy)
@@ -792,11 +804,7 @@ class _SpikeConvCL(torch.autograd.Function):
         else:
             _lib.im2col_cl_bf16(x_cl, A, NB, h, w, Cin, k, stride, pad, ho, wo)
         Wt = weight.permute(2, 3, 1, 0).reshape(K, Cout)                          # row index = (ky, kx, c): the im2col column order
-        Wh = Wt.to(torch.bfloat16)
-        r = Wt - Wh.float()
-        Wm = r.to(torch.bfloat16)
-        Wl = (r - Wm.float()).to(torch.bfloat16)
-        y3 = torch.mm(A, torch.cat((Wh, Wm, Wl), 1), out_dtype=torch.float32)   # [M, 3*Cout]
+        y3 = torch.mm(A, _split3_cols(Wt.float()), out_dtype=torch.float32)       # [M, 3*Cout] = A @ [Wh | Wm | Wl]
         y = y3.view(M, 3, Cout).sum(1).view(NB, ho, wo, Cout)
         ctx.save_for_backward(A, weight)
         ctx.geom = (NB, h, w, Cin, Cout, k, stride, pad, ho, wo)

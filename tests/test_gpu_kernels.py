@@ -640,6 +640,23 @@ def test_backward_with_forked_output_gradients(kind, T, N):
         _lib.neuron_bwd_fork(g1, g2, None, None, x, None, v0, gx_c, None, None, None, *args)      # saved-h form + second gradient
 
 
+def test_weight_split_in_one_launch_equals_the_torch_definition():
+    """fused._split3_cols / _split3_bf16 (the exact three-term bf16 split of a synapse's weights through ss_split3_bf16, one launch) ==
+    the cast / subtract / cast chain they replace, bit for bit; the three terms sum back to the fp32 weight exactly."""
+    from stereospike_amd import fused
+    torch.manual_seed(3)
+    for K, N in ((3200, 256), (800, 64), (27, 12)):
+        Wt = (torch.randn(K, N, device=DEV) * torch.logspace(-6, 1, N, device=DEV)).contiguous()
+        Wh = Wt.to(torch.bfloat16)
+        r = Wt - Wh.float()
+        Wm = r.to(torch.bfloat16)
+        Wl = (r - Wm.float()).to(torch.bfloat16)
+        cols = fused._split3_cols(Wt)
+        assert cols.dtype == torch.bfloat16 and torch.equal(cols, torch.cat((Wh, Wm, Wl), 1))
+        assert torch.equal(fused._split3_bf16(Wt), torch.cat((Wh, Wm, Wl), 0))
+        assert torch.equal(cols[:, :N].double() + cols[:, N:2 * N].double() + cols[:, 2 * N:].double(), Wt.double())
+
+
 @pytest.mark.parametrize('kind', ['IF', 'LIF', 'PLIF'])
 @pytest.mark.parametrize('T,rows,C', [(5, 96, 32), (5, 17, 64), (10, 8, 128), (1, 3, 256), (4, 5, 512), (2, 7, 4), (5, 40000, 32), (8, 33, 16)])
 def test_backward_with_low_rank_second_gradient(kind, T, rows, C):
