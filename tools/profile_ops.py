@@ -31,13 +31,13 @@ for e in prof.key_averages(group_by_input_shape=True):
     t = getattr(e, 'self_device_time_total', None)
     if t is None:
         t = getattr(e, 'self_cuda_time_total', 0)
-    if t and t / STEPS >= 30:
+    if t and t / STEPS >= float(os.environ.get('MIN_US', 30)):
         rows.append((t / STEPS, e.count / STEPS, e.key, str(e.input_shapes)[:150]))
 rows.sort(key=lambda r: -r[0])
 skip = ('mm', 'bmm', 'convolution', 'miopen', '_FusedNeuron', 'UpConv', 'SpikeConv', 'IPool', 'ScaleLoss')
 tot = 0
 for t, c, k, sh in rows:
-    if any(s in k for s in skip):
+    if any(s in k for s in skip) or (os.environ.get('ATEN_ONLY') and not k.startswith('aten::')):
         continue
     tot += t
     print(f'{t / 1e3:7.3f} ms/step x{c:5.1f}  {k:40s} {sh}')
