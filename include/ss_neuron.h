@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 3
+#define SS_ABI_VERSION 4
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` to ss_neuron_bwd_f32 when g_k != NULL. */
@@ -136,7 +136,7 @@ int ss_neuron_bwd_fork_f32(const float* g_out_seq, const float* g_out2_seq, floa
                            void* stream);
 
 /*
- * ss_neuron_bwd_fork_f32 (recompute form) whose SECOND gradient arrives in low-rank form.  The second consumer of a decoder stage's
+ * ABI 4.  ss_neuron_bwd_fork_f32 (recompute form) whose SECOND gradient arrives in low-rank form.  The second consumer of a decoder stage's
  * output — and, through the fused skip add, of the full-resolution encoder layer's — is a prediction head: a 3 x 3 synapse with ONE output
  * channel on the projected form (/root/reference/network/SNN_models.py:150-163, blocks.py:110-132), so its input gradient is
  * g2[t][pixel][c] = sum_{j < 9} lr_p[t][pixel][j] * lr_w[j][c]: 9 floats per pixel instead of C.  The kernel forms g2 in registers
