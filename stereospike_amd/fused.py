@@ -705,8 +705,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
         lowp = ctx.lowp
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         # one-channel 3 x 3 head on a forked neuron output: g_x = g_P [rows, 9] @ W2 [9, C_in] is left to the consumer's backward kernel
+        # (anomaly detection scans every backward output for NaNs and would trip over the anchor: it gets the dense form)
         lowrank = (need_x and ctx.lowrank_grad and LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
-                   and ctx.x_dtype == torch.float32 and Cin % 4 == 0 and 1024 % Cin == 0)
+                   and ctx.x_dtype == torch.float32 and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
         g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
