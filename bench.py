@@ -388,9 +388,18 @@ def main():
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
         line = json.dumps(out)
     if use_dp:
-        dist.destroy_process_group()          # RCCL prints its version banner to stdout around here: keep the JSON line the LAST line
+        dist.destroy_process_group()
+    # RCCL writes its version banner with C stdio: block-buffered when stdout is a pipe or a file, i.e. it would come out at process exit,
+    # AFTER the JSON line.  Every rank drains the C buffers now; rank 0 prints a moment later, so the JSON line is the last line of the job.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
-        sys.stdout.flush()
+        if use_dp and world > 1:
+            time.sleep(1.0)
         print(line, flush=True)
 
 
