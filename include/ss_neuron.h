@@ -49,10 +49,13 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 4
+#define SS_ABI_VERSION 5
 int ss_abi_version(void);
 
-/* Number of floats the caller must provide as `g_k_ws` to ss_neuron_bwd_f32 when g_k != NULL. */
+/* Number of floats the caller must provide as `g_k_ws` (8-byte aligned) to the ss_neuron_bwd_* entry points when g_k != NULL.
+ * ABI 5: the workspace holds the per-workgroup partials of the PLIF dL/dk sum as DOUBLES — that scalar is one heavily cancelling sum over
+ * every neuron and step of a layer (condition number ~1e3 on the bottleneck layers), so it is accumulated in fp64 from the lane to the
+ * last addition and rounded to fp32 once (g_k). */
 long long ss_neuron_gk_ws_floats(void);
 
 /*
@@ -202,6 +205,8 @@ int ss_neuron_bwd_fork_x16(const void* g_out_seq, const void* g_out2_seq, void* 
  *    be NULL (forward 4.25 B/update instead of 8: read x 4 + write 0.25) or also be written for a consumer that needs fp32.
  *    skip_packed != NULL reads the skip operand from a packed tensor (0.25 B/update instead of 4).  fp32 activations, compile-time
  *    T (ss_neuron_bwd_rc_supported(T)), N % 16 == 0, h_seq == NULL (training recomputes h: ss_neuron_bwd_rc_f32); else SS_EINVAL.
+ *    CONTRACT: z + skip <= 3 (the reference's largest value; a dense skip_seq is read modulo 4 and an out code above 3 saturates at 3 —
+ *    a 2-bit field never spills into its neighbour, but such an output is not the sum any more: keep wider skips on the dense form).
  *    Readers for the consumers: ss_unpack_spikes, ss_im2col_cl_bf16_packed, and skip_packed itself.
  *  - FIRING-RATE COUNTERS WITHOUT SAME-ADDRESS ATOMICS: with cnt_ws (ss_neuron_cnt_ws_words(N) 32-bit words) every workgroup stores
  *    its two partial counts and a one-workgroup second pass adds their sum to nnz[0..1]; the launch keeps its full grid (with

@@ -125,7 +125,7 @@ int ss_ref_neuron_bwd_f32(const float *g_out_seq, const float *g_v_last, const f
                 }
                 g_x = g_h * k;
                 g_v = g_h - g_x;
-                acc_k += (double)(g_h * ((h - v_prev) / k));
+                acc_k += (double)g_h * (double)((h - v_prev) / k);   /* as the kernel: fp32 factors, fp64 product and sum */
             }
             g_x_seq[i] = g_x * scale;
         }
