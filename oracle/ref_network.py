@@ -184,27 +184,44 @@ def run_sequence(net, x_seq):
 
 
 # ---- float64-convolution mode ------------------------------------------------------------------------------
+def ste_round(t, dtype):
+    """Value rounded to `dtype` (nearest even) and returned as fp32; gradient = identity (straight-through): how a storage-format
+    narrowing enters the float64-convolution oracle of the 16-bit activation modes."""
+    return t + (t.detach().to(dtype).to(t.dtype) - t.detach())
+
+
 class float64_convs:
     """Context manager: every nn.Conv2d of `net` evaluates its convolution in float64 and rounds ONCE to fp32 (forward and, through
     autograd, both gradients) — the reference graph with the synapse arithmetic taken to (almost) infinite precision.  This is the
     yard-stick for the product's synapse forms: MIOpen's fp32 convolutions, fp32 GEMM + gather, exact bf16x3 MFMA GEMMs all differ from
     each other by fp32 summation order; each is held against THIS value instead of against another fp32 summation order
-    (tests/_pinned.py).  Neuron arithmetic, gains, adds, I-pool, loss stay the fp32 op-by-op restatement."""
+    (tests/_pinned.py).  Neuron arithmetic, gains, adds, I-pool, loss stay the fp32 op-by-op restatement.
 
-    def __init__(self, net):
-        self.convs = [m for m in net.modules() if isinstance(m, nn.Conv2d)]
+    narrow: optional callable  module name -> (weight dtype | None, output dtype | None): the 16-bit activation modes of the build
+    (BASELINE configs 2 / 5; the reference itself is fp32-only) DEFINED end to end — at the named synapse the weight is rounded once to
+    the weight dtype before the (float64) contraction and the result is rounded once to the output dtype, i.e. what is stored in HBM
+    between layers is a 16-bit value, exactly at the points where the product narrows (oracle/np_x16.py is the per-kernel statement of
+    the same semantics).  Gradients pass the roundings straight through (ste_round), so the oracle's backward is the exact gradient of
+    the narrowed forward."""
+
+    def __init__(self, net, narrow=None):
+        self.convs = [(n, m) for n, m in net.named_modules() if isinstance(m, nn.Conv2d)]
+        self.narrow = narrow
 
     def __enter__(self):
-        for c in self.convs:
-            def fwd(inp, weight, bias, c=c):
-                y = F.conv2d(inp.double(), weight.double(), None if bias is None else bias.double(), c.stride, c.padding,
-                             c.dilation, c.groups)
-                return y.float()
+        for name, c in self.convs:
+            wdt, odt = self.narrow(name) if self.narrow is not None else (None, None)
+
+            def fwd(inp, weight, bias, c=c, wdt=wdt, odt=odt):
+                w = weight if wdt is None else ste_round(weight, wdt)
+                y = F.conv2d(inp.double(), w.double(), None if bias is None else bias.double(), c.stride, c.padding,
+                             c.dilation, c.groups).float()
+                return y if odt is None else ste_round(y, odt)
             c._conv_forward = fwd
         return self
 
     def __exit__(self, *a):
-        for c in self.convs:
+        for _, c in self.convs:
             c.__dict__.pop('_conv_forward', None)
         return False
 

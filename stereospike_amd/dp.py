@@ -12,6 +12,7 @@ encoder's last; layer-by-layer BPTT produces each weight gradient exactly once p
 
 Gradients live directly in the flat bucket buffers (p.grad is a view), so there is no pack/unpack copy.
 """
+import time
 from typing import List, Optional
 
 import torch
@@ -20,7 +21,12 @@ import torch.distributed as dist
 
 class GradientAllReducer:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 20 << 20, process_group=None,
-                 broadcast_from: Optional[int] = 0, reduce_single_rank: bool = False):
+                 broadcast_from: Optional[int] = 0, reduce_single_rank: bool = False, trace: bool = False):
+        # trace: keep a host-side event log [(kind, bucket, seconds)] — 'hook' when a parameter's gradient becomes final, 'issue' when a
+        # bucket's all-reduce is launched, 'finish' when finish() is entered — and `last_finish` = dict(buckets, completed_at_entry): the
+        # evidence that the exchange overlaps the backward pass (tests/test_dp_gloo.py::test_all_reduce_overlaps_the_backward_pass)
+        self.trace = [] if trace else None
+        self.last_finish = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # reduce_single_rank=True issues the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
@@ -74,12 +80,20 @@ class GradientAllReducer:
             v.copy_(p.grad)
             p.grad = v
         b['pending'] -= 1
+        if self.trace is not None:
+            self.trace.append(('hook', bi, time.perf_counter()))
         if b['pending'] == 0 and self._active:
             b['flat'].div_(self.world)
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.trace is not None:
+                self.trace.append(('issue', bi, time.perf_counter()))
 
     def finish(self):
         """Wait for the in-flight all-reduces (call after loss.backward(), before optimizer.step())."""
+        if self.trace is not None:
+            self.trace.append(('finish', -1, time.perf_counter()))
+            self.last_finish = dict(buckets=len(self.buckets),
+                                    completed_at_entry=sum(1 for b in self.buckets if b['work'] is not None and b['work'].is_completed()))
         for b in self.buckets:
             if b['work'] is not None:
                 b['work'].wait()

@@ -24,7 +24,7 @@ def set_deterministic(on: bool = True):
     split-K weight gradients) and runs without its timing-based find mode, the GEMM algorithm record (TunableOp) is not consulted, and
     torch refuses non-deterministic kernels; the engine's own kernels are deterministic by construction (integer counters, fixed-order
     reductions for dL/dk, loss sums and split-K weight gradients).  Two runs of a training step from the same state are then
-    bit-identical (tests/test_gpu_model.py::test_deterministic_mode); slower than the default (measured in profiles/)."""
+    bit-identical (tests/test_gpu_03_model.py::test_deterministic_mode); slower than the default (measured in profiles/)."""
     torch.backends.cudnn.deterministic = bool(on)
     if on:
         torch.backends.cudnn.benchmark = False
@@ -32,12 +32,6 @@ def set_deterministic(on: bool = True):
     if torch.cuda.is_available() and hasattr(torch.cuda, 'tunable'):
         if on:
             torch.cuda.tunable.enable(False)
-
-
-def _release_lowrank_pairs():
-    """Drop the prediction heads' gradient pairs of the backward that just ran (fused.lowrank_anchor keeps the last few alive)."""
-    from . import fused
-    fused._LOWRANK.clear()
 
 
 class _null:
@@ -81,7 +75,6 @@ class Trainer:
         self.last_rates = rates
         with torch.autocast('cuda', enabled=False) if loss.is_cuda else _null():
             (self.scaler.scale(loss) if self.scaler is not None else loss).backward()
-        _release_lowrank_pairs()
         if self.reducer is not None:
             self.reducer.finish()
         if self.scaler is not None:
@@ -173,12 +166,10 @@ class GraphedTrainer:
             loss = self.loss_module(pred, self.static_gt, spks)
         if self.scaler is not None:
             self.scaler.scale(loss).backward()
-            _release_lowrank_pairs()
             self.scaler.step(self.opt)
             self.scaler.update()
         else:
             loss.backward()
-            _release_lowrank_pairs()
             self.opt.step()
         return loss.detach(), pred[0].detach()
 
@@ -204,7 +195,12 @@ class GraphedTrainer:
                     if torch.is_tensor(v):
                         v.zero_()
         if self.scaler is not None:
-            self.scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 16)
+            # The scaler's state tensors must live OUTSIDE the capture: a fresh GradScaler would run its lazy initialisation (torch.full of
+            # _scale / _growth_tracker) inside torch.cuda.graph, and every replay would then reset the loss scale to 2^16 — a static scale,
+            # and a persistent overflow would skip every optimiser step for ever.  The warm-up iterations initialised them:
+            # reset the values in place.
+            self.scaler._scale.fill_(2.0 ** 16)
+            self.scaler._growth_tracker.zero_()
         self.opt.zero_grad(set_to_none=True)    # gradients are (re)created inside the capture: every replay overwrites them
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -9,7 +9,6 @@ blocks.py:171) and, in backward, the autograd chain through surrogate.ATan / sur
 
 Everything here needs the HIP library and HIP tensors; there is no eager fallback.
 """
-import collections as _collections
 import os as _os
 from dataclasses import dataclass
 from typing import Optional
@@ -99,28 +98,65 @@ def unpack_dense(packed, shape, dtype=torch.float32):
 
 # Low-rank gradient of a prediction head (3 x 3 taps, ONE output channel): d loss / d input = g_P [rows, 9] @ W2 [9, C].  Instead of running
 # that GEMM and writing the C-channel result (which the neuron backward of the stage — and, through the fused skip add, of the full-resolution
-# encoder layer — would then read at 4 B/update), the head's backward hands the PAIR to the consumer: autograd carries a NaN-filled zero-stride
-# anchor (any consumer that does not know about the pair fails loudly), the pair travels in this registry keyed by the anchor's storage, and
-# ss_neuron_bwd_fork_lr_f32 forms the gradient in registers from 36 / C B/update.
+# encoder layer — would then read at 4 B/update), the head's backward hands the PAIR to the consumer, and ss_neuron_bwd_fork_lr_f32 forms the
+# gradient in registers from 36 / C B/update.
+#
+# How the pair travels (no module-level state: VERDICT r02 weak #9): ONE flat fp32 buffer [4 NaNs | g_P (rows x 9) | pad | W2 (9 x C)] is
+# allocated per head and backward; the adjoint kernel writes g_P straight into it.  The gradient autograd carries is a ZERO-STRIDE view of the
+# buffer's first element with the logical shape of the dense gradient — the pair lives exactly as long as autograd keeps that gradient, any
+# view of it (fork handles, flatten) still shares the storage, two networks or retain_graph need no bookkeeping.  The consumer recognises it by
+# layout alone (all strides 0, offset 0, storage longer than the 4-element header — an ordinary expanded scalar gradient has a 1-element
+# storage) and checks that the storage length is the one its own shape implies; a mismatch RAISES.  A consumer that knows nothing about pairs
+# and materialises the view sees NaNs everywhere.
 LOWRANK_HEAD_GRAD = _os.environ.get('SS_LOWRANK_HEAD_GRAD', '1') == '1'
-_LOWRANK = _collections.OrderedDict()       # anchor storage pointer -> (anchor base tensor: keeps the pointer unique, lr_p, lr_w)
-_LOWRANK_KEEP = 8                           # two backward passes' worth of heads; older pairs are dropped (bounded memory)
+_LR_HDR = 4                                  # floats before g_P (keeps g_P and W2 16-byte aligned)
+_LR_RANK = 9
+
+
+def _lr_layout(rows, C, rank=_LR_RANK):
+    """(offset of g_P, offset of W2, total floats) of the pair buffer."""
+    o_w = _LR_HDR + (rows * rank + 3) // 4 * 4
+    return _LR_HDR, o_w, o_w + rank * C
+
+
+def lowrank_buffer(shape, device, rank=_LR_RANK):
+    """shape [..., C] of the dense gradient the pair stands for -> (anchor, g_P [rows, rank], W2 [rank, C]): the zero-stride gradient to
+    return to autograd and the two views the producer fills (g_P by the adjoint kernel, W2 by a copy of the head's weight)."""
+    C = int(shape[-1])
+    rows = 1
+    for d in shape[:-1]:
+        rows *= int(d)
+    o_p, o_w, n = _lr_layout(rows, C, rank)
+    buf = torch.empty(n, dtype=torch.float32, device=device)
+    buf[:_LR_HDR].fill_(float('nan'))
+    return buf.as_strided(tuple(shape), (0,) * len(shape)), buf[o_p:o_p + rows * rank].view(rows, rank), buf[o_w:o_w + rank * C].view(rank, C)
 
 
 def lowrank_anchor(shape, lr_p, lr_w):
-    base = torch.full((1,), float('nan'), dtype=torch.float32, device=lr_p.device)
-    _LOWRANK[base.untyped_storage().data_ptr()] = (base, lr_p, lr_w)
-    while len(_LOWRANK) > _LOWRANK_KEEP:
-        _LOWRANK.popitem(last=False)
-    return base.as_strided(tuple(shape), (0,) * len(shape))
+    """The anchor of an existing pair (copies both into a fresh buffer; the product path fills a lowrank_buffer in place instead)."""
+    a, p, w = lowrank_buffer(shape, lr_p.device, lr_w.shape[0])
+    p.copy_(lr_p)
+    w.copy_(lr_w)
+    return a
 
 
-def lowrank_of(g):
-    """(lr_p, lr_w) when g is (a view of) a low-rank anchor, else None."""
-    if g is None or not _LOWRANK or g.dtype != torch.float32 or any(g.stride()):
+def lowrank_of(g, rank=_LR_RANK):
+    """(lr_p [rows, rank], lr_w [rank, C]) when g is (a view of) a low-rank anchor, else None.  Raises when g has the layout of an anchor
+    but not the storage length its shape implies (an anchor that reached a layer it was not made for)."""
+    if g is None or g.dtype != torch.float32 or g.dim() == 0 or any(g.stride()) or g.storage_offset() != 0:
         return None
-    ent = _LOWRANK.get(g.untyped_storage().data_ptr())
-    return None if ent is None else ent[1:]
+    st = g.untyped_storage()
+    n = st.nbytes() // 4
+    if n <= _LR_HDR:
+        return None                          # an ordinary expanded scalar (e.g. the gradient of a sum)
+    C = int(g.shape[-1])
+    rows = g.numel() // C
+    o_p, o_w, need = _lr_layout(rows, C, rank)
+    if n != need:
+        raise _lib.SSNeuronError(f'zero-stride gradient of shape {tuple(g.shape)} over a {n}-float storage: neither an expanded scalar nor the '
+                                 f'low-rank pair of this shape ({need} floats) — a prediction head\'s gradient pair reached a layer it does not fit')
+    flat = torch.empty(0, dtype=torch.float32, device=g.device).set_(st, 0, (n,), (1,))
+    return flat[o_p:o_p + rows * rank].view(rows, rank), flat[o_w:o_w + rank * C].view(rank, C)
 
 
 def lowrank_dense(lr, shape):
@@ -173,7 +209,8 @@ class _FusedNeuron(torch.autograd.Function):
         es = 2 if half else 4
         per = es * (1 + (0 if pack == 2 else 1)) + (0.25 if pack else 0) + (0.25 if skip_packed is not None else (es if skip_seq is not None else 0)) \
             + (4 if h_seq is not None else 0)
-        TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else ''),
+        TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else '')
+                   + ('+h' if h_seq is not None else ''),      # '+h': the saved-h form (run-time T / RECOMPUTE_H off), never the benchmarked kernels
                    int(per * T * N), T * N)
         ctx.cfg = cfg
         ctx.T, ctx.N = T, N
@@ -200,8 +237,8 @@ class _FusedNeuron(torch.autograd.Function):
         cfg, T, N = ctx.cfg, ctx.T, ctx.N
         half = ctx.io_dtype in (torch.float16, torch.bfloat16)
         lr = lr_anchor = None
-        if _LOWRANK:                                   # a prediction head's gradient as a low-rank pair (see lowrank_anchor)
-            l1, l2 = lowrank_of(g_out_seq), lowrank_of(g_out2_seq)
+        l1, l2 = lowrank_of(g_out_seq), lowrank_of(g_out2_seq)    # a prediction head's gradient as a low-rank pair (see lowrank_buffer)
+        if l1 is not None or l2 is not None:
             if l1 is not None and l2 is not None:      # two pairs: one stays low-rank
                 g_out_seq, l1 = lowrank_dense(l1, h_seq.shape), None
             if l1 is not None:
@@ -257,7 +294,7 @@ class _FusedNeuron(torch.autograd.Function):
                 bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
             bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                 T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, ('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd', (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
+        TIMER.stop(e0, (('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd') + ('' if ctx.recompute else '+savedh'), (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
         g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
         return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
 
@@ -564,21 +601,32 @@ FUSED_UPCONV_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN',
                                    # than adjoint kernel + ss_spike_wgrad_f32 (4 workgroup kinds re-load every window; profiles/r02/fused_bwd.log)
 
 
+def _extents_of(y_lo, y_hi, x_lo, x_hi):
+    def span(lo, hi, n):
+        return max(hi[min(i + n - 1, len(lo) - 1)] - lo[i] for i in range(0, len(lo), n)) + 4
+    return (span(y_lo, y_hi, 4), span(y_lo, y_hi, 2), span(x_lo, x_hi, 16),
+            max(max(b - a for a, b in zip(y_lo, y_hi)), max(b - a for a, b in zip(x_lo, x_hi))))
+
+
+def register_extents(tables, host_tables):
+    """Called where the resize tables are BUILT (NNConvUpsampling._tables, from the host copies): the extents are then known without ever
+    reading a device tensor back — no host synchronisation in backward, nothing that could land inside a stream capture."""
+    _EXTENTS[id(tables)] = (tables, _extents_of(*(host_tables[i].tolist() for i in (1, 2, 4, 5))))
+
+
 def adjoint_extents(tables):
     """(max_rows4, max_rows2, max_cols16, max_span) of the inverse resize tables (y_lo, y_hi, x_lo, x_hi at indices 1, 2, 4, 5): the output
     window that 4 / 2 consecutive source rows and 16 consecutive source columns need (incl. the 4 extra tap rows / columns), and the widest
-    per-source range — what ss_upconv_bwd_fused_supported checks against its on-chip window.  Host-side, cached on the tables tuple."""
-    key = id(tables)
-    hit = _EXTENTS.get(key)
+    per-source range — what ss_upconv_bwd_fused_supported checks against its on-chip window.  Host-side, cached on the tables tuple
+    (register_extents); tables built elsewhere are read back once, and never during a stream capture."""
+    hit = _EXTENTS.get(id(tables))
     if hit is not None and hit[0] is tables:
         return hit[1]
-    y_lo, y_hi, x_lo, x_hi = (tables[i].cpu().tolist() for i in (1, 2, 4, 5))
-
-    def span(lo, hi, n):
-        return max(hi[min(i + n - 1, len(lo) - 1)] - lo[i] for i in range(0, len(lo), n)) + 4
-    ext = (span(y_lo, y_hi, 4), span(y_lo, y_hi, 2), span(x_lo, x_hi, 16),
-           max(max(b - a for a, b in zip(y_lo, y_hi)), max(b - a for a, b in zip(x_lo, x_hi))))
-    _EXTENTS[key] = (tables, ext)
+    if tables[1].is_cuda and torch.cuda.is_current_stream_capturing():
+        raise _lib.SSNeuronError('adjoint_extents: resize tables without registered extents inside a stream capture (build them through '
+                                 'NNConvUpsampling._tables, or run one eager backward first)')
+    ext = _extents_of(*(tables[i].cpu().tolist() for i in (1, 2, 4, 5)))
+    _EXTENTS[id(tables)] = (tables, ext)
     return ext
 
 
@@ -728,12 +776,16 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
                 _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
             else:
-                g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
+                if lowrank:      # the adjoint writes g_P straight into the pair buffer the consumer's neuron backward will read
+                    lr_anchor, g_P, lr_w = lowrank_buffer(x_cl.shape, x_cl.device, kk * Cout)
+                    lr_w.copy_(W2)
+                else:
+                    g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
                 (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
                 if lowp:
                     g_P = g_P.to(torch.bfloat16)
             if lowrank:
-                g_x = lowrank_anchor(x_cl.shape, g_P, W2)
+                g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
             elif need_x and not lowp and GEMM6_DGRAD and Cin in GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
                 # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy): the fp32 GEMM is compute-bound here
                 _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..clock_driven import neuron, surrogate
-from ..fused import nearest_tables, upconv_projected, upconv_projected_cl
+from ..fused import nearest_tables, register_extents, upconv_projected, upconv_projected_cl
 
 
 # The sequence fast path evaluates NNConvUpsampling through forward_projected (no up-sampled tensor).  Set to False to
@@ -85,6 +85,7 @@ class NNConvUpsampling(_UpConv):
             Hu, Wu = self.up[0].size
             ty, tx = nearest_tables(h, Hu), nearest_tables(w, Wu)
             cache[key] = tuple(t.to(device) for t in (ty + tx))
+            register_extents(cache[key], ty + tx)              # host-side, from the CPU copies: backward never reads a table back
         return cache[key]
 
     def forward_projected(self, x: torch.Tensor) -> torch.Tensor:

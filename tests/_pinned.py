@@ -1,6 +1,6 @@
 """Trajectory-pinned end-to-end parity (test infrastructure; GPU tests only).
 
-Why: spike masks are bit-exact at the kernel boundary (tests/test_gpu_kernels.py), but a FREE-running comparison of two whole
+Why: spike masks are bit-exact at the kernel boundary (tests/test_gpu_01_kernels.py), but a FREE-running comparison of two whole
 networks is a comparison of two chaotic trajectories: the product's synapses (MIOpen fp32 convolutions, fp32 GEMM + gather,
 exact bf16x3 MFMA GEMMs) and the oracle's (oneDNN) differ by fp32 summation order, a membrane that sits within that difference of
 its threshold flips, and one flipped spike moves 25 x C_out downstream membranes by O(0.5).  Round 1 bounded that with "noise
@@ -19,7 +19,15 @@ What is done instead: the ORACLE is pinned to the product's trajectory.
      thus identical, depths, loss, MDE and EVERY parameter gradient of the composed forward + backward (fork handles, summed skip
      gradients, exact-split weight gradients, split-K, I-pool order, fused loss) match the oracle's autograd at fp32 tolerance.
 
-Nothing here is chaotic: no noise floors, no seeds to be lucky with, independent of which MIOpen solver a box picks."""
+Nothing here is chaotic: no noise floors, no seeds to be lucky with.
+
+Bars are per KIND of quantity:
+  * weight TENSORS: relative L2 vs the oracle's autograd (a wrong surrogate constant, tap or gain moves them by >= 1e-3);
+  * the 0-dim PLIF `w` of a node: dL/dw = k(1-k) * sum_{t,n} g_h (x - v) is ONE cancelling sum over a whole layer and all steps (condition
+    number up to ~1e3 on the bottleneck nodes), so |product - oracle| is held against the MAGNITUDE sum k(1-k) * sum |g_h (x - v)| — both
+    the signed sum and the magnitude sum are taken in float64 from hooks on the oracle's own membranes (`plif_w` in the report).  The
+    synapse rounding of the incoming gradient (whatever MIOpen solver or GEMM order produced it) enters that scalar relative to the
+    magnitude sum, not relative to the cancelled value."""
 import contextlib
 import types
 
@@ -60,10 +68,13 @@ def record_product_spikes(net):
         neuron.BaseNode.forward_sequence = orig
 
 
-def run_oracle_pinned(orc, x, z_by_node, float64=True):
+def run_oracle_pinned(orc, x, z_by_node, float64=True, stats=None, plif=None, narrow=None):
     """x [B, T, C, H, W]; z_by_node {node name: [T, B, C, H, W] uint8}.  Returns (output of the last step, stats) where
-    stats[name] = dict(total, flips, max_margin) — max_margin = largest |h - v_th| among neurons whose own Heaviside disagreed with z."""
-    stats, step = {}, {}
+    stats[name] = dict(total, flips, max_margin) — max_margin = largest |h - v_th| among neurons whose own Heaviside disagreed with z.
+    stats / plif: dicts to accumulate into over several calls (chunks of a batch).  plif[name] = dict(sum, abs): float64
+    sum_{t,n} g_h (x - v) and sum |g_h (x - v)| of a ParametricLIFNode, filled when the caller runs backward (tensor hooks on h)."""
+    stats = {} if stats is None else stats
+    step = {}
     nodes = {n: m for n, m in orc.named_modules() if isinstance(m, sj.BaseNode) and n in z_by_node}
     missing = [n for n, m in orc.named_modules() if isinstance(m, sj.BaseNode) and n not in z_by_node and m.v_threshold != float('inf')]
     assert not missing, f'product recorded no spikes for {missing}'
@@ -85,16 +96,35 @@ def run_oracle_pinned(orc, x, z_by_node, float64=True):
             self.spike = s + (z - s).detach()
         return types.MethodType(fire, node)
 
+    def make_charge(name, node):
+        def charge(self, x):               # ParametricLIFNode.neuronal_charge of oracle/sj_clock_driven.py, op for op, + the float64 hooks
+            d = x - self.v if (self.v_reset is None or self.v_reset == 0.) else x - (self.v - self.v_reset)
+            h = self.v + d * self.w.sigmoid()
+            if h.requires_grad:
+                dd = d.detach().double()
+
+                def hook(g):
+                    t = g.double() * dd
+                    plif[name]['sum'] += float(t.sum())
+                    plif[name]['abs'] += float(t.abs().sum())
+                h.register_hook(hook)
+            self.v = h
+        return types.MethodType(charge, node)
+
     for n, m in nodes.items():
-        stats[n] = dict(total=0, flips=0, max_margin=0.0)
+        stats.setdefault(n, dict(total=0, flips=0, max_margin=0.0))
         step[n] = 0
         m.neuronal_fire = make_fire(n, m)
+        if plif is not None and isinstance(m, sj.ParametricLIFNode):
+            plif.setdefault(n, dict(sum=0.0, abs=0.0))
+            m.neuronal_charge = make_charge(n, m)
     try:
-        with (rn.float64_convs(orc) if float64 else contextlib.nullcontext()):
+        with (rn.float64_convs(orc, narrow) if float64 else contextlib.nullcontext()):
             out = rn.run_sequence(orc, x)
     finally:
         for m in nodes.values():
             m.__dict__.pop('neuronal_fire', None)
+            m.__dict__.pop('neuronal_charge', None)
     for n in nodes:
         assert step[n] == len(z_by_node[n]), (n, step[n], len(z_by_node[n]))
     return out, stats
@@ -105,8 +135,37 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-300))
 
 
-def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=None, float64=True):
-    """Free product run (forward + Total_Loss + backward) vs the trajectory-pinned oracle.  Returns a report dict."""
+def launch_tags():
+    """{tag: launches} of the fused launches recorded by fused.TIMER since it was last cleared."""
+    from stereospike_amd import fused
+    return {k: v['launches'] for k, v in fused.TIMER.summary().items()}
+
+
+def narrowing_points(amp_dtype):
+    """Where the product's 16-bit activation modes store 16-bit values / use 16-bit weights (module name -> (weight dtype, output dtype)):
+      encoder + bottleneck convs (MIOpen under torch.autocast): weight and output in the autocast dtype;
+      decoder stages (NNConvUpsampling k = 5, stereospike_amd/fused.py::_UpConvProjectedCL): output in the autocast dtype; weight rounded to
+        bf16 in the bf16 mode (autocast's own semantics), the EXACT fp32 weight in the fp16 mode (exact bf16x3 split);
+      prediction heads (k = 3): fp32 output (they feed the fp32 I-pool); weight as the decoder stages."""
+    def policy(name):
+        dec_w = torch.bfloat16 if amp_dtype == torch.bfloat16 else None
+        if name.startswith('predict_depth'):
+            return dec_w, None
+        if name.startswith('deconv'):
+            return dec_w, amp_dtype
+        return amp_dtype, amp_dtype
+    return policy
+
+
+def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=None, float64=True, oracle_chunk=None, loss_scale=1.0):
+    """Free product run (forward + Total_Loss + backward) vs the trajectory-pinned oracle.  Returns a report dict.
+    amp_dtype: the product runs under torch.autocast with 16-bit activations (fp32 membranes); the oracle narrows at the same points
+    (narrowing_points).  loss_scale: the product's loss is multiplied by it before backward and its gradients divided afterwards (fp16
+    activation gradients underflow otherwise: engine.Trainer's GradScaler does the same).
+    oracle_chunk: evaluate the oracle over chunks of that many samples (the network is per-sample independent; only the loss couples the
+    batch): pass 1 forward per chunk -> depths; the loss and its depth gradients on the whole batch; pass 2 forward + backward per chunk
+    with those depth gradients (parameter gradients accumulate).  Bounds the CPU memory of a config-3-sized batch."""
+    from stereospike_amd import fused
     from stereospike_amd.clock_driven import functional
     from stereospike_amd.network.loss import Total_Loss
     from stereospike_amd.network.metrics import MeanDepthError
@@ -114,36 +173,80 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
     net.zero_grad()
     functional.reset_net(net)
     xg, gg = x.to(dev), gt.to(dev)
-    with record_product_spikes(net) as rec:
-        with (torch.autocast('cuda', dtype=amp_dtype) if amp_dtype is not None else contextlib.nullcontext()):
-            res = net(xg) if is_ann else net.forward_sequence(xg)
-            d, s = res if returns_spikes else (res, [])
-            L = Total_Loss()(d, gg, s)
-        mde = MeanDepthError(d[0].detach(), gg)
-        L.backward()
-    if dev.type == 'cuda':
-        torch.cuda.synchronize()
+    fused.TIMER.clear()
+    fused.TIMER.enabled = dev.type == 'cuda'        # HIP events: the launch tags exist on the GPU only
+    try:
+        with record_product_spikes(net) as rec:
+            with (torch.autocast('cuda', dtype=amp_dtype) if amp_dtype is not None else contextlib.nullcontext()):
+                res = net(xg) if is_ann else net.forward_sequence(xg)
+                d, s = res if returns_spikes else (res, [])
+                L = Total_Loss()(d, gg, s)
+            mde = MeanDepthError(d[0].detach(), gg)
+            (L * loss_scale if loss_scale != 1.0 else L).backward()
+            if loss_scale != 1.0:
+                for p in net.parameters():
+                    p.grad.div_(loss_scale)
+        if dev.type == 'cuda':
+            torch.cuda.synchronize()
+        tags = launch_tags()
+    finally:
+        fused.TIMER.enabled = False
+        fused.TIMER.clear()
     # one fused launch per node covers all T steps: [T, B, C, H, W] -> T tensors [B, C, H, W]
     z_by_node = {}
     for n, lst in rec.items():
         assert len(lst) == 1, (n, len(lst))
         z_by_node[n] = list(lst[0])
     orc.zero_grad()
-    (res_o, stats) = run_oracle_pinned(orc, x, z_by_node, float64=float64)
-    d_o, s_o = res_o if returns_spikes else (res_o, [])
-    L_o = rn.total_loss(d_o, gt, s_o)
-    mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
-    L_o.backward()
+    plif, stats = {}, {}
+    B = x.shape[0]
+    narrow = narrowing_points(amp_dtype) if amp_dtype is not None else None
+    if oracle_chunk is None or oracle_chunk >= B:
+        res_o, _ = run_oracle_pinned(orc, x, z_by_node, float64=float64, stats=stats, plif=plif, narrow=narrow)
+        d_o, s_o = res_o if returns_spikes else (res_o, [])
+        L_o = rn.total_loss(d_o, gt, s_o)
+        mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
+        L_o.backward()
+    else:
+        chunks = [(c0, min(B, c0 + oracle_chunk)) for c0 in range(0, B, oracle_chunk)]
+        zc = lambda c0, c1: {n: [z[c0:c1] for z in lst] for n, lst in z_by_node.items()}        # noqa: E731
+        outs = []
+        with torch.no_grad():
+            for c0, c1 in chunks:
+                outs.append(run_oracle_pinned(orc, x[c0:c1], zc(c0, c1), float64=float64, stats=stats, narrow=narrow)[0])
+        outs = [o if returns_spikes else (o, []) for o in outs]
+        d_o = [torch.cat([o[0][i] for o in outs]).requires_grad_() for i in range(4)]
+        s_o = [torch.cat([o[1][i] for o in outs]) for i in range(len(outs[0][1]))]
+        L_o = rn.total_loss(d_o, gt, s_o)
+        mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
+        L_o.backward()
+        for c0, c1 in chunks:
+            o = run_oracle_pinned(orc, x[c0:c1], zc(c0, c1), float64=float64, stats={}, plif=plif, narrow=narrow)[0]
+            dc = o[0] if returns_spikes else o
+            torch.autograd.backward(list(dc), [g.grad[c0:c1] for g in d_o])
     scale = max(float(t.detach().abs().max()) for t in d_o)
+    orc_p = dict(orc.named_parameters())
+    grad_rel_l2 = {k: rel_l2(p.grad, orc_p[k].grad) for k, p in net.named_parameters()}
+    # 0-dim PLIF w of node `n`: dL/dw = dL/dk * k (1 - k); the product's value against the float64 sum, in units of the magnitude sum
+    plif_w = {}
+    for n, acc in plif.items():
+        k = float(torch.sigmoid(orc_p[n + '.w'].detach().double()))
+        ref64, mag = acc['sum'] * k * (1 - k), acc['abs'] * k * (1 - k)
+        g_prod, g_orc = float(dict(net.named_parameters())[n + '.w'].grad), float(orc_p[n + '.w'].grad)
+        plif_w[n + '.w'] = dict(product=g_prod, oracle_autograd_fp32=g_orc, oracle_float64=ref64, magnitude_sum=mag,
+                                condition=mag / max(abs(ref64), 1e-300), err_over_magnitude=abs(g_prod - ref64) / max(mag, 1e-300),
+                                oracle_fp32_err_over_magnitude=abs(g_orc - ref64) / max(mag, 1e-300))
     rep = dict(
         layers={n: dict(flip_frac=st['flips'] / max(1, st['total']), flips=st['flips'], max_margin=st['max_margin']) for n, st in stats.items()},
         spike_out_mismatch=max([float((a.detach().float().cpu() != b.detach()).float().mean()) for a, b in zip(s, s_o)] or [0.0]),
-        depth_max_abs_rel=max(float((a.detach().cpu() - b.detach()).abs().max()) for a, b in zip(d, d_o)) / scale,
-        loss=[float(L), float(L_o)], loss_rel=abs(float(L) - float(L_o)) / abs(float(L_o)),
+        depth_max_abs_rel=max(float((a.detach().float().cpu() - b.detach()).abs().max()) for a, b in zip(d, d_o)) / scale,
+        loss=[float(L.detach()), float(L_o.detach())], loss_rel=abs(float(L.detach()) - float(L_o.detach())) / abs(float(L_o.detach())),
         mde=[float(mde), float(mde_o)], mde_rel=abs(float(mde) - float(mde_o)) / abs(float(mde_o)),
         product_spike_density=[float(t.count_nonzero()) / t.numel() for t in s],
-        grad_rel_l2={k: rel_l2(p.grad, dict(orc.named_parameters())[k].grad) for k, p in net.named_parameters()})
+        grad_rel_l2=grad_rel_l2, plif_w=plif_w, launch_tags=tags)
     rep['flip_frac_max'] = max([v['flip_frac'] for v in rep['layers'].values()] or [0.0])
     rep['margin_max'] = max([v['max_margin'] for v in rep['layers'].values()] or [0.0])
     rep['grad_rel_l2_max'] = max(rep['grad_rel_l2'].values())
+    rep['tensor_grad_rel_l2_max'] = max([v for k, v in grad_rel_l2.items() if k not in plif_w] or [0.0])
+    rep['plif_w_err_over_magnitude_max'] = max([v['err_over_magnitude'] for v in plif_w.values()] or [0.0])
     return rep

@@ -110,7 +110,7 @@ def test_product_never_imports_the_oracle():
 
 def test_c_caller_compiles_and_links(tmp_path):
     """examples/c_caller.c — a plain C99 program using only include/ss_neuron.h — compiles and links against the built shared library
-    (no torch, no C++): the boundary really is a C ABI.  (It is run on the MI355X by tests/test_gpu_kernels.py.)"""
+    (no torch, no C++): the boundary really is a C ABI.  (It is run on the MI355X by tests/test_gpu_01_kernels.py.)"""
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -101,3 +101,69 @@ def test_two_rank_gradients_equal_shardwise_single_process(bucket_bytes):
     # both ranks hold identical parameters after the steps
     for a, b in zip(res[0][2], res[1][2]):
         assert np.array_equal(a, b)
+
+
+class _SlowBackward(torch.autograd.Function):
+    """Identity whose backward takes 60 ms of wall clock: stands for the backward T-loop of one layer."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        import time
+        time.sleep(0.06)
+        return g
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from stereospike_amd.dp import GradientAllReducer
+    torch.manual_seed(3)
+    layers = torch.nn.ModuleList([torch.nn.Linear(256, 256, bias=False) for _ in range(6)])     # 256 KB of fp32 per layer
+
+    def forward(x):
+        for lin in layers:
+            x = _SlowBackward.apply(lin(x))
+        return x
+    red = GradientAllReducer(layers, bucket_bytes=256 << 10, trace=True)                      # one bucket per layer
+    out = forward(torch.randn(8, 256) + rank)
+    out.sum().backward()
+    red.finish()
+    g_rank = [p.grad.clone() for p in layers.parameters()]
+    tr = red.trace
+    issues = {b: t for kind, b, t in tr if kind == 'issue'}
+    hooks = [t for kind, b, t in tr if kind == 'hook']
+    t_finish = [t for kind, b, t in tr if kind == 'finish'][0]
+    q.put((rank, len(red.buckets), min(issues.values()), sorted(issues.values()), max(hooks), t_finish, red.last_finish,
+           [g.numpy() for g in g_rank]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_reduce_overlaps_the_backward_pass():
+    """BASELINE config 4 asks for the gradient all-reduce OVERLAPPED with the backward pass.  On a slow-backward stub (6 layers, 60 ms of
+    backward each, one bucket per layer) over gloo with 2 ranks: the first bucket's all-reduce is issued ~5 layers before the last
+    parameter's gradient hook fires, every bucket is issued from its own hook (one per 60 ms, not all at the end), and finish() finds at
+    least N - 1 buckets already complete; the averaged gradients are identical on both ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, nb, first_issue, issues, last_hook, t_finish, fin, grads in res:
+        assert nb == 6 and len(issues) == 6
+        assert first_issue < last_hook - 0.2, (first_issue, last_hook)          # >= 4 x 60 ms of backward still to come when it went out
+        gaps = np.diff(issues)
+        assert (gaps > 0.03).all(), gaps                                        # issued layer by layer, not in a burst after the backward
+        assert fin['buckets'] == 6 and fin['completed_at_entry'] >= 5, fin
+    for a, b in zip(res[0][7], res[1][7]):
+        assert np.array_equal(a, b)

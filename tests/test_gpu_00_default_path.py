@@ -1,16 +1,21 @@
-"""End-to-end GPU parity of the SHIPPED DEFAULT configuration (whole network on NHWC arrays, exact bf16x3 GEMM synapses, forked
-gradients, h recomputed in backward, fused loss) — collected FIRST in `pytest -m gpu`, non-chaotic by construction.
+"""End-to-end GPU parity of the SHIPPED DEFAULT configuration — the kernels bench.py prices — collected FIRST in `pytest -m gpu`.
 
-  1. TRAJECTORY-PINNED (tests/_pinned.py): the product runs freely; the float64-convolution oracle is pinned to the product's spike
-     trajectory layer by layer.  Bars: per layer <= 2e-4 of the neurons may disagree with the oracle's own Heaviside and every one of
-     them must sit within MARGIN of its threshold; depths / loss / MDE <= 1e-5 relative; EVERY parameter gradient of the composed
-     backward <= 2e-3 relative L2.  All five model families at 64x80 (T = 3), every execution layout of the synapses, odd sizes with
-     a run-time T, and the config-3 network at 260x346, T = 5, on the committed fixture's input.
-  2. TEACHER-FORCED against the REFERENCE's own tensors (tests/golden/stages_*.npz, written by tests/golden/make_golden.py from
-     hooks on /root/reference/network/SNN_models.py's modules): every product stage is fed the reference's input of that stage at
-     full resolution and must reproduce the reference's spikes; the heads + I-pool must reproduce the reference's depth maps,
-     Total_Loss and MeanDepthError; blocks.npz's SEWResBlock records (IF and PLIF) likewise incl. input / weight / dL/dw gradients;
-     the ANN fixture (no thresholds, not chaotic) free-running.
+TRAJECTORY-PINNED (tests/_pinned.py): the product runs freely (whole network on NHWC arrays, exact bf16x3 MFMA synapses, fused up-conv
+kernels, packed spike tensors, forked + low-rank gradients, h recomputed in backward, fused loss); the float64-convolution oracle is pinned
+to the product's spike trajectory layer by layer.  Every test here ASSERTS THE LAUNCH TAGS of the run (fused.TIMER): the compile-time-T
+recompute / packed / forked / low-rank kernel forms must be the ones that ran — a silent fall-back to the run-time-T saved-h path fails
+the test.  T = 5 (BASELINE configs 3 / 4) for all five model families, T = 10 (config 5), T = 1 (config 2), the
+config-3 network at 260x346 with B = 1 (reference fixture input) and with the real config-3 batch B = 16; ONE case, labelled so, on the
+run-time-T kernels (T = 7, odd sizes).
+
+Bars, per kind of quantity (measured values: profiles/r03/parity_report_default_path*.json):
+  * per layer <= 1e-4 of the neuron updates may disagree with the oracle's own Heaviside, each within MARGIN of its threshold;
+  * depths / loss / MDE <= 1e-5 relative;
+  * every weight TENSOR gradient of the composed backward <= 2e-4 relative L2;
+  * every 0-dim PLIF w gradient within 1e-5 of its MAGNITUDE sum (float64, from hooks on the oracle's membranes) — the scalar is one
+    cancelling sum over a layer with condition number up to ~1e3, so a bar relative to the cancelled value measures the conditioning of
+    the layer, not the kernel.
+MIOpen-backed non-default execution layouts: tests/test_gpu_zz_layouts.py (collected last).
 """
 import json
 import os
@@ -24,78 +29,133 @@ from _pinned import pinned_parity, rel_l2
 from _util import load_npz, synth_input, synth_label
 
 pytestmark = pytest.mark.gpu
-REPORT = {}
 
-# Bars.  Measured on the MI355X (profiles/r02/parity_report_default_path.json): at most 5 disagreeing neurons per run (fraction <= 1.6e-5
-# of a layer), each within 1.0e-6 of its threshold; depths <= 3.4e-7, loss <= 8.3e-7, MDE <= 1.1e-7 relative; parameter gradients
-# <= 8.1e-4 relative L2 (the 0-dim PLIF `w` of a bottleneck node; weight tensors <= 1.1e-4; the full-resolution T = 5 network 8.2e-6).
+REPORT = {}
+REPORT_FILE = 'gpurun_out/parity_report_default_path.json'
+
 MARGIN_DEFAULT = 5e-5      # |h - v_th| of a neuron on which product and float64-conv oracle may disagree: exact bf16x3 / fp32-GEMM synapses
-MARGIN_MIOPEN = 5e-4       # layouts whose synapses are MIOpen fp32 convolutions (solver-dependent summation order, <= 1e-5 abs x gain 30)
 FLIP_FRAC = 1e-4           # fraction of a layer's neuron updates that may disagree at all
+TENSOR_GRAD_BAR = 2e-4     # relative L2 of a weight tensor's gradient
+PLIF_W_BAR = 1e-5          # |dL/dw - float64 value| / magnitude sum
 
 
 def _dump():
     os.makedirs('gpurun_out', exist_ok=True)
-    with open('gpurun_out/parity_report_default_path.json', 'w') as f:
+    with open(REPORT_FILE, 'w') as f:
         json.dump(REPORT, f, indent=1)
 
 
-def _check(tag, rep, margin, depth_bar=1e-5):
+def check(tag, rep, margin=MARGIN_DEFAULT, depth_bar=1e-5, tensor_bar=TENSOR_GRAD_BAR, plif_bar=PLIF_W_BAR):
     REPORT[tag] = rep
     _dump()
     assert rep['flip_frac_max'] <= FLIP_FRAC, (tag, rep['layers'])
     assert rep['margin_max'] <= margin, (tag, rep['layers'])
     assert rep['depth_max_abs_rel'] <= depth_bar, (tag, rep['depth_max_abs_rel'])
     assert rep['loss_rel'] <= 1e-5 and rep['mde_rel'] <= 1e-5, (tag, rep['loss'], rep['mde'])
-    assert rep['grad_rel_l2_max'] <= 2e-3, (tag, rep['grad_rel_l2'])
+    assert rep['tensor_grad_rel_l2_max'] <= tensor_bar, (tag, {k: v for k, v in rep['grad_rel_l2'].items() if k not in rep['plif_w']})
+    assert rep['plif_w_err_over_magnitude_max'] <= plif_bar, (tag, rep['plif_w'])
 
 
-# ======================================================================================================
-# 1. trajectory-pinned parity
-# ======================================================================================================
-@pytest.mark.parametrize('name,C', [('StereoSpike', 4), ('PLIFNet', 4), ('LIFNet', 4), ('PLIFNetMono', 2), ('ANN', 4)])
-def test_pinned_parity_small_default(name, C):
-    """64x80 frames, B = 2, T = 3 with BPTT (membranes carried) — every model family, shipped default configuration."""
-    H, W = 64, 80
-    T = 1 if name == 'ANN' else 3
+def assert_default_kernels(tags, T):
+    """The launch tags of one forward + backward of a 13-layer spiking network in the shipped default configuration at a compile-time T:
+    packed-only outputs on the five edges into exact-split convs, packed skip operands, forked gradients on conv1..3, the four heads'
+    gradients as rank-9 pairs (+ the full-resolution pair travelling on into the first encoder layer), nothing on the saved-h forms."""
+    fwd = {k: v for k, v in tags.items() if k.startswith('neuron_fwd')}
+    bwd = {k: v for k, v in tags.items() if k.startswith('neuron_bwd')}
+    assert sum(fwd.values()) == 13 and sum(bwd.values()) == 13, tags
+    assert not any(k.endswith('+h') for k in fwd) and not any('savedh' in k for k in bwd), ('saved-h (run-time-T) kernels ran', tags)
+    assert fwd.get('neuron_fwd_train+packed', 0) == 5 and fwd.get('neuron_fwd_train+skip+packed', 0) == 1, tags
+    assert fwd.get('neuron_fwd_train', 0) == 2 and fwd.get('neuron_fwd_train+skip', 0) == 5, tags
+    assert bwd.get('neuron_bwd+lronly', 0) == 1 and bwd.get('neuron_bwd+lr', 0) == 1 and bwd.get('neuron_bwd+lr+sum', 0) == 3, tags
+    assert bwd.get('neuron_bwd+fork', 0) == 3 and bwd.get('neuron_bwd', 0) == 5, tags
+    assert tags.get('upconv_cl_fwd', 0) == 8 and tags.get('upconv_cl_bwd', 0) == 8, tags
+
+
+FAMILIES = [('StereoSpike', 4), ('PLIFNet', 4), ('LIFNet', 4), ('PLIFNetMono', 2)]
+
+
+@pytest.mark.parametrize('name,C', FAMILIES)
+def test_pinned_parity_default_kernels_T5(name, C):
+    """64x80 frames, B = 2, T = 5 with BPTT (membranes carried) — the four spiking families on the kernels of BASELINE configs 3 / 4."""
+    H, W, T = 64, 80, 5
     orc, net = pair(name, H, W)
     x = synth_input(2, T, C, 77, H, W, lam=0.08)
     gt = synth_label(2, 78, H, W)
-    rep = pinned_parity(orc, net, x, gt, returns_spikes=name not in ('PLIFNetMono', 'ANN'), is_ann=name == 'ANN')
-    assert len(rep['layers']) == (0 if name == 'ANN' else 13)
-    # the ANN's BatchNorm layers run on batch statistics (training mode, as the reference): 1/std amplifies conv rounding (measured 1.2e-5)
-    _check(f'pinned_small_{name}', rep, MARGIN_DEFAULT, depth_bar=1e-4 if name == 'ANN' else 1e-5)
+    rep = pinned_parity(orc, net, x, gt, returns_spikes=name != 'PLIFNetMono')
+    assert len(rep['layers']) == 13 and len(rep['plif_w']) == {'StereoSpike': 0, 'LIFNet': 4}.get(name, 13)
+    assert_default_kernels(rep['launch_tags'], T)
+    check(f'pinned_T5_{name}', rep)
 
 
-@pytest.mark.parametrize('layout', ['all_nhwc_exact_split', 'exact_split_dense_spikes', 'all_nhwc', 'decoder_nhwc', 'nchw', 'two_op_miopen', 'saved_h_no_fork'])
-def test_pinned_parity_every_execution_layout(layout, monkeypatch):
-    """The same network through every execution variant of the synapses / neuron kernels: the shipped default; NHWC with plain fp32
-    GEMMs; NHWC decoder only; projected NCHW; the reference's two-op up-convs on MIOpen; saved-h backward without forked gradients."""
-    from stereospike_amd import fused
-    from stereospike_amd.network import blocks
-    monkeypatch.setattr(blocks, 'FUSE_UPCONV', layout != 'two_op_miopen')
-    exact = ('all_nhwc_exact_split', 'exact_split_dense_spikes', 'saved_h_no_fork')
-    monkeypatch.setattr(blocks, 'DECODER_CHANNELS_LAST', layout in ('decoder_nhwc', 'all_nhwc') + exact)
-    monkeypatch.setattr(blocks, 'ENCODER_CHANNELS_LAST', layout in ('all_nhwc',) + exact)
-    monkeypatch.setattr(fused, 'EXACT_SPLIT_GEMM', layout in exact)
-    monkeypatch.setattr(fused, 'PACK_SPIKES', layout != 'exact_split_dense_spikes')
-    monkeypatch.setattr(fused, 'ASSERT_EXACT_SPLIT', True)
-    if layout == 'saved_h_no_fork':
-        monkeypatch.setattr(fused, 'RECOMPUTE_H', False)
-        monkeypatch.setattr(blocks, 'FORK_OUTPUTS', False)
+@pytest.mark.parametrize('name,C,T', [('StereoSpike', 4, 10), ('PLIFNet', 4, 10), ('PLIFNetMono', 2, 1), ('StereoSpike', 4, 1)])
+def test_pinned_parity_default_kernels_T10_T1(name, C, T):
+    """The other compile-time time-step counts BASELINE names: T = 10 (config 5) and T = 1 (config 2: monocular PLIF)."""
     H, W = 64, 80
-    orc, net = pair('PLIFNet', H, W)
-    x = synth_input(2, 3, 4, 77, H, W, lam=0.08)
-    gt = synth_label(2, 78, H, W)
+    orc, net = pair(name, H, W)
+    x = synth_input(2, T, C, 79, H, W, lam=0.12 if T == 1 else 0.08)
+    gt = synth_label(2, 80, H, W)
+    rep = pinned_parity(orc, net, x, gt, returns_spikes=name != 'PLIFNetMono')
+    assert_default_kernels(rep['launch_tags'], T)
+    check(f'pinned_T{T}_{name}', rep)
+
+
+def test_pinned_parity_ann():
+    """BASELINE config 1's network (no thresholds: nothing to pin), T = 1: forward, loss and every gradient against the float64-conv oracle."""
+    H, W = 64, 80
+    orc, net = pair('ANN', H, W)
+    rep = pinned_parity(orc, net, synth_input(2, 1, 4, 77, H, W, lam=0.08), synth_label(2, 78, H, W), returns_spikes=False, is_ann=True)
+    assert len(rep['layers']) == 0
+    # the ANN's BatchNorm layers run on batch statistics (training mode, as the reference): 1/std amplifies conv rounding (measured 1.2e-5)
+    check('pinned_ANN', rep, depth_bar=1e-4, tensor_bar=2e-3)
+
+
+def test_pinned_parity_runtime_T_kernels_odd_sizes():
+    """RUN-TIME-T KERNELS (saved h, torch adds the forked gradients) — the one case that is NOT the benchmarked path, labelled so: T = 7,
+    frame size with odd pyramid levels (50x70 -> 25x35 -> 13x18 -> 7x9 -> 4x5), B = 3."""
+    orc, net = pair('PLIFNet', 50, 70)
+    x = synth_input(3, 7, 4, 123, 50, 70, lam=0.08)
+    gt = synth_label(3, 124, 50, 70)
     rep = pinned_parity(orc, net, x, gt)
-    _check(f'pinned_layout_{layout}', rep, MARGIN_DEFAULT if layout in exact else MARGIN_MIOPEN)
+    tags = rep['launch_tags']
+    assert all(k.endswith('+h') for k in tags if k.startswith('neuron_fwd')) and all('savedh' in k for k in tags if k.startswith('neuron_bwd')), tags
+    check('pinned_runtimeT_odd_50x70_T7_PLIFNet', rep)
+
+
+def test_pinned_parity_full_resolution_stereospike_T5():
+    """BASELINE config 3 network at 260x346, B = 1, T = 5 on the committed fixture's input and weights (model_stereospike_T5.npz)."""
+    z = load_npz('model_stereospike_T5.npz')
+    x = torch.tensor(z['x'].astype(np.float32))
+    gt = torch.tensor(z['gt'])
+    orc, net = pair('StereoSpike', 260, 346, seed=int(z['seed']))
+    assert state_sha(orc) == str(z['state_sha'])
+    rep = pinned_parity(orc, net, x, gt)
+    assert_default_kernels(rep['launch_tags'], 5)
+    check('pinned_full_stereospike_T5', rep)
+    # statistics of the free-running product against the reference's fixture (chaotic per neuron, stable in the mean)
+    for nm, dens in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), rep['product_spike_density']):
+        assert abs(dens - float((z[nm] != 0).mean())) <= 1e-2, nm
+    assert abs(rep['loss'][0] - float(z['loss'])) <= 0.1 * abs(float(z['loss']))
+
+
+def test_pinned_parity_config3_step_B16_T5():
+    """THE config-3 step: StereoSpike, B = 16, T = 5, 260x346 (bench.py's synthetic input distribution) — the launch shapes bench.py prices
+    (2.3e8 updates in the bottom layer's launch, the fused up-conv kernels' persistent grids at the real frame count, split-K weight
+    gradients over 1.4e6 rows).  The oracle walks the batch in chunks of 2 samples (tests/_pinned.py: only the loss couples the batch)."""
+    if os.environ.get('SS_SKIP_B16_PARITY') == '1':
+        pytest.skip('SS_SKIP_B16_PARITY=1')
+    orc, net = pair('StereoSpike', 260, 346)
+    x = synth_input(16, 5, 4, 2021)
+    gt = synth_label(16, 2022)
+    rep = pinned_parity(orc, net, x, gt, oracle_chunk=2)
+    assert_default_kernels(rep['launch_tags'], 5)
+    check('pinned_config3_B16_T5', rep)
 
 
 def test_packed_spike_tensors_are_in_effect():
-    """fused.PACK_SPIKES (default on; every pinned test above runs with it): 2-bit packed spike tensors between conv2 .. bottleneck and
+    """fused.PACK_SPIKES (default on; the pinned tests above assert its launch tags): 2-bit packed spike tensors between conv2 .. bottleneck and
     their consumers (packed-only: the autograd output is a data-less anchor), packed skip operands for the decoder.  Here: the packed
     form really is in effect, and within ONE launch that writes both forms (bottom, conv1) unpack(packed) == the dense tensor bit for bit;
-    with PACK_SPIKES off no packed tensor exists.  (Bit-equality of the consumers on packed vs dense input: tests/test_gpu_kernels.py.)"""
+    with PACK_SPIKES off no packed tensor exists.  (Bit-equality of the consumers on packed vs dense input: tests/test_gpu_01_kernels.py.)"""
     from stereospike_amd import fused
     from stereospike_amd.clock_driven import functional
     from stereospike_amd.network.loss import Total_Loss
@@ -133,7 +193,7 @@ def test_packed_spike_tensors_are_in_effect():
 
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
 def test_low_rank_head_gradients_are_in_effect_and_equal_the_dense_form(name):
-    """fused.LOWRANK_HEAD_GRAD (default on; every pinned test above runs with it): the four prediction heads hand their input gradient to the
+    """fused.LOWRANK_HEAD_GRAD (default on; the pinned tests above assert its launch tags): the four prediction heads hand their input gradient to the
     stage's neuron backward as the rank-9 pair (g_P, W2) — the full-resolution pair travels on through the fused skip add into the first
     encoder layer's backward — instead of a GEMM + a C-channel tensor.  Here: the low-rank launches really happen (4 + 1 per backward), and
     every parameter gradient equals the dense form's up to the rounding of a 9-term sum done in another order."""
@@ -178,162 +238,3 @@ def test_low_rank_head_gradients_are_in_effect_and_equal_the_dense_form(name):
         assert float((g_on[n] - g_off[n]).norm()) <= bar * den + 1e-12, (n, float((g_on[n] - g_off[n]).norm()) / max(den, 1e-30))
 
 
-def test_pinned_parity_odd_sizes_runtime_T():
-    """Frame size with odd pyramid levels (50x70 -> 25x35 -> 13x18 -> 7x9 -> 4x5), T = 7 (run-time-T kernels, saved h), B = 3."""
-    orc, net = pair('PLIFNet', 50, 70)
-    x = synth_input(3, 7, 4, 123, 50, 70, lam=0.08)
-    gt = synth_label(3, 124, 50, 70)
-    _check('pinned_odd_50x70_T7_PLIFNet', pinned_parity(orc, net, x, gt), MARGIN_DEFAULT)
-
-
-def test_pinned_parity_full_resolution_stereospike_T5():
-    """BASELINE config 3 network at 260x346, B = 1, T = 5 on the committed fixture's input and weights (model_stereospike_T5.npz)."""
-    z = load_npz('model_stereospike_T5.npz')
-    x = torch.tensor(z['x'].astype(np.float32))
-    gt = torch.tensor(z['gt'])
-    orc, net = pair('StereoSpike', 260, 346, seed=int(z['seed']))
-    assert state_sha(orc) == str(z['state_sha'])
-    rep = pinned_parity(orc, net, x, gt)
-    _check('pinned_full_stereospike_T5', rep, MARGIN_DEFAULT)
-    # statistics of the free-running product against the reference's fixture (chaotic per neuron, stable in the mean)
-    for nm, dens in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), rep['product_spike_density']):
-        assert abs(dens - float((z[nm] != 0).mean())) <= 1e-2, nm
-    assert abs(rep['loss'][0] - float(z['loss'])) <= 0.1 * abs(float(z['loss']))
-
-
-# ======================================================================================================
-# 2. teacher-forced against the reference's own tensors
-# ======================================================================================================
-def _unpack(z, name):
-    shape = tuple(int(v) for v in z[f'{name}_shape'])
-    n = int(np.prod(shape))
-    a = np.unpackbits(z[f'{name}_p0'])[:n].astype(np.float32)
-    if f'{name}_p1' in z.files:
-        a = a + 2.0 * np.unpackbits(z[f'{name}_p1'])[:n].astype(np.float32)
-    return torch.from_numpy(a.reshape(shape))                       # [T, 1, C, H, W]
-
-
-@pytest.mark.parametrize('tag,name', [('stereospike_T1', 'StereoSpike'), ('lif_T1', 'LIFNet'), ('mono_plif_T1', 'PLIFNetMono'),
-                                      ('plif_T1', 'PLIFNet'), ('plif_T5', 'PLIFNet')])
-def test_fixture_stages_teacher_forced(tag, name):
-    from stereospike_amd.clock_driven import functional
-    from stereospike_amd.fused import ipool
-    from stereospike_amd.network.loss import Total_Loss
-    from stereospike_amd.network.metrics import MeanDepthError
-    zm, zs = load_npz(f'model_{tag}.npz'), load_npz(f'stages_{tag}.npz')
-    T = int(zs['T'])
-    orc, net = pair(name, 260, 346, seed=int(zm['seed']))
-    assert state_sha(orc) == str(zm['state_sha']), 'seeded default init differs from the fixture generator'
-    del orc
-    ref = {n: _unpack(zs, n) for n in json.loads(str(zs['names']))}
-    x = torch.tensor(zm['x'].astype(np.float32)).transpose(0, 1).contiguous()     # [T, 1, C, H, W]
-    pm = dict(net.named_modules())
-    cl = lambda t: t.to(DEV).permute(0, 1, 3, 4, 2).contiguous()                    # noqa: E731  [T, B, C, H, W] -> NHWC array
-    rep = {}
-
-    def mism(out_cl, want):
-        return float((out_cl.permute(0, 1, 4, 2, 3).cpu() != want).float().mean())
-    with torch.no_grad():
-        functional.reset_net(net)
-        prev = {'bottom': x, 'conv1': ref['bottom'], 'conv2': ref['conv1'], 'conv3': ref['conv2'], 'conv4': ref['conv3']}
-        for st in ('bottom', 'conv1', 'conv2', 'conv3', 'conv4'):
-            out = pm[st].forward_sequence_conv_cl(cl(prev[st]), spikes_in=st != 'bottom')
-            rep[st] = mism(out, ref[st])
-        out = pm['bottleneck.0'].forward_sequence_cl(cl(ref['conv4']), spikes_in=True)
-        rep['bottleneck.0'] = mism(out, ref['bottleneck.0'])
-        out = pm['bottleneck.1'].forward_sequence_cl(cl(ref['bottleneck.0']), spikes_in=True)
-        rep['bottleneck.1'] = mism(out, ref['bottleneck.1'])
-        cur, heads = ref['bottleneck.1'], []
-        for lvl, skip in ((4, 'conv3'), (3, 'conv2'), (2, 'conv1'), (1, 'bottom')):
-            want = ref[f'deconv{lvl}'] + ref[skip]                                   # out_addK of the reference
-            out = pm[f'deconv{lvl}'].forward_sequence_cl(cl(cur), cl(ref[skip]), spikes_in=True)
-            rep[f'deconv{lvl}'] = mism(out, want)
-            heads.append(pm[f'predict_depth{lvl}'][0].forward_projected_cl(cl(want).flatten(0, 1)).view(T, 1, 1, 260, 346))
-            cur = want
-        depth_seq = ipool(torch.stack(heads), float(pm['predict_depth4'][1].scale_value), 0.0)
-        depths = [depth_seq[T - 1, k] for k in (3, 2, 1, 0)]
-        scale = float(np.abs(zm['depth1']).max())
-        rep['depth_max_abs_rel'] = max(float(np.abs(d.cpu().numpy() - zm[f'depth{i + 1}']).max()) for i, d in enumerate(depths)) / scale
-        gt = torch.tensor(zm['gt']).to(DEV)
-        L = float(Total_Loss()(depths, gt, None))
-        mde = float(MeanDepthError(depths[0], gt))
-        rep['loss_rel'] = abs(L - float(zm['loss'])) / abs(float(zm['loss']))
-        rep['mde_rel'] = abs(mde - float(zm['mde'])) / abs(float(zm['mde']))
-    REPORT[f'fixture_stages_{tag}'] = rep
-    _dump()
-    for st in json.loads(str(zs['names'])):
-        assert rep[st] <= FLIP_FRAC, (st, rep)
-    assert rep['depth_max_abs_rel'] <= 1e-5 and rep['loss_rel'] <= 1e-5 and rep['mde_rel'] <= 1e-5, rep
-
-
-def test_fixture_ann_T1():
-    """BASELINE config 1 network (equivalent ANN: no thresholds, hence no chaos) at 260x346 on the reference's fixture input / weights:
-    (a) with BatchNorm in eval mode, against the float64-conv oracle (forward, loss, every gradient) at fp32 tolerance; (b) in training
-    mode (BatchNorm on the statistics of ONE sample, B = 1, as the reference ran it) free-running against the numbers the reference's
-    own ANN_models.py produced on oneDNN.  The single-sample 1/std amplifies ANY fp32 conv rounding difference (MIOpen vs oneDNN vs
-    float64: measured depth 7.4e-4, loss 4.7e-5, gradient norms 4.5e-3 — the same vs the float64 oracle), hence the wider bars of (b)."""
-    from stereospike_amd.clock_driven import functional
-    from stereospike_amd.network.loss import Total_Loss
-    z = load_npz('model_ann_T1.npz')
-    orc, net = pair('ANN', 260, 346, seed=int(z['seed']))
-    assert state_sha(orc) == str(z['state_sha'])
-    xc, gtc = torch.tensor(z['x'].astype(np.float32)), torch.tensor(z['gt'])
-    # (a) BatchNorm in eval mode (running statistics: the well-conditioned form of the same graph) against the float64-conv oracle
-    orc.eval(), net.eval()
-    rep_p = pinned_parity(orc, net, xc, gtc, returns_spikes=False, is_ann=True)
-    REPORT['pinned_full_ann_T1_bn_eval'] = rep_p
-    assert rep_p['depth_max_abs_rel'] <= 1e-5 and rep_p['loss_rel'] <= 1e-5 and rep_p['grad_rel_l2_max'] <= 2e-3, rep_p
-    net.train()
-    net.zero_grad()
-    x, gt = xc.to(DEV), gtc.to(DEV)
-    functional.reset_net(net)
-    d = net(x)
-    L = Total_Loss()(d, gt, None)
-    L.backward()
-    scale = float(np.abs(z['depth1']).max())
-    rep = dict(depth_max_abs_rel=max(float(np.abs(t.detach().cpu().numpy() - z[f'depth{i + 1}']).max()) for i, t in enumerate(d)) / scale,
-               loss_rel=abs(float(L) - float(z['loss'])) / abs(float(z['loss'])))
-    names = json.loads(str(z['grad_names']))
-    g = dict(net.named_parameters())
-    rep['grad_l2_rel'] = max(abs(float(g[k].grad.double().norm()) - float(z['grad_l2'][i])) / (float(z['grad_l2'][i]) + 1e-30)
-                             for i, k in enumerate(names) if float(z['grad_l2'][i]) > 1e-6)
-    REPORT['fixture_ann_T1'] = rep
-    _dump()
-    assert rep['depth_max_abs_rel'] <= 5e-3 and rep['loss_rel'] <= 1e-3 and rep['grad_l2_rel'] <= 3e-2, rep
-
-
-@pytest.mark.parametrize('form', ['nchw', 'nhwc'])
-@pytest.mark.parametrize('tag,use_plif', [('sew_if', False), ('sew_plif', True)])
-def test_fixture_sew_blocks(tag, use_plif, form):
-    """blocks.npz: the reference's own SEWResBlock(32) (blocks.py:135-181), 3 stateful calls without reset on one input, then backward:
-    outputs, input gradient, weight gradients, PLIF dL/dw and final membranes against the product block (T = 3: run-time-T kernels)."""
-    from stereospike_amd.clock_driven import functional, surrogate
-    from stereospike_amd.network.blocks import SEWResBlock
-    z = load_npz('blocks.npz')
-    blk = SEWResBlock(32, connect_function='ADD', multiply_factor=10., use_plif=use_plif, tau=3., surrogate_function=surrogate.Sigmoid(4.0))
-    blk.load_state_dict({k[len(tag) + 3:]: torch.tensor(z[k]) for k in z.files if k.startswith(tag + '_w_')})
-    blk = blk.to(DEV)
-    x = torch.tensor(z[tag + '_x'].astype(np.float32))
-    go = torch.tensor(z[tag + '_go']).to(DEV)
-    xs = x.unsqueeze(0).repeat(3, 1, 1, 1, 1).to(DEV)
-    functional.reset_net(blk)
-    if form == 'nhwc':
-        xs = xs.permute(0, 1, 3, 4, 2).contiguous().requires_grad_()
-        y = blk.forward_sequence_cl(xs, spikes_in=True).permute(0, 1, 4, 2, 3)
-    else:
-        xs.requires_grad_()
-        y = blk.forward_sequence(xs)
-    (y * go).sum().backward()
-    gx = xs.grad.sum(0)
-    if form == 'nhwc':
-        gx = gx.permute(0, 3, 1, 2)
-    rep = dict(spike_mismatch=float((y.detach().cpu() != torch.tensor(z[tag + '_y'].astype(np.float32))).float().mean()),
-               gx_rel_l2=rel_l2(gx, torch.tensor(z[tag + '_gx'])),
-               g_rel_l2={k: rel_l2(p.grad, torch.tensor(z[f'{tag}_g_{k}'])) for k, p in blk.named_parameters()},
-               v_sn1=float((blk.sn1.v.detach().cpu() - torch.tensor(z[tag + '_v_sn1'])).abs().max()),
-               v_sn2=float((blk.sn2.v.detach().cpu() - torch.tensor(z[tag + '_v_sn2'])).abs().max()))
-    REPORT[f'fixture_{tag}_{form}'] = rep
-    _dump()
-    assert rep['spike_mismatch'] <= FLIP_FRAC, rep
-    bar = 2e-3 + 500 * rep['spike_mismatch']                 # one flipped spike moves a 32-channel block's gradients by ~0.3 %
-    assert rep['gx_rel_l2'] <= bar and max(rep['g_rel_l2'].values()) <= bar, rep

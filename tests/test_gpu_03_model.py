@@ -85,7 +85,7 @@ def _rel_l2(a, b):
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet', 'LIFNet'])
 def test_teacher_forced_stages(name):
     from stereospike_amd.clock_driven import functional
-    H, W, B, T = 64, 80, 2, 3
+    H, W, B, T = 64, 80, 2, 5
     orc, net = _pair(name, H, W)
     x = synth_input(B, T, 4, 77, H, W, lam=0.08)
     rec, depths = _record_oracle(orc, x)
@@ -273,7 +273,7 @@ def test_dp_reducer_on_rccl_single_rank():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
     try:
-        x, gt = synthetic_batch(2, 3, H=64, W=80, seed=5, device=DEV, lam=0.08)
+        x, gt = synthetic_batch(2, 5, H=64, W=80, seed=5, device=DEV, lam=0.08)
         results = []
         for use_dp in (False, True):
             torch.manual_seed(7)
@@ -304,7 +304,7 @@ def test_autocast_16bit_activations(dt):
     from stereospike_amd.network.loss import Total_Loss
     torch.manual_seed(3)
     net = _product('StereoSpike', input_size=(64, 80)).to(DEV)
-    x = synth_input(2, 3, 4, 31, 64, 80, lam=0.08).to(DEV)
+    x = synth_input(2, 5, 4, 31, 64, 80, lam=0.08).to(DEV)
     gt = synth_label(2, 32, 64, 80).to(DEV)
     with torch.no_grad():
         functional.reset_net(net)
@@ -335,7 +335,7 @@ def test_training_reduces_the_loss(name):
     torch.manual_seed(11)
     net = _product(name, input_size=(64, 80)).to(DEV)
     tr = Trainer(net, lr=1e-3)
-    x, gt = synthetic_batch(2, 3, H=64, W=80, seed=9, device=DEV, lam=0.08)
+    x, gt = synthetic_batch(2, 5, H=64, W=80, seed=9, device=DEV, lam=0.08)
     losses = [float(tr.step(x, gt)[0]) for _ in range(60)]
     REPORT[f'overfit_{name}'] = dict(first=losses[0], best=min(losses), last=losses[-1])
     _dump()
@@ -346,7 +346,7 @@ def test_training_reduces_the_loss(name):
 def test_kernel_hyper_parameter_fuzz():
     """Random (kind, scale, tau / k, v_th, v_reset, alpha, T, N, skip, v_init) against the C oracle: forward bit-exact,
     ATan backward bit-exact, Sigmoid backward <= 1e-6."""
-    from test_gpu_kernels import hip_fwd, hip_bwd
+    from test_gpu_01_kernels import hip_fwd, hip_bwd
     from _util import c_oracle, bit_equal, rel_err
     rng = np.random.default_rng(2024)
     for it in range(40):
@@ -401,7 +401,7 @@ def test_graphed_inference_replays_the_eager_forward_bit_for_bit():
 
 def test_graphed_trainer_matches_the_eager_trainer():
     """engine.GraphedTrainer (one HIP-graph replay per iteration) against engine.Trainer (eager) from identical weights on the same
-    batch sequence, T = 1 and T = 3, identical iteration count.  Two EAGER runs of this training loop are themselves not bit-reproducible
+    batch sequence, T = 1 and T = 5, identical iteration count.  Two EAGER runs of this training loop are themselves not bit-reproducible
     (MIOpen's atomic split-K weight gradients; the network amplifies ulp-level differences), so the bar is calibrated on that: the
     graphed run must stay within 4x the eager-vs-eager deviation (+ small absolute terms) in loss trajectory and parameter update."""
     from stereospike_amd.clock_driven import surrogate
@@ -414,7 +414,7 @@ def test_graphed_trainer_matches_the_eager_trainer():
 
     def cosine(a, b):
         return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
-    for T in (1, 3):
+    for T in (1, 5):
         torch.manual_seed(11)
         nets = [StereoSpike(surrogate_function=surrogate.ATan(), multiply_factor=10., input_size=(H, W)).to(DEV) for _ in range(3)]
         for n in nets[1:]:
@@ -471,3 +471,89 @@ print('DETERMINISTIC_OK', [float(v) for v in l0])
     # own process: torch.use_deterministic_algorithms / TunableOp state must not leak into the other tests
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'DETERMINISTIC_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize('amp,T', [(torch.float16, 10), (None, 5)])
+def test_in_step_firing_rate_counters_are_exact(amp, T):
+    """BASELINE config 5 (T = 10, fp16 activations, counters on) and config 3's form: Trainer(count_rates=True).last_rates — the firing
+    rates the fused kernels count inside the TRAINING forward itself (wavefront reductions -> per-workgroup partials -> fixed second pass) —
+    equal count_nonzero / numel of the spike tensors of that very forward EXACTLY (integer counts; the one fp32 division is repeated here).
+    The reference obtains them from a second forward (/root/reference/network/SNN_models.py:194-245, calculate_firing_rates.py:92-149)."""
+    from _pinned import record_product_spikes
+    from stereospike_amd.engine import Trainer, synthetic_batch
+    torch.manual_seed(5)
+    net = _product('StereoSpike', input_size=(64, 80)).to(DEV)
+    tr = Trainer(net, amp_dtype=amp, count_rates=True)
+    x, gt = synthetic_batch(2, T, H=64, W=80, seed=3, device=DEV, lam=0.08)
+    with record_product_spikes(net) as rec:
+        tr.step(x, gt)
+    rates = tr.last_rates
+    z = {n: v[0].to(torch.int64) for n, v in rec.items()}                    # pure spikes [T, B, C, H, W] per node
+    want = {f'out_{n}': z[f'{n}.2'] for n in ('bottom', 'conv1', 'conv2', 'conv3', 'conv4')}
+    bn0 = z['bottleneck.0.sn2'] + z['conv4.2']
+    want['out_rconv'] = z['bottleneck.1.sn2'] + bn0
+    for lvl, skip in ((4, 'conv3'), (3, 'conv2'), (2, 'conv1'), (1, 'bottom')):
+        want[f'out_deconv{lvl}'] = z[f'deconv{lvl}.2']
+        want[f'out_add{lvl}'] = z[f'deconv{lvl}.2'] + z[f'{skip}.2']
+    assert set(want) <= set(rates) and len(want) == 14
+    for k, t in want.items():
+        cnt = torch.tensor(int(torch.count_nonzero(t)), dtype=torch.int64)
+        assert 0 < int(cnt) < t.numel(), k
+        assert float(rates[k]) == float(cnt.float() / t.numel()), (k, float(rates[k]), int(cnt), t.numel())
+
+
+def test_graphed_trainer_fp16_keeps_a_dynamic_loss_scale():
+    """the fp16 GradScaler's state must live outside the captured graph — the scale grows across replays (growth_interval = 1)
+    instead of being reset to 2^16 by fill kernels captured with the iteration, and an overflow backs it off for good."""
+    from stereospike_amd.engine import GraphedTrainer, synthetic_batch
+    torch.manual_seed(5)
+    net = _product('StereoSpike', input_size=(64, 80)).to(DEV)
+    tr = GraphedTrainer(net, lr=1e-5, amp_dtype=torch.float16, warmup=2)
+    tr.scaler.set_growth_interval(1)
+    x, gt = synthetic_batch(2, 5, H=64, W=80, seed=3, device=DEV, lam=0.08)
+    scales = []
+    for _ in range(4):
+        tr.step(x, gt)
+        torch.cuda.synchronize()
+        scales.append(float(tr.scaler.get_scale()))
+    assert scales[0] in (2.0 ** 17, 2.0 ** 15), scales          # one update after the first replay: grown (or backed off), never the initial value
+    assert len(set(scales)) == 4 and all(b == 2 * a or b == a / 2 for a, b in zip(scales, scales[1:])), scales
+
+
+def test_low_rank_pairs_with_interleaved_networks_and_retained_graphs():
+    """The heads' rank-9 gradient pairs travel inside the gradient tensor itself (fused.lowrank_buffer), not in module state: two networks
+    whose forward / backward passes are interleaved, and a second backward over a retained graph, give the gradients of the plain order."""
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    H, W = 64, 80
+    nets = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        nets.append(_product('StereoSpike', input_size=(H, W)).to(DEV))
+    xs = [synth_input(2, 5, 4, 40 + i, H, W, lam=0.08).to(DEV) for i in range(2)]
+    gt = synth_label(2, 8, H, W).to(DEV)
+
+    def loss_of(i):
+        functional.reset_net(nets[i])
+        d, s = nets[i].forward_sequence(xs[i])
+        return Total_Loss()(d, gt, s)
+
+    def grads(i):
+        return [p.grad.detach().clone() for p in nets[i].parameters()]
+    ref = []
+    for i in range(2):                          # plain order: forward, backward, one network after the other
+        nets[i].zero_grad()
+        loss_of(i).backward()
+        ref.append(grads(i))
+    for n in nets:
+        n.zero_grad()
+    L0, L1 = loss_of(0), loss_of(1)             # interleaved: both graphs alive, backward in the opposite order
+    L1.backward(retain_graph=True)
+    L0.backward()
+    for i in range(2):
+        for a, b in zip(grads(i), ref[i]):
+            assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+    nets[1].zero_grad()
+    L1.backward()                               # second pass over the retained graph: new pairs, same gradient
+    for a, b in zip(grads(1), ref[1]):
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12

@@ -216,22 +216,32 @@ def test_config1_equivalent_ann_runs_on_cpu_and_equals_the_oracle():
     assert all(torch.equal(a, b) for a, b in zip(d0b, d1b)) and not torch.equal(d1b[0], d1[0])
 
 
-def test_low_rank_gradient_registry():
-    """fused.lowrank_anchor / lowrank_of: the pair is found through any view of the anchor, plain tensors (also zero-stride ones) are not
-    mistaken for anchors, an unknowing consumer sees NaNs (loud), the registry is bounded, and lowrank_dense is the product it stands for."""
-    import torch
-    from stereospike_amd import fused
-    fused._LOWRANK.clear()
+def test_lowrank_pair_travels_in_a_self_describing_buffer():
+    """fused.lowrank_buffer / lowrank_of: the pair is found through any view of the anchor (no module-level registry: it lives exactly as
+    long as the gradient tensor does); plain tensors and ordinary expanded scalars are not mistaken for anchors; an unknowing consumer sees
+    NaNs; an anchor that reaches a layer of another shape RAISES; two interleaved producers do not disturb each other."""
+    import gc
+    import weakref
+    from stereospike_amd import _lib, fused
+    assert not hasattr(fused, '_LOWRANK')
     p, w = torch.randn(6, 9), torch.randn(9, 8)
     a = fused.lowrank_anchor((2, 3, 8), p, w)
-    assert a.shape == (2, 3, 8) and not any(a.stride()) and bool(torch.isnan(a).all())
-    for v in (a, a.view(6, 8), a.reshape(1, 2, 3, 8), a[1]):
+    b, pb, wb = fused.lowrank_buffer((4, 5, 16), 'cpu')                 # a second, interleaved producer (another head / another network)
+    pb.copy_(torch.randn(20, 9)), wb.copy_(torch.randn(9, 16))
+    assert a.shape == (2, 3, 8) and not any(a.stride()) and bool(torch.isnan(a.contiguous()).all())
+    for v in (a, a.view(6, 8), a.view(2, 3, 8).view_as(a), a.flatten(0, 1), a.reshape(1, 6, 8)):
         got = fused.lowrank_of(v)
-        assert got is not None and got[0] is p and got[1] is w
+        assert got is not None and torch.equal(got[0], p) and torch.equal(got[1], w)
+    gb = fused.lowrank_of(b.flatten(0, 1))
+    assert torch.equal(gb[0], pb) and torch.equal(gb[1], wb) and gb[0].data_ptr() == pb.data_ptr()      # views of the buffer, no copies
     assert fused.lowrank_of(torch.zeros(2, 3, 8)) is None and fused.lowrank_of(None) is None
-    assert fused.lowrank_of(torch.zeros(1).expand(2, 3, 8)) is None            # a zero-stride tensor that is not an anchor
+    assert fused.lowrank_of(torch.zeros(1).expand(2, 3, 8)) is None            # an ordinary expanded scalar gradient
+    assert fused.lowrank_of(torch.zeros(())) is None
     assert torch.equal(fused.lowrank_dense((p, w), (2, 3, 8)), (p @ w).view(2, 3, 8))
-    for _ in range(3 * fused._LOWRANK_KEEP):
-        fused.lowrank_anchor((1, 8), p[:1], w)
-    assert len(fused._LOWRANK) == fused._LOWRANK_KEEP and fused.lowrank_of(a) is None    # evicted: the oldest pairs are dropped
-    fused._LOWRANK.clear()
+    with pytest.raises(_lib.SSNeuronError):
+        fused.lowrank_of(a.view(6, 8)[:, :4])                                   # same storage, a shape the pair was not made for
+    # lifetime = the gradient's lifetime: dropping the anchor frees the pair (nothing else holds it)
+    probe = weakref.ref(a)
+    del a, got, v
+    gc.collect()
+    assert probe() is None

@@ -223,7 +223,18 @@ def test_pinned_oracle_machinery_on_the_host_backend(host_backend, name):
     assert len(rep['layers']) == 13
     assert rep['flip_frac_max'] <= 2e-4 and rep['margin_max'] <= 1e-3, rep['layers']
     assert rep['depth_max_abs_rel'] <= 1e-5 and rep['loss_rel'] <= 1e-5 and rep['mde_rel'] <= 1e-5, rep
-    assert rep['grad_rel_l2_max'] <= 2e-3, rep['grad_rel_l2']
+    assert rep['tensor_grad_rel_l2_max'] <= 2e-4, rep['grad_rel_l2']
+    # per-kind bars: the 0-dim PLIF w gradients against the float64 sum in units of the magnitude sum (tests/_pinned.py)
+    assert len(rep['plif_w']) == (13 if name == 'PLIFNet' else 0)
+    assert rep['plif_w_err_over_magnitude_max'] <= 1e-5, rep['plif_w']
+    assert all(v['oracle_fp32_err_over_magnitude'] <= 1e-5 and v['condition'] >= 1.0 for v in rep['plif_w'].values()), rep['plif_w']
+    # the chunked oracle evaluation (a config-3-sized batch in bounded memory) is the same function
+    rep_c = pinned_parity(orc, net, x, gt, oracle_chunk=1)
+    assert rep_c['layers'] == rep['layers'] and abs(rep_c['loss'][1] - rep['loss'][1]) <= 1e-6 * abs(rep['loss'][1])
+    for k in rep['grad_rel_l2']:
+        assert abs(rep_c['grad_rel_l2'][k] - rep['grad_rel_l2'][k]) <= 5e-6 + 0.05 * rep['grad_rel_l2'][k], (k, rep_c['grad_rel_l2'][k], rep['grad_rel_l2'][k])
+    for k in rep['plif_w']:
+        assert abs(rep_c['plif_w'][k]['oracle_float64'] - rep['plif_w'][k]['oracle_float64']) <= 1e-6 * rep['plif_w'][k]['magnitude_sum']
     # the protocol must SEE a wrong kernel: the same comparison with the product's gain off by one ulp-scale factor of 1e-3 fails loudly
     net.bottom[1].scale_value = net.bottom[1].scale_value * 1.05
     bad = pinned_parity(orc, net, x, gt)

@@ -175,7 +175,9 @@ def test_oracle_network_vs_reference_fixture(tag, name, kw, T):
     if tag == 'stereospike_T1':      # one backward is enough for the CPU budget
         loss.backward()
         l2 = np.array([p.grad.double().norm().item() for p in net.parameters()])
-        assert np.allclose(l2, z['grad_l2'], rtol=1e-12 if exact else 2e-2, atol=0)
+        # forward values are bit-stable on one machine; oneDNN's backward kernels reduce in an order that depends on the thread partition of
+        # the moment (this test alone vs inside the suite differ by 4e-8 relative): fp32 reduction-order tolerance, not 1e-12
+        assert np.allclose(l2, z['grad_l2'], rtol=1e-6 if exact else 2e-2, atol=0)
 
 
 def test_loss_and_mde_restatement_vs_pure_reference_fixture():
