@@ -307,7 +307,7 @@ int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, lo
  * weight gradient of ss_spike_wgrad_f32 in one pass — a lane computes g_P for 8 consecutive source pixels of one column, which IS the MFMA
  * fragment of the contraction over sources; g_P is written once (for the data-gradient GEMM) and never read back for g_w.
  *   g_out [NB][H][W][C_out] fp32 (gradient of the stage output), x [NB][h][w][C_in] fp32 spike counts, tables as for ss_upconv_cl_bwd_f32,
- *   g_P [NB*h*w][25*C_out] (tap-major columns), g_w [C_in][25*C_out] (+= when accumulate), ws: ss_upconv_bwd_fused_ws_floats floats.
+ *   g_P [NB*h*w][25*C_out] (tap-major columns; NULLABLE since ABI 5: not written), g_w [C_in][25*C_out] (+= when accumulate), ws: ss_upconv_bwd_fused_ws_floats floats.
  * ss_upconv_bwd_fused_supported: compiled stage shapes ((64,32), (128,64), k = 5) whose tables fit the on-chip window: max_rows4 / max_rows2 =
  * largest output-row span incl. the 4 extra tap rows of 4 / 2 consecutive source rows, max_cols16 = the same for 16 consecutive source columns,
  * max_span = most rows / columns a source pixel collects per tap (<= 3) — the caller derives them from the tables.
@@ -317,6 +317,25 @@ long long ss_upconv_bwd_fused_ws_floats(int Cin, int Cout, long long NB, int h, 
 int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                             float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
                             int accumulate, void* stream);
+
+/*
+ * ABI 5 — decoder DATA gradient with g_P on chip only (ss_upconv_bwd.hip).  Replaces, for one decoder stage, the pair
+ * ss_upconv_cl_bwd_f32 (g_P -> HBM) + fp32 GEMM / ss_gemm6_f32 (g_P <- HBM) of the autograd backward of NNConvUpsampling w.r.t. its input
+ * (/root/reference/network/blocks.py:110-132; call sites SNN_models.py:110-129):
+ *   g_x[nb][sy][sx][ci] = sum_{ky,kx,co} ( sum over the output pixels (y, x) with src_y[y+ky] == sy, src_x[x+kx] == sx of g_out[nb][y][x][co] )
+ *                                        * weight[co][ci][ky][kx]
+ * g_out [NB][H][W][C_out], g_x [NB][h][w][C_in] NHWC fp32; weight [C_out][C_in][5][5] (the Conv2d parameter as it is); ws:
+ * ss_upconv_bwd_dgrad_ws_floats(C_in, C_out) floats.  The inner sums are formed in LDS / registers in ss_upconv_cl_bwd_f32's order (bit-identical
+ * g_P), the contraction runs on the bf16 matrix cores with the six cross terms of ss_gemm6_f32: |g_x - float64| <= 2^-21 sum |g_P| |W|.
+ * With g_P == NULL in ss_upconv_bwd_fused_f32 (weight gradient) the per-tap gradient tensor of a stage reaches HBM nowhere.
+ * ss_upconv_bwd_dgrad_supported: k = 5, C_in % 64 == 0, C_out in {32, 64, 128, 256}, tables that fit the on-chip window: max_rows4 <= 13,
+ * max_cols32 <= 72 (largest output-row / -column span incl. the 4 tap rows / columns of 4 consecutive source rows / 32 consecutive source
+ * columns), 1 <= max_span <= 3.
+ */
+int ss_upconv_bwd_dgrad_supported(int Cin, int Cout, int k, int max_rows4, int max_cols32, int max_span);
+long long ss_upconv_bwd_dgrad_ws_floats(int Cin, int Cout);
+int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                            float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W, void* stream);
 
 /*
  * Dense x dense fp32 GEMM on the bf16 matrix cores with six cross terms (ABI 3) — the decoder's data gradient g_x = g_P @ W2 (autograd of

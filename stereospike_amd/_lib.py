@@ -120,6 +120,12 @@ def lib():
     L.ss_upconv_bwd_fused_ws_floats.restype = i64
     L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_bwd_fused_f32.restype = i32
+    L.ss_upconv_bwd_dgrad_supported.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.ss_upconv_bwd_dgrad_supported.restype = i32
+    L.ss_upconv_bwd_dgrad_ws_floats.argtypes = [i32, i32]
+    L.ss_upconv_bwd_dgrad_ws_floats.restype = i64
+    L.ss_upconv_bwd_dgrad_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_bwd_dgrad_f32.restype = i32
     L.ss_gemm6_supported.argtypes = [i32, i32]
     L.ss_gemm6_supported.restype = i32
     L.ss_gemm6_ws_floats.argtypes = [i32, i32]
@@ -164,6 +170,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
+           'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
@@ -483,20 +490,37 @@ def upconv_fused2_x16(x, weight, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, m
 
 
 def upconv_bwd_fused_supported(Cin, Cout, k, extents):
-    """extents = (max_rows4, max_rows2, max_cols16, max_span) from fused.adjoint_extents(tables)."""
-    return bool(lib().ss_upconv_bwd_fused_supported(int(Cin), int(Cout), int(k), *[int(v) for v in extents]))
+    """extents = (max_rows4, max_rows2, max_cols16, max_span[, max_cols32]) from fused.adjoint_extents(tables)."""
+    return bool(lib().ss_upconv_bwd_fused_supported(int(Cin), int(Cout), int(k), *[int(v) for v in extents[:4]]))
 
 
 def upconv_bwd_fused(g_out, x, y_lo, y_hi, x_lo, x_hi, g_P, g_w, NB, Cin, Cout, h, w, H, W, accumulate=False):
-    """Adjoint gather (g_P written) + exact bf16x3 MFMA weight gradient (g_w [Cin, 25 * Cout]) in one pass."""
+    """Adjoint gather (g_P written unless None) + exact bf16x3 MFMA weight gradient (g_w [Cin, 25 * Cout]) in one pass."""
     _require_hip(g_out, 'g_out')
     ws = torch.empty(int(lib().ss_upconv_bwd_fused_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g_out.device)
     with torch.cuda.device(g_out.device):
         rc = lib().ss_upconv_bwd_fused_f32(_f32(g_out, 'g_out', NB * H * W * Cout), _f32(x, 'x', NB * h * w * Cin), _i32(y_lo, 'y_lo', h),
                                            _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
-                                           _f32(g_P, 'g_P', NB * h * w * 25 * Cout), _f32(g_w, 'g_w', Cin * 25 * Cout), _f32(ws, 'ws'),
+                                           None if g_P is None else _f32(g_P, 'g_P', NB * h * w * 25 * Cout), _f32(g_w, 'g_w', Cin * 25 * Cout), _f32(ws, 'ws'),
                                            NB, Cin, Cout, h, w, H, W, int(bool(accumulate)), _stream(g_out))
     _check(rc, 'ss_upconv_bwd_fused_f32')
+
+
+def upconv_bwd_dgrad_supported(Cin, Cout, k, extents):
+    """extents = (max_rows4, max_rows2, max_cols16, max_span, max_cols32) from fused.adjoint_extents(tables)."""
+    return bool(lib().ss_upconv_bwd_dgrad_supported(int(Cin), int(Cout), int(k), int(extents[0]), int(extents[4]), int(extents[3])))
+
+
+def upconv_bwd_dgrad(g_out, weight, y_lo, y_hi, x_lo, x_hi, g_x, NB, Cin, Cout, h, w, H, W):
+    """Decoder data gradient g_x [NB, h, w, Cin] from g_out [NB, H, W, Cout] and the Conv2d weight [Cout, Cin, 5, 5]: adjoint gather + six-term
+    bf16 MFMA contraction in one kernel, the per-tap gradient tensor g_P only on chip."""
+    _require_hip(g_out, 'g_out')
+    ws = torch.empty(int(lib().ss_upconv_bwd_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=g_out.device)
+    with torch.cuda.device(g_out.device):
+        rc = lib().ss_upconv_bwd_dgrad_f32(_f32(g_out, 'g_out', NB * H * W * Cout), _f32(weight, 'weight', Cout * Cin * 25), _i32(y_lo, 'y_lo', h),
+                                           _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w), _f32(g_x, 'g_x', NB * h * w * Cin),
+                                           _f32(ws, 'ws'), NB, Cin, Cout, h, w, H, W, _stream(g_out))
+    _check(rc, 'ss_upconv_bwd_dgrad_f32')
 
 
 def gemm6_supported(K, N):

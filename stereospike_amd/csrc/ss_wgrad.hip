@@ -538,10 +538,12 @@ __global__ __launch_bounds__(kSwThreads, CIN == 64 ? 4 : 2) void upconv_bwd_fuse
                             gv[e] = a;
                         }
                         // g_P[(srow * w + sx)][n], n = 32 tile + (lane & 31)
-                        float* const gp = gP + (srow * w + sx0 + 8 * (lane >> 5)) * N + 32 * tile + (lane & 31);
+                        if (gP) {                                                 // nullable (ABI 5): the data gradient comes from ss_upconv_bwd_dgrad_f32
+                            float* const gp = gP + (srow * w + sx0 + 8 * (lane >> 5)) * N + 32 * tile + (lane & 31);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (valid & (1u << e)) store_out(gp + (long long)e * N, gv[e]);
+                            for (int e = 0; e < 8; ++e)
+                                if (valid & (1u << e)) store_out(gp + (long long)e * N, gv[e]);
+                        }
                         s16x8 gs[3];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -910,7 +912,7 @@ int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo,
                             float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
                             int accumulate, void* stream)
 {
-    if (!g_out || !x || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (!g_out || !x || !y_lo || !y_hi || !x_lo || !x_hi || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
     if (!ss_upconv_fused_supported(Cin, Cout, 5) || !aligned16(g_out) || !aligned16(ws) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
     int Q = 0, slices = 0;
     if (!upconv_bwd_fused_plan(Cin, Cout, &Q, &slices)) return SS_ELAUNCH;

@@ -597,6 +597,9 @@ GEMM6_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_GEMM6_CIN', '256,512
 FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather + exact MFMA weight gradient in one kernel (g_P written once, read only by dgrad)
 
 
+FUSED_UPCONV_DGRAD = _os.environ.get('SS_FUSED_DGRAD', '1') == '1'   # decoder data gradient: adjoint gather + six-term MFMA contraction in ONE kernel, g_P only on chip
+FUSED_UPCONV_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_DGRAD_CIN', '64,128').split(',') if c)   # C_in 256 / 512: ss_gemm6_f32 on g_P (1.5 / 0.8 GB) stays
+FUSED_UPCONV_BWD_CIN_NOGP = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN_NOGP', '64,128').split(',') if c)   # fused adjoint + weight gradient WITHOUT its g_P store
 FUSED_UPCONV_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN', '64').split(',') if c)   # C_in 128 (deconv2): the fused form is slower
                                    # than adjoint kernel + ss_spike_wgrad_f32 (4 workgroup kinds re-load every window; profiles/r02/fused_bwd.log)
 
@@ -605,7 +608,7 @@ def _extents_of(y_lo, y_hi, x_lo, x_hi):
     def span(lo, hi, n):
         return max(hi[min(i + n - 1, len(lo) - 1)] - lo[i] for i in range(0, len(lo), n)) + 4
     return (span(y_lo, y_hi, 4), span(y_lo, y_hi, 2), span(x_lo, x_hi, 16),
-            max(max(b - a for a, b in zip(y_lo, y_hi)), max(b - a for a, b in zip(x_lo, x_hi))))
+            max(max(b - a for a, b in zip(y_lo, y_hi)), max(b - a for a, b in zip(x_lo, x_hi))), span(x_lo, x_hi, 32))
 
 
 def register_extents(tables, host_tables):
@@ -615,7 +618,7 @@ def register_extents(tables, host_tables):
 
 
 def adjoint_extents(tables):
-    """(max_rows4, max_rows2, max_cols16, max_span) of the inverse resize tables (y_lo, y_hi, x_lo, x_hi at indices 1, 2, 4, 5): the output
+    """(max_rows4, max_rows2, max_cols16, max_span, max_cols32) of the inverse resize tables (y_lo, y_hi, x_lo, x_hi at indices 1, 2, 4, 5): the output
     window that 4 / 2 consecutive source rows and 16 consecutive source columns need (incl. the 4 extra tap rows / columns), and the widest
     per-source range — what ss_upconv_bwd_fused_supported checks against its on-chip window.  Host-side, cached on the tables tuple
     (register_extents); tables built elsewhere are read back once, and never during a stream capture."""
@@ -766,9 +769,20 @@ class _UpConvProjectedCL(torch.autograd.Function):
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
+            # data gradient with g_P on chip only: adjoint gather + six-term MFMA contraction in one kernel (ss_upconv_bwd_dgrad_f32)
+            dgrad_fused = (FUSED_UPCONV_DGRAD and need_x and not lowrank and not lowp and not g16 and k == 5 and g_out.dtype == torch.float32
+                           and Cin in FUSED_UPCONV_DGRAD_CIN and _lib.upconv_bwd_dgrad_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
             fused_bwd = (FUSED_UPCONV_BWD and need_w and ctx.exact and not lowp and not g16 and k == 5 and x_cl.dtype == torch.float32
-                         and Cin in FUSED_UPCONV_BWD_CIN and _lib.upconv_bwd_fused_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
-            if fused_bwd:
+                         and Cin in (FUSED_UPCONV_BWD_CIN_NOGP if dgrad_fused else FUSED_UPCONV_BWD_CIN)
+                         and _lib.upconv_bwd_fused_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
+            if dgrad_fused:
+                _lib.upconv_bwd_dgrad(g_out[c0:c1], Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous(), y_lo, y_hi, x_lo, x_hi,
+                                      g_x[c0:c1], c1 - c0, Cin, Cout, h, w, H, W)
+            if dgrad_fused and (fused_bwd or not need_w):
+                g_P = None                                                        # the per-tap gradient tensor never reaches HBM
+                if fused_bwd:
+                    _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, None, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True)
+            elif fused_bwd:
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
                 _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True)
             elif lowp and k == 5:
@@ -786,6 +800,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
                     g_P = g_P.to(torch.bfloat16)
             if lowrank:
                 g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
+            elif dgrad_fused:
+                pass                                                              # g_x written by the fused kernel above
             elif need_x and not lowp and GEMM6_DGRAD and Cin in GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
                 # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy): the fp32 GEMM is compute-bound here
                 _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)

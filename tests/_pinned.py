@@ -135,6 +135,80 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-300))
 
 
+def _oracle_chunk_worker(conn, orc, x, z_by_node, float64, amp_dtype, returns_spikes, threads):
+    """One chunk of samples of a large batch in its own process (oracle on CPU only; the parent holds the GPU): forward WITH the graph kept,
+    depths to the parent, depth gradients back, backward, parameter gradients + flip statistics + PLIF sums to the parent."""
+    torch.set_num_threads(max(1, int(threads)))
+    stats, plif = {}, {}
+    orc.zero_grad()
+    narrow = narrowing_points(amp_dtype) if amp_dtype is not None else None
+    out, _ = run_oracle_pinned(orc, x, z_by_node, float64=float64, stats=stats, plif=plif, narrow=narrow)
+    d, s = out if returns_spikes else (out, [])
+    # payloads travel as numpy arrays (pickled by value): torch's shared-memory tensor passing needs the sender to outlive the receive
+    conn.send(([t.detach().numpy() for t in d], [t.detach().numpy() for t in s], stats))
+    g = [torch.from_numpy(a) for a in conn.recv()]
+    torch.autograd.backward(list(d), g)
+    conn.send(({k: p.grad.numpy() for k, p in orc.named_parameters()}, plif))
+    conn.recv()                                   # the parent's acknowledgement: only now may this process go away
+    conn.close()
+
+
+def _oracle_in_processes(orc, x, gt, z_by_node, chunk, returns_spikes, float64, amp_dtype, stats, plif):
+    """The chunked oracle evaluation of pinned_parity with every chunk in its own process, all at once (a config-3-sized batch on the GPU
+    box's 256 host cores: 16 samples in the time of two).  Same function as the sequential form (tests/test_host_wiring.py)."""
+    import os
+    import torch.multiprocessing as mp
+    B = x.shape[0]
+    chunks = [(c0, min(B, c0 + chunk)) for c0 in range(0, B, chunk)]
+    ctx = mp.get_context('spawn')
+    sj.reset_net(orc)                             # the module travels by pickle: no graph-attached membranes / gradients on it
+    orc.zero_grad(set_to_none=True)
+    threads = max(1, (os.cpu_count() or 8) // len(chunks))
+    procs, keep = [], []
+    for c0, c1 in chunks:
+        a, b = ctx.Pipe()
+        zc = {n: [z[c0:c1].clone() for z in lst] for n, lst in z_by_node.items()}
+        xc = x[c0:c1].clone()
+        keep.append(xc)
+        pr = ctx.Process(target=_oracle_chunk_worker, args=(b, orc, xc, zc, float64, amp_dtype, returns_spikes, threads))
+        pr.start()
+        b.close()
+        procs.append((pr, a))
+        keep.append((zc,))                        # arguments travel through shared memory: alive until the workers are done
+    try:
+        fw = [a.recv() for _, a in procs]
+        d_o = [torch.cat([torch.from_numpy(f[0][i]) for f in fw]).requires_grad_() for i in range(4)]
+        s_o = [torch.cat([torch.from_numpy(f[1][i]) for f in fw]) for i in range(len(fw[0][1]))]
+        for f in fw:
+            for n, st in f[2].items():
+                acc = stats.setdefault(n, dict(total=0, flips=0, max_margin=0.0))
+                acc['total'] += st['total']
+                acc['flips'] += st['flips']
+                acc['max_margin'] = max(acc['max_margin'], st['max_margin'])
+        L_o = rn.total_loss(d_o, gt, s_o)
+        L_o.backward()
+        for (_, a), (c0, c1) in zip(procs, chunks):
+            a.send([g.grad[c0:c1].numpy().copy() for g in d_o])
+        params = dict(orc.named_parameters())
+        for _, a in procs:                        # chunks in order: a fixed summation order of the parameter gradients
+            grads, pl = a.recv()
+            for k, g in grads.items():
+                g = torch.from_numpy(g)
+                params[k].grad = g.clone() if params[k].grad is None else params[k].grad + g
+            for n, v in pl.items():
+                acc = plif.setdefault(n, dict(sum=0.0, abs=0.0))
+                acc['sum'] += v['sum']
+                acc['abs'] += v['abs']
+            a.send('done')
+    finally:
+        for pr, _ in procs:
+            pr.join(60)
+            if pr.is_alive():
+                pr.terminate()
+    assert all(pr.exitcode == 0 for pr, _ in procs), [pr.exitcode for pr, _ in procs]
+    return d_o, s_o, L_o
+
+
 def launch_tags():
     """{tag: launches} of the fused launches recorded by fused.TIMER since it was last cleared."""
     from stereospike_amd import fused
@@ -157,14 +231,16 @@ def narrowing_points(amp_dtype):
     return policy
 
 
-def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=None, float64=True, oracle_chunk=None, loss_scale=1.0):
+def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=None, float64=True, oracle_chunk=None, loss_scale=1.0,
+                  oracle_procs=False):
     """Free product run (forward + Total_Loss + backward) vs the trajectory-pinned oracle.  Returns a report dict.
     amp_dtype: the product runs under torch.autocast with 16-bit activations (fp32 membranes); the oracle narrows at the same points
     (narrowing_points).  loss_scale: the product's loss is multiplied by it before backward and its gradients divided afterwards (fp16
     activation gradients underflow otherwise: engine.Trainer's GradScaler does the same).
     oracle_chunk: evaluate the oracle over chunks of that many samples (the network is per-sample independent; only the loss couples the
     batch): pass 1 forward per chunk -> depths; the loss and its depth gradients on the whole batch; pass 2 forward + backward per chunk
-    with those depth gradients (parameter gradients accumulate).  Bounds the CPU memory of a config-3-sized batch."""
+    with those depth gradients (parameter gradients accumulate).  Bounds the CPU memory of a config-3-sized batch.
+    oracle_procs: every chunk in its own process, all at once, one forward each (the graph is kept while the parent forms the loss)."""
     from stereospike_amd import fused
     from stereospike_amd.clock_driven import functional
     from stereospike_amd.network.loss import Total_Loss
@@ -207,6 +283,9 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
         L_o = rn.total_loss(d_o, gt, s_o)
         mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
         L_o.backward()
+    elif oracle_procs:
+        d_o, s_o, L_o = _oracle_in_processes(orc, x, gt, z_by_node, oracle_chunk, returns_spikes, float64, amp_dtype, stats, plif)
+        mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
     else:
         chunks = [(c0, min(B, c0 + oracle_chunk)) for c0 in range(0, B, oracle_chunk)]
         zc = lambda c0, c1: {n: [z[c0:c1] for z in lst] for n, lst in z_by_node.items()}        # noqa: E731

@@ -11,8 +11,8 @@ run-time-T kernels (T = 7, odd sizes).
 Bars, per kind of quantity (measured values: profiles/r03/parity_report_default_path*.json):
   * per layer <= 1e-4 of the neuron updates may disagree with the oracle's own Heaviside, each within MARGIN of its threshold;
   * depths / loss / MDE <= 1e-5 relative;
-  * every weight TENSOR gradient of the composed backward <= 2e-4 relative L2;
-  * every 0-dim PLIF w gradient within 1e-5 of its MAGNITUDE sum (float64, from hooks on the oracle's membranes) — the scalar is one
+  * every weight TENSOR gradient of the composed backward <= 1e-4 relative L2;
+  * every 0-dim PLIF w gradient within 2e-6 of its MAGNITUDE sum (float64, from hooks on the oracle's membranes) — the scalar is one
     cancelling sum over a layer with condition number up to ~1e3, so a bar relative to the cancelled value measures the conditioning of
     the layer, not the kernel.
 MIOpen-backed non-default execution layouts: tests/test_gpu_zz_layouts.py (collected last).
@@ -35,8 +35,8 @@ REPORT_FILE = 'gpurun_out/parity_report_default_path.json'
 
 MARGIN_DEFAULT = 5e-5      # |h - v_th| of a neuron on which product and float64-conv oracle may disagree: exact bf16x3 / fp32-GEMM synapses
 FLIP_FRAC = 1e-4           # fraction of a layer's neuron updates that may disagree at all
-TENSOR_GRAD_BAR = 2e-4     # relative L2 of a weight tensor's gradient
-PLIF_W_BAR = 1e-5          # |dL/dw - float64 value| / magnitude sum
+TENSOR_GRAD_BAR = 1e-4     # relative L2 of a weight tensor's gradient (measured <= 3.0e-5 over every spiking case of this suite)
+PLIF_W_BAR = 2e-6          # |dL/dw - float64 value| / magnitude sum (measured <= 1.6e-7; condition numbers of the scalar up to 8.7e4)
 
 
 def _dump():
@@ -140,13 +140,14 @@ def test_pinned_parity_full_resolution_stereospike_T5():
 def test_pinned_parity_config3_step_B16_T5():
     """THE config-3 step: StereoSpike, B = 16, T = 5, 260x346 (bench.py's synthetic input distribution) — the launch shapes bench.py prices
     (2.3e8 updates in the bottom layer's launch, the fused up-conv kernels' persistent grids at the real frame count, split-K weight
-    gradients over 1.4e6 rows).  The oracle walks the batch in chunks of 2 samples (tests/_pinned.py: only the loss couples the batch)."""
+    gradients over 1.4e6 rows).  The oracle walks the batch in chunks of 2 samples, one host process per chunk (tests/_pinned.py: only the loss
+    couples the batch): 645 s sequentially on the GPU box, ~90 s this way."""
     if os.environ.get('SS_SKIP_B16_PARITY') == '1':
         pytest.skip('SS_SKIP_B16_PARITY=1')
     orc, net = pair('StereoSpike', 260, 346)
     x = synth_input(16, 5, 4, 2021)
     gt = synth_label(16, 2022)
-    rep = pinned_parity(orc, net, x, gt, oracle_chunk=2)
+    rep = pinned_parity(orc, net, x, gt, oracle_chunk=2, oracle_procs=True)
     assert_default_kernels(rep['launch_tags'], 5)
     check('pinned_config3_B16_T5', rep)
 

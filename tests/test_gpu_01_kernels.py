@@ -1172,6 +1172,84 @@ def test_upconv_bwd_fused(Cin, Cout, hw, HW, NB):
     assert torch.equal(g_w2, g_w + g_w)
 
 
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 3),
+                                                (64, 32, (32, 40), (64, 80), 2), (128, 64, (16, 20), (32, 40), 2), (128, 64, (13, 18), (25, 35), 5),
+                                                (64, 32, (9, 11), (17, 19), 1), (256, 128, (8, 10), (16, 20), 3), (512, 256, (4, 5), (8, 10), 2)])
+def test_upconv_bwd_dgrad_fused(Cin, Cout, hw, HW, NB):
+    """ss_upconv_bwd_dgrad_f32 (adjoint gather + six-term MFMA contraction, g_P on chip only) against the two-kernel form it replaces:
+    g_x == (adjoint kernel's g_P, float64) @ W2 within 2^-21 sum |g_P| |W| element-wise — the bound of ss_gemm6_f32, which holds only if the
+    on-chip g_P has the adjoint kernel's values; at least as accurate as the library's fp32 GEMM on the materialised g_P (x 2 slack); no coherent
+    drift; ragged tiles (frame edges, 3-replica rows / columns, C_in blocks of 64, C_out chunks of 32); deterministic.  And the weight
+    gradient of ss_upconv_bwd_fused_f32 without its g_P store is bit-identical to the one with it."""
+    from stereospike_amd import _lib, fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    (h, w), (H, W) = hw, HW
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
+    tables = up._tables(h, w, torch.device(DEV))
+    ext = fused.adjoint_extents(tables)
+    assert _lib.upconv_bwd_dgrad_supported(Cin, Cout, 5, ext), ext
+    assert not _lib.upconv_bwd_dgrad_supported(Cin, Cout, 3, ext) and not _lib.upconv_bwd_dgrad_supported(Cin + 32, Cout, 5, ext)
+    gen = torch.Generator(device=DEV).manual_seed(17 + Cin)
+    # gradients with a per-pixel dynamic range (loss gradients span orders of magnitude across pixels), zero blocks included
+    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen) * torch.exp(2.0 * torch.randn(NB, H, W, 1, device=DEV, generator=gen))
+    g[:, : H // 5] = 0
+    weight = up.up[1].weight.detach()
+    R, N = NB * h * w, 25 * Cout
+    g_P = torch.empty(R, N, device=DEV)
+    _lib.upconv_cl_bwd(g, tables[1], tables[2], tables[4], tables[5], g_P, NB, 5, Cout, h, w, H, W)
+    W2 = weight.permute(2, 3, 0, 1).reshape(N, Cin).contiguous()              # rows (tap, co), columns ci
+    g_x = torch.full((NB, h, w, Cin), float('nan'), device=DEV)
+    _lib.upconv_bwd_dgrad(g, weight.contiguous(), tables[1], tables[2], tables[4], tables[5], g_x, NB, Cin, Cout, h, w, H, W)
+    ref = g_P.double() @ W2.double()
+    bound = (g_P.double().abs() @ W2.double().abs()) * 2.0 ** -21 + 1e-30
+    err = (g_x.view(R, Cin).double() - ref).abs()
+    assert bool(torch.isfinite(g_x).all()) and bool((err <= bound).all()), float((err / bound).max())
+    lib32 = g_P @ W2
+    assert float(err.max()) <= 2.0 * float((lib32.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
+    if R * Cin >= 50000:
+        assert abs(float(((g_x.view(R, Cin).double() - ref) / bound).mean())) * 2.0 ** -21 <= 1e-9
+    g_x2 = torch.empty_like(g_x)
+    _lib.upconv_bwd_dgrad(g, weight.contiguous(), tables[1], tables[2], tables[4], tables[5], g_x2, NB, Cin, Cout, h, w, H, W)
+    assert torch.equal(g_x, g_x2)
+    if _lib.upconv_bwd_fused_supported(Cin, Cout, 5, ext):
+        x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float())
+        gw_a, gw_b, gp = torch.empty(Cin, N, device=DEV), torch.empty(Cin, N, device=DEV), torch.empty(R, N, device=DEV)
+        _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], gp, gw_a, NB, Cin, Cout, h, w, H, W)
+        _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], None, gw_b, NB, Cin, Cout, h, w, H, W)
+        assert torch.equal(gw_a, gw_b) and torch.equal(gp, g_P)
+
+
+def test_decoder_stage_backward_keeps_g_P_on_chip(monkeypatch):
+    """The autograd path of a decoder stage (fused._UpConvProjectedCL.backward) with the fused data gradient on: same gradients as the
+    two-kernel form (g_P in HBM) to the six-term bound's accuracy, the weight gradient bit-identical, and no [rows, 25 C_out] tensor is
+    allocated (peak memory of the backward stays below the size of g_P)."""
+    from stereospike_amd import fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    Cin, Cout, (h, w), (H, W), NB = 64, 32, (65, 87), (130, 173), 8
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float()
+    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen)
+
+    def run(on):
+        monkeypatch.setattr(fused, 'FUSED_UPCONV_DGRAD', on)
+        xx = x.clone().requires_grad_()
+        up.zero_grad()
+        y = up.forward_projected_cl(xx, spikes_in=True)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y.backward(g)
+        torch.cuda.synchronize()
+        return xx.grad.clone(), up.up[1].weight.grad.clone(), torch.cuda.max_memory_allocated() - base
+    gx1, gw1, peak1 = run(True)
+    gx0, gw0, peak0 = run(False)
+    gp_bytes = NB * h * w * 25 * Cout * 4
+    assert peak0 >= gp_bytes and peak1 < gp_bytes // 2, (peak0, peak1, gp_bytes)
+    assert torch.equal(gw1, gw0)
+    assert float((gx1 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max())
+
+
 # ======================================================================================================
 # dense x dense GEMM with six bf16 cross terms (ss_gemm6_f32): the decoder's data gradient
 # ======================================================================================================

@@ -47,12 +47,11 @@ def _run(layout, T):
     return pinned_parity(orc, net, x, gt)
 
 
-@pytest.mark.parametrize('T', [5, 3])
-@pytest.mark.parametrize('layout', LAYOUTS)
+@pytest.mark.parametrize('layout,T', [(lay, 5) for lay in LAYOUTS] + [('all_nhwc_exact_split', 3), ('nchw', 3), ('two_op_miopen', 3)])
 def test_pinned_parity_every_execution_layout(layout, T, monkeypatch):
     """The same network through every execution variant of the synapses / neuron kernels: the shipped default; dense instead of packed
     spikes; saved-h backward without forked gradients; NHWC with plain fp32 GEMMs; NHWC decoder only; projected NCHW; the reference's
-    two-op up-convs on MIOpen — at T = 5 (compile-time-T kernels) and T = 3 (run-time-T kernels)."""
+    two-op up-convs on MIOpen — at T = 5 (compile-time-T kernels), three of them also at T = 3 (run-time-T kernels)."""
     _configure(layout, monkeypatch.setattr)
     rep = _run(layout, T)
     try:

@@ -101,6 +101,7 @@ def host_backend(monkeypatch):
     from stereospike_amd import fused as fused_mod
     monkeypatch.setattr(fused_mod, 'EXACT_SPLIT_GEMM', False)         # torch.mm(bf16, bf16, out_dtype=fp32) exists on the GPU only
     monkeypatch.setattr(fused_mod, 'GEMM6_DGRAD', False)              # hand-written MFMA kernels: GPU only (the fp32 GEMM runs instead)
+    monkeypatch.setattr(fused_mod, 'FUSED_UPCONV_DGRAD', False)       # fused adjoint + data-gradient MFMA kernel: GPU only
     monkeypatch.setattr(_lib, 'loss_stats', loss_stats)
     monkeypatch.setattr(_lib, 'loss_grad', loss_grad)
     monkeypatch.setattr(_lib, 'loss_ws_doubles', lambda: 1)
@@ -235,6 +236,13 @@ def test_pinned_oracle_machinery_on_the_host_backend(host_backend, name):
         assert abs(rep_c['grad_rel_l2'][k] - rep['grad_rel_l2'][k]) <= 5e-6 + 0.05 * rep['grad_rel_l2'][k], (k, rep_c['grad_rel_l2'][k], rep['grad_rel_l2'][k])
     for k in rep['plif_w']:
         assert abs(rep_c['plif_w'][k]['oracle_float64'] - rep['plif_w'][k]['oracle_float64']) <= 1e-6 * rep['plif_w'][k]['magnitude_sum']
+    if name == 'PLIFNet':     # ... and so is the form with one process per chunk (what the config-3 B = 16 GPU test uses)
+        rep_p = pinned_parity(orc, net, x, gt, oracle_chunk=1, oracle_procs=True)
+        assert rep_p['layers'] == rep['layers'] and abs(rep_p['loss'][1] - rep['loss'][1]) <= 1e-6 * abs(rep['loss'][1])
+        for k in rep['grad_rel_l2']:
+            assert abs(rep_p['grad_rel_l2'][k] - rep['grad_rel_l2'][k]) <= 5e-6 + 0.05 * rep['grad_rel_l2'][k], (k, rep_p['grad_rel_l2'][k], rep['grad_rel_l2'][k])
+        for k in rep['plif_w']:
+            assert abs(rep_p['plif_w'][k]['oracle_float64'] - rep['plif_w'][k]['oracle_float64']) <= 1e-6 * rep['plif_w'][k]['magnitude_sum']
     # the protocol must SEE a wrong kernel: the same comparison with the product's gain off by one ulp-scale factor of 1e-3 fails loudly
     net.bottom[1].scale_value = net.bottom[1].scale_value * 1.05
     bad = pinned_parity(orc, net, x, gt)
