@@ -24,6 +24,9 @@
 
 namespace {
 
+#ifndef SS_DG_ABLATE
+#define SS_DG_ABLATE 0                         // development aid (make variant DEFS=-DSS_DG_ABLATE=mask; tools/bench_upconv_bwd.py SS_LIB=...): 1 weight
+#endif                                       // stream, 2 row sums, 4 MFMAs, 8 bf16 split, 16 per-k-step barrier — wrong results, timing only
 constexpr int kDgThreads = 512;
 constexpr int kDgTR = 4;                     // source rows per tile (one per wavefront pair)
 constexpr int kDgTC = 32;                    // source columns per tile = MFMA M
@@ -127,17 +130,27 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
-            // ---- g_y window (32 channels of this chunk) -> LDS, zero outside the image and in the two slack columns
+            // ---- g_y window (32 channels of this chunk) -> LDS, zero outside the image and in the two slack columns.  All loads of a thread
+            //      are issued before the first store (a rolled loop with a run-time trip count serialised ~15 L2 round trips per tile:
+            //      0.9 of the first version's 2.1 ms at deconv1, profiles/r03/upconv_bwd_dgrad_ablations.log)
             {
-                const int per_row = (WCt + 2) * 8;
-                for (int i = threadIdx.x; i < WRt * per_row; i += kDgThreads) {
-                    const int wy = i / per_row, rem = i - wy * per_row;
+                constexpr int kPerRow = kDgWC * 8, kIter = (kDgWR * kPerRow + kDgThreads - 1) / kDgThreads;
+                f4 buf[kIter];
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    const int i = threadIdx.x + kDgThreads * u;
+                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
                     const int col = rem >> 3, q = rem & 7;
                     const int y = wy0 + wy, x = wx0 + col;
-                    f4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (col < WCt && y >= 0 && y < H && x >= 0 && x < W)
-                        v = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT + 32 * c) + q);
-                    *reinterpret_cast<f4*>(wnd + wy * kDgRowB + col * kDgPix + q * 16) = v;
+                    buf[u] = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (wy < WRt && col < WCt && y >= 0 && y < H && x >= 0 && x < W)
+                        buf[u] = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT + 32 * c) + q);
+                }
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    const int i = threadIdx.x + kDgThreads * u;
+                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
+                    if (wy < WRt && (rem >> 3) < WCt + 2) *reinterpret_cast<f4*>(wnd + wy * kDgRowB + (rem >> 3) * kDgPix + (rem & 7) * 16) = buf[u];
                 }
             }
             // ---- weight stage 0 of this (ci block, chunk)
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
 #pragma unroll 1
             for (int grp = 0; grp < 5; ++grp) {                                 // vertical tap ky = 4 - grp is completed by window row ry - 1 + grp
                 float cs[5][8], p2[5][8];
-                if (active) {
+                if (active && !((SS_DG_ABLATE & 2) && grp > 0)) {
                     rowsums(ry - 1 + grp, cs);
                     if (ry > 2) rowsums(ry - 3 + grp, p2);                      // the third replica row (1 source row in ~30): re-summed, not carried
                 }
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
 #pragma unroll
                 for (int kx = 0; kx < 5; ++kx) {
                     const int s = grp * 5 + kx;
-                    const bool more = s + 1 < 25;
+                    const bool more = s + 1 < 25 && !(SS_DG_ABLATE & 1);
                     if (more) {
                         st0 = *reinterpret_cast<const f4*>(bsrc + (long long)(s + 1) * kDgStage + threadIdx.x * 16);
                         if (threadIdx.x < 256) st1 = *reinterpret_cast<const f4*>(bsrc + (long long)(s + 1) * kDgStage + (512 + threadIdx.x) * 16);
@@ -184,6 +197,10 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
                             else if (ry > 1) v = p1[kx][e] + cs[kx][e];
                             else v = cs[kx][e];
                             v *= sgn;
+#if SS_DG_ABLATE & 8
+                            ah[e] = (short)(__float_as_uint(v) >> 16); am[e] = (short)__float_as_uint(v); al[e] = am[e];
+                            continue;
+#endif
                             const __bf16 h1 = (__bf16)v;
                             const float r1 = v - (float)h1;
                             const __bf16 h2 = (__bf16)r1;
@@ -195,6 +212,9 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
                         s16x8 b[6];                                             // [0,1] hi, [2,3] mid, [4,5] lo of ci tiles 0, 1
 #pragma unroll
                         for (int u = 0; u < 6; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
+#if SS_DG_ABLATE & 4
+                        acc[0][0] += (float)(ah[0] + am[1] + al[2] + b[0][0] + b[3][1] + b[5][2]);
+#else
 #pragma unroll
                         for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[4 + u], acc[u], 0, 0, 0);
 #pragma unroll
@@ -207,13 +227,14 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
                         for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0 + u], acc[u], 0, 0, 0);
 #pragma unroll
                         for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0 + u], acc[u], 0, 0, 0);
+#endif
                     }
                     if (more) {
                         unsigned char* const dst = bst + ((s + 1) & 1) * kDgStage;
                         *reinterpret_cast<f4*>(dst + threadIdx.x * 16) = st0;
                         if (threadIdx.x < 256) *reinterpret_cast<f4*>(dst + (512 + threadIdx.x) * 16) = st1;
                     }
-                    __syncthreads();
+                    if (!(SS_DG_ABLATE & 16)) __syncthreads();
                 }
                 if (active) {
 #pragma unroll

@@ -477,14 +477,31 @@ __global__ __launch_bounds__(kSwThreads, CIN == 64 ? 4 : 2) void upconv_bwd_fuse
         const int wx0 = x_lo[sx0] - 4, WCt = x_hi[min(sx0 + 15, w - 1)] - wx0;
         __syncthreads();                                                  // the previous tile's reads of the window are done
         // ---- g_y window -> LDS (zero outside the image)
-        const int rowf4 = min(WCt + 2, WCM) * C4;                          // + 2: the multiplied-by-zero third column must be finite
-        for (int i = threadIdx.x; i < WRt * rowf4; i += kSwThreads) {
-            const int wy = i / rowf4, rem = i - wy * rowf4;
-            const int y = wy0 + wy, x = wx0 + rem / C4;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y >= 0 && y < H && x >= 0 && x < W)
-                v = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT) + (rem % C4));
-            *reinterpret_cast<f4*>(wnd + wy * ROWB + rem * 16) = v;
+        // all loads of a thread are issued before its first store, over the compile-time window extent (a rolled loop with a run-time trip
+        // count serialised one L2 / HBM round trip per iteration: profiles/r03/upconv_bwd_dgrad_ablations.log)
+        {
+            constexpr int kPerRow = WCM * C4, kIter = (WRM * kPerRow + kSwThreads - 1) / kSwThreads;
+            const int cols = min(WCt + 2, WCM);                              // + 2: the multiplied-by-zero third column must be finite
+            constexpr int kBatch = CIN == 64 ? 9 : 7;                        // loads in flight per thread (the C_in 128 form has 128 accumulator registers)
+#pragma unroll 1
+            for (int u0 = 0; u0 < kIter; u0 += kBatch) {
+                f4 buf[kBatch];
+#pragma unroll
+                for (int v = 0; v < kBatch; ++v) {
+                    const int i = threadIdx.x + kSwThreads * (u0 + v);
+                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
+                    const int y = wy0 + wy, x = wx0 + rem / C4;
+                    buf[v] = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (u0 + v < kIter && wy < WRt && rem / C4 < cols && y >= 0 && y < H && x >= 0 && x < W)
+                        buf[v] = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT) + (rem % C4));
+                }
+#pragma unroll
+                for (int v = 0; v < kBatch; ++v) {
+                    const int i = threadIdx.x + kSwThreads * (u0 + v);
+                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
+                    if (u0 + v < kIter && wy < WRt && rem / C4 < cols) *reinterpret_cast<f4*>(wnd + wy * ROWB + rem * 16) = buf[v];
+                }
+            }
         }
         // ---- this lane's 8 source columns: window byte offset of their first contributing column at kx = 0, and 0 / 1 multipliers of the
         //      second / third column (fma(r, 1, cs) == cs + r and fma(r, 0, cs) == cs exactly: the adjoint kernel's sums, no selects)
