@@ -27,30 +27,35 @@ namespace {
 #ifndef SS_DG_ABLATE
 #define SS_DG_ABLATE 0                         // development aid (make variant DEFS=-DSS_DG_ABLATE=mask; tools/bench_upconv_bwd.py SS_LIB=...): 1 weight
 #endif                                       // stream, 2 row sums, 4 MFMAs, 8 bf16 split, 16 per-k-step barrier — wrong results, timing only
-constexpr int kDgThreads = 512;
-constexpr int kDgTR = 4;                     // source rows per tile (one per wavefront pair)
+#ifndef SS_DG_PIPE
+#define SS_DG_PIPE 1                           // the next k-step's fragment is split before (1) / after (0) this k-step's MFMAs in program order
+#endif
+constexpr int kDgThreads = 256;              // 4 wavefronts = the 4 source rows of a tile; TWO workgroups per CU (74 KB of LDS each): one loads its
+                                             // window while the other computes (the first version — one 8-wavefront workgroup per CU, 155 KB — spent
+                                             // 0.9 of its 2.1 ms at deconv1 in unoverlapped per-tile latency: profiles/r03/upconv_bwd_dgrad_ablations.log)
+constexpr int kDgTR = 4;                     // source rows per tile (one per wavefront)
 constexpr int kDgTC = 32;                    // source columns per tile = MFMA M
 constexpr int kDgWR = 13;                    // window rows: 4 source rows x <= 3 replicas + 4 tap rows (measured max 13 at every pyramid level)
 constexpr int kDgWCmax = 72;                 // window columns of real data: 32 source columns (measured max 72: 40 -> 84)
 constexpr int kDgWC = kDgWCmax + 2;          // + 2 slack columns (the unconditional 6th / 7th column reads of a 2-replica pixel: multiplied by 0)
-constexpr int kDgPix = 32 * 4 + 16;          // bytes per window pixel: 32 channels fp32 + 16 B pad (lanes = consecutive source columns step 2 pixels:
-                                             // 288 B = 8 banks apart -> 8 lanes x 16 B cover distinct banks)
+constexpr int kDgCh = 16;                    // output channels per chunk = the k extent of one MFMA k-step
+constexpr int kDgPix = kDgCh * 4;            // bytes per window pixel: 4 granules of 16 B, granule g of window column c stored at slot g ^ ((c >> 1) & 3):
+                                             // lanes = consecutive source columns step 2 window columns, so 8 lanes x 16 B hit 8 distinct bank groups
 constexpr int kDgRowB = kDgWC * kDgPix;
-constexpr int kDgStage = 2 * 3 * 2 * 1024;   // one k-step of weights: [channel half][split term][ci tile of 32][lane][8 bf16]
+constexpr int kDgStage = 3 * 2 * 1024;       // one k-step of weights: [split term][ci tile of 32][lane][8 bf16]
 
-// weight [C_out][C_in][5][5] fp32 -> Bf[ci block of 64][chunk of 32 co][s][half][split][tile][lane][8] bf16, s = (4 - ky) * 5 + kx (the order in
-// which the row scan completes the taps), element e of a lane = split term of W[co = 32 chunk + 16 half + 8 (lane >> 5) + e][ci = 64 blk + 32 tile
+// weight [C_out][C_in][5][5] fp32 -> Bf[ci block of 64][chunk of 16 co][s][split][tile][lane][8] bf16, s = (4 - ky) * 5 + kx (the order in
+// which the row scan completes the taps), element e of a lane = split term of W[co = 16 chunk + 8 (lane >> 5) + e][ci = 64 blk + 32 tile
 // + (lane & 31)][ky][kx]  (round-to-nearest split, as gemm6_prep_b_kernel)
 __global__ __launch_bounds__(kBlock) void upconv_bwd_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, int Cin, int Cout)
 {
-    const int NCH = Cout / 32;
-    const long long total = (long long)(Cin / 64) * NCH * 25 * 2 * 3 * 2 * 64;
+    const int NCH = Cout / kDgCh;
+    const long long total = (long long)(Cin / 64) * NCH * 25 * 3 * 2 * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
         long long r = i >> 6;
         const int t = (int)(r % 2); r /= 2;
         const int sp = (int)(r % 3); r /= 3;
-        const int half = (int)(r % 2); r /= 2;
         const int s = (int)(r % 25); r /= 25;
         const int c = (int)(r % NCH); const int blk = (int)(r / NCH);
         const int ky = 4 - s / 5, kx = s % 5;
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void upconv_bwd_dgrad_prep_kernel(const flo
         u16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int co = 32 * c + 16 * half + 8 * (lane >> 5) + e;
+            const int co = kDgCh * c + 8 * (lane >> 5) + e;
             const float v = W[(((long long)co * Cin + ci) * 5 + ky) * 5 + kx];
             const unsigned short h1 = narrow<SS_DT_BF16>(v);
             const float r1 = v - widen<SS_DT_BF16>(h1);
@@ -70,18 +75,36 @@ __global__ __launch_bounds__(kBlock) void upconv_bwd_dgrad_prep_kernel(const flo
     }
 }
 
-template <int COUT>
-__global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const float* __restrict__ gy, const unsigned short* __restrict__ Bf,
-                                                                      const int* __restrict__ y_lo, const int* __restrict__ y_hi,
-                                                                      const int* __restrict__ x_lo, const int* __restrict__ x_hi,
-                                                                      float* __restrict__ gx, int NB, int h, int w, int H, int W, int CIN)
+// 8 fp32 values -> three bf16 terms (round to nearest: residuals <= 2^-8, 2^-16), as ss_gemm6_f32 splits its A operand
+__device__ __forceinline__ void dg_split(const float (&v)[8], float sgn, s16x8& ah, s16x8& am, s16x8& al)
 {
-    constexpr int NCH = COUT / 32;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * sgn;
+#if SS_DG_ABLATE & 8
+        ah[e] = (short)(__float_as_uint(x) >> 16); am[e] = (short)__float_as_uint(x); al[e] = am[e];
+#else
+        const __bf16 h1 = (__bf16)x;                                            // v_cvt_pk_bf16_f32 on gfx950 (round to nearest even)
+        const float r1 = x - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        const __bf16 h3 = (__bf16)r2;
+        ah[e] = __builtin_bit_cast(short, h1); am[e] = __builtin_bit_cast(short, h2); al[e] = __builtin_bit_cast(short, h3);
+#endif
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(kDgThreads, 2) void upconv_bwd_dgrad_kernel(const float* __restrict__ gy, const unsigned short* __restrict__ Bf,
+                                                                         const int* __restrict__ y_lo, const int* __restrict__ y_hi,
+                                                                         const int* __restrict__ x_lo, const int* __restrict__ x_hi,
+                                                                         float* __restrict__ gx, int NB, int h, int w, int H, int W, int CIN)
+{
+    constexpr int NCH = COUT / kDgCh;
     __shared__ __attribute__((aligned(16))) unsigned char wnd[kDgWR * kDgRowB];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kDgStage];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mb = wave >> 1, kh = wave & 1;
+    const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // wavefront = source row of the tile
     const int NBLK = CIN / 64, RG = (h + kDgTR - 1) / kDgTR, CG = (w + kDgTC - 1) / kDgTC;
     const long long n_tiles = (long long)NB * RG * CG * NBLK;
     // a contiguous range of tiles per workgroup, neighbouring ranges on the same XCD (window halos and the weights are shared through its L2)
@@ -104,7 +127,9 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
         const int sxc = min(sx0 + (lane & 31), w - 1);
         const int xlo = x_lo[sxc], rx = x_hi[sxc] - xlo;
         const float m1 = rx > 1 ? 1.f : 0.f, m2 = rx > 2 ? 1.f : 0.f;           // fma(r, 1, cs) == cs + r, fma(r, 0, cs) == cs exactly: no selects
-        const unsigned char* const lane_base = wnd + (ylo - 4 - wy0) * kDgRowB + (xlo - 4 - wx0) * kDgPix + (16 * kh + 8 * (lane >> 5)) * 4;
+        const int wc0 = xlo - 4 - wx0;                                          // window column of this lane's first tap column
+        const unsigned char* const row_base = wnd + (ylo - 4 - wy0) * kDgRowB;
+        const int g0 = 2 * (lane >> 5);                                         // this lane's channel octet = granules g0, g0 + 1 of a pixel
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -113,62 +138,77 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
         bool neg = false;
         // row sums of one window row for the 5 horizontal taps: cs[kx] = row[4 - kx] (+ row[5 - kx] (+ row[6 - kx])), the adjoint kernel's order
         auto rowsums = [&](int j, float (&cs)[5][8]) {
-            const unsigned char* const rp = lane_base + j * kDgRowB;
-            float row[7][8];
+            const unsigned char* const rp = row_base + j * kDgRowB;
 #pragma unroll
-            for (int c = 0; c < 7; ++c) {
-                const f4 a = *reinterpret_cast<const f4*>(rp + c * kDgPix), b = *reinterpret_cast<const f4*>(rp + c * kDgPix + 16);
+            for (int c = 0; c < 7; ++c) {                                       // columns stream through 8 registers: column c is tap kx's first
+                const int wc = wc0 + c;                                         // column for kx = 4 - c, its second for 5 - c, its third for 6 - c
+                const unsigned char* const pp = rp + wc * kDgPix + ((g0 ^ ((wc >> 1) & 3)) << 4);
+                const f4 a = *reinterpret_cast<const f4*>(pp);
+                const f4 b = *reinterpret_cast<const f4*>(reinterpret_cast<const unsigned char*>((uintptr_t)pp ^ 16u));   // granule g0 + 1: slot ^ 1
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { row[c][e] = a[e]; row[c][4 + e] = b[e]; }
+                for (int kx = 0; kx < 5; ++kx) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float r = e < 4 ? a[e & 3] : b[e & 3];
+                        if (c == 4 - kx) cs[kx][e] = r;
+                        else if (c == 5 - kx) cs[kx][e] = __builtin_fmaf(r, m1, cs[kx][e]);
+                        else if (c == 6 - kx) cs[kx][e] = __builtin_fmaf(r, m2, cs[kx][e]);
+                    }
+                }
             }
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx)
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    cs[kx][e] = __builtin_fmaf(row[6 - kx][e], m2, __builtin_fmaf(row[5 - kx][e], m1, row[4 - kx][e]));
         };
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
-            // ---- g_y window (32 channels of this chunk) -> LDS, zero outside the image and in the two slack columns.  All loads of a thread
-            //      are issued before the first store (a rolled loop with a run-time trip count serialised ~15 L2 round trips per tile:
-            //      0.9 of the first version's 2.1 ms at deconv1, profiles/r03/upconv_bwd_dgrad_ablations.log)
+            // ---- g_y window (16 channels of this chunk) -> LDS, zero outside the image and in the two slack columns.  All loads of a thread
+            //      are issued before its first store.
             {
-                constexpr int kPerRow = kDgWC * 8, kIter = (kDgWR * kPerRow + kDgThreads - 1) / kDgThreads;
-                f4 buf[kIter];
+                constexpr int kPerRow = kDgWC * 4, kIter = (kDgWR * kPerRow + kDgThreads - 1) / kDgThreads, kBatch = 8;
+#pragma unroll 1
+                for (int u0 = 0; u0 < kIter; u0 += kBatch) {
+                    f4 buf[kBatch];
 #pragma unroll
-                for (int u = 0; u < kIter; ++u) {
-                    const int i = threadIdx.x + kDgThreads * u;
-                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
-                    const int col = rem >> 3, q = rem & 7;
-                    const int y = wy0 + wy, x = wx0 + col;
-                    buf[u] = (f4){0.f, 0.f, 0.f, 0.f};
-                    if (wy < WRt && col < WCt && y >= 0 && y < H && x >= 0 && x < W)
-                        buf[u] = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT + 32 * c) + q);
-                }
+                    for (int v = 0; v < kBatch; ++v) {
+                        const int i = threadIdx.x + kDgThreads * (u0 + v);
+                        const int wy = i / kPerRow, rem = i - wy * kPerRow;
+                        const int col = rem >> 2, q = rem & 3;
+                        const int y = wy0 + wy, x = wx0 + col;
+                        buf[v] = (f4){0.f, 0.f, 0.f, 0.f};
+                        if (wy < WRt && col < WCt && y >= 0 && y < H && x >= 0 && x < W)
+                            buf[v] = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT + kDgCh * c) + q);
+                    }
 #pragma unroll
-                for (int u = 0; u < kIter; ++u) {
-                    const int i = threadIdx.x + kDgThreads * u;
-                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
-                    if (wy < WRt && (rem >> 3) < WCt + 2) *reinterpret_cast<f4*>(wnd + wy * kDgRowB + (rem >> 3) * kDgPix + (rem & 7) * 16) = buf[u];
+                    for (int v = 0; v < kBatch; ++v) {
+                        const int i = threadIdx.x + kDgThreads * (u0 + v);
+                        const int wy = i / kPerRow, rem = i - wy * kPerRow;
+                        const int col = rem >> 2, q = rem & 3;
+                        if (wy < WRt && col < WCt + 2) *reinterpret_cast<f4*>(wnd + wy * kDgRowB + col * kDgPix + ((q ^ ((col >> 1) & 3)) << 4)) = buf[v];
+                    }
                 }
             }
             // ---- weight stage 0 of this (ci block, chunk)
             const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + ((long long)blk * NCH + c) * 25 * kDgStage;
             f4 st0, st1 = {0.f, 0.f, 0.f, 0.f};
             st0 = *reinterpret_cast<const f4*>(bsrc + threadIdx.x * 16);
-            if (threadIdx.x < 256) st1 = *reinterpret_cast<const f4*>(bsrc + (512 + threadIdx.x) * 16);
+            if (threadIdx.x < 128) st1 = *reinterpret_cast<const f4*>(bsrc + (256 + threadIdx.x) * 16);
             *reinterpret_cast<f4*>(bst + threadIdx.x * 16) = st0;
-            if (threadIdx.x < 256) *reinterpret_cast<f4*>(bst + (512 + threadIdx.x) * 16) = st1;
+            if (threadIdx.x < 128) *reinterpret_cast<f4*>(bst + (256 + threadIdx.x) * 16) = st1;
             __syncthreads();
             float p1[5][8];                                                     // row sums of the previous window row
             if (active && ry > 1) rowsums(ry - 2, p1);
 #pragma unroll 1
             for (int grp = 0; grp < 5; ++grp) {                                 // vertical tap ky = 4 - grp is completed by window row ry - 1 + grp
-                float cs[5][8], p2[5][8];
+                float cs[5][8];
                 if (active && !((SS_DG_ABLATE & 2) && grp > 0)) {
+                    if (ry > 2) {                                               // the third replica row (1 source row in ~30): re-summed, not carried,
+                        float p2[5][8];                                         // and folded into p1 — (p2 + p1) + cs is the adjoint kernel's order
+                        rowsums(ry - 3 + grp, p2);
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) p1[kx][e] = p2[kx][e] + p1[kx][e];
+                    }
                     rowsums(ry - 1 + grp, cs);
-                    if (ry > 2) rowsums(ry - 3 + grp, p2);                      // the third replica row (1 source row in ~30): re-summed, not carried
                 }
                 // The bf16 MFMA's fp32 accumulation drifts down by ~2^-28 of the magnitude sum (ss_gemm6_f32): the sign of the running sum
                 // alternates per vertical tap, which cancels the drift in expectation.
@@ -180,38 +220,33 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
                         for (int r = 0; r < 16; ++r) acc[t][r] = -acc[t][r];
                 }
                 const float sgn = neg ? -1.f : 1.f;
+                // g_P[src][tap (ky, kx)][co]: rows oldest first, as ss_upconv_cl_bwd_f32
+                auto tap_value = [&](int kx, float (&v)[8]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = ry > 1 ? p1[kx][e] + cs[kx][e] : cs[kx][e];
+                    }
+                };
+                s16x8 ah, am, al;
+                if (active) { float v[8]; tap_value(0, v); dg_split(v, sgn, ah, am, al); }
 #pragma unroll
                 for (int kx = 0; kx < 5; ++kx) {
                     const int s = grp * 5 + kx;
                     const bool more = s + 1 < 25 && !(SS_DG_ABLATE & 1);
                     if (more) {
                         st0 = *reinterpret_cast<const f4*>(bsrc + (long long)(s + 1) * kDgStage + threadIdx.x * 16);
-                        if (threadIdx.x < 256) st1 = *reinterpret_cast<const f4*>(bsrc + (long long)(s + 1) * kDgStage + (512 + threadIdx.x) * 16);
+                        if (threadIdx.x < 128) st1 = *reinterpret_cast<const f4*>(bsrc + (long long)(s + 1) * kDgStage + (256 + threadIdx.x) * 16);
                     }
                     if (active) {
-                        s16x8 ah, am, al;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float v;                                            // g_P[src][tap (ky, kx)][co]: rows oldest first, as ss_upconv_cl_bwd_f32
-                            if (ry > 2) v = (p2[kx][e] + p1[kx][e]) + cs[kx][e];
-                            else if (ry > 1) v = p1[kx][e] + cs[kx][e];
-                            else v = cs[kx][e];
-                            v *= sgn;
-#if SS_DG_ABLATE & 8
-                            ah[e] = (short)(__float_as_uint(v) >> 16); am[e] = (short)__float_as_uint(v); al[e] = am[e];
-                            continue;
-#endif
-                            const __bf16 h1 = (__bf16)v;
-                            const float r1 = v - (float)h1;
-                            const __bf16 h2 = (__bf16)r1;
-                            const float r2 = r1 - (float)h2;
-                            const __bf16 h3 = (__bf16)r2;
-                            ah[e] = __builtin_bit_cast(short, h1); am[e] = __builtin_bit_cast(short, h2); al[e] = __builtin_bit_cast(short, h3);
-                        }
-                        const unsigned char* const bk = bst + (s & 1) * kDgStage + kh * (3 * 2 * 1024) + lane * 16;
+                        const unsigned char* const bk = bst + (s & 1) * kDgStage + lane * 16;
                         s16x8 b[6];                                             // [0,1] hi, [2,3] mid, [4,5] lo of ci tiles 0, 1
 #pragma unroll
                         for (int u = 0; u < 6; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
+                        // the NEXT k-step's fragment is split (VALU) in the shadow of this k-step's twelve MFMAs
+                        s16x8 nh = ah, nm = am, nl = al;
+#if SS_DG_PIPE
+                        if (kx < 4) { float v[8]; tap_value(kx + 1, v); dg_split(v, sgn, nh, nm, nl); }
+#endif
 #if SS_DG_ABLATE & 4
                         acc[0][0] += (float)(ah[0] + am[1] + al[2] + b[0][0] + b[3][1] + b[5][2]);
 #else
@@ -228,13 +263,18 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
 #pragma unroll
                         for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0 + u], acc[u], 0, 0, 0);
 #endif
+                        ah = nh; am = nm; al = nl;
+#if !SS_DG_PIPE
+                        if (kx < 4) { float v[8]; tap_value(kx + 1, v); dg_split(v, sgn, ah, am, al); }
+#endif
                     }
                     if (more) {
                         unsigned char* const dst = bst + ((s + 1) & 1) * kDgStage;
                         *reinterpret_cast<f4*>(dst + threadIdx.x * 16) = st0;
-                        if (threadIdx.x < 256) *reinterpret_cast<f4*>(dst + (512 + threadIdx.x) * 16) = st1;
+                        if (threadIdx.x < 128) *reinterpret_cast<f4*>(dst + (256 + threadIdx.x) * 16) = st1;
                     }
                     if (!(SS_DG_ABLATE & 16)) __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);                        // keep the later k-steps' VALU work below (register pressure)
                 }
                 if (active) {
 #pragma unroll
@@ -244,25 +284,16 @@ __global__ __launch_bounds__(kDgThreads) void upconv_bwd_dgrad_kernel(const floa
                 }
             }
         }
-        // ---- tile epilogue: g_x = (channel-half 0 partial) + (channel-half 1 partial), D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31]
-        const float fin = neg ? -1.f : 1.f;
-        float* const scr = reinterpret_cast<float*>(wnd);                       // the window is dead (last barrier of the k loop)
-        if (kh == 1 && active) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) scr[((mb * 2 + t) * 16 + r) * 64 + lane] = acc[t][r] * fin;
-        }
-        __syncthreads();
-        if (kh == 0 && active) {
+        // ---- tile epilogue: D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31]
+        if (active) {
+            const float fin = neg ? -1.f : 1.f;
             const long long rowbase = ((long long)nb * h + (sy0 + mb)) * w;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int sxm = sx0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float v = acc[t][r] * fin + scr[((mb * 2 + t) * 16 + r) * 64 + lane];
-                    if (sxm < w) store_out(gx + (rowbase + sxm) * CIN + 64 * blk + 32 * t + (lane & 31), v);
+                    if (sxm < w) store_out(gx + (rowbase + sxm) * CIN + 64 * blk + 32 * t + (lane & 31), acc[t][r] * fin);
                 }
         }
     }
@@ -276,7 +307,7 @@ int ss_upconv_bwd_dgrad_supported(int Cin, int Cout, int k, int max_rows4, int m
 {
     // max_rows4 / max_cols32: largest output-row / -column span (incl. the k - 1 taps) of 4 consecutive source rows / 32 consecutive source
     // columns; max_span: most output rows / columns one source pixel collects per tap — computed by the caller from the resize tables
-    if (k != 5 || Cin < 64 || Cin % 64 != 0 || (Cout != 32 && Cout != 64 && Cout != 128 && Cout != 256)) return 0;
+    if (k != 5 || Cin < 64 || Cin % 64 != 0 || (Cout != 32 && Cout != 64 && Cout != 128 && Cout != 256)) return 0;      // C_out % 16 == 0
     return max_span >= 1 && max_span <= 3 && max_rows4 > 0 && max_rows4 <= kDgWR && max_cols32 > 0 && max_cols32 <= kDgWCmax;
 }
 
@@ -299,7 +330,7 @@ int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* 
     hipLaunchKernelGGL(upconv_bwd_dgrad_prep_kernel, dim3(grid_for((long long)25 * Cout * Cin * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const long long n_tiles = NB * ((h + kDgTR - 1) / kDgTR) * ((w + kDgTC - 1) / kDgTC) * (Cin / 64);
-    const unsigned grid = (unsigned)(n_tiles < cus ? n_tiles : cus);             // one workgroup per CU (155 KB of LDS), persistent over its tile range
+    const unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);     // two workgroups per CU (74 KB of LDS each), persistent over their tile ranges
 #define SS_DG(CO) hipLaunchKernelGGL((upconv_bwd_dgrad_kernel<CO>), dim3(grid), dim3(kDgThreads), 0, s, g_out, Bf, y_lo, y_hi, x_lo, x_hi, g_x, \
                                      (int)NB, h, w, H, W, Cin)
     switch (Cout) {

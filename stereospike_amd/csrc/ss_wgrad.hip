@@ -477,9 +477,21 @@ __global__ __launch_bounds__(kSwThreads, CIN == 64 ? 4 : 2) void upconv_bwd_fuse
         const int wx0 = x_lo[sx0] - 4, WCt = x_hi[min(sx0 + 15, w - 1)] - wx0;
         __syncthreads();                                                  // the previous tile's reads of the window are done
         // ---- g_y window -> LDS (zero outside the image)
-        // all loads of a thread are issued before its first store, over the compile-time window extent (a rolled loop with a run-time trip
-        // count serialised one L2 / HBM round trip per iteration: profiles/r03/upconv_bwd_dgrad_ablations.log)
-        {
+        if constexpr (CIN == 64) {
+            // C_in 64 (4 workgroups' worth of wavefronts per SIMD): the rolled loop is FASTER — other wavefronts cover its latency, and the batched
+            // form below costs registers / issue slots here (2.54 -> 3.14 ms at deconv1, profiles/r03/upconv_bwd_variants.log)
+            const int rowf4 = min(WCt + 2, WCM) * C4;                      // + 2: the multiplied-by-zero third column must be finite
+            for (int i = threadIdx.x; i < WRt * rowf4; i += kSwThreads) {
+                const int wy = i / rowf4, rem = i - wy * rowf4;
+                const int y = wy0 + wy, x = wx0 + rem / C4;
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (y >= 0 && y < H && x >= 0 && x < W)
+                    v = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT) + (rem % C4));
+                *reinterpret_cast<f4*>(wnd + wy * ROWB + rem * 16) = v;
+            }
+        } else
+        {   // C_in 128 (2 wavefronts per SIMD): loads of a thread issued in batches before its stores (a rolled loop serialised one L2 / HBM
+            // round trip per iteration: 2.81 -> 2.08 ms at deconv2)
             constexpr int kPerRow = WCM * C4, kIter = (WRM * kPerRow + kSwThreads - 1) / kSwThreads;
             const int cols = min(WCt + 2, WCM);                              // + 2: the multiplied-by-zero third column must be finite
             constexpr int kBatch = CIN == 64 ? 9 : 7;                        // loads in flight per thread (the C_in 128 form has 128 accumulator registers)

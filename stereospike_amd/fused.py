@@ -598,8 +598,9 @@ FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather 
 
 
 FUSED_UPCONV_DGRAD = _os.environ.get('SS_FUSED_DGRAD', '1') == '1'   # decoder data gradient: adjoint gather + six-term MFMA contraction in ONE kernel, g_P only on chip
-FUSED_UPCONV_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_DGRAD_CIN', '64,128').split(',') if c)   # C_in 256 / 512: ss_gemm6_f32 on g_P (1.5 / 0.8 GB) stays
-FUSED_UPCONV_BWD_CIN_NOGP = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN_NOGP', '64,128').split(',') if c)   # fused adjoint + weight gradient WITHOUT its g_P store
+FUSED_UPCONV_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_DGRAD_CIN', '64').split(',') if c)   # deconv1 (g_P 5.76 GB at config 3): 4.17 -> 3.7 ms;
+                                   # deconv2 .. 4: the two-kernel form on g_P (2.9 / 1.5 / 0.8 GB) is faster (profiles/r03/upconv_bwd_variants.log)
+FUSED_UPCONV_BWD_CIN_NOGP = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN_NOGP', '64').split(',') if c)   # fused adjoint + weight gradient WITHOUT its g_P store
 FUSED_UPCONV_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN', '64').split(',') if c)   # C_in 128 (deconv2): the fused form is slower
                                    # than adjoint kernel + ss_spike_wgrad_f32 (4 workgroup kinds re-load every window; profiles/r02/fused_bwd.log)
 

@@ -45,10 +45,10 @@ def _dump():
         json.dump(REPORT, f, indent=1)
 
 
-def check(tag, rep, margin=MARGIN_DEFAULT, depth_bar=1e-5, tensor_bar=TENSOR_GRAD_BAR, plif_bar=PLIF_W_BAR):
+def check(tag, rep, margin=MARGIN_DEFAULT, depth_bar=1e-5, tensor_bar=TENSOR_GRAD_BAR, plif_bar=PLIF_W_BAR, flip_frac=FLIP_FRAC):
     REPORT[tag] = rep
     _dump()
-    assert rep['flip_frac_max'] <= FLIP_FRAC, (tag, rep['layers'])
+    assert rep['flip_frac_max'] <= flip_frac, (tag, rep['layers'])
     assert rep['margin_max'] <= margin, (tag, rep['layers'])
     assert rep['depth_max_abs_rel'] <= depth_bar, (tag, rep['depth_max_abs_rel'])
     assert rep['loss_rel'] <= 1e-5 and rep['mde_rel'] <= 1e-5, (tag, rep['loss'], rep['mde'])

@@ -18,7 +18,15 @@ from _pinned import pinned_parity, rel_l2
 from _util import load_npz, synth_input, synth_label
 
 pytestmark = pytest.mark.gpu
+import test_gpu_00_default_path as _t00
 from test_gpu_00_default_path import check, MARGIN_DEFAULT
+
+@pytest.fixture(autouse=True)
+def _own_report(monkeypatch):
+    monkeypatch.setattr(_t00, 'REPORT_FILE', 'gpurun_out/parity_report_layouts.json')
+    monkeypatch.setattr(_t00, 'REPORT', {} if not hasattr(_own_report, 'rep') else _own_report.rep)
+    _own_report.rep = _t00.REPORT
+
 
 MARGIN_MIOPEN = 5e-4       # layouts whose synapses are MIOpen fp32 convolutions (solver-dependent summation order, <= 1e-5 abs x gain 30)
 EXACT = ('all_nhwc_exact_split', 'exact_split_dense_spikes', 'saved_h_no_fork')

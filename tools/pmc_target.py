@@ -46,5 +46,13 @@ if mode == 'rc':
         _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
         _lib.upconv_fused_fwd(xs, None, Wf, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win)
         _lib.upconv_fused_fwd(xs, None, Wf2, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win, 2)
+    # round 3: the decoder backward of deconv1 with g_P on chip only: adjoint + data gradient (ss_upconv_bwd_dgrad_f32), adjoint + weight gradient
+    # without its g_P store (ss_upconv_bwd_fused_f32, g_P = NULL)
+    gy = torch.randn(NB, H, W, Cout, device=dev)
+    gxs, gw = torch.empty(NB, h, w, Cin, device=dev), torch.empty(Cin, 25 * Cout, device=dev)
+    wt = up.up[1].weight.detach().contiguous()
+    for _ in range(5):
+        _lib.upconv_bwd_dgrad(gy, wt, tabs[1], tabs[2], tabs[4], tabs[5], gxs, NB, Cin, Cout, h, w, H, W)
+        _lib.upconv_bwd_fused(gy, xs, tabs[1], tabs[2], tabs[4], tabs[5], None, gw, NB, Cin, Cout, h, w, H, W)
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
