@@ -84,7 +84,13 @@ def test_pinned_parity_16bit_activations(dt, name, T):
     x = synth_input(2, T, 4, 81, H, W, lam=0.08)
     gt = synth_label(2, 82, H, W)
     scale = _largest_finite_loss_scale(net, x, gt) if dt == torch.float16 else 1.0
-    rep = pinned_parity(orc, net, x, gt, amp_dtype=dt, loss_scale=scale)
+    for _ in range(3):
+        rep = pinned_parity(orc, net, x, gt, amp_dtype=dt, loss_scale=scale)
+        if all(math.isfinite(v) for v in rep['grad_rel_l2'].values()):
+            break
+        # at the largest finite scale an fp16 gradient sits next to 65504: MIOpen's atomic split-K order can push one over in the next run.
+        # GradScaler skips such a step and backs off; so does the test
+        scale /= 4.0
     rep['loss_scale'] = scale
     assert_x16_kernels(rep['launch_tags'])
     u = U[dt]
