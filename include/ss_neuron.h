@@ -365,6 +365,20 @@ int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* 
                             int w, int accumulate, void* stream);     /* x_packed != NULL: the input as a 2-bit packed spike tensor (x may be NULL) */
 
 /*
+ * ABI 5 — FORWARD of the stride-2 5x5 encoder convolutions on spike inputs as an exact bf16x3 implicit GEMM on the matrix cores
+ * (ss_spike_conv.hip).  Replaces torch.nn.functional.conv2d (MIOpen fp32) for conv1 / conv2 of the reference's encoder
+ * (/root/reference/network/SNN_models.py:80-90: nn.Conv2d(C, 2C, kernel_size=5, stride=2, padding=2, bias=False) on the previous stage's spikes):
+ *   out[nb][oy][ox][co] = sum_{ky,kx,ci} x[nb][2 oy + ky - 2][2 ox + kx - 2][ci] * weight[co][ci][ky][kx]       (zero padding)
+ * x [NB][h][w][C_in] NHWC: a dense fp32 spike tensor (values exact in bf16) or, when x_packed != NULL, the 2-bit packed form (x may then be
+ * NULL); weight [C_out][C_in][5][5] fp32 (split exactly into three bf16 terms: every product exact, fp32 accumulation — fp32-convolution
+ * accuracy); out [NB][ho][wo][C_out] fp32, ho = (h - 1) / 2 + 1.  ws: ss_spike_conv_fwd_ws_floats floats.  Compiled shapes: (32 -> 64), (64 -> 128).
+ */
+int ss_spike_conv_fwd_supported(int Cin, int Cout, int k, int stride, int pad);
+long long ss_spike_conv_fwd_ws_floats(int Cin, int Cout);
+int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const float* weight, float* out, float* ws,
+                          long long NB, int Cin, int Cout, int h, int w, void* stream);
+
+/*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
  * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
  *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]

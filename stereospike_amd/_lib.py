@@ -120,6 +120,12 @@ def lib():
     L.ss_upconv_bwd_fused_ws_floats.restype = i64
     L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_bwd_fused_f32.restype = i32
+    L.ss_spike_conv_fwd_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_spike_conv_fwd_supported.restype = i32
+    L.ss_spike_conv_fwd_ws_floats.argtypes = [i32, i32]
+    L.ss_spike_conv_fwd_ws_floats.restype = i64
+    L.ss_spike_conv_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, p]
+    L.ss_spike_conv_fwd_f32.restype = i32
     L.ss_upconv_bwd_dgrad_supported.argtypes = [i32, i32, i32, i32, i32, i32]
     L.ss_upconv_bwd_dgrad_supported.restype = i32
     L.ss_upconv_bwd_dgrad_ws_floats.argtypes = [i32, i32]
@@ -171,6 +177,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
            'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
+           'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
@@ -544,6 +551,24 @@ def gemm6_batched(A, B, C_, batch, R, K, N):
         rc = lib().ss_gemm6_batched_f32(_f32(A, 'A', batch * R * K), _f32(B, 'B', batch * K * N), _f32(C_, 'C', batch * R * N), _f32(ws, 'ws'),
                                         batch, R, K, N, _stream(A))
     _check(rc, 'ss_gemm6_batched_f32')
+
+
+def spike_conv_fwd_supported(Cin, Cout, k, stride, pad):
+    return bool(lib().ss_spike_conv_fwd_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def spike_conv_fwd(x, x_packed, weight, out, NB, Cin, Cout, h, w):
+    """out [NB, ho, wo, Cout] = conv2d(x, weight, stride 2, pad 2) on a spike input (dense fp32 NHWC x, or the 2-bit packed x_packed): exact
+    bf16x3 implicit GEMM on the matrix cores, no im2col."""
+    _require_hip(out, 'out')
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ws = torch.empty(int(lib().ss_spike_conv_fwd_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=out.device)
+    with torch.cuda.device(out.device):
+        rc = lib().ss_spike_conv_fwd_f32(None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
+                                         _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                                         _f32(weight, 'weight', Cout * Cin * 25), _f32(out, 'out', NB * ho * wo * Cout), _f32(ws, 'ws'),
+                                         NB, Cin, Cout, h, w, _stream(out))
+    _check(rc, 'ss_spike_conv_fwd_f32')
 
 
 def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):

@@ -1,0 +1,262 @@
+// ss_spike_conv.hip — forward of the stride-2 5x5 encoder convolutions on SPIKE inputs as an exact bf16x3 implicit GEMM on the matrix cores
+// (include/ss_neuron.h: ss_spike_conv_fwd_f32).
+//
+// Reference: conv1 / conv2 of the encoder, nn.Conv2d(C, 2C, kernel_size=5, stride=2, padding=2, bias=False)
+// (/root/reference/network/SNN_models.py:80-90, 268-278, 455-465), whose input is the spike tensor of the previous stage (values 0 / 1: exact in
+// bf16).  Until round 3 their forward was MIOpen's fp32 implicit GEMM: 1.42 ms each at BASELINE config 3, AT the fp32-MFMA rate (130 of 157
+// TFLOP/s) — the contraction itself had to change to go faster.  With a spike operand the fp32 weight split EXACTLY into three bf16 terms gives
+// exact products on v_mfma_f32_32x32x16_bf16 (3 MFMAs at 16x the fp32 rate), fp32 accumulation: fp32-convolution accuracy, as every other
+// exact-split synapse of the build.  No im2col: its patch matrix would be 25x the input (2.9 GB at conv1; measured slower than
+// MIOpen in round 1, profiles/r01/conv_as_gemm.log).
+//
+//   out[nb][oy][ox][co] = sum_{ky,kx,ci} x[nb][2 oy + ky - 2][2 ox + kx - 2][ci] * W[co][ci][ky][kx]        (zero padding)
+//
+// GEMM view: M = output pixels, N = C_out, K = (tap, ci).  A workgroup (4 wavefronts, TWO per CU) owns a tile of 4 output rows x 32 output
+// columns — a wavefront = one output row = the M dimension of the MFMA:
+//   * the input window of the tile (11 rows x 67 columns, 32 input channels at a time) is staged in LDS as bf16 — expanded from the 2-bit
+//     packed spike tensor (16x less to read than fp32; or converted from a dense fp32 tensor) — 64-B pixels whose 16-B granules sit at slot
+//     g ^ ((col >> 2) & 3): lanes = consecutive output columns = every second window column read 8 distinct bank groups per LDS cycle;
+//   * an A fragment of a k-step (one tap, 16 input channels) is ONE 16-B LDS read per lane — no VALU work in the main loop at all;
+//   * the weight fragments (split once, fragment-ordered by spike_conv_fwd_prep_kernel) stream L2 -> LDS, double-buffered, one k-step per
+//     stage, shared by the four wavefronts; 3 x C_out / 32 MFMAs per k-step and wavefront.
+// HBM traffic: the packed input (58 MB at conv1), the weights from L2, the output once.
+#include "ss_common.hpp"
+
+namespace {
+
+constexpr int kScThreads = 256;
+constexpr int kScTR = 4, kScTC = 32;                   // output rows (one per wavefront) x output columns (= MFMA M) of a tile
+constexpr int kScWR = 2 * (kScTR - 1) + 5;             // 11 window rows
+constexpr int kScWC = 2 * (kScTC - 1) + 5;             // 67 window columns
+constexpr int kScPix = 64;                             // bytes per window pixel: 32 input channels as bf16 = 4 granules of 8 channels
+constexpr int kScRowB = kScWC * kScPix;
+
+// weight [C_out][C_in][5][5] fp32 -> Bf[chunk of 32 ci][s = tap * 2 + ci16 group][split][co tile][lane][8] bf16: element e of a lane = split term
+// of W[co = 32 tile + (lane & 31)][ci = 32 chunk + 16 group + 8 (lane >> 5) + e][ky][kx]   (exact 3-way split, round to nearest)
+__global__ __launch_bounds__(kBlock) void spike_conv_fwd_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, int Cin, int Cout)
+{
+    const int NT = Cout / 32;
+    const long long total = (long long)(Cin / 32) * 50 * 3 * NT * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int t = (int)(r % NT); r /= NT;
+        const int sp = (int)(r % 3); r /= 3;
+        const int s = (int)(r % 50); const int c = (int)(r / 50);
+        const int tap = s >> 1, g = s & 1, ky = tap / 5, kx = tap - 5 * ky;
+        const int co = 32 * t + (lane & 31);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 32 * c + 16 * g + 8 * (lane >> 5) + e;
+            const float v = W[(((long long)co * Cin + ci) * 5 + ky) * 5 + kx];
+            const unsigned short h1 = narrow<SS_DT_BF16>(v);
+            const float r1 = v - widen<SS_DT_BF16>(h1);
+            const unsigned short h2 = narrow<SS_DT_BF16>(r1);
+            const float r2 = r1 - widen<SS_DT_BF16>(h2);
+            o[e] = sp == 0 ? h1 : (sp == 1 ? h2 : narrow<SS_DT_BF16>(r2));
+        }
+        *reinterpret_cast<u16x8*>(Bf + i * 8) = o;
+    }
+}
+
+template <int CIN, int COUT, bool PACKED>
+__global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Bf,
+                                                                       float* __restrict__ out, int NB, int h, int w, int ho, int wo)
+{
+    constexpr int NT = COUT / 32, NCH = CIN / 32;
+    constexpr int STG = 3 * NT * 1024;                                          // bytes of one weight stage (one k-step)
+    constexpr int LPT = STG / 16 / kScThreads;                                  // whole 16-B pieces per thread and stage (+ a partial round)
+    constexpr int REM = STG / 16 - LPT * kScThreads;
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[kScWR * kScRowB];
+    __shared__ __attribute__((aligned(16))) unsigned char bst[2 * STG];
+    const int lane = threadIdx.x & 63;
+    const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // wavefront = output row of the tile
+    const int RG = (ho + kScTR - 1) / kScTR, CG = (wo + kScTC - 1) / kScTC;
+    const long long n_tiles = (long long)NB * RG * CG;
+    const unsigned g = xcd_remap(blockIdx.x, gridDim.x);                        // contiguous tile ranges, neighbours on one XCD (halo rows in its L2)
+    const long long t_begin = n_tiles * g / gridDim.x, t_end = n_tiles * (g + 1) / gridDim.x;
+    const int tx = lane & 31, half = lane >> 5;
+    f4 st[LPT + 1];
+    auto stage_issue = [&](const unsigned char* src) {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) st[u] = *reinterpret_cast<const f4*>(src + (threadIdx.x + kScThreads * u) * 16);
+        if (REM && (int)threadIdx.x < REM) st[LPT] = *reinterpret_cast<const f4*>(src + (threadIdx.x + kScThreads * LPT) * 16);
+    };
+    auto stage_commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) *reinterpret_cast<f4*>(dst + (threadIdx.x + kScThreads * u) * 16) = st[u];
+        if (REM && (int)threadIdx.x < REM) *reinterpret_cast<f4*>(dst + (threadIdx.x + kScThreads * LPT) * 16) = st[LPT];
+    };
+#pragma unroll 1
+    for (long long tl = t_begin; tl < t_end; ++tl) {
+        const int cg = (int)(tl % CG);
+        long long rr = tl / CG;
+        const int rg = (int)(rr % RG);
+        const int nb = (int)(rr / RG);
+        const int oy0 = kScTR * rg, ox0 = kScTC * cg;
+        const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;                         // input coordinates of window (0, 0)
+        const bool active = oy0 + mb < ho;                                      // wave-uniform
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
+            // ---- input window (32 channels of this chunk) -> LDS as bf16, zero outside the image
+            if constexpr (PACKED) {
+                const unsigned* xp = static_cast<const unsigned*>(xin);
+                constexpr int kItems = kScWR * kScWC * 2, kIter = (kItems + kScThreads - 1) / kScThreads;   // (pixel, 16-channel word)
+                unsigned wv[kIter];
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    const int i = threadIdx.x + kScThreads * u;
+                    const int pix = i >> 1, j = i & 1;
+                    const int wy = pix / kScWC, col = pix - wy * kScWC;
+                    const int iy = iy0 + wy, ix = ix0 + col;
+                    wv[u] = 0u;
+                    if (i < kItems && iy >= 0 && iy < h && ix >= 0 && ix < w)
+                        wv[u] = xp[((((long long)nb * h + iy) * w + ix) * CIN + 32 * c) / 16 + j];
+                }
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    const int i = threadIdx.x + kScThreads * u;
+                    const int pix = i >> 1, j = i & 1;
+                    const int wy = pix / kScWC, col = pix - wy * kScWC;
+                    if (i < kItems) {
+                        unsigned char* const pp = wnd + wy * kScRowB + col * kScPix;
+                        const int swz = (col >> 2) & 3;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {                             // granule 2 j + q = channels 16 j + 8 q .. + 7
+                            u16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = code_to_bf16((wv[u] >> (2 * (8 * q + e))) & 3u);
+                            *reinterpret_cast<u16x8*>(pp + (((2 * j + q) ^ swz) << 4)) = o;
+                        }
+                    }
+                }
+            } else {
+                const float* x = static_cast<const float*>(xin);
+                constexpr int kItems = kScWR * kScWC * 4, kIter = (kItems + kScThreads - 1) / kScThreads;   // (pixel, 8-channel granule)
+#pragma unroll 1
+                for (int u0 = 0; u0 < kIter; u0 += 4) {
+                    f4 va[4], vb[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = threadIdx.x + kScThreads * (u0 + v);
+                        const int pix = i >> 2, q = i & 3;
+                        const int wy = pix / kScWC, col = pix - wy * kScWC;
+                        const int iy = iy0 + wy, ix = ix0 + col;
+                        va[v] = (f4){0.f, 0.f, 0.f, 0.f}; vb[v] = va[v];
+                        if (i < kItems && iy >= 0 && iy < h && ix >= 0 && ix < w) {
+                            const float* p = x + (((long long)nb * h + iy) * w + ix) * CIN + 32 * c + 8 * q;
+                            va[v] = *reinterpret_cast<const f4*>(p); vb[v] = *reinterpret_cast<const f4*>(p + 4);
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = threadIdx.x + kScThreads * (u0 + v);
+                        const int pix = i >> 2, q = i & 3;
+                        const int wy = pix / kScWC, col = pix - wy * kScWC;
+                        if (i < kItems) {
+                            u16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {                         // spike counts: exact in bf16 (the high half of the fp32 pattern)
+                                o[e] = (unsigned short)(__float_as_uint(va[v][e]) >> 16);
+                                o[4 + e] = (unsigned short)(__float_as_uint(vb[v][e]) >> 16);
+                            }
+                            *reinterpret_cast<u16x8*>(wnd + wy * kScRowB + col * kScPix + ((q ^ ((col >> 2) & 3)) << 4)) = o;
+                        }
+                    }
+                }
+            }
+            // ---- weight stage 0 of this chunk
+            const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + (long long)c * 50 * STG;
+            stage_issue(bsrc);
+            stage_commit(bst);
+            __syncthreads();
+            // window byte offset of this lane's pixel at tap (0, 0): row 2 mb, column 2 tx
+            const unsigned char* const lane_row = wnd + (2 * mb) * kScRowB;
+#pragma unroll 1
+            for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const int s = (ky * 5 + kx) * 2 + gi;
+                        const bool more = s + 1 < 50;
+                        if (more) stage_issue(bsrc + (long long)(s + 1) * STG);
+                        if (active) {
+                            const int col = 2 * tx + kx;
+                            const s16x8 a = *reinterpret_cast<const s16x8*>(lane_row + ky * kScRowB + col * kScPix + (((2 * gi + half) ^ ((col >> 2) & 3)) << 4));
+                            const unsigned char* const bk = bst + (s & 1) * STG + lane * 16;
+                            s16x8 b[3 * NT];                                    // [split][tile]
+#pragma unroll
+                            for (int u = 0; u < 3 * NT; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
+#pragma unroll
+                            for (int sp = 2; sp >= 0; --sp)                     // smallest terms first
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[sp * NT + t], acc[t], 0, 0, 0);
+                        }
+                        if (more) stage_commit(bst + ((s + 1) & 1) * STG);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+        // ---- D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] -> out[nb][oy][ox0 + row][32 t + col]
+        if (active) {
+            const long long rowbase = ((long long)nb * ho + (oy0 + mb)) * wo;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (ox < wo) store_out(out + (rowbase + ox) * COUT + 32 * t + tx, acc[t][r]);
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_spike_conv_fwd_supported(int Cin, int Cout, int k, int stride, int pad)
+{
+    return k == 5 && stride == 2 && pad == 2 && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128));
+}
+
+long long ss_spike_conv_fwd_ws_floats(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
+    return (long long)25 * Cin * Cout * 3 / 2;                                  // the weight as three bf16 terms in fragment order
+}
+
+int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const float* weight, float* out, float* ws,
+                          long long NB, int Cin, int Cout, int h, int w, void* stream)
+{
+    if ((!x && !x_packed) || !weight || !out || !ws || NB <= 0 || h <= 0 || w <= 0) return SS_EINVAL;
+    if (!ss_spike_conv_fwd_supported(Cin, Cout, 5, 2, 2) || !aligned16(out) || !aligned16(ws) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
+    const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
+    if (NB * h * (long long)w * Cin > 0x7fffffffffLL || (x_packed && (NB * h * (long long)w * Cin) % 16 != 0)) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
+    hipLaunchKernelGGL(spike_conv_fwd_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    const long long n_tiles = NB * ((ho + kScTR - 1) / kScTR) * ((wo + kScTC - 1) / kScTC);
+    const unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);     // two workgroups per CU, persistent over their tile ranges
+#define SS_SC(CI, CO) do { if (x_packed) hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, true>), dim3(grid), dim3(kScThreads), 0, s, \
+                               static_cast<const void*>(x_packed), Bf, out, (int)NB, h, w, ho, wo); \
+                           else hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, false>), dim3(grid), dim3(kScThreads), 0, s, \
+                               static_cast<const void*>(x), Bf, out, (int)NB, h, w, ho, wo); } while (0)
+    if (Cin == 32) SS_SC(32, 64); else SS_SC(64, 128);
+#undef SS_SC
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+}  // extern "C"

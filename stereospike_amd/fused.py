@@ -941,6 +941,8 @@ def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return g_x
 
 
+SPIKE_CONV_FWD_MFMA = _os.environ.get('SS_CONV_FWD_MFMA', '1') == '1'     # conv1 / conv2 FORWARD as the exact bf16x3 implicit-GEMM kernel ss_spike_conv_fwd_f32 (was MIOpen fp32:
+                                   # 1.42 ms each at config 3, at the fp32-MFMA rate); reads the 2-bit packed spikes, so bottom / conv1 write no dense output
 SPIKE_CONV_WGRAD_MFMA = _os.environ.get('SS_CONV_WGRAD_MFMA', '1') == '1'   # conv1 / conv2 (5x5, stride 2, spike inputs): forward and data gradient on
                                    # MIOpen, weight gradient as the hand-written exact bf16x3 MFMA contraction ss_spike_conv_wgrad_f32
 
@@ -953,10 +955,27 @@ class _SpikeConvWgradCL(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x_cl, weight, x_packed=None):
-        x_cl = x_cl.contiguous()
-        w_cl = weight.contiguous(memory_format=torch.channels_last)
-        y = torch.nn.functional.conv2d(x_cl.permute(0, 3, 1, 2), w_cl, None, 2, 2).permute(0, 2, 3, 1)
-        y = y if y.is_contiguous() else y.contiguous()
+        NB, h, w, Cin = x_cl.shape
+        Cout = weight.shape[0]
+        if SPIKE_CONV_FWD_MFMA and _lib.spike_conv_fwd_supported(Cin, Cout, 5, 2, 2):
+            # forward as the exact bf16x3 implicit GEMM on the matrix cores, reading the packed spikes when the producer wrote them
+            # (x_cl may then be a data-less anchor)
+            if x_packed is None:
+                x_cl = x_cl.contiguous()
+                if ASSERT_EXACT_SPLIT:
+                    assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spike_conv: the input is not exact in bf16'
+            y = torch.empty((NB, (h - 1) // 2 + 1, (w - 1) // 2 + 1, Cout), dtype=torch.float32, device=x_cl.device)
+            e0 = TIMER.start()
+            _lib.spike_conv_fwd(None if x_packed is not None else x_cl, None if x_packed is None else x_packed.contiguous(),
+                                weight.detach().float().contiguous(), y, NB, Cin, Cout, h, w)
+            TIMER.stop(e0, 'spike_conv_fwd', 4 * y.numel() + (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()), y.numel())
+        else:
+            if x_cl.stride(-1) == 0:
+                raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
+            x_cl = x_cl.contiguous()
+            w_cl = weight.contiguous(memory_format=torch.channels_last)
+            y = torch.nn.functional.conv2d(x_cl.permute(0, 3, 1, 2), w_cl, None, 2, 2).permute(0, 2, 3, 1)
+            y = y if y.is_contiguous() else y.contiguous()
         # the backward's operand copy reads the 2-bit packed form when the producer wrote one (16x less to read than the fp32 tensor)
         ctx.save_for_backward(x_cl, weight, x_packed)
         return y
@@ -982,12 +1001,23 @@ class _SpikeConvWgradCL(torch.autograd.Function):
         return g_x, g_w, None
 
 
+def spike_conv_fwd_applies(conv, device, dtype=torch.float32) -> bool:
+    """True when `conv` on a spike NHWC array runs its FORWARD through ss_spike_conv_fwd_f32 (and can therefore take a packed-only input)."""
+    import torch.nn as nn
+    return bool(SPIKE_CONV_FWD_MFMA and SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and device.type == 'cuda' and dtype == torch.float32
+                and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+                and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2)
+                and _lib.spike_conv_fwd_supported(conv.in_channels, conv.out_channels, 5, 2, 2)
+                and _lib.spike_conv_wgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2))
+
+
 def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """conv on a spike NHWC array through _SpikeConvWgradCL, or None when it does not apply (caller then uses the plain MIOpen convolution)."""
     import torch.nn as nn
     if not (SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
             and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
-            and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2) and x_cl.stride(-1) == 1
+            and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2)
+            and (x_cl.stride(-1) == 1 or (x_packed is not None and spike_conv_fwd_applies(conv, x_cl.device, x_cl.dtype)))   # anchor: packed-only input
             and _lib.spike_conv_wgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2)):
         return None
     return _SpikeConvWgradCL.apply(x_cl, conv.weight, x_packed)

@@ -142,7 +142,7 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             def mode(next_conv):
                 if not pk_on:
                     return 0
-                return 2 if _fused.spike_conv_applies(next_conv, x_seq.device) else 1
+                return 2 if (_fused.spike_conv_applies(next_conv, x_seq.device) or _fused.spike_conv_fwd_applies(next_conv, x_seq.device)) else 1
 
             def packed_in(conv, packed):      # hand the packed form only to a synapse that reads it (exact-split im2col; the operand copy of
                 if packed is None:            # the MFMA weight gradient of conv1 / conv2, which still takes the dense form for MIOpen's forward)

@@ -202,13 +202,13 @@ def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False, x_pa
         y = spike_conv_cl(x_arr, conv, x_packed)
         if y is not None:
             return y
-    if x_packed is not None and x_arr.stride(-1) == 0:
-        raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
     if spikes_in and isinstance(conv, nn.Conv2d):
         from ..fused import spike_conv_wgrad_cl
-        y = spike_conv_wgrad_cl(x_arr, conv, x_packed)    # conv1 / conv2: MIOpen forward / data gradient, exact MFMA weight gradient
-        if y is not None:
+        y = spike_conv_wgrad_cl(x_arr, conv, x_packed)    # conv1 / conv2: exact MFMA forward (implicit GEMM on the packed spikes) and weight
+        if y is not None:                                 # gradient, MIOpen data gradient
             return y
+    if x_packed is not None and x_arr.stride(-1) == 0:
+        raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
     if isinstance(conv, nn.Conv2d):
         w = conv.weight.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x_arr.permute(0, 3, 1, 2), w, conv.bias, conv.stride, conv.padding,

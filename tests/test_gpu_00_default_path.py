@@ -58,14 +58,15 @@ def check(tag, rep, margin=MARGIN_DEFAULT, depth_bar=1e-5, tensor_bar=TENSOR_GRA
 
 def assert_default_kernels(tags, T):
     """The launch tags of one forward + backward of a 13-layer spiking network in the shipped default configuration at a compile-time T:
-    packed-only outputs on the five edges into exact-split convs, packed skip operands, forked gradients on conv1..3, the four heads'
+    packed-only outputs on the seven edges into exact-split / implicit-GEMM convs, packed skip operands, forked gradients on conv1..3, the four heads'
     gradients as rank-9 pairs (+ the full-resolution pair travelling on into the first encoder layer), nothing on the saved-h forms."""
     fwd = {k: v for k, v in tags.items() if k.startswith('neuron_fwd')}
     bwd = {k: v for k, v in tags.items() if k.startswith('neuron_bwd')}
     assert sum(fwd.values()) == 13 and sum(bwd.values()) == 13, tags
     assert not any(k.endswith('+h') for k in fwd) and not any('savedh' in k for k in bwd), ('saved-h (run-time-T) kernels ran', tags)
-    assert fwd.get('neuron_fwd_train+packed', 0) == 5 and fwd.get('neuron_fwd_train+skip+packed', 0) == 1, tags
-    assert fwd.get('neuron_fwd_train', 0) == 2 and fwd.get('neuron_fwd_train+skip', 0) == 5, tags
+    assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 1, tags
+    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 5, tags
+    assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert bwd.get('neuron_bwd+lronly', 0) == 1 and bwd.get('neuron_bwd+lr', 0) == 1 and bwd.get('neuron_bwd+lr+sum', 0) == 3, tags
     assert bwd.get('neuron_bwd+fork', 0) == 3 and bwd.get('neuron_bwd', 0) == 5, tags
     assert tags.get('upconv_cl_fwd', 0) == 8 and tags.get('upconv_cl_bwd', 0) == 8, tags
@@ -176,11 +177,21 @@ def test_packed_spike_tensors_are_in_effect():
     d, s = net.forward_sequence(x)
     Total_Loss()(d, gt, s).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
-    for st in (net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
-        assert st.last_packed is not None and st.last_packed.dtype == torch.int32
-    assert net.bottom[2].last_packed is not None and net.conv1[2].last_packed is not None       # dense + packed (MIOpen reads the dense form)
+    for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
+        assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
     assert net.deconv1[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
-    assert torch.equal(fused.unpack_dense(net.bottom[2].last_packed, rec['shape']), rec['bottom_out'])
+    assert not any(rec['bottom_out'].stride())                                                  # bottom's dense output is a data-less anchor
+    packed_only = fused.unpack_dense(net.bottom[2].last_packed, rec['shape'])
+    # with conv1's forward back on MIOpen (which reads dense activations) bottom writes BOTH forms in one launch: unpack(packed) == dense
+    fused.SPIKE_CONV_FWD_MFMA = False
+    try:
+        functional.reset_net(net)
+        with torch.no_grad():
+            net.forward_sequence(x)
+        assert any(rec['bottom_out'].stride()) and torch.equal(fused.unpack_dense(net.bottom[2].last_packed, rec['shape']), rec['bottom_out'])
+        assert torch.equal(rec['bottom_out'], packed_only)
+    finally:
+        fused.SPIKE_CONV_FWD_MFMA = True
     assert 0.02 < float(rec['bottom_out'].mean()) < 0.9
     fused.PACK_SPIKES = False
     try:

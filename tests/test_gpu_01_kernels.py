@@ -1341,3 +1341,70 @@ def test_spike_conv_wgrad_mfma(NB, Cin, Cout, hw):
         assert torch.equal(gw, gw3)
     _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w, accumulate=True)
     assert torch.equal(gw2, gw + gw)
+
+
+# ======================================================================================================
+# exact MFMA FORWARD of the stride-2 5x5 encoder convs on spike inputs (ss_spike_conv_fwd_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('NB,Cin,Cout,hw', [(2, 32, 64, (64, 80)), (3, 64, 128, (33, 45)), (1, 32, 64, (7, 9)), (5, 64, 128, (130, 173)), (4, 32, 64, (260, 346)),
+                                            (2, 32, 64, (50, 70))])
+def test_spike_conv_fwd_mfma(NB, Cin, Cout, hw):
+    """== conv2d(x, w, stride 2, padding 2) evaluated in float64 within fp32 accumulation error of EXACT products (element-wise bound 2^-22 of
+    the magnitude sum sum |x||w|: the exact 3-way bf16 split of the weight times spike counts, fp32 accumulation in the MFMA); at least as close
+    to float64 as MIOpen's fp32 convolution (x 2); packed input == dense input bit for bit; odd sizes / ragged tiles / frame edges; deterministic."""
+    import torch.nn.functional as F
+    from stereospike_amd import _lib
+    h, w = hw
+    gen = torch.Generator(device=DEV).manual_seed(NB + h)
+    x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float()
+         + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.03).float())                      # values 0 .. 3
+    wt = torch.randn(Cout, Cin, 5, 5, device=DEV, generator=gen) * 0.05
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert _lib.spike_conv_fwd_supported(Cin, Cout, 5, 2, 2) and not _lib.spike_conv_fwd_supported(Cin, Cout, 3, 1, 1)
+    y = torch.full((NB, ho, wo, Cout), float('nan'), device=DEV)
+    _lib.spike_conv_fwd(x, None, wt, y, NB, Cin, Cout, h, w)
+
+    def conv(xx, ww):
+        return F.conv2d(xx.permute(0, 3, 1, 2), ww, None, 2, 2).permute(0, 2, 3, 1)
+    ref = conv(x.double(), wt.double())
+    mag = conv(x.double(), wt.double().abs())
+    err = (y.double() - ref).abs()
+    assert bool(torch.isfinite(y).all()) and bool((err <= mag * 2.0 ** -22 + 1e-30).all()), float((err / (mag * 2.0 ** -22 + 1e-30)).max())
+    mi = conv(x, wt)
+    assert float(err.max()) <= 2.0 * float((mi.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
+    y2 = torch.empty_like(y)
+    _lib.spike_conv_fwd(x, None, wt, y2, NB, Cin, Cout, h, w)
+    assert torch.equal(y, y2)
+    if (NB * h * w * Cin) % 16 == 0:                         # the 2-bit packed spike input: same values, bit for bit
+        from oracle import np_pack
+        xp = torch.from_numpy(np_pack.pack(x.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
+        y3 = torch.full_like(y, float('nan'))
+        _lib.spike_conv_fwd(None, xp, wt, y3, NB, Cin, Cout, h, w)
+        assert torch.equal(y, y3)
+
+
+def test_spike_conv_stage_packed_only_input_matches_dense(monkeypatch):
+    """SpikingStage.forward_sequence_conv_cl on a packed-only input (a data-less anchor + the packed tensor: what bottom / conv1 hand on in the
+    default configuration) == on the dense tensor: output spikes, weight gradient and input gradient."""
+    from stereospike_amd import fused
+    from stereospike_amd.clock_driven import functional, neuron, surrogate
+    from stereospike_amd.network.blocks import MultiplyBy, SpikingStage
+    from oracle import np_pack
+    T, B, h, w, Cin, Cout = 5, 2, 64, 80, 32, 64
+    torch.manual_seed(3)
+    st = SpikingStage(torch.nn.Conv2d(Cin, Cout, 5, 2, 2, bias=False), MultiplyBy(10.), neuron.IFNode(surrogate_function=surrogate.ATan(), detach_reset=True)).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    x = (torch.rand(T, B, h, w, Cin, device=DEV, generator=gen) < 0.2).float()
+    xp = torch.from_numpy(np_pack.pack(x.cpu().numpy().reshape(T, -1)).view(np.int32)).to(DEV)
+    g = torch.randn(T, B, h // 2, w // 2, Cout, device=DEV, generator=gen)
+    outs = []
+    for packed in (False, True):
+        st.zero_grad()
+        functional.reset_net(st)
+        xin = (fused.spike_anchor(x.shape, x.dtype, x.device) if packed else x.clone()).requires_grad_()
+        y = st.forward_sequence_conv_cl(xin, spikes_in=True, x_packed=xp if packed else None)
+        (y * g).sum().backward()
+        outs.append((y.detach().clone(), st[0].weight.grad.clone(), xin.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][0].mean()) > 0.01
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-6 * float(outs[0][2].abs().max())       # MIOpen's data gradient (atomics: not bit-stable)
