@@ -1349,8 +1349,8 @@ def test_spike_conv_wgrad_mfma(NB, Cin, Cout, hw):
 @pytest.mark.parametrize('NB,Cin,Cout,hw', [(2, 32, 64, (64, 80)), (3, 64, 128, (33, 45)), (1, 32, 64, (7, 9)), (5, 64, 128, (130, 173)), (4, 32, 64, (260, 346)),
                                             (2, 32, 64, (50, 70))])
 def test_spike_conv_fwd_mfma(NB, Cin, Cout, hw):
-    """== conv2d(x, w, stride 2, padding 2) evaluated in float64 within fp32 accumulation error of EXACT products (element-wise bound 2^-22 of
-    the magnitude sum sum |x||w|: the exact 3-way bf16 split of the weight times spike counts, fp32 accumulation in the MFMA); at least as close
+    """== conv2d(x, w, stride 2, padding 2) evaluated in float64 within fp32 accumulation error of EXACT products (element-wise bound 2^-21 of
+    the magnitude sum sum |x||w| over K = 800 / 1600 terms: the exact 3-way bf16 split of the weight times spike counts, fp32 accumulation in the MFMA); at least as close
     to float64 as MIOpen's fp32 convolution (x 2); packed input == dense input bit for bit; odd sizes / ragged tiles / frame edges; deterministic."""
     import torch.nn.functional as F
     from stereospike_amd import _lib
@@ -1369,7 +1369,7 @@ def test_spike_conv_fwd_mfma(NB, Cin, Cout, hw):
     ref = conv(x.double(), wt.double())
     mag = conv(x.double(), wt.double().abs())
     err = (y.double() - ref).abs()
-    assert bool(torch.isfinite(y).all()) and bool((err <= mag * 2.0 ** -22 + 1e-30).all()), float((err / (mag * 2.0 ** -22 + 1e-30)).max())
+    assert bool(torch.isfinite(y).all()) and bool((err <= mag * 2.0 ** -21 + 1e-30).all()), float((err / (mag * 2.0 ** -21 + 1e-30)).max())
     mi = conv(x, wt)
     assert float(err.max()) <= 2.0 * float((mi.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
     y2 = torch.empty_like(y)
