@@ -170,7 +170,8 @@ def test_packed_spike_tensors_are_in_effect():
 
     def spy(x_seq, *a, **kw):
         r = orig(x_seq, *a, **kw)
-        rec['bottom_out'], rec['shape'] = (r[0] if isinstance(r, tuple) else r).detach().clone(), x_seq.shape
+        r0 = r[0] if isinstance(r, tuple) else r
+        rec['bottom_out'], rec['shape'], rec['anchor'] = r0.detach().clone(), x_seq.shape, not any(r0.stride())
         return r
     net.bottom[2].forward_sequence = spy
     functional.reset_net(net)
@@ -180,7 +181,7 @@ def test_packed_spike_tensors_are_in_effect():
     for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
         assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
     assert net.deconv1[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
-    assert not any(rec['bottom_out'].stride())                                                  # bottom's dense output is a data-less anchor
+    assert rec['anchor']                                                                        # bottom's dense output is a data-less anchor
     packed_only = fused.unpack_dense(net.bottom[2].last_packed, rec['shape'])
     # with conv1's forward back on MIOpen (which reads dense activations) bottom writes BOTH forms in one launch: unpack(packed) == dense
     fused.SPIKE_CONV_FWD_MFMA = False
@@ -188,7 +189,7 @@ def test_packed_spike_tensors_are_in_effect():
         functional.reset_net(net)
         with torch.no_grad():
             net.forward_sequence(x)
-        assert any(rec['bottom_out'].stride()) and torch.equal(fused.unpack_dense(net.bottom[2].last_packed, rec['shape']), rec['bottom_out'])
+        assert not rec['anchor'] and torch.equal(fused.unpack_dense(net.bottom[2].last_packed, rec['shape']), rec['bottom_out'])
         assert torch.equal(rec['bottom_out'], packed_only)
     finally:
         fused.SPIKE_CONV_FWD_MFMA = True
