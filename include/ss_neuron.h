@@ -377,6 +377,11 @@ int ss_spike_conv_fwd_supported(int Cin, int Cout, int k, int stride, int pad);
 long long ss_spike_conv_fwd_ws_floats(int Cin, int Cout);
 int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const float* weight, float* out, float* ws,
                           long long NB, int Cin, int Cout, int h, int w, void* stream);
+/* The FIRST encoder layer, nn.Conv2d(C_in = 4 | 2, 32, kernel_size=5, stride=1, padding=2, bias=False) on the event-voxel input
+ * (/root/reference/network/SNN_models.py:75-79, 450-454): x [NB][h][w][C_in] dense fp32 (ANY values: both operands are split into three bf16
+ * terms, six cross terms kept — exact for integer event counts, fp32-product accuracy otherwise), weight [32][C_in][5][5], out [NB][h][w][32]. */
+int ss_dense_conv_s1_fwd_supported(int Cin, int Cout, int k, int stride, int pad);
+int ss_dense_conv_s1_fwd_f32(const float* x, const float* weight, float* out, long long NB, int Cin, int Cout, int h, int w, void* stream);
 
 /*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2

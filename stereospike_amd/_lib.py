@@ -126,6 +126,10 @@ def lib():
     L.ss_spike_conv_fwd_ws_floats.restype = i64
     L.ss_spike_conv_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, p]
     L.ss_spike_conv_fwd_f32.restype = i32
+    L.ss_dense_conv_s1_fwd_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_dense_conv_s1_fwd_supported.restype = i32
+    L.ss_dense_conv_s1_fwd_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
+    L.ss_dense_conv_s1_fwd_f32.restype = i32
     L.ss_upconv_bwd_dgrad_supported.argtypes = [i32, i32, i32, i32, i32, i32]
     L.ss_upconv_bwd_dgrad_supported.restype = i32
     L.ss_upconv_bwd_dgrad_ws_floats.argtypes = [i32, i32]
@@ -178,6 +182,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
            'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
+           'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
@@ -569,6 +574,20 @@ def spike_conv_fwd(x, x_packed, weight, out, NB, Cin, Cout, h, w):
                                          _f32(weight, 'weight', Cout * Cin * 25), _f32(out, 'out', NB * ho * wo * Cout), _f32(ws, 'ws'),
                                          NB, Cin, Cout, h, w, _stream(out))
     _check(rc, 'ss_spike_conv_fwd_f32')
+
+
+def dense_conv_s1_fwd_supported(Cin, Cout, k, stride, pad):
+    return bool(lib().ss_dense_conv_s1_fwd_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def dense_conv_s1_fwd(x, weight, out, NB, Cin, Cout, h, w):
+    """out [NB, h, w, 32] = conv2d(x, weight, stride 1, pad 2), x [NB, h, w, Cin] dense fp32 (any values), Cin in (4, 2): six-term bf16 MFMA
+    implicit GEMM, the whole weight in registers."""
+    _require_hip(out, 'out')
+    with torch.cuda.device(out.device):
+        rc = lib().ss_dense_conv_s1_fwd_f32(_f32(x, 'x', NB * h * w * Cin), _f32(weight, 'weight', Cout * Cin * 25), _f32(out, 'out', NB * h * w * Cout),
+                                            NB, Cin, Cout, h, w, _stream(out))
+    _check(rc, 'ss_dense_conv_s1_fwd_f32')
 
 
 def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):

@@ -234,6 +234,124 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// First encoder layer: nn.Conv2d(C_in = 4 | 2, 32, kernel_size=5, stride=1, padding=2, bias=False) on the event-voxel input
+// (/root/reference/network/SNN_models.py:75-79, 263-267, 450-454).  K = 25 C_in <= 100: the layer is bound by WRITING its 32-channel output
+// (0.92 GB at config 3), MIOpen's grouped-conv kernel takes 1.6 ms for it.  Here: implicit GEMM with BOTH operands split into three bf16 terms
+// and the six cross terms of ss_gemm6_f32 kept — exact for the integer event counts the voxeliser produces, fp32-product accuracy for ANY
+// fp32 input (no precondition on the data).  The whole weight (<= 7 k-steps x 3 terms) lives in registers as fragments: no staging, no barrier
+// in the main loop.  k = (tap, ci) flattened, zero rows beyond tap 24.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kS1Threads = 256;
+constexpr int kS1TR = 16, kS1TC = 32;                  // output rows (4 per wavefront) x output columns of a tile
+constexpr int kS1WR = kS1TR + 4, kS1WC = kS1TC + 4;
+
+template <int CI>
+__global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ out,
+                                                                        int NB, int h, int w)
+{
+    constexpr int COUT = 32, KS = (25 * CI + 15) / 16, TPL = 8 / CI;           // k-steps; taps per lane and k-step
+    constexpr int PIXB = CI * 2, PLANE = kS1WR * kS1WC * PIXB;                 // bytes per window pixel and per split plane
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * PLANE + 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tx = lane & 31, half = lane >> 5;
+    // ---- the weight as B fragments in registers: b[ks][split], element e = split of W[co = tx][ci][ky][kx], k = 16 ks + 8 half + e = tap * CI + ci
+    s16x8 b[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = 16 * ks + 8 * half + e, tap = kk / CI, ci = kk - tap * CI;
+            const float v = tap < 25 ? W[((long long)tx * CI + ci) * 25 + tap] : 0.f;
+            const __bf16 h1 = (__bf16)v;
+            const float r1 = v - (float)h1;
+            const __bf16 h2 = (__bf16)r1;
+            const __bf16 h3 = (__bf16)(r1 - (float)h2);
+            b[ks][0][e] = __builtin_bit_cast(short, h1); b[ks][1][e] = __builtin_bit_cast(short, h2); b[ks][2][e] = __builtin_bit_cast(short, h3);
+        }
+    // window byte offsets of this lane's taps (relative to its output pixel), per k-step: tap -> (ky, kx); padding taps read tap 24 (B is zero there)
+    int toff[KS][TPL];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int q = 0; q < TPL; ++q) {
+            const int tap = min((16 * ks + 8 * half) / CI + q, 24), ky = tap / 5, kx = tap - 5 * ky;
+            toff[ks][q] = (ky * kS1WC + kx) * PIXB;
+        }
+    const int RG = (h + kS1TR - 1) / kS1TR, CG = (w + kS1TC - 1) / kS1TC;
+    const long long n_tiles = (long long)NB * RG * CG;
+#pragma unroll 1
+    for (long long tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int cg = (int)(tl % CG);
+        long long rr = tl / CG;
+        const int rg = (int)(rr % RG);
+        const int nb = (int)(rr / RG);
+        const int oy0 = kS1TR * rg, ox0 = kS1TC * cg;
+        __syncthreads();
+        // ---- input window -> three bf16 split planes (x = xh + xm + xl: exact for integers < 2^24, fp32 accuracy otherwise), zero outside the image
+        for (int i = threadIdx.x; i < kS1WR * kS1WC; i += kS1Threads) {
+            const int wy = i / kS1WC, col = i - wy * kS1WC;
+            const int iy = oy0 - 2 + wy, ix = ox0 - 2 + col;
+            float v[CI];
+#pragma unroll
+            for (int c = 0; c < CI; ++c) v[c] = 0.f;
+            if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+                const float* p = x + (((long long)nb * h + iy) * w + ix) * CI;
+#pragma unroll
+                for (int c = 0; c < CI; ++c) v[c] = p[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CI; ++c) {
+                const __bf16 h1 = (__bf16)v[c];
+                const float r1 = v[c] - (float)h1;
+                const __bf16 h2 = (__bf16)r1;
+                const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                unsigned short* const q = reinterpret_cast<unsigned short*>(wnd + i * PIXB) + c;
+                q[0] = __builtin_bit_cast(unsigned short, h1);
+                q[PLANE / 2] = __builtin_bit_cast(unsigned short, h2);
+                q[PLANE] = __builtin_bit_cast(unsigned short, h3);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rb = 0; rb < kS1TR / 4; ++rb) {                                // this wavefront's 4 output rows, one M block (32 columns) each
+            const int ty = 4 * wave + rb;
+            if (oy0 + ty >= h) break;                                           // wave-uniform
+            const unsigned char* const pix = wnd + (ty * kS1WC + tx) * PIXB;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s16x8 a[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                    for (int q = 0; q < TPL; ++q) {
+                        const unsigned short* const src = reinterpret_cast<const unsigned short*>(pix + sp * PLANE + toff[ks][q]);
+#pragma unroll
+                        for (int c = 0; c < CI; ++c) a[sp][q * CI + c] = (short)src[c];
+                    }
+                // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ks][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][0], acc, 0, 0, 0);
+            }
+            const long long rowbase = ((long long)nb * h + (oy0 + ty)) * w;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ox < w) store_out(out + (rowbase + ox) * COUT + tx, acc[r]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -270,6 +388,23 @@ int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const fl
                                static_cast<const void*>(x), Bf, out, (int)NB, h, w, ho, wo); } while (0)
     if (Cin == 32) SS_SC(32, 64); else SS_SC(64, 128);
 #undef SS_SC
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_dense_conv_s1_fwd_supported(int Cin, int Cout, int k, int stride, int pad)
+{
+    return k == 5 && stride == 1 && pad == 2 && Cout == 32 && (Cin == 4 || Cin == 2);
+}
+
+int ss_dense_conv_s1_fwd_f32(const float* x, const float* weight, float* out, long long NB, int Cin, int Cout, int h, int w, void* stream)
+{
+    if (!x || !weight || !out || NB <= 0 || h <= 0 || w <= 0 || !ss_dense_conv_s1_fwd_supported(Cin, Cout, 5, 1, 2)) return SS_EINVAL;
+    if (NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n_tiles = NB * ((h + kS1TR - 1) / kS1TR) * ((w + kS1TC - 1) / kS1TC);
+    const unsigned grid = (unsigned)(n_tiles < 4096 ? n_tiles : 4096);
+    if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_fwd_kernel<4>), dim3(grid), dim3(kS1Threads), 0, s, x, weight, out, (int)NB, h, w);
+    else hipLaunchKernelGGL((dense_conv_s1_fwd_kernel<2>), dim3(grid), dim3(kS1Threads), 0, s, x, weight, out, (int)NB, h, w);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -1023,6 +1023,52 @@ def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tenso
     return _SpikeConvWgradCL.apply(x_cl, conv.weight, x_packed)
 
 
+DENSE_CONV_S1_MFMA = _os.environ.get('SS_CONV_S1_MFMA', '1') == '1'   # first encoder layer (C_in 4 | 2 -> 32, 5x5, stride 1) FORWARD as ss_dense_conv_s1_fwd_f32
+
+
+class _DenseConvS1CL(torch.autograd.Function):
+    """The first encoder layer (/root/reference/network/SNN_models.py:75-79: Conv2d(4 | 2, 32, 5, stride 1, padding 2) on the event-voxel input)
+    on an NHWC array: forward = the six-term bf16 MFMA implicit GEMM (no precondition on the input values), weight (and, if asked for, input)
+    gradient = MIOpen's convolution backward as before."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x_cl, weight):
+        x_cl = x_cl.contiguous()
+        NB, h, w, Cin = x_cl.shape
+        Cout = weight.shape[0]
+        y = torch.empty((NB, h, w, Cout), dtype=torch.float32, device=x_cl.device)
+        e0 = TIMER.start()
+        _lib.dense_conv_s1_fwd(x_cl, weight.detach().float().contiguous(), y, NB, Cin, Cout, h, w)
+        TIMER.stop(e0, 'dense_conv_s1_fwd', 4 * (y.numel() + x_cl.numel()), y.numel())
+        ctx.save_for_backward(x_cl, weight)
+        return y
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, g):
+        x_cl, weight = ctx.saved_tensors
+        g = g.float().contiguous()
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            g.permute(0, 3, 1, 2), x_cl.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last), None,
+            [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        if gx is not None:
+            gx = gx.permute(0, 2, 3, 1)
+            gx = gx if gx.is_contiguous() else gx.contiguous()
+        return gx, gw
+
+
+def dense_conv_s1_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
+    """conv (the first encoder layer's geometry) on a dense NHWC array through _DenseConvS1CL, or None when it does not apply."""
+    import torch.nn as nn
+    if not (DENSE_CONV_S1_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
+            and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.kernel_size == (5, 5) and conv.stride == (1, 1) and conv.padding == (2, 2)
+            and _lib.dense_conv_s1_fwd_supported(conv.in_channels, conv.out_channels, 5, 1, 2)):
+        return None
+    return _DenseConvS1CL.apply(x_cl, conv.weight)
+
+
 SPIKE_CONV_WGRAD_SPLIT = 8         # profiles/r01/wgrad_splitk.log
 SPIKE_CONV_MIN_CIN = 128           # conv3 (128), conv4 (256), bottleneck (512); below: im2col traffic outweighs the MFMA gain
 

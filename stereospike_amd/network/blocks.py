@@ -210,6 +210,10 @@ def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False, x_pa
     if x_packed is not None and x_arr.stride(-1) == 0:
         raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
     if isinstance(conv, nn.Conv2d):
+        from ..fused import dense_conv_s1_cl
+        y = dense_conv_s1_cl(x_arr, conv)                   # the first encoder layer: six-term MFMA implicit GEMM (any input values)
+        if y is not None:
+            return y
         w = conv.weight.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x_arr.permute(0, 3, 1, 2), w, conv.bias, conv.stride, conv.padding,
                                        conv.dilation, conv.groups)

@@ -1410,3 +1410,33 @@ def test_spike_conv_stage_packed_only_input_matches_dense(monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][0].mean()) > 0.01
     assert torch.equal(outs[0][1], outs[1][1])
     assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-6 * float(outs[0][2].abs().max())       # MIOpen's data gradient (atomics: not bit-stable)
+
+
+@pytest.mark.parametrize('NB,Cin,hw', [(2, 4, (64, 80)), (3, 2, (33, 45)), (1, 4, (7, 9)), (4, 4, (260, 346)), (2, 2, (260, 346)), (2, 4, (50, 70))])
+def test_dense_conv_s1_fwd_mfma(NB, Cin, hw):
+    """The first encoder layer's forward (Conv2d(4 | 2, 32, 5, stride 1, pad 2)) as the six-term bf16 MFMA implicit GEMM: on integer event counts
+    (what the voxeliser produces) and on ARBITRARY fp32 inputs |y - float64| <= 2^-21 sum |x||w| element-wise and within 2x of MIOpen's fp32
+    convolution's distance to float64 (+ its own rms); odd sizes / ragged tiles; deterministic."""
+    import torch.nn.functional as F
+    from stereospike_amd import _lib
+    h, w = hw
+    gen = torch.Generator(device=DEV).manual_seed(NB + h + Cin)
+    wt = torch.randn(32, Cin, 5, 5, device=DEV, generator=gen) * 0.1
+    assert _lib.dense_conv_s1_fwd_supported(Cin, 32, 5, 1, 2) and not _lib.dense_conv_s1_fwd_supported(8, 32, 5, 1, 2)
+    for kind in ('counts', 'real'):
+        x = torch.poisson(torch.full((NB, h, w, Cin), 0.3, device=DEV), generator=gen) if kind == 'counts' else \
+            torch.randn(NB, h, w, Cin, device=DEV, generator=gen) * torch.exp(torch.randn(NB, h, w, 1, device=DEV, generator=gen))
+        y = torch.full((NB, h, w, 32), float('nan'), device=DEV)
+        _lib.dense_conv_s1_fwd(x, wt, y, NB, Cin, 32, h, w)
+
+        def conv(xx, ww):
+            return F.conv2d(xx.permute(0, 3, 1, 2), ww, None, 1, 2).permute(0, 2, 3, 1)
+        ref = conv(x.double(), wt.double())
+        mag = conv(x.double().abs(), wt.double().abs())
+        err = (y.double() - ref).abs()
+        assert bool(torch.isfinite(y).all()) and bool((err <= mag * 2.0 ** -21 + 1e-30).all()), (kind, float((err / (mag * 2.0 ** -21 + 1e-30)).max()))
+        mi = conv(x, wt)
+        assert float(err.max()) <= 2.0 * float((mi.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max()), kind
+        y2 = torch.empty_like(y)
+        _lib.dense_conv_s1_fwd(x, wt, y2, NB, Cin, 32, h, w)
+        assert torch.equal(y, y2)

@@ -44,3 +44,27 @@ for name, Cin, Cout, (h, w) in [('conv1', 32, 64, (260, 346)), ('conv2', 64, 128
     for k, ms in best.items():
         t = 3 if 'spike' in k else 1
         print(f'   {name} {k:34s} {ms:7.3f} ms   {2 * t * macs / ms / 1e9:7.1f} TFLOP/s {"bf16 (%.3f of MFMA peak)" % (2 * t * macs / ms / 1e9 / 2500) if t == 3 else "fp32"}', flush=True)
+
+for name, Cin, (h, w) in [('bottom', 4, (260, 346))]:
+    x = torch.poisson(torch.full((NB, h, w, Cin), 0.05, device=dev))
+    wt = torch.randn(32, Cin, 5, 5, device=dev) * 0.1
+    y = torch.empty(NB, h, w, 32, device=dev)
+    w_cl = wt.contiguous(memory_format=torch.channels_last)
+    cases = {'MIOpen fp32 conv (NHWC)': lambda: F.conv2d(x.permute(0, 3, 1, 2), w_cl, None, 1, 2),
+             'dense_conv_s1_fwd (six-term MFMA)': lambda: _lib.dense_conv_s1_fwd(x, wt, y, NB, Cin, 32, h, w)}
+    for f in cases.values():
+        f()
+    torch.cuda.synchronize()
+    ref = cases['MIOpen fp32 conv (NHWC)']().permute(0, 2, 3, 1)
+    print(name, 'max |diff| / max vs MIOpen', float((ref - y).abs().max() / ref.abs().max()), flush=True)
+    for k, f in cases.items():
+        best = 1e9
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(4):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 4)
+        print(f'   {name} {k:34s} {best:7.3f} ms   output {4 * y.numel() / best / 1e6:7.1f} GB/s', flush=True)
