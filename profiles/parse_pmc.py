@@ -23,6 +23,10 @@ def key_of(name):
         return 'upconv_fused2'
     if 'upconv_fused_fwd_kernel' in name:
         return 'upconv_fused'
+    if 'spike_conv_fwd_kernel' in name:
+        return 'spike_conv_fwd'
+    if 'dense_conv_s1_fwd_kernel' in name:
+        return 'dense_conv_s1_fwd'
     if 'upconv_bwd_dgrad_kernel' in name:
         return 'upconv_bwd_dgrad'
     if 'upconv_bwd_fused_kernel' in name:
@@ -70,8 +74,10 @@ alg['upconv_fused'] = 4 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 3 * 
 alg['upconv_fused2'] = alg['upconv_fused']                          # the shipped form: wavefront-specialised persistent workgroups
 alg['upconv_bwd_dgrad'] = 4 * (80 * 260 * 346 * 32 + 80 * 130 * 173 * 64) + 2 * 3 * 25 * 64 * 32   # deconv1: g_y in + g_x out + split weights (g_P: none)
 alg['upconv_bwd_wgrad_nogp'] = 4 * 80 * 260 * 346 * 32 + 2 * 80 * 130 * 176 * 64 + 4 * 25 * 32 * 64      # deconv1: g_y in + bf16 transposed spikes in + g_W partials
+alg['spike_conv_fwd'] = 80 * 260 * 346 * 32 // 4 + 4 * 80 * 130 * 173 * 64 + 2 * 3 * 25 * 32 * 64        # conv1: packed spikes in + fp32 out + split weights
+alg['dense_conv_s1_fwd'] = 4 * 80 * 260 * 346 * (4 + 32) + 4 * 25 * 4 * 32                                # bottom: voxel input + fp32 out + weights
 res['algorithmic_bytes_per_launch'] = alg
-for k in ('neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
+for k in ('spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
     if k in fetch and k in write:
         hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],

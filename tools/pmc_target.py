@@ -54,5 +54,18 @@ if mode == 'rc':
     for _ in range(5):
         _lib.upconv_bwd_dgrad(gy, wt, tabs[1], tabs[2], tabs[4], tabs[5], gxs, NB, Cin, Cout, h, w, H, W)
         _lib.upconv_bwd_fused(gy, xs, tabs[1], tabs[2], tabs[4], tabs[5], None, gw, NB, Cin, Cout, h, w, H, W)
+    # round 3: conv1's forward as the exact MFMA implicit GEMM on the packed spikes (ss_spike_conv_fwd_f32), the first layer's forward (ss_dense_conv_s1_fwd_f32)
+    xb = (torch.rand(NB, H, W, 32, device=dev) < 0.3).float()
+    import numpy as np
+    from oracle import np_pack
+    xbp = torch.from_numpy(np_pack.pack(xb.cpu().numpy().reshape(-1)).view(np.int32)).to(dev)
+    w1 = torch.randn(64, 32, 5, 5, device=dev) * 0.05
+    y1 = torch.empty(NB, h, w, 64, device=dev)
+    xv = torch.poisson(torch.full((NB, H, W, 4), 0.05, device=dev))
+    w0 = torch.randn(32, 4, 5, 5, device=dev) * 0.1
+    y0 = torch.empty(NB, H, W, 32, device=dev)
+    for _ in range(5):
+        _lib.spike_conv_fwd(None, xbp, w1, y1, NB, 32, 64, H, W)
+        _lib.dense_conv_s1_fwd(xv, w0, y0, NB, 4, 32, H, W)
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
