@@ -592,7 +592,7 @@ def _split3_bf16(Wt):
 
 
 GEMM6_DGRAD = _os.environ.get('SS_GEMM6_DGRAD', '1') == '1'   # decoder data gradient g_x = g_P @ W2 of the two wide stages as ss_gemm6_f32 (six bf16 cross terms, fp32-product accuracy)
-GEMM6_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_GEMM6_CIN', '256,512').split(',') if c)   # C_in 64 / 128: the library's fp32 GEMM is
+GEMM6_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_GEMM6_CIN', '128,256,512').split(',') if c)   # C_in 64 / 128: the library's fp32 GEMM is
                                    # HBM-bound there and faster (profiles/r02/decoder_backward_kernels.log)
 FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather + exact MFMA weight gradient in one kernel (g_P written once, read only by dgrad)
 

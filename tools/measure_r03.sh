@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03f; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 SS_CONV_FWD_MFMA=0 SS_CONV_S1_MFMA=0 SS_FUSED_DGRAD=0 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_round2_kernels_only.json 2>/dev/null
+SS_GEMM6_CIN=256,512 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_gemm6_cin128_off.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --dtype bf16 > $O/bench_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --dtype f16 > $O/bench_f16.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --model PLIFNet > $O/bench_plif.json 2>/dev/null
@@ -14,7 +15,7 @@ python tools/bench_spike_conv.py > $O/spike_conv_fwd.log 2>&1
 python tools/bench_upconv_bwd.py > $O/upconv_bwd_variants.log 2>&1
 bash profiles/run_profile.sh r03f --steps 13 --warmup 3 > /dev/null 2>&1
 bash profiles/collect_pmc.sh r03f rc > /dev/null 2>&1
-for f in bench_default bench_round2_kernels_only bench_bf16 bench_f16 bench_plif bench_count_rates bench_f16_T10_B32_rates bench_force_dp; do python - "$O/$f.json" <<'PY'
+for f in bench_default bench_round2_kernels_only bench_gemm6_cin128_off bench_bf16 bench_f16 bench_plif bench_count_rates bench_f16_T10_B32_rates bench_force_dp; do python - "$O/$f.json" <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d['roofline']
