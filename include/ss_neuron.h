@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 5
+#define SS_ABI_VERSION 6
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` (8-byte aligned) to the ss_neuron_bwd_* entry points when g_k != NULL.
@@ -382,6 +382,21 @@ int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const fl
  * terms, six cross terms kept — exact for integer event counts, fp32-product accuracy otherwise), weight [32][C_in][5][5], out [NB][h][w][32]. */
 int ss_dense_conv_s1_fwd_supported(int Cin, int Cout, int k, int stride, int pad);
 int ss_dense_conv_s1_fwd_f32(const float* x, const float* weight, float* out, long long NB, int Cin, int Cout, int h, int w, void* stream);
+
+/*
+ * ABI 6 — DATA gradient of the stride-2 5x5 encoder convolutions as a six-term bf16 implicit GEMM on the matrix cores (ss_conv_dgrad.hip).
+ * Replaces torch's convolution_backward (MIOpen fp32 igemm_bwd) w.r.t. the INPUT of conv1 .. conv4 of the reference's encoder
+ * (/root/reference/network/SNN_models.py:80-101: nn.Conv2d(C, 2C, kernel_size=5, stride=2, padding=2, bias=False); autograd in the reference):
+ *   g_x[nb][iy][ix][ci] = sum_{ky,kx,co} g[nb][(iy + 2 - ky) / 2][(ix + 2 - kx) / 2][co] * weight[co][ci][ky][kx]
+ *                         over the taps with iy + 2 - ky, ix + 2 - kx even and inside the [ho][wo] map, ho = (h - 1) / 2 + 1
+ * g [NB][ho][wo][C_out] fp32 NHWC (ANY values), weight [C_out][C_in][5][5] fp32, g_x [NB][h][w][C_in] fp32 NHWC — every element written.
+ * Both operands are split into three bf16 terms, six cross terms kept: |g_x - float64| <= 2^-21 sum |g||w| element-wise (fp32-product accuracy,
+ * fp32 accumulation); deterministic (no atomics, fixed summation order).  ws: ss_conv_s2_dgrad_ws_floats floats, 16-byte aligned.
+ * Compiled shapes: C_in in {32, 64, 128, 256}, C_out = 2 C_in.
+ */
+int ss_conv_s2_dgrad_supported(int Cin, int Cout, int k, int stride, int pad);
+long long ss_conv_s2_dgrad_ws_floats(int Cin, int Cout);
+int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, void* stream);
 
 /*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2

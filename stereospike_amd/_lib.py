@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1
@@ -130,6 +130,12 @@ def lib():
     L.ss_dense_conv_s1_fwd_supported.restype = i32
     L.ss_dense_conv_s1_fwd_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
     L.ss_dense_conv_s1_fwd_f32.restype = i32
+    L.ss_conv_s2_dgrad_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_conv_s2_dgrad_supported.restype = i32
+    L.ss_conv_s2_dgrad_ws_floats.argtypes = [i32, i32]
+    L.ss_conv_s2_dgrad_ws_floats.restype = i64
+    L.ss_conv_s2_dgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, p]
+    L.ss_conv_s2_dgrad_f32.restype = i32
     L.ss_upconv_bwd_dgrad_supported.argtypes = [i32, i32, i32, i32, i32, i32]
     L.ss_upconv_bwd_dgrad_supported.restype = i32
     L.ss_upconv_bwd_dgrad_ws_floats.argtypes = [i32, i32]
@@ -183,6 +189,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
+           'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
@@ -588,6 +595,22 @@ def dense_conv_s1_fwd(x, weight, out, NB, Cin, Cout, h, w):
         rc = lib().ss_dense_conv_s1_fwd_f32(_f32(x, 'x', NB * h * w * Cin), _f32(weight, 'weight', Cout * Cin * 25), _f32(out, 'out', NB * h * w * Cout),
                                             NB, Cin, Cout, h, w, _stream(out))
     _check(rc, 'ss_dense_conv_s1_fwd_f32')
+
+
+def conv_s2_dgrad_supported(Cin, Cout, k, stride, pad):
+    return bool(lib().ss_conv_s2_dgrad_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def conv_s2_dgrad(g, weight, g_x, NB, Cin, Cout, h, w):
+    """g_x [NB, h, w, Cin] = data gradient of conv2d(x, weight, stride 2, pad 2) for the output gradient g [NB, ho, wo, Cout] (dense fp32 NHWC, any
+    values): six-term bf16 MFMA implicit GEMM, every element of g_x written."""
+    _require_hip(g, 'g')
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ws = torch.empty(int(lib().ss_conv_s2_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_conv_s2_dgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), _f32(weight, 'weight', Cout * Cin * 25), _f32(g_x, 'g_x', NB * h * w * Cin),
+                                        _f32(ws, 'ws'), NB, Cin, Cout, h, w, _stream(g))
+    _check(rc, 'ss_conv_s2_dgrad_f32')
 
 
 def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):

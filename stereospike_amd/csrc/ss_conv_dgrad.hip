@@ -1,0 +1,320 @@
+// ss_conv_dgrad.hip — DATA gradient of the stride-2 5x5 encoder convolutions as a six-term bf16 implicit GEMM on the matrix cores
+// (include/ss_neuron.h: ss_conv_s2_dgrad_f32).
+//
+// Reference: autograd's backward of conv1 .. conv4 of the encoder w.r.t. their INPUT — nn.Conv2d(C, 2C, kernel_size=5, stride=2, padding=2,
+// bias=False) (/root/reference/network/SNN_models.py:80-101, 268-289, 455-476; torch's convolution_backward in the reference).  Both operands
+// are dense fp32 (the neuron backward's g_x and the weight), so until now this was MIOpen's fp32 implicit GEMM (igemm_bwd_gtcx35_nhwc_fp32):
+// 1.5 - 2.0 ms per layer at BASELINE config 3, AT the fp32-MFMA rate (92 - 119 of 157 TFLOP/s), 7 ms of a 42 ms step.  Here both operands are
+// split into three bf16 terms and the SIX cross terms of ss_gemm6_f32 are kept (hh, hm, mh, hl, lh, mm: relative error 2^-24 per product —
+// fp32-product accuracy, fp32 accumulation) on v_mfma_f32_32x32x16_bf16: 6 MFMAs per fp32 product at 16x the rate.
+//
+//   g_x[nb][iy][ix][ci] = sum_{ky,kx,co} g[nb][(iy + 2 - ky) / 2][(ix + 2 - kx) / 2][co] * W[co][ci][ky][kx]     over the taps with
+//                         iy + 2 - ky and ix + 2 - kx even and inside the output map
+//
+// A stride-2 transposed convolution decomposes by the PARITY of the input pixel: pixel (2 j + py, 2 i + px) only sees the taps with
+// ky = py, kx = px (mod 2) — 9 / 6 / 6 / 4 taps for the four classes — at the output pixels (j + dy, i + dx), dy = (py + 2 - ky) / 2 in
+// {-1, 0, 1}: four stride-1 convolutions over g that share one window.  GEMM view per class: M = the class's pixels, N = C_in,
+// K = (tap of the class, co).
+//   * Rows are counted in a PADDED row space: every frame owns ho + 1 rows, the last one a zero row — the vertical padding of this frame and
+//     of the next — so tiles run across frame boundaries (no ragged row tiles: the small maps of conv3 / conv4 would waste a third of the
+//     matrix cores on them).
+//   * A workgroup (4 wavefronts, two per CU) owns 4 RB padded rows x CB columns of (j, i) (RB * CB = 32 = the MFMA's M); wavefront = RB rows; it
+//     carries the accumulators of all four classes (4 x NT tiles of 32 input channels).
+//   * The window of g (4 RB + 2 rows x CB + 2 columns, 32 output channels at a time) is split ONCE per element while it is staged: three bf16
+//     planes in LDS, 64-B pixels with swizzled 16-B granules.  An A fragment is then three 16-B LDS reads per lane — no VALU work on the
+//     operands in the main loop.
+//   * The weight (split once, sign-alternated, in fragment order: conv_s2_dgrad_prep_kernel) streams L2 -> LDS double-buffered, one tap (two
+//     k-steps) per stage and barrier.
+//   * The bf16 MFMA's fp32 accumulation drifts down by ~2^-28 of the magnitude sum per instruction; the running sum of a class
+//     changes sign before every tap (acc = -acc; the weight fragments of that tap carry the sign), which cancels the drift.
+// HBM traffic: g once per (C_in / 32 NT) workgroup kinds (neighbours: L2), the weights from L2, g_x once.
+#include "ss_common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kDgThreads = 256;
+
+__host__ __device__ constexpr int dg_cnt(int cls) { return cls == 0 ? 9 : (cls == 3 ? 4 : 6); }     // taps of class (py, px) = (cls >> 1, cls & 1)
+
+// weight [C_out][C_in][5][5] fp32 -> Bf[chunk c of 32 co][tap][g][split][ci tile t][lane][8] bf16: element e of a lane = split term of
+// s * W[co = 32 c + 16 g + 8 (lane >> 5) + e][ci = 32 t + (lane & 31)][ky][kx], s = (-1)^n for the n-th tap of its class over all chunks
+__global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, int Cin, int Cout)
+{
+    const int NTALL = Cin / 32;
+    const long long total = (long long)(Cout / 32) * 25 * 2 * 3 * NTALL * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long r = i >> 6;
+        const int t = (int)(r % NTALL); r /= NTALL;
+        const int sp = (int)(r % 3); r /= 3;
+        const int g = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 25); const int c = (int)(r / 25);
+        const int ky = tap / 5, kx = tap - 5 * ky;
+        const int cls = (ky & 1) * 2 + (kx & 1);
+        const int n = c * dg_cnt(cls) + (ky >> 1) * ((kx & 1) ? 2 : 3) + (kx >> 1);
+        const int ci = 32 * t + (lane & 31);
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = 32 * c + 16 * g + 8 * (lane >> 5) + e;
+            float v = W[(((long long)co * Cin + ci) * 5 + ky) * 5 + kx];
+            if (n & 1) v = -v;
+            const unsigned short h1 = narrow<SS_DT_BF16>(v);
+            const float r1 = v - widen<SS_DT_BF16>(h1);
+            const unsigned short h2 = narrow<SS_DT_BF16>(r1);
+            const float r2 = r1 - widen<SS_DT_BF16>(h2);
+            o[e] = sp == 0 ? h1 : (sp == 1 ? h2 : narrow<SS_DT_BF16>(r2));
+        }
+        *reinterpret_cast<u16x8*>(Bf + i * 8) = o;
+    }
+}
+
+template <int CO, int NTALL, int NT, int CB>
+__global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const float* __restrict__ G, const unsigned short* __restrict__ Bf,
+                                                                      float* __restrict__ gx, int NB, int h, int w, int ho, int wo)
+{
+    constexpr int CI = 32 * NTALL, KINDS = NTALL / NT, NCH = CO / 32;
+    constexpr int RB = 32 / CB, TJR = 4 * RB, WR = TJR + 2, WC = CB + 2, ROWB = WC * 64, PLANE = WR * ROWB;
+    constexpr int STG = 6 * NT * 1024;                                          // bytes of one weight stage: one tap = 2 k-steps x 3 splits x NT tiles
+    constexpr int LPT = STG / 16 / kDgThreads, REM = STG / 16 - LPT * kDgThreads;
+    constexpr int kItems = WR * WC * 4, kIter = (kItems + kDgThreads - 1) / kDgThreads;     // (window pixel, 8-channel granule)
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char bst[2 * STG];
+    const int lane = threadIdx.x & 63;
+    const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // wavefront = RB padded rows of the tile
+    const int tx = lane & 31, half = lane >> 5;
+    const int rr = tx / CB, cc = tx - rr * CB;                                  // this lane's pixel of the M block
+    const int HP = ho + 1;                                                      // padded rows per frame
+    const long long RT = (long long)NB * HP;
+    const int RG = (int)((RT + TJR - 1) / TJR), CG = (wo + CB - 1) / CB;
+    const long long n_items = (long long)RG * CG * KINDS;
+    const unsigned gidx = xcd_remap(blockIdx.x, gridDim.x);
+    const long long t_begin = n_items * gidx / gridDim.x, t_end = n_items * (gidx + 1) / gridDim.x;
+    // LDS byte offsets of this lane's A fragments (plane 0, dy = 0, first k-step) for dx = -1, 0, 1; the second k-step is ^ 32
+    int abase[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int row = RB * mb + rr + 1, col = cc + d;
+        abase[d] = row * ROWB + col * 64 + ((half ^ (((col >> 2) + 2 * row) & 3)) << 4);
+    }
+    f4 st[LPT + 1];
+    auto stage_issue = [&](long long stage, int kind) {                         // stage = c * 25 + tap
+#pragma unroll
+        for (int u = 0; u <= LPT; ++u) {
+            if (u == LPT && (REM == 0 || (int)threadIdx.x >= REM)) break;
+            const int pidx = threadIdx.x + kDgThreads * u;                      // 16-B piece of the stage: [g][split][tile of this kind][lane]
+            const int ln = pidx & 63, tt = (pidx >> 6) % NT, gs = (pidx >> 6) / NT;
+            st[u] = *reinterpret_cast<const f4*>(Bf + (((stage * 6 + gs) * NTALL + kind * NT + tt) * 64 + ln) * 8);
+        }
+    };
+    auto stage_commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int u = 0; u <= LPT; ++u) {
+            if (u == LPT && (REM == 0 || (int)threadIdx.x >= REM)) break;
+            *reinterpret_cast<f4*>(dst + (threadIdx.x + kDgThreads * u) * 16) = st[u];
+        }
+    };
+#pragma unroll 1
+    for (long long it = t_begin; it < t_end; ++it) {
+        const int kind = (int)(it % KINDS);
+        const long long tl = it / KINDS;
+        const int cg = (int)(tl % CG);
+        const long long R0 = (tl / CG) * TJR;                                   // first padded row of the tile
+        const int i0 = cg * CB;
+        const bool active = R0 + RB * mb < RT;                                  // wave-uniform
+        // ---- global offsets of this thread's window items (channel 0 of the chunk), -1 outside the map / in a padding row
+        long long goff[kIter];
+#pragma unroll
+        for (int u = 0; u < kIter; ++u) {
+            const int i = threadIdx.x + kDgThreads * u;
+            const int pix = i >> 2, q = i & 3;
+            const int wy = pix / WC, wc = pix - wy * WC;
+            const long long Rp = R0 - 1 + wy;
+            const int ox = i0 - 1 + wc;
+            goff[u] = -1;
+            if (i < kItems && Rp >= 0 && Rp < RT && ox >= 0 && ox < wo) {
+                const long long nb = Rp / HP;
+                const int j = (int)(Rp - nb * HP);
+                if (j < ho) goff[u] = ((nb * ho + j) * wo + ox) * CO + 8 * q;
+            }
+        }
+        f32x16 acc[4][NT];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][t][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
+            // ---- window of g (32 channels of this chunk) -> three bf16 planes in LDS (g = gh + gm + gl exactly), zero outside
+            {
+                f4 va[kIter], vb[kIter];
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    va[u] = (f4){0.f, 0.f, 0.f, 0.f}; vb[u] = va[u];
+                    if (goff[u] >= 0) {
+                        const float* p = G + goff[u] + 32 * c;
+                        va[u] = *reinterpret_cast<const f4*>(p); vb[u] = *reinterpret_cast<const f4*>(p + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    const int i = threadIdx.x + kDgThreads * u;
+                    const int pix = i >> 2, q = i & 3;
+                    const int wy = pix / WC, wc = pix - wy * WC;
+                    if (i < kItems) {
+                        u16x8 o1, o2, o3;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = e < 4 ? va[u][e] : vb[u][e - 4];
+                            const __bf16 h1 = (__bf16)v;
+                            const float r1 = v - (float)h1;
+                            const __bf16 h2 = (__bf16)r1;
+                            const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                            o1[e] = __builtin_bit_cast(unsigned short, h1); o2[e] = __builtin_bit_cast(unsigned short, h2);
+                            o3[e] = __builtin_bit_cast(unsigned short, h3);
+                        }
+                        unsigned char* const pp = wnd + wy * ROWB + wc * 64 + ((q ^ (((wc >> 2) + 2 * wy) & 3)) << 4);
+                        *reinterpret_cast<u16x8*>(pp) = o1;
+                        *reinterpret_cast<u16x8*>(pp + PLANE) = o2;
+                        *reinterpret_cast<u16x8*>(pp + 2 * PLANE) = o3;
+                    }
+                }
+            }
+            // ---- weight stage 0 of this chunk
+            stage_issue((long long)c * 25, kind);
+            stage_commit(bst);
+            __syncthreads();
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int tap = ky * 5 + kx;
+                    const int py = ky & 1, px = kx & 1, cls = py * 2 + px;
+                    const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;   // (py + 2 - ky) is even: exact, also for -2
+                    const int idx = (ky >> 1) * (px ? 2 : 3) + (kx >> 1);       // index of the tap within its class
+                    const bool more = tap + 1 < 25;
+                    if (more) stage_issue((long long)c * 25 + tap + 1, kind);
+                    if (active) {
+                        if (idx > 0 || c > 0) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[cls][t][r] = -acc[cls][t][r];
+                        }
+                        const unsigned char* const bk = bst + (tap & 1) * STG + lane * 16;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            // the granule swizzle depends on the window row: one row up / down moves the slot by 2 (^ 32 bytes), like the second k-step
+                            const unsigned char* const ap = wnd + dy * ROWB + (abase[dx + 1] ^ ((g ^ (dy & 1)) << 5));
+                            s16x8 a[3], b[3][NT];
+#pragma unroll
+                            for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const s16x8*>(ap + sp * PLANE);
+#pragma unroll
+                            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>(bk + ((g * 3 + sp) * NT + t) * 1024);
+                            // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], acc[cls][t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][t], acc[cls][t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][t], acc[cls][t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][t], acc[cls][t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][t], acc[cls][t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][t], acc[cls][t], 0, 0, 0);
+                        }
+                    }
+                    if (more) stage_commit(bst + ((tap + 1) & 1) * STG);
+                    __syncthreads();
+                }
+            }
+        }
+        // ---- D[row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] -> g_x[nb][2 j + py][2 (i0 + cc_m) + px][32 (kind NT + t) + col]
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const long long Rp = R0 + RB * mb + q;                          // wave-uniform
+                if (Rp >= RT) break;
+                const long long nb = Rp / HP;
+                const int j = (int)(Rp - nb * HP);
+                if (j >= ho) continue;                                          // the frame's padding row
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) {
+                    const int py = cls >> 1, px = cls & 1;
+                    const int iy = 2 * j + py;
+                    if (iy >= h) continue;
+                    const bool flip = ((NCH * dg_cnt(cls) - 1) & 1) != 0;       // sign of the last tap of the class
+                    const long long rowbase = (nb * h + iy) * w;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m0 = (r & 3) + 8 * (r >> 2);                  // + 4 half
+                        if ((m0 / CB) != q && ((m0 + 4) / CB) != q) continue;   // compile-time after unrolling
+                        const int m = m0 + 4 * half;
+                        if (m / CB != q) continue;
+                        const int ix = 2 * (i0 + (m - q * CB)) + px;
+                        if (ix < w) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                store_out(gx + (rowbase + ix) * CI + 32 * (kind * NT + t) + tx, flip ? -acc[cls][t][r] : acc[cls][t][r]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_conv_s2_dgrad_supported(int Cin, int Cout, int k, int stride, int pad)
+{
+    return k == 5 && stride == 2 && pad == 2 && Cout == 2 * Cin && (Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256);
+}
+
+long long ss_conv_s2_dgrad_ws_floats(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
+    return (long long)25 * Cin * Cout * 3 / 2;                                  // the weight as three bf16 terms in fragment order
+}
+
+int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, void* stream)
+{
+    if (!g || !weight || !g_x || !ws || NB <= 0 || h <= 0 || w <= 0) return SS_EINVAL;
+    if (!ss_conv_s2_dgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(g) || !aligned16(ws) || !aligned16(g_x)) return SS_EINVAL;
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    if (NB * h * (long long)w * Cin > 0x7fffffffffLL || NB > 0x3fffffff) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
+    hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    // column blocking of the (j, i) grid: 8 columns x 4 rows per wavefront wastes <= 1 / 8 of a block on any width; 32 x 1 only when it fits as well
+    bool wide = ((wo + 31) / 32) * 32 <= ((wo + 7) / 8) * 8;
+    if (const char* e = getenv("SS_DGRAD_CB")) wide = e[0] == '3';              // tuning knob (tools/bench_conv_dgrad.py): 32 | 8
+    const int CB = wide ? 32 : 8, TJR = 4 * (32 / CB);
+    const int kinds = Cin <= 64 ? 1 : Cin / 64;
+    const long long n_items = ((NB * (ho + 1) + TJR - 1) / TJR) * ((wo + CB - 1) / CB) * kinds;
+    const unsigned grid = (unsigned)(n_items < 2 * cus ? n_items : 2 * cus);     // two workgroups per CU, persistent over their item ranges
+#define SS_DG(CO_, NTALL_, NT_) do { \
+        if (wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 32>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo); \
+        else hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 8>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo); } while (0)
+    if (Cin == 32) SS_DG(64, 1, 1);
+    else if (Cin == 64) SS_DG(128, 2, 2);
+    else if (Cin == 128) SS_DG(256, 4, 2);
+    else SS_DG(512, 8, 2);
+#undef SS_DG
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+}  // extern "C"

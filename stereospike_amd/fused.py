@@ -899,6 +899,8 @@ class _SpikeConvCL(torch.autograd.Function):
             g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
         if ctx.needs_input_grad[0] and WINOGRAD_DGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 4 == 0 and Cout % 4 == 0:
             g_x = winograd_dgrad_cl(g, weight)
+        elif ctx.needs_input_grad[0] and CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, k, stride, pad):
+            g_x = conv_s2_dgrad_cl(g, weight, h, w)
         elif ctx.needs_input_grad[0]:
             x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
             g_x = torch.ops.aten.convolution_backward(
@@ -912,6 +914,22 @@ class _SpikeConvCL(torch.autograd.Function):
 
 WINOGRAD_DGRAD = True              # data gradient of the 3x3 / stride 1 convs (the four bottleneck convs) as Winograd F(2x2, 3x3): hand-written
                                    # transforms around one batched fp32 GEMM, 2.25x fewer multiplications (1.14 -> 0.7 ms per layer at config 3)
+
+
+CONV_DGRAD_MFMA = _os.environ.get('SS_CONV_DGRAD_MFMA', '1') == '1'   # data gradient of conv1 .. conv4 (5x5, stride 2: dense x dense) as the six-term bf16 MFMA implicit GEMM
+                                   # ss_conv_s2_dgrad_f32 (was MIOpen's fp32 igemm_bwd at the fp32-MFMA rate: 7.1 -> 4.4 ms per step at config 3, profiles/r03/conv_dgrad.log)
+
+
+def conv_s2_dgrad_cl(g: torch.Tensor, weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """Data gradient of conv2d(x [NB, h, w, C_in], weight [C_out, C_in, 5, 5], stride 2, padding 2) for g [NB, ho, wo, C_out] (contiguous NHWC array,
+    fp32) -> g_x [NB, h, w, C_in].  Autograd's backward of the reference's encoder convs w.r.t. their input (/root/reference/network/SNN_models.py:80-101)."""
+    NB, ho, wo, Cout = g.shape
+    Cin = weight.shape[1]
+    g_x = torch.empty((NB, h, w, Cin), dtype=torch.float32, device=g.device)
+    e0 = TIMER.start()
+    _lib.conv_s2_dgrad(g, weight.detach().float().contiguous(), g_x, NB, Cin, Cout, h, w)
+    TIMER.stop(e0, 'conv_s2_dgrad', 4 * (g.numel() + g_x.numel()), g_x.numel())
+    return g_x
 
 
 WINOGRAD_GEMM6 = _os.environ.get('SS_WINOGRAD_GEMM6', '0') == '1'   # the transform-domain products as ss_gemm6_batched_f32 instead of the library's fp32 batched
@@ -991,7 +1009,9 @@ class _SpikeConvWgradCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g_w = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
             _lib.spike_conv_wgrad(g, x_cl, g_w, NB, Cin, Cout, h, w, x_packed=None if x_packed is None else x_packed.contiguous())
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, 5, 2, 2):
+            g_x = conv_s2_dgrad_cl(g, weight, h, w)
+        elif ctx.needs_input_grad[0]:
             x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
             g_x = torch.ops.aten.convolution_backward(
                 g.permute(0, 3, 1, 2), x_meta, weight.contiguous(memory_format=torch.channels_last), None,

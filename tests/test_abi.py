@@ -39,7 +39,9 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_gemm6_f32', 'ss_gemm6_batched_f32', 'ss_spike_conv_wgrad_supported',
                                   'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
                                   # ABI 4
-                                  'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32'])
+                                  'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32',
+                                  # ABI 6
+                                  'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -50,7 +52,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == _lib.ABI_VERSION == 5
+    assert L.ss_abi_version() == _lib.ABI_VERSION == 6
     assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()

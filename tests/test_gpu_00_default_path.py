@@ -68,6 +68,7 @@ def assert_default_kernels(tags, T):
     assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 5, tags
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
+    assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)
     assert bwd.get('neuron_bwd+lronly', 0) == 1 and bwd.get('neuron_bwd+lr', 0) == 1 and bwd.get('neuron_bwd+lr+sum', 0) == 3, tags
     assert bwd.get('neuron_bwd+fork', 0) == 3 and bwd.get('neuron_bwd', 0) == 5, tags
     assert tags.get('upconv_cl_fwd', 0) == 8 and tags.get('upconv_cl_bwd', 0) == 8, tags
