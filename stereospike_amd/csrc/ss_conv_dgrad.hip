@@ -34,6 +34,9 @@
 namespace {
 
 constexpr int kDgThreads = 256;
+#ifndef SS_DG_ABL
+#define SS_DG_ABL 0              // timing experiments (tools/_abl_dgrad.sh; results are WRONG with any bit set): 1 no per-tap barrier, 2 no sign flip,
+#endif                           // 4 no B-fragment LDS reads, 8 no A-fragment LDS reads, 16 no weight stream (global loads + LDS stores)
 
 __host__ __device__ constexpr int dg_cnt(int cls) { return cls == 0 ? 9 : (cls == 3 ? 4 : 6); }     // taps of class (py, px) = (cls >> 1, cls & 1)
 
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                     const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;   // (py + 2 - ky) is even: exact, also for -2
                     const int idx = (ky >> 1) * (px ? 2 : 3) + (kx >> 1);       // index of the tap within its class
                     const bool more = tap + 1 < 25;
-                    if (more) stage_issue((long long)c * 25 + tap + 1, kind);
+                    if (more && !(SS_DG_ABL & 16)) stage_issue((long long)c * 25 + tap + 1, kind);
                     if (active) {
-                        if (idx > 0 || c > 0) {
+                        if ((idx > 0 || c > 0) && !(SS_DG_ABL & 2)) {
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -212,11 +215,11 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                             const unsigned char* const ap = wnd + dy * ROWB + (abase[dx + 1] ^ ((g ^ (dy & 1)) << 5));
                             s16x8 a[3], b[3][NT];
 #pragma unroll
-                            for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const s16x8*>(ap + sp * PLANE);
+                            for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 8) ? wnd + lane * 16 + sp * 1024 : ap + sp * PLANE);
 #pragma unroll
                             for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>(bk + ((g * 3 + sp) * NT + t) * 1024);
+                                for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 4) ? bst + lane * 16 + (sp * NT + t) * 1024 : bk + ((g * 3 + sp) * NT + t) * 1024);
                             // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
 #pragma unroll
                             for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], acc[cls][t], 0, 0, 0);
@@ -232,8 +235,8 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                             for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][t], acc[cls][t], 0, 0, 0);
                         }
                     }
-                    if (more) stage_commit(bst + ((tap + 1) & 1) * STG);
-                    __syncthreads();
+                    if (more && !(SS_DG_ABL & 16)) stage_commit(bst + ((tap + 1) & 1) * STG);
+                    if (!(SS_DG_ABL & 1)) __syncthreads();
                 }
             }
         }
