@@ -25,8 +25,9 @@
 //     operands in the main loop.
 //   * The weight (split once, sign-alternated, in fragment order: conv_s2_dgrad_prep_kernel) streams L2 -> LDS double-buffered, one tap (two
 //     k-steps) per stage and barrier.
-//   * The bf16 MFMA's fp32 accumulation drifts down by ~2^-28 of the magnitude sum per instruction; the running sum of a class
-//     changes sign before every tap (acc = -acc; the weight fragments of that tap carry the sign), which cancels the drift.
+//   * A tap's 12 NT MFMAs accumulate on a scratch accumulator that starts at zero; the class's running sum takes one fp32 addition per tap.
+//     The bf16 MFMA's fp32 accumulation drifts down by ~2^-28 of the magnitude sum per instruction: the weight fragments of
+//     every second tap of a class are negated and its scratch sum is subtracted instead of added, which cancels the drift.
 // HBM traffic: g once per (C_in / 32 NT) workgroup kinds (neighbours: L2), the weights from L2, g_x once.
 #include "ss_common.hpp"
 #include <stdlib.h>
@@ -36,7 +37,7 @@ namespace {
 constexpr int kDgThreads = 256;
 #ifndef SS_DG_ABL
 #define SS_DG_ABL 0              // timing experiments (tools/_abl_dgrad.sh; results are WRONG with any bit set): 1 no per-tap barrier, 2 no sign flip,
-#endif                           // 4 no B-fragment LDS reads, 8 no A-fragment LDS reads, 16 no weight stream (global loads + LDS stores)
+#endif                           // 4 no B-fragment LDS reads, 8 no A-fragment LDS reads, 16 no weight stream (global loads + LDS stores), 32 no window staging, 64 no g_x stores
 
 __host__ __device__ constexpr int dg_cnt(int cls) { return cls == 0 ? 9 : (cls == 3 ? 4 : 6); }     // taps of class (py, px) = (cls >> 1, cls & 1)
 
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
         const int i0 = cg * CB;
         const bool active = R0 + RB * mb < RT;                                  // wave-uniform
         // ---- global offsets of this thread's window items (channel 0 of the chunk), -1 outside the map / in a padding row
-        long long goff[kIter];
+        int goff[kIter];                                                        // element offsets (the host checks NB ho wo C_out < 2^31)
 #pragma unroll
         for (int u = 0; u < kIter; ++u) {
             const int i = threadIdx.x + kDgThreads * u;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
             if (i < kItems && Rp >= 0 && Rp < RT && ox >= 0 && ox < wo) {
                 const long long nb = Rp / HP;
                 const int j = (int)(Rp - nb * HP);
-                if (j < ho) goff[u] = ((nb * ho + j) * wo + ox) * CO + 8 * q;
+                if (j < ho) goff[u] = (int)(((nb * ho + j) * wo + ox) * CO + 8 * q);
             }
         }
         f32x16 acc[4][NT];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
             // ---- window of g (32 channels of this chunk) -> three bf16 planes in LDS (g = gh + gm + gl exactly), zero outside
-            {
+            if (!(SS_DG_ABL & 32)) {
                 f4 va[kIter], vb[kIter];
 #pragma unroll
                 for (int u = 0; u < kIter; ++u) {
@@ -202,13 +203,11 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                     const bool more = tap + 1 < 25;
                     if (more && !(SS_DG_ABL & 16)) stage_issue((long long)c * 25 + tap + 1, kind);
                     if (active) {
-                        if ((idx > 0 || c > 0) && !(SS_DG_ABL & 2)) {
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) acc[cls][t][r] = -acc[cls][t][r];
-                        }
+                        // The tap's 12 NT MFMAs run on a scratch accumulator that starts at zero; the class's running sum takes ONE fp32 addition
+                        // per tap (25 C_out / 32 roundings of the large sum per element instead of 12 x as many: 3.5x closer to float64 at
+                        // K = 4608, tests).  The tap's products carry the sign (-1)^n of its weight fragments; fma(+-1, tmp, acc) undoes it.
                         const unsigned char* const bk = bst + (tap & 1) * STG + lane * 16;
+                        f32x16 tmp[NT];
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
                             // the granule swizzle depends on the window row: one row up / down moves the slot by 2 (^ 32 bytes), like the second k-step
@@ -221,19 +220,30 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
 #pragma unroll
                                 for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 4) ? bst + lane * 16 + (sp * NT + t) * 1024 : bk + ((g * 3 + sp) * NT + t) * 1024);
                             // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
+                            if (g == 0) {
+                                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], acc[cls][t], 0, 0, 0);
+                                for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], zero, 0, 0, 0);
+                            } else {
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][t], acc[cls][t], 0, 0, 0);
+                                for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], tmp[t], 0, 0, 0);
+                            }
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][t], acc[cls][t], 0, 0, 0);
+                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][t], tmp[t], 0, 0, 0);
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][t], acc[cls][t], 0, 0, 0);
+                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][t], tmp[t], 0, 0, 0);
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][t], acc[cls][t], 0, 0, 0);
+                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][t], tmp[t], 0, 0, 0);
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) acc[cls][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][t], acc[cls][t], 0, 0, 0);
+                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][t], tmp[t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][t], tmp[t], 0, 0, 0);
                         }
+                        const float sgn = (((c * dg_cnt(cls) + idx) & 1) && !(SS_DG_ABL & 2)) ? -1.f : 1.f;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[cls][t][r] = __builtin_fmaf(sgn, tmp[t][r], acc[cls][t][r]);
                     }
                     if (more && !(SS_DG_ABL & 16)) stage_commit(bst + ((tap + 1) & 1) * STG);
                     if (!(SS_DG_ABL & 1)) __syncthreads();
@@ -254,7 +264,6 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                     const int py = cls >> 1, px = cls & 1;
                     const int iy = 2 * j + py;
                     if (iy >= h) continue;
-                    const bool flip = ((NCH * dg_cnt(cls) - 1) & 1) != 0;       // sign of the last tap of the class
                     const long long rowbase = (nb * h + iy) * w;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -263,10 +272,10 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                         const int m = m0 + 4 * half;
                         if (m / CB != q) continue;
                         const int ix = 2 * (i0 + (m - q * CB)) + px;
-                        if (ix < w) {
+                        if (ix < w && (!(SS_DG_ABL & 64) || acc[cls][0][r] == 12345.678f)) {
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
-                                store_out(gx + (rowbase + ix) * CI + 32 * (kind * NT + t) + tx, flip ? -acc[cls][t][r] : acc[cls][t][r]);
+                                store_out(gx + (rowbase + ix) * CI + 32 * (kind * NT + t) + tx, acc[cls][t][r]);
                         }
                     }
                 }
@@ -295,7 +304,7 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
     if (!g || !weight || !g_x || !ws || NB <= 0 || h <= 0 || w <= 0) return SS_EINVAL;
     if (!ss_conv_s2_dgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(g) || !aligned16(ws) || !aligned16(g_x)) return SS_EINVAL;
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-    if (NB * h * (long long)w * Cin > 0x7fffffffffLL || NB > 0x3fffffff) return SS_EINVAL;
+    if (NB * h * (long long)w * Cin > 0x7fffffffffLL || NB * ho * (long long)wo * Cout > 0x7fffffffLL) return SS_EINVAL;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);

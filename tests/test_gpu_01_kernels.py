@@ -1389,11 +1389,10 @@ def test_spike_conv_fwd_mfma(NB, Cin, Cout, hw):
                                        (2, 256, (33, 44)), (1, 32, (5, 3)), (4, 32, (260, 346)), (1, 128, (65, 87)), (7, 64, (1, 70))])
 def test_conv_s2_dgrad_mfma(NB, Cin, hw):
     """ss_conv_s2_dgrad_f32 == the data gradient of conv2d(x, w, stride 2, padding 2) (conv1 .. conv4 of the encoder) evaluated in float64, within fp32
-    accumulation error of fp32-accurate products: element-wise |g_x - float64| <= 2^-20 sum |g||w| (six bf16 cross terms per product, K = 25 C_out / 4
-    .. 9 C_out / 4 terms per element; measured <= 1.1 x 2^-21), rms within 4x of MIOpen's fp32 data gradient's own distance to float64 (measured 1 - 3.1x:
-    one fp32 accumulator per parity class walks all of K in order — up to 9 C_out = 4608 terms at conv4 — where MIOpen sums blocked partials); gradients
-    spanning e^{+-4} between pixels; odd / even sizes, maps smaller than a tile, rows crossing frame boundaries (the padded row space); every element
-    written; deterministic."""
+    accumulation error of fp32-accurate products: element-wise |g_x - float64| <= 2^-21 sum |g||w| (six bf16 cross terms per product; a tap's MFMAs
+    run on a scratch accumulator, the running sum of up to 9 C_out = 4608 terms takes one fp32 addition per tap: measured <= 0.3 x 2^-21), rms within
+    2x of MIOpen's fp32 data gradient's own distance to float64; gradients spanning e^{+-4} between pixels; odd / even sizes, maps smaller than a
+    tile, rows crossing frame boundaries (the padded row space); every element written; deterministic."""
     import torch.nn.functional as F
     from stereospike_amd import _lib
     h, w = hw
@@ -1413,12 +1412,12 @@ def test_conv_s2_dgrad_mfma(NB, Cin, hw):
     mag = dgrad(g.double().abs(), wt.double().abs())
     err = (gx.double() - ref).abs()
     assert bool(torch.isfinite(gx).all()), 'an element of g_x was not written'
-    assert bool((err <= mag * 2.0 ** -20 + 1e-300).all()), float((err / (mag * 2.0 ** -20 + 1e-300)).max())
+    assert bool((err <= mag * 2.0 ** -21 + 1e-300).all()), float((err / (mag * 2.0 ** -21 + 1e-300)).max())
     x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=DEV, memory_format=torch.channels_last)
     mi = torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x_meta, wt.contiguous(memory_format=torch.channels_last), None,
                                              [2, 2], [2, 2], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
     rms = lambda e: float(e.double().pow(2).mean().sqrt())
-    assert rms(err) <= 4.0 * rms(mi.double() - ref) + 1e-9 * rms(ref), (rms(err), rms(mi.double() - ref))
+    assert rms(err) <= 2.0 * rms(mi.double() - ref) + 1e-9 * rms(ref), (rms(err), rms(mi.double() - ref))
     gx2 = torch.full_like(gx, float('nan'))
     _lib.conv_s2_dgrad(g, wt, gx2, NB, Cin, Cout, h, w)
     assert torch.equal(gx, gx2)
