@@ -271,9 +271,13 @@ def main():
         frames = a.batch * world * a.steps
         zero = dict(launches=0, bytes=0, ms=0.0, updates=0)
         # the dominant launch shape of the forward kernel: the largest layer (bottom: B x T x 32 x 260 x 346 updates)
-        fwd_shapes = {k: v for k, v in shapes.items() if k[0] == 'neuron_fwd_train'}
-        dom = max(fwd_shapes, key=lambda k: k[1]) if fwd_shapes else None
+        # (every forward form counts: since round 3 the bottom layer writes packed-only, tag 'neuron_fwd_train+packed'; at equal size the launch
+        # group that took longer — the full-resolution decoder stage, which reads a packed skip and writes a dense output)
+        fwd_shapes = {k: v for k, v in shapes.items() if k[0].startswith('neuron_fwd_train')}
+        dom = max(fwd_shapes, key=lambda k: (k[1], fwd_shapes[k]['ms'])) if fwd_shapes else None
         fwd = fwd_shapes.get(dom, zero)
+        fwd_tag = dom[0] if dom else 'neuron_fwd_train'
+        fwd_pmc = {'neuron_fwd_train': 'neuron_fwd', 'neuron_fwd_train+packed': 'neuron_fwd_packed'}.get(fwd_tag, 'none')
         # backward: the launch group with the most updates; at equal size the forked form without the extra g_sum store (the bottom
         # layer: 16 B/update), which is also the variant the PMC passes measure (tools/pmc_target.py)
         # (since the prediction heads hand over their gradient as a rank-9 pair: the '+lr' form, 13.1 B/update at 32 channels)
@@ -325,12 +329,15 @@ def main():
                        'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': 'default init, seed 2021, multiply_factor 10',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
             'roofline_fwd': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
-                                        f'{bpu(fwd)} B/update) on its dominant launch shape: {dom[1] if dom else 0} updates',
-                                 **roof(fwd),
+                                        f'{bpu(fwd)} B/update'
+                                        f'{", + skip add (2-bit packed skip operand)" if "+skip" in fwd_tag and packed_on else ", + skip add" if "+skip" in fwd_tag else ""}'
+                                        f'{", 2-bit packed output only" if "+packed" in fwd_tag else ""}) on its dominant launch shape: '
+                                        f'{dom[1] if dom else 0} updates (launch tag {fwd_tag})',
+                                 **roof(fwd, 'neuron_fwd', fwd_pmc),
                                  all_launches_of_this_instantiation=inst(
-                                     ['neuron_fwd_train', 'neuron_fwd_train+packed'],
-                                     f'neuron_fwd_kernel<0, {a.T}, false, false, 4, true>' if packed_on
-                                     else f'neuron_fwd_kernel<0, {a.T}, false, {"false" if recompute_h else "true"}, 4, false>')),
+                                     ['neuron_fwd_train+skip', 'neuron_fwd_train+skip+packed'] if '+skip' in fwd_tag else ['neuron_fwd_train', 'neuron_fwd_train+packed'],
+                                     f'neuron_fwd_kernel<0, {a.T}, {"true" if "+skip" in fwd_tag else "false"}, false, 4, true>' if packed_on
+                                     else f'neuron_fwd_kernel<0, {a.T}, {"true" if "+skip" in fwd_tag else "false"}, {"false" if recompute_h else "true"}, 4, false>')),
             'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
                                         f'{", h recomputed from the layer input" if recompute_h else ""}'
                                         f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}'

@@ -399,6 +399,21 @@ long long ss_conv_s2_dgrad_ws_floats(int Cin, int Cout);
 int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, void* stream);
 
 /*
+ * ABI 6 — the full-resolution prediction head on 2-bit packed spikes (ss_head.hip).  predict_depth1 = NNConvUpsampling(32, 1, kernel_size=3)
+ * (/root/reference/network/SNN_models.py:133-148, called at :186-188; blocks.py:110-132) in the projected form of ss_upconv_cl_fwd_f32:
+ *   ss_head_proj_packed_f32 : P[row][tap] = sum_c x[row][c] * Wt[c][tap]   — replaces the library GEMM [rows, C] x [C, 9] on the DENSE spike tensor;
+ *   ss_head_wgrad_packed_f32: g_Wt[c][tap] (+)= sum_row x[row][c] * g_P[row][tap] — replaces the library split-K GEMM (autograd of the head w.r.t.
+ *                             its weight), deterministic (per-wavefront partials, fixed-order fp64 second pass).
+ * x_packed: the head's input [rows][C] (rows = NB * h * w source pixels, NHWC) as 2-bit codes 0 .. 3, 16 per 32-bit word (the out_packed form of
+ * ss_neuron_fwd_ex); Wt [C][9] fp32 (split exactly into three bf16 terms: every product exact, fp32 accumulation on the matrix cores);
+ * P, g_P [rows][9] fp32.  ws: ss_head_wgrad_packed_ws_floats floats.  Compiled: C in {32, 64}, one output channel, 3 x 3 taps.
+ */
+int ss_head_packed_supported(int Cin, int Cout, int k);
+long long ss_head_wgrad_packed_ws_floats(int Cin);
+int ss_head_proj_packed_f32(const unsigned int* x_packed, const float* Wt, float* P, long long rows, int Cin, void* stream);
+int ss_head_wgrad_packed_f32(const unsigned int* x_packed, const float* g_P, float* g_Wt, float* ws, long long rows, int Cin, int accumulate, void* stream);
+
+/*
  * Winograd F(2x2, 3x3) data gradient of a 3x3 / stride 1 / pad 1 convolution in NHWC — the backward of SEWResBlock's conv1 / conv2
  * w.r.t. their input (/root/reference/network/blocks.py:146-159; autograd's conv backward in the reference), ABI 3:
  *     g_in[nb][y][x][ci] = sum_{co, a, b} g[nb][y + a - 1][x + b - 1][co] * W[co][ci][2 - a][2 - b]

@@ -136,6 +136,14 @@ def lib():
     L.ss_conv_s2_dgrad_ws_floats.restype = i64
     L.ss_conv_s2_dgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, p]
     L.ss_conv_s2_dgrad_f32.restype = i32
+    L.ss_head_packed_supported.argtypes = [i32, i32, i32]
+    L.ss_head_packed_supported.restype = i32
+    L.ss_head_wgrad_packed_ws_floats.argtypes = [i32]
+    L.ss_head_wgrad_packed_ws_floats.restype = i64
+    L.ss_head_proj_packed_f32.argtypes = [p, p, p, i64, i32, p]
+    L.ss_head_proj_packed_f32.restype = i32
+    L.ss_head_wgrad_packed_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
+    L.ss_head_wgrad_packed_f32.restype = i32
     L.ss_upconv_bwd_dgrad_supported.argtypes = [i32, i32, i32, i32, i32, i32]
     L.ss_upconv_bwd_dgrad_supported.restype = i32
     L.ss_upconv_bwd_dgrad_ws_floats.argtypes = [i32, i32]
@@ -190,6 +198,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
+           'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
@@ -611,6 +620,29 @@ def conv_s2_dgrad(g, weight, g_x, NB, Cin, Cout, h, w):
         rc = lib().ss_conv_s2_dgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), _f32(weight, 'weight', Cout * Cin * 25), _f32(g_x, 'g_x', NB * h * w * Cin),
                                         _f32(ws, 'ws'), NB, Cin, Cout, h, w, _stream(g))
     _check(rc, 'ss_conv_s2_dgrad_f32')
+
+
+def head_packed_supported(Cin, Cout, k):
+    return bool(lib().ss_head_packed_supported(int(Cin), int(Cout), int(k)))
+
+
+def head_proj_packed(x_packed, Wt, P, rows, Cin):
+    """P [rows, 9] = x [rows, Cin] @ Wt [Cin, 9] with x given as 2-bit packed spike codes (int32 words, 16 codes each): exact bf16x3 products
+    on the matrix cores, fp32 accumulation."""
+    _require_hip(P, 'P')
+    with torch.cuda.device(P.device):
+        rc = lib().ss_head_proj_packed_f32(_ptr(x_packed, 'x_packed', rows * Cin // 16), _f32(Wt, 'Wt', Cin * 9), _f32(P, 'P', rows * 9), rows, Cin, _stream(P))
+    _check(rc, 'ss_head_proj_packed_f32')
+
+
+def head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=False):
+    """g_Wt [Cin, 9] (+)= x^T [Cin, rows] @ g_P [rows, 9] with x given as 2-bit packed spike codes; deterministic."""
+    _require_hip(g_P, 'g_P')
+    ws = torch.empty(int(lib().ss_head_wgrad_packed_ws_floats(int(Cin))), dtype=torch.float32, device=g_P.device)
+    with torch.cuda.device(g_P.device):
+        rc = lib().ss_head_wgrad_packed_f32(_ptr(x_packed, 'x_packed', rows * Cin // 16), _f32(g_P, 'g_P', rows * 9), _f32(g_Wt, 'g_Wt', Cin * 9),
+                                            _f32(ws, 'ws'), rows, Cin, int(bool(accumulate)), _stream(g_P))
+    _check(rc, 'ss_head_wgrad_packed_f32')
 
 
 def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):

@@ -648,7 +648,33 @@ class _UpConvProjectedCL(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
     def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0,
-                lowrank_grad=False):
+                lowrank_grad=False, x_packed=None):
+        # x_packed (one-channel 3 x 3 head on a packed-only neuron output, fp32 mode): the input as a 2-bit packed spike tensor; x_cl is then a
+        # data-less anchor that carries shape and autograd edge.  Projection and weight gradient read the packed form (ss_head_*_packed_f32)
+        ctx.packed_in = x_packed is not None
+        if x_packed is not None:
+            NB, h, w, Cin = x_cl.shape
+            Cout, kk = weight.shape[0], k * k
+            if not (k == 3 and Cout == 1 and not lowp and act_dtype is None and _lib.head_packed_supported(Cin, Cout, k)):
+                raise _lib.SSNeuronError('packed-only spike tensor handed to an up-conv that reads dense activations')
+            ctx.lowrank_grad = bool(lowrank_grad)
+            ctx.x_dtype = x_cl.dtype
+            weight = weight.float()
+            Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()
+            src_y, _, _, src_x, _, _ = tables
+            out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=x_cl.device)
+            rows = NB * h * w
+            P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
+            e0 = TIMER.start()
+            _lib.head_proj_packed(x_packed, Wt, P, rows, Cin)
+            _lib.upconv_cl_fwd(P, src_y, src_x, None if bias is None else bias.float(), out, NB, k, Cout, h, w, H, W)
+            TIMER.stop(e0, 'upconv_cl_fwd', x_cl.numel() // 4 + 4 * out.numel(), out.numel())
+            ctx.save_for_backward(x_cl, Wt, x_packed)
+            ctx.lowp, ctx.exact = False, False
+            ctx.tables, ctx.k, ctx.n = tables, k, NB
+            ctx.wshape = weight.shape
+            ctx.has_bias = bias is not None
+            return out
         # lowrank_grad: the caller guarantees x_cl is consumed by nothing else and produced by a fused neuron layer (a forked handle), so
         # the input gradient of a one-channel 3 x 3 head may be handed over as the pair (g_P, W2) instead of their product (lowrank_anchor)
         ctx.lowrank_grad = bool(lowrank_grad)
@@ -687,7 +713,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             e0 = TIMER.start()
             _lib.upconv_fused2_x16(x_cl, weight.contiguous(), src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
             TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-            ctx.save_for_backward(x_cl, Wt)
+            ctx.save_for_backward(x_cl, Wt, None)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = not lowp
             ctx.tables, ctx.k, ctx.n = tables, k, n
@@ -702,7 +728,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout, form)
             _lib.upconv_fused_fwd(x_cl, None, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
             TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-            ctx.save_for_backward(x_cl, Wt)
+            ctx.save_for_backward(x_cl, Wt, None)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = True
             ctx.tables, ctx.k, ctx.n = tables, k, n
@@ -733,7 +759,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
             (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-        ctx.save_for_backward(xg, Wt)
+        ctx.save_for_backward(xg, Wt, None)
         # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
         # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
         ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
@@ -746,7 +772,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g_out):
-        x_cl, Wt = ctx.saved_tensors
+        x_cl, Wt, x_packed = ctx.saved_tensors                   # x_packed: the packed-only head input (x_cl is then a data-less anchor)
         k, n = ctx.k, ctx.n
         _, y_lo, y_hi, _, x_lo, x_hi = ctx.tables
         NB, h, w, Cin = x_cl.shape
@@ -811,6 +837,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
             if fused_bwd:
                 pass                                                              # g_Wt accumulated by the fused kernel above
+            elif need_w and x_packed is not None:
+                _lib.head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=True)     # reads the 2-bit packed spikes (1/16 of the dense tensor)
             elif (need_w and ctx.exact and not lowp and EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
                     and Cin in EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
                 # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
@@ -845,7 +873,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if g_x is not None and g_x.dtype != ctx.x_dtype:
             g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -1113,8 +1141,34 @@ def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = N
     return _SpikeConvCL.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0], x_packed)
 
 
+PACKED_HEAD = _os.environ.get('SS_PACKED_HEAD', '1') == '1'   # the full-resolution prediction head reads deconv1's output as 2-bit packed spikes (projection and weight
+                                   # gradient: ss_head_*_packed_f32); the largest decoder stage then writes no dense output (4.5 instead of 8.25 B/update)
+
+
+class _UnpackLastStep(torch.autograd.Function):
+    """The last time step of a packed-only spike sequence as a dense tensor (what the models return as `out_add*`; the reference returns the dense
+    tensors of its single step).  Backward (only when a loss term reads the spikes, e.g. Total_Loss(penalize_spikes=True)): a dense gradient for
+    the whole sequence, zero except at the last step."""
+
+    @staticmethod
+    def forward(ctx, anchor, packed):
+        T = anchor.shape[0]
+        ctx.shape = tuple(anchor.shape)
+        return unpack_dense(packed[T - 1:T], anchor.shape[1:], anchor.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        g_seq = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        g_seq[-1] = g
+        return g_seq, None
+
+
+def unpack_last_step(anchor: torch.Tensor, packed: torch.Tensor) -> torch.Tensor:
+    return _UnpackLastStep.apply(anchor, packed)
+
+
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False,
-                        max_window: int = 0, lowrank_grad: bool = False):
+                        max_window: int = 0, lowrank_grad: bool = False, x_packed: Optional[torch.Tensor] = None):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
     spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection.
     max_window: largest source window (rows x columns) of any 16 x 16 output tile (NNConvUpsampling.max_tile_window); > 0 enables the
@@ -1126,4 +1180,4 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
     # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
     act_dtype = adt if (lowp_bwd and k == 5 and ACT16_GATHER) else None
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
-        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad, x_packed)

@@ -181,20 +181,29 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             spikes, heads = [cur], []
             if cl:
                 cur = cur.permute(0, 1, 3, 4, 2).contiguous()          # decoder runs on NHWC arrays [T, B, h, w, C]
+        last_dense = {}                                                # index into `spikes` -> the last step of a packed-only stage output, unpacked
         for lvl in (4, 3, 2, 1):
             stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
             if cl:
                 skip = enc_skip[lvl - 1] if enc_cl else enc[lvl - 1].permute(0, 1, 3, 4, 2).contiguous()
                 # the stage output feeds the next stage and its prediction head: forked handles again
+                # the full-resolution stage feeds its prediction head only: when the head reads 2-bit packed spikes (fused.PACKED_HEAD) the stage
+                # writes no dense output at all
+                C_out = stage[0].up[1].out_channels
+                head_pk = bool(lvl == 1 and enc_cl and _fused.PACK_SPIKES and _fused.PACKED_HEAD and _blocks.FORK_OUTPUTS and cur.dtype == torch.float32
+                               and not torch.is_autocast_enabled('cuda') and _fused._lib.head_packed_supported(C_out, 1, 3))
                 r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_blocks.FORK_OUTPUTS,
-                                              skip_packed=enc_pk[lvl - 1] if enc_cl else None)
+                                              skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else 0)
                 cur, cur_head = r if _blocks.FORK_OUTPUTS else (r, r)
+                out_pk = stage[2].last_packed if head_pk else None     # None: the packed kernel form did not apply, the output is dense
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
+                if out_pk is not None:
+                    last_dense[len(spikes) - 1] = _fused.unpack_last_step(cur, out_pk).permute(0, 3, 1, 2)
                 # the head is the only consumer of its forked handle: its input gradient travels as a rank-9 pair into the stage's neuron backward.
                 # The full-resolution stage has no other gradient, so there the pair itself travels on as dL/dskip — which only another fused
                 # neuron layer (the forked NHWC encoder output) can take
                 lr_ok = bool(_blocks.FORK_OUTPUTS) and (enc_cl or lvl != 1)
-                pd = head[0].forward_projected_cl(cur_head.flatten(0, 1), lowrank_grad=lr_ok)  # [T*B, H, W, 1]: one channel, NHWC == NCHW
+                pd = head[0].forward_projected_cl(cur_head.flatten(0, 1), lowrank_grad=lr_ok, x_packed=out_pk)  # [T*B, H, W, 1]: one channel, NHWC == NCHW
             else:
                 cur = stage.forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
                 spikes.append(cur)
@@ -212,7 +221,7 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         pool = self.Ineurons
         depth_seq = ipool(torch.stack(heads), gain, pool.v_reset, pool._v_init(heads[0][0]))
         pool.v = depth_seq[T - 1, 3]
-        return depth_seq, [s[T - 1] for s in spikes], cnt, (T, B)
+        return depth_seq, [last_dense.get(i, s[T - 1]) if last_dense else s[T - 1] for i, s in enumerate(spikes)], cnt, (T, B)
 
     def forward_sequence(self, x: torch.Tensor, rates: dict = None):
         """x [B, T, C, H, W]: all T frames in one pass, membranes carried from their current state.

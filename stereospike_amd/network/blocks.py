@@ -111,16 +111,18 @@ class NNConvUpsampling(_UpConv):
             cache[(h, w, tile)] = extent(h, Hu) * extent(w, Wu)
         return cache[(h, w, tile)]
 
-    def forward_projected_cl(self, x_cl: torch.Tensor, spikes_in: bool = False, lowrank_grad: bool = False) -> torch.Tensor:
+    def forward_projected_cl(self, x_cl: torch.Tensor, spikes_in: bool = False, lowrank_grad: bool = False,
+                             x_packed: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array).  spikes_in: x_cl is a spike tensor.
         lowrank_grad: x_cl is a forked handle of a fused neuron layer's output with no other consumer — a one-channel 3 x 3 head may then
-        hand its input gradient over as the pair (g_P, W2) for ss_neuron_bwd_fork_lr_f32 (fused.lowrank_anchor)."""
+        hand its input gradient over as the pair (g_P, W2) for ss_neuron_bwd_fork_lr_f32 (fused.lowrank_anchor).
+        x_packed: the input as a 2-bit packed spike tensor (x_cl may then be a data-less anchor; one-channel 3 x 3 heads in fp32 mode only)."""
         conv = self.up[1]
         k = conv.kernel_size[0]
         Hu, Wu = self.up[0].size
         win = self.max_tile_window(x_cl.shape[1], x_cl.shape[2]) if (spikes_in and k == 5) else 0
         return upconv_projected_cl(x_cl, conv.weight, conv.bias, self._tables(x_cl.shape[1], x_cl.shape[2], x_cl.device),
-                                   k, Hu - k + 1, Wu - k + 1, spikes_in, win, lowrank_grad)
+                                   k, Hu - k + 1, Wu - k + 1, spikes_in, win, lowrank_grad, x_packed)
 
 
 class BilinConvUpsampling(_UpConv):
@@ -161,15 +163,15 @@ class SpikingStage(nn.Sequential):
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True, fork=fork, pack=pack)
 
     def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None, spikes_in: bool = False,
-                            fork: bool = False, skip_packed: Optional[torch.Tensor] = None):
+                            fork: bool = False, skip_packed: Optional[torch.Tensor] = None, pack: int = 0):
         """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
         NNConvUpsampling.  spikes_in: x_seq is the output of a spiking layer (+ spike skip adds).  skip_packed: the skip operand as a
-        packed spike tensor (skip_seq then carries the autograd edge only)."""
+        packed spike tensor (skip_seq then carries the autograd edge only).  pack: see BaseNode.forward_sequence (`self[2].last_packed`)."""
         T, B = x_seq.shape[:2]
         y = self[0].forward_projected_cl(x_seq.flatten(0, 1), spikes_in)
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True, fork=fork,
-                                        skip_packed=skip_packed)
+                                        skip_packed=skip_packed, pack=pack)
 
 
 class ResBlock(nn.Module):

@@ -41,7 +41,8 @@ def test_header_declares_the_expected_entry_points():
                                   # ABI 4
                                   'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32',
                                   # ABI 6
-                                  'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32'])
+                                  'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
+                                  'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():

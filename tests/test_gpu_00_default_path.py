@@ -64,8 +64,10 @@ def assert_default_kernels(tags, T):
     bwd = {k: v for k, v in tags.items() if k.startswith('neuron_bwd')}
     assert sum(fwd.values()) == 13 and sum(bwd.values()) == 13, tags
     assert not any(k.endswith('+h') for k in fwd) and not any('savedh' in k for k in bwd), ('saved-h (run-time-T) kernels ran', tags)
-    assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 1, tags
-    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 5, tags
+    # packed-only outputs: the 7 encoder / bottleneck edges, the SEW block's inner layer (with its packed skip) and — its prediction head reads packed
+    # spikes (fused.PACKED_HEAD) — the full-resolution decoder stage
+    assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 2, tags
+    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 4, tags
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
     assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)

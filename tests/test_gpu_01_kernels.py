@@ -1426,6 +1426,86 @@ def test_conv_s2_dgrad_mfma(NB, Cin, hw):
     assert torch.equal(gx2, gx * 2)
 
 
+@pytest.mark.parametrize('rows,C', [(64 * 80 * 3, 32), (1, 32), (33, 64), (260 * 346 * 2, 32), (12345, 64), (31, 32)])
+def test_head_on_packed_spikes(rows, C):
+    """ss_head_proj_packed_f32 / ss_head_wgrad_packed_f32 (the full-resolution prediction head reading 2-bit packed spikes) against float64 on the
+    unpacked codes: projection within 2^-22 of the magnitude sum (exact products — the weight splits exactly into three bf16 terms — and one fp32
+    accumulation over C terms), weight gradient within 2^-18 of it (fma per row, per-wavefront partials, fixed-order fp64 second pass) and within
+    4x of the fp32 library GEMM's own distance to float64 (rms); ragged row counts; accumulate flag; bit-reproducible."""
+    from stereospike_amd import _lib
+    from oracle import np_pack
+    assert _lib.head_packed_supported(C, 1, 3) and not _lib.head_packed_supported(C, 1, 5) and not _lib.head_packed_supported(128, 1, 3)
+    rng = np.random.default_rng(rows + C)
+    n = rows * C
+    codes = rng.choice(4, size=n, p=[0.62, 0.3, 0.07, 0.01]).astype(np.float32)
+    xp = torch.from_numpy(np_pack.pack(codes).view(np.int32)).to(DEV)          # C % 16 == 0: whole words
+    x = torch.from_numpy(codes).to(DEV).view(rows, C)
+    gen = torch.Generator(device=DEV).manual_seed(rows)
+    Wt = torch.randn(C, 9, device=DEV, generator=gen) * 0.1
+    P = torch.full((rows, 9), float('nan'), device=DEV)
+    _lib.head_proj_packed(xp, Wt, P, rows, C)
+    ref = x.double() @ Wt.double()
+    mag = x.double() @ Wt.double().abs()
+    assert bool(torch.isfinite(P).all())
+    assert bool(((P.double() - ref).abs() <= mag * 2.0 ** -22 + 1e-300).all()), float(((P.double() - ref).abs() / (mag * 2.0 ** -22 + 1e-300)).max())
+    P2 = torch.empty_like(P)
+    _lib.head_proj_packed(xp, Wt, P2, rows, C)
+    assert torch.equal(P, P2)
+    g = torch.randn(rows, 9, device=DEV, generator=gen) * torch.exp(2 * torch.randn(rows, 1, device=DEV, generator=gen)) * 1e-5
+    gW = torch.full((C, 9), float('nan'), device=DEV)
+    _lib.head_wgrad_packed(xp, g, gW, rows, C)
+    refw = x.double().t() @ g.double()
+    magw = x.double().t() @ g.double().abs()
+    errw = (gW.double() - refw).abs()
+    assert bool(torch.isfinite(gW).all()) and bool((errw <= magw * 2.0 ** -18 + 1e-300).all()), float((errw / (magw * 2.0 ** -18 + 1e-300)).max())
+    lib32 = x.t() @ g
+    rms = lambda e: float(e.double().pow(2).mean().sqrt())
+    assert rms(errw) <= 4.0 * rms(lib32.double() - refw) + 1e-9 * rms(refw), (rms(errw), rms(lib32.double() - refw))
+    gW2 = gW.clone()
+    _lib.head_wgrad_packed(xp, g, gW2, rows, C, accumulate=True)
+    assert float((gW2.double() - 2 * refw).abs().max()) <= 2.0 ** -17 * float(magw.max()) + 1e-30
+    gW3 = torch.empty_like(gW)
+    _lib.head_wgrad_packed(xp, g, gW3, rows, C)
+    assert torch.equal(gW, gW3)
+
+
+def test_packed_head_matches_the_dense_head(monkeypatch):
+    """StereoSpike with the full-resolution head on packed spikes (fused.PACKED_HEAD, default) against the same step with the dense head: identical
+    spikes and depth maps up to the two GEMMs' fp32 summation order (depths <= 1e-6 relative), every gradient tensor <= 1e-5 relative L2 (the one-element biases 1e-4), the returned
+    last-step `out_add1` tensor identical; and the stage's dense output is really gone (peak memory)."""
+    from stereospike_amd import fused
+    from stereospike_amd.clock_driven import functional, surrogate
+    from stereospike_amd.network.SNN_models import StereoSpike
+    from stereospike_amd.network.loss import Total_Loss
+    H, W, T, B = 64, 80, 5, 2
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(fused, 'PACKED_HEAD', on)
+        torch.manual_seed(5)
+        net = StereoSpike(surrogate_function=surrogate.ATan(), multiply_factor=10., input_size=(H, W)).to(DEV)
+        gen = torch.Generator().manual_seed(6)
+        x = torch.poisson(torch.full((B, T, 4, H, W), 0.08), generator=gen).to(DEV)
+        gt = (0.5 + 9.5 * torch.rand(B, 1, H, W, generator=gen)).to(DEV)
+        functional.reset_net(net)
+        fused.TIMER.enabled = True
+        fused.TIMER.clear()
+        pred, spks = net.forward_sequence(x)
+        loss = Total_Loss()(pred, gt, spks)
+        loss.backward()
+        torch.cuda.synchronize()
+        tags = {k: v['launches'] for k, v in fused.TIMER.summary().items()}
+        fused.TIMER.enabled = False
+        assert tags.get('neuron_fwd_train+skip+packed', 0) == (2 if on else 1), tags
+        res.append(([p.detach().clone() for p in pred], [s.detach().clone() for s in spks], {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (p1, s1, g1), (p0, s0, g0) = res
+    for a, b in zip(s1, s0):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for a, b in zip(p1, p0):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    for k in g0:                                             # (one-element tensors — the heads' biases — are cancelling sums over every pixel: 1e-4)
+        assert float((g1[k] - g0[k]).norm()) <= (1e-4 if g0[k].numel() == 1 else 1e-5) * float(g0[k].norm()) + 1e-12, k
+
+
 def test_spike_conv_stage_packed_only_input_matches_dense(monkeypatch):
     """SpikingStage.forward_sequence_conv_cl on a packed-only input (a data-less anchor + the packed tensor: what bottom / conv1 hand on in the
     default configuration) == on the dense tensor: output spikes, weight gradient and input gradient."""
