@@ -382,6 +382,13 @@ int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const fl
  * terms, six cross terms kept — exact for integer event counts, fp32-product accuracy otherwise), weight [32][C_in][5][5], out [NB][h][w][32]. */
 int ss_dense_conv_s1_fwd_supported(int Cin, int Cout, int k, int stride, int pad);
 int ss_dense_conv_s1_fwd_f32(const float* x, const float* weight, float* out, long long NB, int Cin, int Cout, int h, int w, void* stream);
+/* ABI 6 — its WEIGHT gradient (autograd in the reference): g_w[32][C_in][5][5] (+)= sum over pixels of g[nb][y][x][co] * x[nb][y + ky - 2][x + kx - 2][ci],
+ * g [NB][h][w][32], x [NB][h][w][C_in] dense fp32 NHWC (ANY values: six bf16 cross terms per product on the matrix cores, fp32 accumulation per tile,
+ * fixed-order fp64 second pass — deterministic).  ws: ss_dense_conv_s1_wgrad_ws_floats floats, 16-byte aligned.  Replaces MIOpen's igemm_wrw — the
+ * last MIOpen call of the default training step. */
+int ss_dense_conv_s1_wgrad_supported(int Cin, int Cout, int k, int stride, int pad);
+long long ss_dense_conv_s1_wgrad_ws_floats(int Cin);
+int ss_dense_conv_s1_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate, void* stream);
 
 /*
  * ABI 6 — DATA gradient of the stride-2 5x5 encoder convolutions as a six-term bf16 implicit GEMM on the matrix cores (ss_conv_dgrad.hip).

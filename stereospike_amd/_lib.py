@@ -136,6 +136,12 @@ def lib():
     L.ss_conv_s2_dgrad_ws_floats.restype = i64
     L.ss_conv_s2_dgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, p]
     L.ss_conv_s2_dgrad_f32.restype = i32
+    L.ss_dense_conv_s1_wgrad_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_dense_conv_s1_wgrad_supported.restype = i32
+    L.ss_dense_conv_s1_wgrad_ws_floats.argtypes = [i32]
+    L.ss_dense_conv_s1_wgrad_ws_floats.restype = i64
+    L.ss_dense_conv_s1_wgrad_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_dense_conv_s1_wgrad_f32.restype = i32
     L.ss_head_packed_supported.argtypes = [i32, i32, i32]
     L.ss_head_packed_supported.restype = i32
     L.ss_head_wgrad_packed_ws_floats.argtypes = [i32]
@@ -198,6 +204,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
+           'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
            'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
@@ -620,6 +627,21 @@ def conv_s2_dgrad(g, weight, g_x, NB, Cin, Cout, h, w):
         rc = lib().ss_conv_s2_dgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), _f32(weight, 'weight', Cout * Cin * 25), _f32(g_x, 'g_x', NB * h * w * Cin),
                                         _f32(ws, 'ws'), NB, Cin, Cout, h, w, _stream(g))
     _check(rc, 'ss_conv_s2_dgrad_f32')
+
+
+def dense_conv_s1_wgrad_supported(Cin, Cout, k, stride, pad):
+    return bool(lib().ss_dense_conv_s1_wgrad_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def dense_conv_s1_wgrad(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False):
+    """g_w [32, Cin, 5, 5] (+)= weight gradient of conv2d(x, ., stride 1, pad 2): g [NB, h, w, 32], x [NB, h, w, Cin] dense fp32 NHWC (any values):
+    six-term bf16 MFMA contraction over the pixels, deterministic."""
+    _require_hip(g, 'g')
+    ws = torch.empty(int(lib().ss_dense_conv_s1_wgrad_ws_floats(int(Cin))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_dense_conv_s1_wgrad_f32(_f32(g, 'g', NB * h * w * Cout), _f32(x, 'x', NB * h * w * Cin), _f32(g_w, 'g_w', Cout * Cin * 25), _f32(ws, 'ws'),
+                                              NB, Cin, Cout, h, w, int(bool(accumulate)), _stream(g))
+    _check(rc, 'ss_dense_conv_s1_wgrad_f32')
 
 
 def head_packed_supported(Cin, Cout, k):

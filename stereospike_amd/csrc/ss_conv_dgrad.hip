@@ -330,3 +330,209 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------------
+// WEIGHT gradient of the first encoder layer, nn.Conv2d(C_in = 4 | 2, 32, kernel_size=5, stride=1, padding=2, bias=False) on the event-voxel
+// input (/root/reference/network/SNN_models.py:75-79, 263-267, 450-454; autograd in the reference; include/ss_neuron.h: ss_dense_conv_s1_wgrad_f32):
+//     g_W[co][ci][ky][kx] = sum_{nb, y, x} g[nb][y][x][co] * x[nb][y + ky - 2][x + kx - 2][ci]
+// — the last MIOpen call of the default training step (igemm_wrw, 0.68 ms at config 3 for 23 GMAC: the contraction runs over 7.2 M pixels into a
+// 32 x 100 result).  Here: v_mfma_f32_32x32x16_bf16 with M = co, N = (tap, ci) in tiles of 32, K = 16 pixels along a row; BOTH operands split
+// into three bf16 terms, six cross terms kept (any input values; exact for the voxeliser's integer counts), fp32 accumulation.
+//   * A workgroup owns tiles of 8 rows x 32 columns of pixels.  g is staged TRANSPOSED in LDS (gT[co][pixel], fp32), so that a lane's 8 consecutive
+//     pixels of one output channel are two 16-B reads, split in registers once per k-step and used for all N tiles; the input window
+//     (12 x 36 pixels) is split once while it is staged: three bf16 planes xT[plane][ci][row][col].  A B fragment — 8 consecutive columns
+//     starting at an arbitrary column (the tap's kx) — is five aligned 4-B reads funnel-shifted by the column parity (v_alignbyte).
+//   * A wavefront handles every fourth k-step of the tile for ALL N tiles (the A fragment is built once); a tile's MFMAs accumulate on a scratch
+//     accumulator that starts at zero, the running sum takes one fp32 addition per tile (sign alternating per tile: the MFMA drift of DESIGN.md
+//     3.8); wavefront and workgroup partials meet in a fixed-order fp64 second pass: deterministic.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kW1Threads = 256;
+constexpr int kW1TR = 8, kW1TC = 32;                   // pixel rows x columns of a tile: 16 k-steps of 16 pixels
+constexpr int kW1WR = kW1TR + 4, kW1WC = 40;           // window rows; window columns padded from 36 to 40 (80-B rows: 4-B aligned reads)
+constexpr int kW1GS = kW1TR * kW1TC + 4;               // pixel stride (floats) of a channel's row in gT: 16-B aligned, banks spread
+constexpr int kW1Groups = 1024;                        // workgroups = partial blocks of the second pass
+
+template <int CI>
+__global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ part,
+                                                                            int NB, int h, int w)
+{
+    constexpr int NV = 25 * CI, NT = (NV + 31) / 32;                            // valid (tap, ci) columns; N tiles
+    constexpr int PL = CI * kW1WR * kW1WC;                                      // elements of one bf16 plane of the window
+    __shared__ __attribute__((aligned(16))) float gT[32 * kW1GS];
+    __shared__ __attribute__((aligned(16))) unsigned short xT[3 * PL + 8];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mn = lane & 31, kq = lane >> 5;                                   // A: m = co; B: n = column of the N tile; k group of 8 pixels
+    const int RG = (h + kW1TR - 1) / kW1TR, CG = (w + kW1TC - 1) / kW1TC;
+    const long long n_tiles = (long long)NB * RG * CG;
+    const long long t_begin = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    // this lane's B columns: (tap, ci) of N tile t -> element offset of (ci, ky, kx) inside a plane, for the pixel at tile row 0, column 0
+    int boff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nv = min(32 * t + mn, NV - 1), tap = nv / CI, ci = nv - tap * CI, ky = tap / 5, kx = tap - 5 * ky;
+        boff[t] = (ci * kW1WR + ky) * kW1WC + kx;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    bool neg = false;
+#pragma unroll 1
+    for (long long tl = t_begin; tl < t_end; ++tl) {
+        const int cg = (int)(tl % CG);
+        const long long rr = tl / CG;
+        const int rg = (int)(rr % RG), nb = (int)(rr / RG);
+        const int y0 = kW1TR * rg, x0 = kW1TC * cg;
+        __syncthreads();                                                        // the previous tile's readers are done
+        // ---- g tile -> gT[co][pixel] (zero outside the image)
+#pragma unroll
+        for (int u = 0; u < (kW1TR * kW1TC * 8) / kW1Threads; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            const int pix = i >> 3, q = i & 7, py = pix / kW1TC, px = pix - py * kW1TC;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y0 + py < h && x0 + px < w) v = load_stream(reinterpret_cast<const f4*>(G + (((long long)nb * h + y0 + py) * w + x0 + px) * 32) + q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gT[(4 * q + e) * kW1GS + pix] = v[e];
+        }
+        // ---- input window -> three bf16 planes (x = xh + xm + xl), zero outside the image and in the padding columns
+        for (int i = threadIdx.x; i < kW1WR * kW1WC; i += kW1Threads) {
+            const int wy = i / kW1WC, wx = i - wy * kW1WC;
+            const int iy = y0 - 2 + wy, ix = x0 - 2 + wx;
+            float v[CI];
+#pragma unroll
+            for (int c = 0; c < CI; ++c) v[c] = 0.f;
+            if (wx < kW1TC + 4 && iy >= 0 && iy < h && ix >= 0 && ix < w) {
+                const float* p = X + (((long long)nb * h + iy) * w + ix) * CI;
+#pragma unroll
+                for (int c = 0; c < CI; ++c) v[c] = p[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CI; ++c) {
+                const __bf16 h1 = (__bf16)v[c];
+                const float r1 = v[c] - (float)h1;
+                const __bf16 h2 = (__bf16)r1;
+                const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                unsigned short* const q = xT + (c * kW1WR + wy) * kW1WC + wx;
+                q[0] = __builtin_bit_cast(unsigned short, h1);
+                q[PL] = __builtin_bit_cast(unsigned short, h2);
+                q[2 * PL] = __builtin_bit_cast(unsigned short, h3);
+            }
+        }
+        __syncthreads();
+        const float sgn = neg ? -1.f : 1.f;
+        f32x16 tmp[NT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                           // this wavefront's k-steps: ks = wv + 4 j -> tile row, column half
+            const int ks = wv + 4 * j, py = ks >> 1, pxb = 16 * (ks & 1) + 8 * kq;
+            const float* const gp = gT + mn * kW1GS + py * kW1TC + pxb;
+            const f4 ga = *reinterpret_cast<const f4*>(gp), gb = *reinterpret_cast<const f4*>(gp + 4);
+            s16x8 ah, am, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (e < 4 ? ga[e] : gb[e - 4]) * sgn;
+                const __bf16 h1 = (__bf16)v;
+                const float r1 = v - (float)h1;
+                const __bf16 h2 = (__bf16)r1;
+                const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                ah[e] = __builtin_bit_cast(short, h1); am[e] = __builtin_bit_cast(short, h2); al[e] = __builtin_bit_cast(short, h3);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                // 8 consecutive window columns starting at element `el` of a plane: five aligned dwords, shifted by the start's parity
+                const int el = boff[t] + py * kW1WC + pxb;
+                const unsigned sh = (el & 1) * 2;
+                s16x8 b[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const unsigned* const d = reinterpret_cast<const unsigned*>(xT + sp * PL + (el & ~1));
+                    unsigned dw[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) dw[q] = d[q];
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    u4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_alignbyte(dw[q + 1], dw[q], sh);
+                    b[sp] = __builtin_bit_cast(s16x8, o);
+                }
+                // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
+                if (j == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0], zero, 0, 0, 0);
+                } else {
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0], tmp[t], 0, 0, 0);
+                }
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0], tmp[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf(sgn, tmp[t][r], acc[t][r]);
+        neg = !neg;
+    }
+    // ---- D[row = co = (r & 3) + 8 (r >> 2) + 4 kq][col = n] -> part[workgroup][wavefront][co][32 t + n]
+    float* const pp = part + ((long long)blockIdx.x * 4 + wv) * 32 * NT * 32;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2) + 4 * kq) * (NT * 32) + 32 * t + mn] = acc[t][r];
+}
+
+// second pass: g_W[co][ci][ky][kx] (+)= sum over all wavefront partials of D[co][tap * CI + ci], fixed order, fp64 — one workgroup per element
+__global__ __launch_bounds__(kBlock) void dense_conv_s1_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ gW, int n_part, int CI, int NTW,
+                                                                            int accumulate)
+{
+    __shared__ double sh[kBlock];
+    const int i = blockIdx.x, co = i / (25 * CI), rem = i - co * 25 * CI, ci = rem / 25, tap = rem - ci * 25;     // i = flat index of g_W [32][CI][25]
+    const long long src = (long long)co * NTW + tap * CI + ci;
+    double s = 0.0;
+    for (int p = threadIdx.x; p < n_part; p += kBlock) s += (double)part[(long long)p * 32 * NTW + src];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = kBlock / 2; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gW[i] = accumulate ? (float)((double)gW[i] + sh[0]) : (float)sh[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_dense_conv_s1_wgrad_supported(int Cin, int Cout, int k, int stride, int pad)
+{
+    return k == 5 && stride == 1 && pad == 2 && Cout == 32 && (Cin == 4 || Cin == 2);
+}
+
+long long ss_dense_conv_s1_wgrad_ws_floats(int Cin)
+{
+    if (Cin != 4 && Cin != 2) return 0;
+    return (long long)kW1Groups * 4 * 32 * ((25 * Cin + 31) / 32) * 32;
+}
+
+int ss_dense_conv_s1_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate, void* stream)
+{
+    if (!g || !x || !g_w || !ws || NB <= 0 || NB > 0x7fffffff || h <= 0 || w <= 0 || !ss_dense_conv_s1_wgrad_supported(Cin, Cout, 5, 1, 2)) return SS_EINVAL;
+    if (!aligned16(g) || !aligned16(ws)) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n_tiles = NB * ((h + kW1TR - 1) / kW1TR) * ((w + kW1TC - 1) / kW1TC);
+    const unsigned grid = (unsigned)(n_tiles < kW1Groups ? n_tiles : kW1Groups);
+    const int NTW = ((25 * Cin + 31) / 32) * 32;
+    if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<4>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
+    else hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<2>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    hipLaunchKernelGGL(dense_conv_s1_wgrad_finish_kernel, dim3(32 * Cin * 25), dim3(kBlock), 0, s, ws, g_w, (int)grid * 4, Cin, NTW, accumulate);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+}  // extern "C"

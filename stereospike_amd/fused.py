@@ -1071,13 +1071,14 @@ def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tenso
     return _SpikeConvWgradCL.apply(x_cl, conv.weight, x_packed)
 
 
+DENSE_CONV_S1_WGRAD_MFMA = _os.environ.get('SS_CONV_S1_WGRAD_MFMA', '1') == '1'   # ... and its WEIGHT gradient as ss_dense_conv_s1_wgrad_f32 (was MIOpen's igemm_wrw)
 DENSE_CONV_S1_MFMA = _os.environ.get('SS_CONV_S1_MFMA', '1') == '1'   # first encoder layer (C_in 4 | 2 -> 32, 5x5, stride 1) FORWARD as ss_dense_conv_s1_fwd_f32
 
 
 class _DenseConvS1CL(torch.autograd.Function):
     """The first encoder layer (/root/reference/network/SNN_models.py:75-79: Conv2d(4 | 2, 32, 5, stride 1, padding 2) on the event-voxel input)
-    on an NHWC array: forward = the six-term bf16 MFMA implicit GEMM (no precondition on the input values), weight (and, if asked for, input)
-    gradient = MIOpen's convolution backward as before."""
+    on an NHWC array: forward and weight gradient = six-term bf16 MFMA contractions (no precondition on the input values); an input gradient, if
+    ever asked for, = MIOpen's convolution backward."""
 
     @staticmethod
     @_fwd32
@@ -1097,9 +1098,21 @@ class _DenseConvS1CL(torch.autograd.Function):
     def backward(ctx, g):
         x_cl, weight = ctx.saved_tensors
         g = g.float().contiguous()
+        NB, h, w, Cin = x_cl.shape
+        own_w = bool(ctx.needs_input_grad[1]) and DENSE_CONV_S1_WGRAD_MFMA and _lib.dense_conv_s1_wgrad_supported(Cin, weight.shape[0], 5, 1, 2)
+        gw_own = None
+        if own_w:                                            # six-term MFMA contraction over the pixels (was MIOpen's igemm_wrw: the step's last MIOpen call)
+            gw_own = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            e0 = TIMER.start()
+            _lib.dense_conv_s1_wgrad(g, x_cl, gw_own, NB, Cin, weight.shape[0], h, w)
+            TIMER.stop(e0, 'dense_conv_s1_wgrad', 4 * (g.numel() + x_cl.numel()), g.numel())
+            if not ctx.needs_input_grad[0]:
+                return None, gw_own
         gx, gw, _ = torch.ops.aten.convolution_backward(
             g.permute(0, 3, 1, 2), x_cl.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last), None,
-            [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+            [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]) and not own_w, False])
+        if own_w:
+            gw = gw_own
         if gx is not None:
             gx = gx.permute(0, 2, 3, 1)
             gx = gx if gx.is_contiguous() else gx.contiguous()

@@ -42,6 +42,7 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32',
                                   # ABI 6
                                   'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
+                                  'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
                                   'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32'])
 
 

@@ -71,6 +71,7 @@ def assert_default_kernels(tags, T):
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
     assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)
+    assert tags.get('dense_conv_s1_wgrad', 0) == 1, tags                  # the first layer's weight gradient: six-term MFMA contraction (the step's last MIOpen call is gone)
     assert bwd.get('neuron_bwd+lronly', 0) == 1 and bwd.get('neuron_bwd+lr', 0) == 1 and bwd.get('neuron_bwd+lr+sum', 0) == 3, tags
     assert bwd.get('neuron_bwd+fork', 0) == 3 and bwd.get('neuron_bwd', 0) == 5, tags
     assert tags.get('upconv_cl_fwd', 0) == 8 and tags.get('upconv_cl_bwd', 0) == 8, tags
@@ -159,7 +160,8 @@ def test_pinned_parity_config3_step_B16_T5():
 
 def test_packed_spike_tensors_are_in_effect():
     """fused.PACK_SPIKES (default on; the pinned tests above assert its launch tags): 2-bit packed spike tensors between conv2 .. bottleneck and
-    their consumers (packed-only: the autograd output is a data-less anchor), packed skip operands for the decoder.  Here: the packed
+    their consumers and on the full-resolution decoder stage's output (packed-only: the autograd output is a data-less anchor), packed skip operands
+    for the decoder.  Here: the packed
     form really is in effect, and within ONE launch that writes both forms (bottom, conv1) unpack(packed) == the dense tensor bit for bit;
     with PACK_SPIKES off no packed tensor exists.  (Bit-equality of the consumers on packed vs dense input: tests/test_gpu_01_kernels.py.)"""
     from stereospike_amd import fused
@@ -184,7 +186,13 @@ def test_packed_spike_tensors_are_in_effect():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
         assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
-    assert net.deconv1[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    assert net.deconv2[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    # the full-resolution decoder stage: packed only (its prediction head reads the packed form); the model returns its last step unpacked
+    pk1 = net.deconv1[2].last_packed
+    assert pk1 is not None and pk1.dtype == torch.int32
+    T, B = 5, 2
+    last = fused.unpack_dense(pk1[T - 1:T], (1, B, H, W, 32))[0].permute(0, 3, 1, 2)
+    assert tuple(s[-1].shape) == (B, 32, H, W) and torch.equal(s[-1], last) and 0.02 < float(last.mean()) < 2.0
     assert rec['anchor']                                                                        # bottom's dense output is a data-less anchor
     packed_only = fused.unpack_dense(net.bottom[2].last_packed, rec['shape'])
     # with conv1's forward back on MIOpen (which reads dense activations) bottom writes BOTH forms in one launch: unpack(packed) == dense

@@ -1426,6 +1426,43 @@ def test_conv_s2_dgrad_mfma(NB, Cin, hw):
     assert torch.equal(gx2, gx * 2)
 
 
+@pytest.mark.parametrize('NB,Cin,hw', [(2, 4, (64, 80)), (3, 2, (33, 45)), (1, 4, (7, 9)), (4, 4, (260, 346)), (2, 2, (130, 173)), (5, 4, (50, 70)), (1, 2, (1, 1))])
+def test_dense_conv_s1_wgrad_mfma(NB, Cin, hw):
+    """The first encoder layer's WEIGHT gradient (Conv2d(4 | 2, 32, 5, stride 1, pad 2)) as the six-term bf16 MFMA contraction over the pixels: on
+    integer event counts and on arbitrary fp32 inputs |g_w - float64| <= 2^-20 sum |g||x| element-wise (six cross terms per product, one fp32 addition
+    of the running sum per tile, fp64 second pass), rms within 2x of MIOpen's fp32 weight gradient's own distance to float64; odd sizes / ragged tiles
+    / a single pixel; accumulate flag; bit-reproducible."""
+    import torch.nn.functional as F
+    from stereospike_amd import _lib
+    h, w = hw
+    gen = torch.Generator(device=DEV).manual_seed(NB + h + Cin)
+    assert _lib.dense_conv_s1_wgrad_supported(Cin, 32, 5, 1, 2) and not _lib.dense_conv_s1_wgrad_supported(8, 32, 5, 1, 2)
+    g = torch.randn(NB, h, w, 32, device=DEV, generator=gen) * torch.exp(2 * torch.randn(NB, h, w, 1, device=DEV, generator=gen)) * 1e-4
+    wt = torch.randn(32, Cin, 5, 5, device=DEV, generator=gen) * 0.1
+    for kind in ('counts', 'real'):
+        x = torch.poisson(torch.full((NB, h, w, Cin), 0.3, device=DEV), generator=gen) if kind == 'counts' else \
+            torch.randn(NB, h, w, Cin, device=DEV, generator=gen) * torch.exp(3 * torch.randn(NB, h, w, 1, device=DEV, generator=gen))
+        gw = torch.full((32, Cin, 5, 5), float('nan'), device=DEV)
+        _lib.dense_conv_s1_wgrad(g, x, gw, NB, Cin, 32, h, w)
+
+        def wgrad(gg, xx):
+            return torch.ops.aten.convolution_backward(gg.permute(0, 3, 1, 2), xx.permute(0, 3, 1, 2), wt.to(device=xx.device, dtype=xx.dtype), None,
+                                                       [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        ref = wgrad(g.double().cpu(), x.double().cpu()).to(DEV)
+        mag = wgrad(g.double().abs().cpu(), x.double().abs().cpu()).to(DEV)
+        err = (gw.double() - ref).abs()
+        assert bool(torch.isfinite(gw).all()) and bool((err <= mag * 2.0 ** -20 + 1e-300).all()), (kind, float((err / (mag * 2.0 ** -20 + 1e-300)).max()))
+        mi = wgrad(g, x)
+        rms = lambda e: float(e.double().pow(2).mean().sqrt())
+        assert rms(err) <= 2.0 * rms(mi.double() - ref) + 1e-8 * rms(ref), (kind, rms(err), rms(mi.double() - ref))
+        gw2 = gw.clone()
+        _lib.dense_conv_s1_wgrad(g, x, gw2, NB, Cin, 32, h, w, accumulate=True)
+        assert float((gw2.double() - 2 * ref).abs().max()) <= 2.0 ** -19 * float(mag.max()) + 1e-30
+        gw3 = torch.empty_like(gw)
+        _lib.dense_conv_s1_wgrad(g, x, gw3, NB, Cin, 32, h, w)
+        assert torch.equal(gw, gw3)
+
+
 @pytest.mark.parametrize('rows,C', [(64 * 80 * 3, 32), (1, 32), (33, 64), (260 * 346 * 2, 32), (12345, 64), (31, 32)])
 def test_head_on_packed_spikes(rows, C):
     """ss_head_proj_packed_f32 / ss_head_wgrad_packed_f32 (the full-resolution prediction head reading 2-bit packed spikes) against float64 on the

@@ -119,6 +119,26 @@ def host_backend(monkeypatch):
         if out_packed is not None:
             out_packed.copy_(torch.from_numpy(np_pack.pack(dense.numpy().reshape(T, N)).view(np.int32)).view_as(out_packed))
 
+    # the full-resolution prediction head on packed spikes (fused.PACKED_HEAD): numpy restatements on the unpacked codes
+    def unpack_spikes(packed, out, n, row_len=0, copies=1):
+        from oracle import np_pack
+        assert copies == 1
+        out.copy_(torch.from_numpy(np_pack.unpack(packed.numpy().view(np.uint32).reshape(-1))[:n]).view_as(out))
+
+    def head_proj_packed(x_packed, Wt, P, rows, Cin):
+        from oracle import np_pack
+        x = np_pack.unpack(x_packed.numpy().view(np.uint32).reshape(-1)).reshape(rows, Cin)
+        P.copy_(torch.from_numpy(x) @ Wt)
+
+    def head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=False):
+        from oracle import np_pack
+        x = torch.from_numpy(np_pack.unpack(x_packed.numpy().view(np.uint32).reshape(-1)).reshape(rows, Cin))
+        g = x.t() @ g_P
+        g_Wt.copy_(g_Wt + g if accumulate else g)
+
+    monkeypatch.setattr(_lib, 'unpack_spikes', unpack_spikes)
+    monkeypatch.setattr(_lib, 'head_proj_packed', head_proj_packed)
+    monkeypatch.setattr(_lib, 'head_wgrad_packed', head_wgrad_packed)
     monkeypatch.setattr(_lib, 'neuron_fwd', neuron_fwd)
     monkeypatch.setattr(_lib, 'neuron_fwd_ex', neuron_fwd_ex)
     monkeypatch.setattr(_lib, 'cnt_ws_words', lambda N: 1)

@@ -68,3 +68,25 @@ for name, Cin, (h, w) in [('bottom', 4, (260, 346))]:
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 4)
         print(f'   {name} {k:34s} {best:7.3f} ms   output {4 * y.numel() / best / 1e6:7.1f} GB/s', flush=True)
+
+    g = torch.randn(NB, h, w, 32, device=dev) * 1e-4
+    gw = torch.empty(32, Cin, 5, 5, device=dev)
+    cases = {'MIOpen fp32 weight gradient (NHWC)': lambda: torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w_cl, None, [1, 1], [2, 2], [1, 1],
+                                                                                               False, [0, 0], 1, [False, True, False])[1],
+             'dense_conv_s1_wgrad (six-term MFMA)': lambda: _lib.dense_conv_s1_wgrad(g, x, gw, NB, Cin, 32, h, w)}
+    for f in cases.values():
+        f()
+    torch.cuda.synchronize()
+    ref = cases['MIOpen fp32 weight gradient (NHWC)']()
+    print(name, 'weight gradient max |diff| / max vs MIOpen', float((ref - gw).abs().max() / ref.abs().max()), flush=True)
+    for k, f in cases.items():
+        best = 1e9
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(4):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 4)
+        print(f'   {name} {k:38s} {best:7.3f} ms', flush=True)
