@@ -277,7 +277,8 @@ def main():
         dom = max(fwd_shapes, key=lambda k: (k[1], fwd_shapes[k]['ms'])) if fwd_shapes else None
         fwd = fwd_shapes.get(dom, zero)
         fwd_tag = dom[0] if dom else 'neuron_fwd_train'
-        fwd_pmc = {'neuron_fwd_train': 'neuron_fwd', 'neuron_fwd_train+packed': 'neuron_fwd_packed'}.get(fwd_tag, 'none')
+        fwd_pmc = {'neuron_fwd_train': 'neuron_fwd', 'neuron_fwd_train+packed': 'neuron_fwd_packed',
+                   'neuron_fwd_train+skip+packed': 'neuron_fwd_skip_packed'}.get(fwd_tag, 'none')
         # backward: the launch group with the most updates; at equal size the forked form without the extra g_sum store (the bottom
         # layer: 16 B/update), which is also the variant the PMC passes measure (tools/pmc_target.py)
         # (since the prediction heads hand over their gradient as a rank-9 pair: the '+lr' form, 13.1 B/update at 32 channels)

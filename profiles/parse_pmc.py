@@ -18,7 +18,17 @@ def key_of(name):
         import re
         m = re.search(r'neuron_fwd_kernel<([^>]*)>', name)
         args = [a.strip() for a in m.group(1).split(',')] if m else []
-        return 'neuron_fwd_packed' if (len(args) >= 6 and args[5] == 'true') else 'neuron_fwd'      # 6th template argument = PK
+        if len(args) >= 6 and args[5] == 'true':                                                     # 6th template argument = PK, 3rd = SKIP
+            return 'neuron_fwd_skip_packed' if args[2] == 'true' else 'neuron_fwd_packed'
+        return 'neuron_fwd'
+    if 'conv_s2_dgrad_kernel' in name:
+        return 'conv_s2_dgrad'
+    if 'dense_conv_s1_wgrad_kernel' in name:
+        return 'dense_conv_s1_wgrad'
+    if 'head_proj_packed_kernel' in name:
+        return 'head_proj_packed'
+    if 'head_wgrad_packed_kernel' in name:
+        return 'head_wgrad_packed'
     if 'upconv_fused2_fwd_kernel' in name:
         return 'upconv_fused2'
     if 'upconv_fused_fwd_kernel' in name:
@@ -76,8 +86,13 @@ alg['upconv_bwd_dgrad'] = 4 * (80 * 260 * 346 * 32 + 80 * 130 * 173 * 64) + 2 * 
 alg['upconv_bwd_wgrad_nogp'] = 4 * 80 * 260 * 346 * 32 + 2 * 80 * 130 * 176 * 64 + 4 * 25 * 32 * 64      # deconv1: g_y in + bf16 transposed spikes in + g_W partials
 alg['spike_conv_fwd'] = 80 * 260 * 346 * 32 // 4 + 4 * 80 * 130 * 173 * 64 + 2 * 3 * 25 * 32 * 64        # conv1: packed spikes in + fp32 out + split weights
 alg['dense_conv_s1_fwd'] = 4 * 80 * 260 * 346 * (4 + 32) + 4 * 25 * 4 * 32                                # bottom: voxel input + fp32 out + weights
+alg['neuron_fwd_skip_packed'] = int(4.5 * T * N)                    # x 4 B + packed skip 0.25 B + packed output 0.25 B per update (deconv1 since the packed head)
+alg['conv_s2_dgrad'] = 4 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 3 * 25 * 32 * 64       # conv1: g in + g_x out + split weights
+alg['dense_conv_s1_wgrad'] = 4 * 80 * 260 * 346 * (32 + 4) + 4 * 1024 * 4 * 32 * 128                 # bottom: g + x in, wavefront partials out
+alg['head_proj_packed'] = 80 * 260 * 346 * (32 // 4 + 9 * 4) + 4 * 32 * 9                            # packed spikes in + P out
+alg['head_wgrad_packed'] = 80 * 260 * 346 * (32 // 4 + 9 * 4) + 4 * 4096 * 32 * 9                    # packed spikes + g_P in, partials out
 res['algorithmic_bytes_per_launch'] = alg
-for k in ('spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
+for k in ('conv_s2_dgrad', 'dense_conv_s1_wgrad', 'head_proj_packed', 'head_wgrad_packed', 'neuron_fwd_skip_packed', 'spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
     if k in fetch and k in write:
         hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],

@@ -339,28 +339,30 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
 // — the last MIOpen call of the default training step (igemm_wrw, 0.68 ms at config 3 for 23 GMAC: the contraction runs over 7.2 M pixels into a
 // 32 x 100 result).  Here: v_mfma_f32_32x32x16_bf16 with M = co, N = (tap, ci) in tiles of 32, K = 16 pixels along a row; BOTH operands split
 // into three bf16 terms, six cross terms kept (any input values; exact for the voxeliser's integer counts), fp32 accumulation.
-//   * A workgroup owns tiles of 8 rows x 32 columns of pixels.  g is staged TRANSPOSED in LDS (gT[co][pixel], fp32), so that a lane's 8 consecutive
+//   * A workgroup owns tiles of 4 rows x 32 columns of pixels, loaded one tile ahead into registers.  g is staged TRANSPOSED in LDS (gT[co][pixel], fp32), so that a lane's 8 consecutive
 //     pixels of one output channel are two 16-B reads, split in registers once per k-step and used for all N tiles; the input window
-//     (12 x 36 pixels) is split once while it is staged: three bf16 planes xT[plane][ci][row][col].  A B fragment — 8 consecutive columns
+//     (8 x 36 pixels) is split once while it is staged: three bf16 planes xT[plane][ci][row][col].  A B fragment — 8 consecutive columns
 //     starting at an arbitrary column (the tap's kx) — is five aligned 4-B reads funnel-shifted by the column parity (v_alignbyte).
 //   * A wavefront handles every fourth k-step of the tile for ALL N tiles (the A fragment is built once); a tile's MFMAs accumulate on a scratch
 //     accumulator that starts at zero, the running sum takes one fp32 addition per tile (sign alternating per tile: the MFMA drift of DESIGN.md
-//     3.8); wavefront and workgroup partials meet in a fixed-order fp64 second pass: deterministic.
+//     3.8); the wavefronts' sums meet in LDS, the workgroup partials in a fixed-order fp64 second pass: deterministic.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
 constexpr int kW1Threads = 256;
-constexpr int kW1TR = 8, kW1TC = 32;                   // pixel rows x columns of a tile: 16 k-steps of 16 pixels
+constexpr int kW1TR = 4, kW1TC = 32;                   // pixel rows x columns of a tile: 8 k-steps of 16 pixels (two per wavefront)
 constexpr int kW1WR = kW1TR + 4, kW1WC = 40;           // window rows; window columns padded from 36 to 40 (80-B rows: 4-B aligned reads)
 constexpr int kW1GS = kW1TR * kW1TC + 4;               // pixel stride (floats) of a channel's row in gT: 16-B aligned, banks spread
-constexpr int kW1Groups = 1024;                        // workgroups = partial blocks of the second pass
+constexpr int kW1Groups = 512;                         // workgroups (two per CU) = partial blocks of the second pass
 
 template <int CI>
 __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ part,
                                                                             int NB, int h, int w)
 {
     constexpr int NV = 25 * CI, NT = (NV + 31) / 32;                            // valid (tap, ci) columns; N tiles
-    constexpr int PL = CI * kW1WR * kW1WC;                                      // elements of one bf16 plane of the window
+    constexpr int CS = kW1WR * kW1WC + 2;                                       // elements per input channel of a plane: + one dword, so that the CI lanes of a tap
+                                                                                // (same window position, consecutive channels) read CI different banks
+    constexpr int PL = CI * CS;                                                 // elements of one bf16 plane of the window
     __shared__ __attribute__((aligned(16))) float gT[32 * kW1GS];
     __shared__ __attribute__((aligned(16))) unsigned short xT[3 * PL + 8];
     const int lane = threadIdx.x & 63;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int nv = min(32 * t + mn, NV - 1), tap = nv / CI, ci = nv - tap * CI, ky = tap / 5, kx = tap - 5 * ky;
-        boff[t] = (ci * kW1WR + ky) * kW1WC + kx;
+        boff[t] = ci * CS + ky * kW1WC + kx;
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -382,52 +384,76 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     bool neg = false;
-#pragma unroll 1
-    for (long long tl = t_begin; tl < t_end; ++tl) {
+    // a tile's g values and window pixels are loaded into registers one tile AHEAD (the loads fly during the previous tile's MFMAs) and written
+    // to LDS — g transposed, the window split into its three bf16 planes — once that tile's readers are done
+    constexpr int GU = (kW1TR * kW1TC * 8) / kW1Threads, XU = (kW1WR * kW1WC + kW1Threads - 1) / kW1Threads;
+    f4 gv[GU];
+    float xv[XU][CI];
+    auto load_tile = [&](long long tl) {
         const int cg = (int)(tl % CG);
         const long long rr = tl / CG;
         const int rg = (int)(rr % RG), nb = (int)(rr / RG);
         const int y0 = kW1TR * rg, x0 = kW1TC * cg;
-        __syncthreads();                                                        // the previous tile's readers are done
-        // ---- g tile -> gT[co][pixel] (zero outside the image)
 #pragma unroll
-        for (int u = 0; u < (kW1TR * kW1TC * 8) / kW1Threads; ++u) {
+        for (int u = 0; u < GU; ++u) {
             const int i = threadIdx.x + kW1Threads * u;
             const int pix = i >> 3, q = i & 7, py = pix / kW1TC, px = pix - py * kW1TC;
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y0 + py < h && x0 + px < w) v = load_stream(reinterpret_cast<const f4*>(G + (((long long)nb * h + y0 + py) * w + x0 + px) * 32) + q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gT[(4 * q + e) * kW1GS + pix] = v[e];
+            gv[u] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (y0 + py < h && x0 + px < w) gv[u] = load_stream(reinterpret_cast<const f4*>(G + (((long long)nb * h + y0 + py) * w + x0 + px) * 32) + q);
         }
-        // ---- input window -> three bf16 planes (x = xh + xm + xl), zero outside the image and in the padding columns
-        for (int i = threadIdx.x; i < kW1WR * kW1WC; i += kW1Threads) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
             const int wy = i / kW1WC, wx = i - wy * kW1WC;
             const int iy = y0 - 2 + wy, ix = x0 - 2 + wx;
-            float v[CI];
 #pragma unroll
-            for (int c = 0; c < CI; ++c) v[c] = 0.f;
-            if (wx < kW1TC + 4 && iy >= 0 && iy < h && ix >= 0 && ix < w) {
+            for (int c = 0; c < CI; ++c) xv[u][c] = 0.f;
+            if (i < kW1WR * kW1WC && wx < kW1TC + 4 && iy >= 0 && iy < h && ix >= 0 && ix < w) {
                 const float* p = X + (((long long)nb * h + iy) * w + ix) * CI;
 #pragma unroll
-                for (int c = 0; c < CI; ++c) v[c] = p[c];
-            }
-#pragma unroll
-            for (int c = 0; c < CI; ++c) {
-                const __bf16 h1 = (__bf16)v[c];
-                const float r1 = v[c] - (float)h1;
-                const __bf16 h2 = (__bf16)r1;
-                const __bf16 h3 = (__bf16)(r1 - (float)h2);
-                unsigned short* const q = xT + (c * kW1WR + wy) * kW1WC + wx;
-                q[0] = __builtin_bit_cast(unsigned short, h1);
-                q[PL] = __builtin_bit_cast(unsigned short, h2);
-                q[2 * PL] = __builtin_bit_cast(unsigned short, h3);
+                for (int c = 0; c < CI; ++c) xv[u][c] = p[c];
             }
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            const int pix = i >> 3, q = i & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gT[(4 * q + e) * kW1GS + pix] = gv[u][e];
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            const int wy = i / kW1WC, wx = i - wy * kW1WC;
+            if (i < kW1WR * kW1WC) {
+#pragma unroll
+                for (int c = 0; c < CI; ++c) {
+                    const float v = xv[u][c];
+                    const __bf16 h1 = (__bf16)v;
+                    const float r1 = v - (float)h1;
+                    const __bf16 h2 = (__bf16)r1;
+                    const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                    unsigned short* const q = xT + c * CS + wy * kW1WC + wx;
+                    q[0] = __builtin_bit_cast(unsigned short, h1);
+                    q[PL] = __builtin_bit_cast(unsigned short, h2);
+                    q[2 * PL] = __builtin_bit_cast(unsigned short, h3);
+                }
+            }
+        }
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+#pragma unroll 1
+    for (long long tl = t_begin; tl < t_end; ++tl) {
+        __syncthreads();                                                        // the previous tile's readers are done
+        store_tile();
         __syncthreads();
+        if (tl + 1 < t_end) load_tile(tl + 1);
         const float sgn = neg ? -1.f : 1.f;
         f32x16 tmp[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                           // this wavefront's k-steps: ks = wv + 4 j -> tile row, column half
+        for (int j = 0; j < kW1TR / 2; ++j) {                                   // this wavefront's k-steps: ks = wv + 4 j -> tile row, column half
             const int ks = wv + 4 * j, py = ks >> 1, pxb = 16 * (ks & 1) + 8 * kq;
             const float* const gp = gT + mn * kW1GS + py * kW1TC + pxb;
             const f4 ga = *reinterpret_cast<const f4*>(gp), gb = *reinterpret_cast<const f4*>(gp + 4);
@@ -479,31 +505,53 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
             for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf(sgn, tmp[t][r], acc[t][r]);
         neg = !neg;
     }
-    // ---- D[row = co = (r & 3) + 8 (r >> 2) + 4 kq][col = n] -> part[workgroup][wavefront][co][32 t + n]
-    float* const pp = part + ((long long)blockIdx.x * 4 + wv) * 32 * NT * 32;
+    // ---- the four wavefronts' sums meet in LDS, wavefront 0 first (fixed order): D[row = co = (r & 3) + 8 (r >> 2) + 4 kq][col = n] -> red[co][32 t + n],
+    //      then one coalesced block part[workgroup][co][32 t + n]
+    float* const red = gT;                                                      // 32 x NT x 32 floats <= the gT slice
+    static_assert(32 * NT * 32 <= 32 * kW1GS, "the reduction block fits the g slice");
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+        if (wv == q) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2) + 4 * kq) * (NT * 32) + 32 * t + mn] = acc[t][r];
+                for (int r = 0; r < 16; ++r) {
+                    float* const d = red + ((r & 3) + 8 * (r >> 2) + 4 * kq) * (NT * 32) + 32 * t + mn;
+                    *d = q == 0 ? acc[t][r] : *d + acc[t][r];
+                }
+        }
+    }
+    __syncthreads();
+    float* const pp = part + (long long)blockIdx.x * 32 * NT * 32;
+    for (int i = threadIdx.x; i < 32 * NT * 32; i += kW1Threads) pp[i] = red[i];
 }
 
-// second pass: g_W[co][ci][ky][kx] (+)= sum over all wavefront partials of D[co][tap * CI + ci], fixed order, fp64 — one workgroup per element
-__global__ __launch_bounds__(kBlock) void dense_conv_s1_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ gW, int n_part, int CI, int NTW,
+// second pass, stage 1: out[range][i] = sum over the partial blocks of the range (in order, fp64) — coalesced over i
+__global__ __launch_bounds__(kBlock) void dense_conv_s1_wgrad_reduce_kernel(const float* __restrict__ part, double* __restrict__ out, int n_part, int per_range, int len)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x, rg = blockIdx.y;
+    if (i >= len) return;
+    const int p0 = rg * per_range, p1 = min(n_part, p0 + per_range);
+    double s = 0.0;
+    for (int p = p0; p < p1; ++p) s += (double)part[(long long)p * len + i];
+    out[(long long)rg * len + i] = s;
+}
+
+// second pass, stage 2: g_W[co][ci][ky][kx] (+)= sum over the ranges (in order) of D[co][tap * CI + ci]
+__global__ __launch_bounds__(kBlock) void dense_conv_s1_wgrad_finish_kernel(const double* __restrict__ mid, float* __restrict__ gW, int n_ranges, int CI, int NTW,
                                                                             int accumulate)
 {
-    __shared__ double sh[kBlock];
-    const int i = blockIdx.x, co = i / (25 * CI), rem = i - co * 25 * CI, ci = rem / 25, tap = rem - ci * 25;     // i = flat index of g_W [32][CI][25]
+    const int i = blockIdx.x * kBlock + threadIdx.x;                            // flat index of g_W [32][CI][25]
+    if (i >= 32 * CI * 25) return;
+    const int co = i / (25 * CI), rem = i - co * 25 * CI, ci = rem / 25, tap = rem - ci * 25;
     const long long src = (long long)co * NTW + tap * CI + ci;
     double s = 0.0;
-    for (int p = threadIdx.x; p < n_part; p += kBlock) s += (double)part[(long long)p * 32 * NTW + src];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = kBlock / 2; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) gW[i] = accumulate ? (float)((double)gW[i] + sh[0]) : (float)sh[0];
+    for (int r = 0; r < n_ranges; ++r) s += mid[(long long)r * 32 * NTW + src];
+    gW[i] = accumulate ? (float)((double)gW[i] + s) : (float)s;
 }
+
+constexpr int kW1Ranges = 16;
 
 }  // namespace
 
@@ -517,7 +565,7 @@ int ss_dense_conv_s1_wgrad_supported(int Cin, int Cout, int k, int stride, int p
 long long ss_dense_conv_s1_wgrad_ws_floats(int Cin)
 {
     if (Cin != 4 && Cin != 2) return 0;
-    return (long long)kW1Groups * 4 * 32 * ((25 * Cin + 31) / 32) * 32;
+    return (long long)(kW1Groups + 2 * kW1Ranges) * 32 * ((25 * Cin + 31) / 32) * 32;      // workgroup partials + the fp64 range sums
 }
 
 int ss_dense_conv_s1_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate, void* stream)
@@ -531,7 +579,10 @@ int ss_dense_conv_s1_wgrad_f32(const float* g, const float* x, float* g_w, float
     if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<4>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
     else hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<2>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
-    hipLaunchKernelGGL(dense_conv_s1_wgrad_finish_kernel, dim3(32 * Cin * 25), dim3(kBlock), 0, s, ws, g_w, (int)grid * 4, Cin, NTW, accumulate);
+    const int len = 32 * NTW, per_range = ((int)grid + kW1Ranges - 1) / kW1Ranges;
+    double* mid = reinterpret_cast<double*>(ws + (long long)kW1Groups * len);
+    hipLaunchKernelGGL(dense_conv_s1_wgrad_reduce_kernel, dim3((len + kBlock - 1) / kBlock, kW1Ranges), dim3(kBlock), 0, s, ws, mid, (int)grid, per_range, len);
+    hipLaunchKernelGGL(dense_conv_s1_wgrad_finish_kernel, dim3((32 * Cin * 25 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, mid, g_w, kW1Ranges, Cin, NTW, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -1445,11 +1445,15 @@ def test_dense_conv_s1_wgrad_mfma(NB, Cin, hw):
         gw = torch.full((32, Cin, 5, 5), float('nan'), device=DEV)
         _lib.dense_conv_s1_wgrad(g, x, gw, NB, Cin, 32, h, w)
 
+        def wgrad64(gg, xx):                                  # float64 on the GPU: g^T @ unfold(x), summed over the frames
+            cols = F.unfold(xx.permute(0, 3, 1, 2), 5, padding=2)                          # [NB, Cin * 25, h * w], row index = (ci, ky, kx)
+            return torch.bmm(gg.reshape(NB, h * w, 32).transpose(1, 2), cols.transpose(1, 2)).sum(0).view(32, Cin, 5, 5)
+
         def wgrad(gg, xx):
-            return torch.ops.aten.convolution_backward(gg.permute(0, 3, 1, 2), xx.permute(0, 3, 1, 2), wt.to(device=xx.device, dtype=xx.dtype), None,
+            return torch.ops.aten.convolution_backward(gg.permute(0, 3, 1, 2), xx.permute(0, 3, 1, 2), wt, None,
                                                        [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        ref = wgrad(g.double().cpu(), x.double().cpu()).to(DEV)
-        mag = wgrad(g.double().abs().cpu(), x.double().abs().cpu()).to(DEV)
+        ref = wgrad64(g.double(), x.double())
+        mag = wgrad64(g.double().abs(), x.double().abs())
         err = (gw.double() - ref).abs()
         assert bool(torch.isfinite(gw).all()) and bool((err <= mag * 2.0 ** -20 + 1e-300).all()), (kind, float((err / (mag * 2.0 ** -20 + 1e-300)).max()))
         mi = wgrad(g, x)

@@ -67,5 +67,20 @@ if mode == 'rc':
     for _ in range(5):
         _lib.spike_conv_fwd(None, xbp, w1, y1, NB, 32, 64, H, W)
         _lib.dense_conv_s1_fwd(xv, w0, y0, NB, 4, 32, H, W)
+    # round 3, third session: conv1's data gradient (ss_conv_s2_dgrad_f32), the first layer's weight gradient (ss_dense_conv_s1_wgrad_f32), the
+    # full-resolution head on packed spikes (ss_head_proj_packed_f32 / ss_head_wgrad_packed_f32), the packed-only forward with a packed skip
+    g1 = torch.randn(NB, h, w, 64, device=dev) * 1e-4
+    gx1 = torch.empty(NB, H, W, 32, device=dev)
+    g0 = torch.randn(NB, H, W, 32, device=dev) * 1e-4
+    gw0 = torch.empty(32, 4, 5, 5, device=dev)
+    rows = NB * H * W
+    Wh = torch.randn(32, 9, device=dev) * 0.1
+    Ph, gPh, gWh = torch.empty(rows, 9, device=dev), torch.randn(rows, 9, device=dev) * 1e-5, torch.empty(32, 9, device=dev)
+    for _ in range(5):
+        _lib.conv_s2_dgrad(g1, w1, gx1, NB, 32, 64, H, W)
+        _lib.dense_conv_s1_wgrad(g0, xv, gw0, NB, 4, 32, H, W)
+        _lib.head_proj_packed(xbp, Wh, Ph, rows, 32)
+        _lib.head_wgrad_packed(xbp, gPh, gWh, rows, 32)
+        _lib.neuron_fwd_ex(x, None, None, xbp.view(T, -1), None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
