@@ -55,7 +55,7 @@ def _run(layout, T):
     return pinned_parity(orc, net, x, gt)
 
 
-@pytest.mark.parametrize('layout,T', [(lay, 5) for lay in LAYOUTS] + [('all_nhwc_exact_split', 3), ('nchw', 3), ('two_op_miopen', 3)])
+@pytest.mark.parametrize('layout,T', [(lay, 5) for lay in LAYOUTS] + [('nchw', 3)])        # (one run-time-T case; the default path has its own: test_gpu_00)
 def test_pinned_parity_every_execution_layout(layout, T, monkeypatch):
     """The same network through every execution variant of the synapses / neuron kernels: the shipped default; dense instead of packed
     spikes; saved-h backward without forked gradients; NHWC with plain fp32 GEMMs; NHWC decoder only; projected NCHW; the reference's
