@@ -74,12 +74,13 @@ __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float*
     }
 }
 
-template <int CO, int NTALL, int NT, int CB>
+template <int CO, int NTALL, int NT, int CB, int MB = 1>
 __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const float* __restrict__ G, const unsigned short* __restrict__ Bf,
                                                                       float* __restrict__ gx, int NB, int h, int w, int ho, int wo)
 {
     constexpr int CI = 32 * NTALL, KINDS = NTALL / NT, NCH = CO / 32;
-    constexpr int RB = 32 / CB, TJR = 4 * RB, WR = TJR + 2, WC = CB + 2, ROWB = WC * 64, PLANE = WR * ROWB;
+    constexpr int RB = 32 / CB, TJR = 4 * RB * MB, WR = TJR + 2, WC = CB + 2, ROWB = WC * 64, PLANE = WR * ROWB;      // MB: M blocks (RB rows each) per wavefront
+    static_assert(MB == 1 || (2 * RB) % 4 == 0, "the granule swizzle of a wavefront's M blocks must agree");
     constexpr int STG = 6 * NT * 1024;                                          // bytes of one weight stage: one tap = 2 k-steps x 3 splits x NT tiles
     constexpr int LPT = STG / 16 / kDgThreads, REM = STG / 16 - LPT * kDgThreads;
     constexpr int kItems = WR * WC * 4, kIter = (kItems + kDgThreads - 1) / kDgThreads;     // (window pixel, 8-channel granule)
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
     int abase[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const int row = RB * mb + rr + 1, col = cc + d;
+        const int row = RB * MB * mb + rr + 1, col = cc + d;
         abase[d] = row * ROWB + col * 64 + ((half ^ (((col >> 2) + 2 * row) & 3)) << 4);
     }
     f4 st[LPT + 1];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
         const int cg = (int)(tl % CG);
         const long long R0 = (tl / CG) * TJR;                                   // first padded row of the tile
         const int i0 = cg * CB;
-        const bool active = R0 + RB * mb < RT;                                  // wave-uniform
+        const bool active = R0 + RB * MB * mb < RT;                             // wave-uniform
         // ---- global offsets of this thread's window items (channel 0 of the chunk), -1 outside the map / in a padding row
         int goff[kIter];                                                        // element offsets (the host checks NB ho wo C_out < 2^31)
 #pragma unroll
@@ -143,13 +144,15 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                 if (j < ho) goff[u] = (int)(((nb * ho + j) * wo + ox) * CO + 8 * q);
             }
         }
-        f32x16 acc[4][NT];
+        f32x16 acc[MB][4][NT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[k][t][r] = 0.f;
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][k][t][r] = 0.f;
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
@@ -207,43 +210,45 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                         // per tap (25 C_out / 32 roundings of the large sum per element instead of 12 x as many: 3.5x closer to float64 at
                         // K = 4608, tests).  The tap's products carry the sign (-1)^n of its weight fragments; fma(+-1, tmp, acc) undoes it.
                         const unsigned char* const bk = bst + (tap & 1) * STG + lane * 16;
-                        f32x16 tmp[NT];
+                        f32x16 tmp[MB][NT];
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
                             // the granule swizzle depends on the window row: one row up / down moves the slot by 2 (^ 32 bytes), like the second k-step
                             const unsigned char* const ap = wnd + dy * ROWB + (abase[dx + 1] ^ ((g ^ (dy & 1)) << 5));
-                            s16x8 a[3], b[3][NT];
+                            s16x8 a[MB][3], b[3][NT];
 #pragma unroll
-                            for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 8) ? wnd + lane * 16 + sp * 1024 : ap + sp * PLANE);
+                            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                                for (int sp = 0; sp < 3; ++sp)
+                                    a[i][sp] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 8) ? wnd + lane * 16 + sp * 1024 : ap + i * RB * ROWB + sp * PLANE);
 #pragma unroll
                             for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
                                 for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 4) ? bst + lane * 16 + (sp * NT + t) * 1024 : bk + ((g * 3 + sp) * NT + t) * 1024);
-                            // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
-                            if (g == 0) {
-                                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh — term-major over the wavefront's M blocks and N tiles
+                            // (consecutive MFMAs run on different accumulators)
+                            constexpr int kTa[6] = {2, 1, 0, 1, 0, 0}, kTb[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], zero, 0, 0, 0);
-                            } else {
+                            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][t], tmp[t], 0, 0, 0);
-                            }
+                                for (int i = 0; i < MB; ++i)
 #pragma unroll
-                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][t], tmp[t], 0, 0, 0);
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][t], tmp[t], 0, 0, 0);
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][t], tmp[t], 0, 0, 0);
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][t], tmp[t], 0, 0, 0);
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][t], tmp[t], 0, 0, 0);
+                                    for (int t = 0; t < NT; ++t) {
+                                        if (g == 0 && q == 0) {
+                                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kTa[q]], b[kTb[q]][t], zero, 0, 0, 0);
+                                        } else {
+                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kTa[q]], b[kTb[q]][t], tmp[i][t], 0, 0, 0);
+                                        }
+                                    }
                         }
                         const float sgn = (((c * dg_cnt(cls) + idx) & 1) && !(SS_DG_ABL & 2)) ? -1.f : 1.f;
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
+                        for (int i = 0; i < MB; ++i)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[cls][t][r] = __builtin_fmaf(sgn, tmp[t][r], acc[cls][t][r]);
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][cls][t][r] = __builtin_fmaf(sgn, tmp[i][t][r], acc[i][cls][t][r]);
                     }
                     if (more && !(SS_DG_ABL & 16)) stage_commit(bst + ((tap + 1) & 1) * STG);
                     if (!(SS_DG_ABL & 1)) __syncthreads();
@@ -253,8 +258,10 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
         // ---- D[row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] -> g_x[nb][2 j + py][2 (i0 + cc_m) + px][32 (kind NT + t) + col]
         if (active) {
 #pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
             for (int q = 0; q < RB; ++q) {
-                const long long Rp = R0 + RB * mb + q;                          // wave-uniform
+                const long long Rp = R0 + RB * (MB * mb + i) + q;               // wave-uniform
                 if (Rp >= RT) break;
                 const long long nb = Rp / HP;
                 const int j = (int)(Rp - nb * HP);
@@ -272,10 +279,10 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                         const int m = m0 + 4 * half;
                         if (m / CB != q) continue;
                         const int ix = 2 * (i0 + (m - q * CB)) + px;
-                        if (ix < w && (!(SS_DG_ABL & 64) || acc[cls][0][r] == 12345.678f)) {
+                        if (ix < w && (!(SS_DG_ABL & 64) || acc[i][cls][0][r] == 12345.678f)) {
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
-                                store_out(gx + (rowbase + ix) * CI + 32 * (kind * NT + t) + tx, acc[cls][t][r]);
+                                store_out(gx + (rowbase + ix) * CI + 32 * (kind * NT + t) + tx, acc[i][cls][t][r]);
                         }
                     }
                 }
@@ -314,14 +321,16 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
     // column blocking of the (j, i) grid: 8 columns x 4 rows per wavefront wastes <= 1 / 8 of a block on any width; 32 x 1 only when it fits as well
     bool wide = ((wo + 31) / 32) * 32 <= ((wo + 7) / 8) * 8;
     if (const char* e = getenv("SS_DGRAD_CB")) wide = e[0] == '3';              // tuning knob (tools/bench_conv_dgrad.py): 32 | 8
-    const int CB = wide ? 32 : 8, TJR = 4 * (32 / CB);
+    const int MB = (Cin == 32 && !wide) ? 2 : 1;                                 // C_in 32 (one N tile): two M blocks per wavefront share the weight fragments
+    const int CB = wide ? 32 : 8, TJR = 4 * (32 / CB) * MB;
     const int kinds = Cin <= 64 ? 1 : Cin / 64;
     const long long n_items = ((NB * (ho + 1) + TJR - 1) / TJR) * ((wo + CB - 1) / CB) * kinds;
     const unsigned grid = (unsigned)(n_items < 2 * cus ? n_items : 2 * cus);     // two workgroups per CU, persistent over their item ranges
 #define SS_DG(CO_, NTALL_, NT_) do { \
         if (wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 32>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo); \
         else hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 8>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo); } while (0)
-    if (Cin == 32) SS_DG(64, 1, 1);
+    if (Cin == 32 && MB == 2) hipLaunchKernelGGL((conv_s2_dgrad_kernel<64, 1, 1, 8, 2>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo);
+    else if (Cin == 32) SS_DG(64, 1, 1);
     else if (Cin == 64) SS_DG(128, 2, 2);
     else if (Cin == 128) SS_DG(256, 4, 2);
     else SS_DG(512, 8, 2);
