@@ -43,8 +43,10 @@ __host__ __device__ constexpr int dg_cnt(int cls) { return cls == 0 ? 9 : (cls =
 
 // weight [C_out][C_in][5][5] fp32 -> Bf[chunk c of 32 co][tap][g][split][ci tile t][lane][8] bf16: element e of a lane = split term of
 // s * W[co = 32 c + 16 g + 8 (lane >> 5) + e][ci = 32 t + (lane & 31)][ky][kx], s = (-1)^n for the n-th tap of its class over all chunks
-__global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, int Cin, int Cout)
+__global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, unsigned* __restrict__ counters,
+                                                                    int Cin, int Cout)
 {
+    if (blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0u;         // the per-XCD item counters of the main kernel
     const int NTALL = Cin / 32;
     const long long total = (long long)(Cout / 32) * 25 * 2 * 3 * NTALL * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float*
 
 template <int CO, int NTALL, int NT, int CB, int MB = 1>
 __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const float* __restrict__ G, const unsigned short* __restrict__ Bf,
-                                                                      float* __restrict__ gx, int NB, int h, int w, int ho, int wo)
+                                                                      float* __restrict__ gx, unsigned* __restrict__ counters, int NB, int h, int w, int ho, int wo)
 {
     constexpr int CI = 32 * NTALL, KINDS = NTALL / NT, NCH = CO / 32;
     constexpr int RB = 32 / CB, TJR = 4 * RB * MB, WR = TJR + 2, WC = CB + 2, ROWB = WC * 64, PLANE = WR * ROWB;      // MB: M blocks (RB rows each) per wavefront
@@ -94,8 +96,13 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
     const long long RT = (long long)NB * HP;
     const int RG = (int)((RT + TJR - 1) / TJR), CG = (wo + CB - 1) / CB;
     const long long n_items = (long long)RG * CG * KINDS;
-    const unsigned gidx = xcd_remap(blockIdx.x, gridDim.x);
-    const long long t_begin = n_items * gidx / gridDim.x, t_end = n_items * (gidx + 1) / gridDim.x;
+    // Work distribution: the items are cut into 8 contiguous ranges, one per XCD (the dispatcher places workgroup b on XCD b % 8: neighbouring
+    // tiles — shared window halos, the same weights — meet in one L2); inside its range a workgroup DRAWS the next item from the range's counter
+    // (zeroed by the prep kernel).  A static split leaves 2 or 3 items per workgroup at conv4 (1 080 items over 512 workgroups) and the launch ends
+    // with the few CUs whose two workgroups both got 3; drawn items end within one item of each other.  Items are independent: same result bits.
+    __shared__ unsigned next_item;
+    const unsigned xcd = blockIdx.x & 7u;
+    const long long t_begin = n_items * xcd / 8, t_end = n_items * (xcd + 1) / 8;
     // LDS byte offsets of this lane's A fragments (plane 0, dy = 0, first k-step) for dx = -1, 0, 1; the second k-step is ^ 32
     int abase[3];
 #pragma unroll
@@ -121,7 +128,12 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
         }
     };
 #pragma unroll 1
-    for (long long it = t_begin; it < t_end; ++it) {
+    for (;;) {
+        __syncthreads();                                                        // everyone has read the previous draw
+        if (threadIdx.x == 0) next_item = atomicAdd(counters + xcd, 1u);
+        __syncthreads();
+        const long long it = t_begin + next_item;
+        if (it >= t_end) break;
         const int kind = (int)(it % KINDS);
         const long long tl = it / KINDS;
         const int cg = (int)(tl % CG);
@@ -303,7 +315,7 @@ int ss_conv_s2_dgrad_supported(int Cin, int Cout, int k, int stride, int pad)
 long long ss_conv_s2_dgrad_ws_floats(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
-    return (long long)25 * Cin * Cout * 3 / 2;                                  // the weight as three bf16 terms in fragment order
+    return (long long)25 * Cin * Cout * 3 / 2 + 8;                              // the weight as three bf16 terms in fragment order + 8 item counters
 }
 
 int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, void* stream)
@@ -316,20 +328,19 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
-    hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
+    unsigned* counters = reinterpret_cast<unsigned*>(ws + (long long)25 * Cin * Cout * 3 / 2);
+    hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, counters, Cin, Cout);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     // column blocking of the (j, i) grid: 8 columns x 4 rows per wavefront wastes <= 1 / 8 of a block on any width; 32 x 1 only when it fits as well
     bool wide = ((wo + 31) / 32) * 32 <= ((wo + 7) / 8) * 8;
     if (const char* e = getenv("SS_DGRAD_CB")) wide = e[0] == '3';              // tuning knob (tools/bench_conv_dgrad.py): 32 | 8
     const int MB = (Cin == 32 && !wide) ? 2 : 1;                                 // C_in 32 (one N tile): two M blocks per wavefront share the weight fragments
-    const int CB = wide ? 32 : 8, TJR = 4 * (32 / CB) * MB;
-    const int kinds = Cin <= 64 ? 1 : Cin / 64;
-    const long long n_items = ((NB * (ho + 1) + TJR - 1) / TJR) * ((wo + CB - 1) / CB) * kinds;
-    const unsigned grid = (unsigned)(n_items < 2 * cus ? n_items : 2 * cus);     // two workgroups per CU, persistent over their item ranges
+
+    const unsigned grid = (unsigned)(2 * cus);                                   // two workgroups per CU, persistent: each draws items from its XCD's range
 #define SS_DG(CO_, NTALL_, NT_) do { \
-        if (wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 32>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo); \
-        else hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 8>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo); } while (0)
-    if (Cin == 32 && MB == 2) hipLaunchKernelGGL((conv_s2_dgrad_kernel<64, 1, 1, 8, 2>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, (int)NB, h, w, ho, wo);
+        if (wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 32>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, counters, (int)NB, h, w, ho, wo); \
+        else hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 8>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, counters, (int)NB, h, w, ho, wo); } while (0)
+    if (Cin == 32 && MB == 2) hipLaunchKernelGGL((conv_s2_dgrad_kernel<64, 1, 1, 8, 2>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, counters, (int)NB, h, w, ho, wo);
     else if (Cin == 32) SS_DG(64, 1, 1);
     else if (Cin == 64) SS_DG(128, 2, 2);
     else if (Cin == 128) SS_DG(256, 4, 2);
