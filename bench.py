@@ -126,6 +126,9 @@ def build_net(model, device):
     return net.to(device)
 
 
+_EVAL_REF = {}
+
+
 def cpu_baseline(model, T, budget_s, B=1, min_iters=5):
     """The oracle's eager port (oracle/ref_network.py on oracle/sj_clock_driven.py — the reference's op sequence)
     running the same training step on the host cores: B = 1, T = 5, 1 warm-up + >= 5 timed iterations (~budget_s seconds,
@@ -148,8 +151,10 @@ def cpu_baseline(model, T, budget_s, B=1, min_iters=5):
         # cascade (1 - 2 % of the last step's spikes, 0.4 % of the MDE: tools/diag_eval_mde.py, profiles/r03/diag_eval_mde.log), and the host's
         # fp32 convolution is itself one such backend — so the product's eval MDE is held against THIS value, the eager fp32 one is reported beside it
         with rn.float64_convs(net):
-            d64 = rn.run_sequence(net, x)[0]
+            r64 = rn.run_sequence(net, x)
+            d64, s64 = r64[0], (r64[1] if len(r64) > 1 else None)
             eval_mde64 = float(rn.mean_depth_error(d64[0], gt))
+        _EVAL_REF['spikes'] = [t.clone() for t in s64] if isinstance(s64, (list, tuple)) else None     # the last step's spike tensors (rconv, out_add4..1)
 
     def step():
         out = rn.run_sequence(net, x)
@@ -398,10 +403,17 @@ def main():
             x0, gt0 = _sb(1, a.T, seed=2021, device=dev)
             with torch.no_grad():
                 _F.reset_net(net0)
-                d0 = net0.forward_sequence(x0)[0]
+                r0 = net0.forward_sequence(x0)
+                d0 = r0[0]
+                s0 = [t.cpu() for t in r0[1]] if isinstance(r0[1], (list, tuple)) else None
                 out['eval_mde_m'] = round(float(MeanDepthError(d0[0], gt0)), 5)
             del net0
             out['cpu_baseline'] = cpu_baseline(a.model, a.T, a.cpu_seconds)
+            if s0 is not None and _EVAL_REF.get('spikes') is not None and len(s0) == len(_EVAL_REF['spikes']):
+                # bit-exact spike masks, end to end and free-running: the last step's returned spike tensors (out_rconv, out_add4 .. out_add1) of the product
+                # against the float64-conv oracle's on the same weights and input — the number of elements that differ
+                out['eval_last_step_spikes_differing_vs_cpu'] = int(sum(int((a_ != b_).sum()) for a_, b_ in zip(s0, _EVAL_REF['spikes'])))
+                out['eval_last_step_spikes_compared'] = int(sum(a_.numel() for a_ in s0))
             if a.cpu_b16_seconds > 0:                     # the CPU port at the bench's own batch size as well
                 out['cpu_baseline_B16'] = cpu_baseline(a.model, a.T, a.cpu_b16_seconds, B=a.batch, min_iters=1)
             # eval MDE "at matching Mean Depth Error": against the oracle with float64 convolutions (see cpu_baseline); the eager fp32 port's own value
