@@ -608,7 +608,8 @@ def test_spike_conv_as_exact_bf16x3_gemm(Cin, Cout, k, s, pad, hw):
         return float((a.double() - b).abs().max())
     assert err(y.permute(0, 3, 1, 2), y64) <= 2 * err(y32, y64) + 1e-7 * float(y64.abs().max())
     assert err(gw, gw64) <= 2 * err(gw32, gw64) + 1e-7 * float(gw64.abs().max())
-    assert err(gx, gx64) <= 2 * err(gx32, gx64) + 1e-7 * float(gx64.abs().max())
+    # the data gradient of the stride-2 5x5 geometries is the six-term MFMA kernel (ss_conv_s2_dgrad_f32; its own bounds: test_conv_s2_dgrad_mfma)
+    assert err(gx, gx64) <= 2 * err(gx32, gx64) + 3e-7 * float(gx64.abs().max())
 
 
 @pytest.mark.parametrize('kind', ['IF', 'PLIF'])
@@ -1417,7 +1418,9 @@ def test_conv_s2_dgrad_mfma(NB, Cin, hw):
     mi = torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x_meta, wt.contiguous(memory_format=torch.channels_last), None,
                                              [2, 2], [2, 2], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
     rms = lambda e: float(e.double().pow(2).mean().sqrt())
-    assert rms(err) <= 2.0 * rms(mi.double() - ref) + 1e-9 * rms(ref), (rms(err), rms(mi.double() - ref))
+    # (+ a floor of 2^-23 of the rms magnitude sum: should MIOpen pick a solver that accumulates in higher precision on some box, this kernel is still
+    # held to fp32-accumulation accuracy, not to that solver's)
+    assert rms(err) <= 2.0 * rms(mi.double() - ref) + 2.0 ** -23 * rms(mag), (rms(err), rms(mi.double() - ref), rms(mag))
     gx2 = torch.full_like(gx, float('nan'))
     _lib.conv_s2_dgrad(g, wt, gx2, NB, Cin, Cout, h, w)
     assert torch.equal(gx, gx2)
@@ -1458,7 +1461,7 @@ def test_dense_conv_s1_wgrad_mfma(NB, Cin, hw):
         assert bool(torch.isfinite(gw).all()) and bool((err <= mag * 2.0 ** -20 + 1e-300).all()), (kind, float((err / (mag * 2.0 ** -20 + 1e-300)).max()))
         mi = wgrad(g, x)
         rms = lambda e: float(e.double().pow(2).mean().sqrt())
-        assert rms(err) <= 2.0 * rms(mi.double() - ref) + 1e-8 * rms(ref), (kind, rms(err), rms(mi.double() - ref))
+        assert rms(err) <= 2.0 * rms(mi.double() - ref) + 2.0 ** -23 * rms(mag), (kind, rms(err), rms(mi.double() - ref), rms(mag))
         gw2 = gw.clone()
         _lib.dense_conv_s1_wgrad(g, x, gw2, NB, Cin, 32, h, w, accumulate=True)
         assert float((gw2.double() - 2 * ref).abs().max()) <= 2.0 ** -19 * float(mag.max()) + 1e-30
@@ -1501,7 +1504,7 @@ def test_head_on_packed_spikes(rows, C):
     assert bool(torch.isfinite(gW).all()) and bool((errw <= magw * 2.0 ** -18 + 1e-300).all()), float((errw / (magw * 2.0 ** -18 + 1e-300)).max())
     lib32 = x.t() @ g
     rms = lambda e: float(e.double().pow(2).mean().sqrt())
-    assert rms(errw) <= 4.0 * rms(lib32.double() - refw) + 1e-9 * rms(refw), (rms(errw), rms(lib32.double() - refw))
+    assert rms(errw) <= 4.0 * rms(lib32.double() - refw) + 2.0 ** -23 * rms(magw), (rms(errw), rms(lib32.double() - refw))
     gW2 = gW.clone()
     _lib.head_wgrad_packed(xp, g, gW2, rows, C, accumulate=True)
     assert float((gW2.double() - 2 * refw).abs().max()) <= 2.0 ** -17 * float(magw.max()) + 1e-30
