@@ -314,7 +314,8 @@ int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, lo
  */
 int ss_upconv_bwd_fused_supported(int Cin, int Cout, int k, int max_rows4, int max_rows2, int max_cols16, int max_span);
 long long ss_upconv_bwd_fused_ws_floats(int Cin, int Cout, long long NB, int h, int w);
-int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const unsigned int* x_packed /* ABI 6: the stage input as 2-bit packed spikes (x may then be NULL) */,
+                            const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                             float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
                             int accumulate, void* stream);
 

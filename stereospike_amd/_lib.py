@@ -118,7 +118,7 @@ def lib():
     L.ss_upconv_bwd_fused_supported.restype = i32
     L.ss_upconv_bwd_fused_ws_floats.argtypes = [i32, i32, i64, i32, i32]
     L.ss_upconv_bwd_fused_ws_floats.restype = i64
-    L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_bwd_fused_f32.restype = i32
     L.ss_spike_conv_fwd_supported.argtypes = [i32, i32, i32, i32, i32]
     L.ss_spike_conv_fwd_supported.restype = i32
@@ -529,12 +529,14 @@ def upconv_bwd_fused_supported(Cin, Cout, k, extents):
     return bool(lib().ss_upconv_bwd_fused_supported(int(Cin), int(Cout), int(k), *[int(v) for v in extents[:4]]))
 
 
-def upconv_bwd_fused(g_out, x, y_lo, y_hi, x_lo, x_hi, g_P, g_w, NB, Cin, Cout, h, w, H, W, accumulate=False):
-    """Adjoint gather (g_P written unless None) + exact bf16x3 MFMA weight gradient (g_w [Cin, 25 * Cout]) in one pass."""
+def upconv_bwd_fused(g_out, x, y_lo, y_hi, x_lo, x_hi, g_P, g_w, NB, Cin, Cout, h, w, H, W, accumulate=False, x_packed=None):
+    """Adjoint gather (g_P written unless None) + exact bf16x3 MFMA weight gradient (g_w [Cin, 25 * Cout]) in one pass.  x_packed: the stage input as a
+    2-bit packed spike tensor (x is then not read)."""
     _require_hip(g_out, 'g_out')
     ws = torch.empty(int(lib().ss_upconv_bwd_fused_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g_out.device)
     with torch.cuda.device(g_out.device):
-        rc = lib().ss_upconv_bwd_fused_f32(_f32(g_out, 'g_out', NB * H * W * Cout), _f32(x, 'x', NB * h * w * Cin), _i32(y_lo, 'y_lo', h),
+        rc = lib().ss_upconv_bwd_fused_f32(_f32(g_out, 'g_out', NB * H * W * Cout), None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
+                                           _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16), _i32(y_lo, 'y_lo', h),
                                            _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
                                            None if g_P is None else _f32(g_P, 'g_P', NB * h * w * 25 * Cout), _f32(g_w, 'g_w', Cin * 25 * Cout), _f32(ws, 'ws'),
                                            NB, Cin, Cout, h, w, H, W, int(bool(accumulate)), _stream(g_out))

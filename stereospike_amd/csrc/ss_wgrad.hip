@@ -609,10 +609,14 @@ __global__ __launch_bounds__(kSwThreads, CIN == 64 ? 4 : 2) void upconv_bwd_fuse
     }
 }
 
-// x [NB * h][w][C_in] fp32 spike counts -> xT[(source row) * KSR + k-step][ci][16 sources] bf16, KSR = ceil(w / 16), zero padded
-__global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const float* __restrict__ x, unsigned short* __restrict__ xT, long long rows, int w,
+// x [NB * h][w][C_in] fp32 spike counts (or, PACKED, the 2-bit packed spike tensor) -> xT[(source row) * KSR + k-step][ci][16 sources] bf16,
+// KSR = ceil(w / 16), zero padded
+template <bool PACKED>
+__global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const void* __restrict__ xv, unsigned short* __restrict__ xT, long long rows, int w,
                                                                   int CIN)
 {
+    const float* x = static_cast<const float*>(xv);
+    const unsigned* xp = static_cast<const unsigned*>(xv);
     const int KSR = (w + 15) / 16;
     const long long total = rows * KSR * CIN;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
@@ -624,7 +628,12 @@ __global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const float* _
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int sx = 16 * c + rr;
-            const unsigned short v = sx < w ? (unsigned short)(__float_as_uint(x[(row * w + sx) * CIN + ci]) >> 16) : (unsigned short)0;
+            const long long el = (row * w + sx) * CIN + ci;
+            unsigned short v = 0;
+            if (sx < w) {
+                if constexpr (PACKED) v = code_to_bf16((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u);
+                else v = (unsigned short)(__float_as_uint(x[el]) >> 16);
+            }
             if (rr < 8) a[rr] = v; else b[rr - 8] = v;
         }
         *reinterpret_cast<u16x8*>(xT + i * 16) = a;
@@ -937,18 +946,22 @@ long long ss_upconv_bwd_fused_ws_floats(int Cin, int Cout, long long NB, int h, 
     return (long long)slices * 25 * Cout * Cin + NB * h * ((w + 15) / 16) * Cin * 8;
 }
 
-int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const unsigned int* x_packed, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                             float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
                             int accumulate, void* stream)
 {
-    if (!g_out || !x || !y_lo || !y_hi || !x_lo || !x_hi || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (x_packed && (NB * h * (long long)w * Cin) % 16 != 0) return SS_EINVAL;
+    if (!g_out || (!x && !x_packed) || !y_lo || !y_hi || !x_lo || !x_hi || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
     if (!ss_upconv_fused_supported(Cin, Cout, 5) || !aligned16(g_out) || !aligned16(ws) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
     int Q = 0, slices = 0;
     if (!upconv_bwd_fused_plan(Cin, Cout, &Q, &slices)) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int N = 25 * Cout;
     unsigned short* xT = reinterpret_cast<unsigned short*>(ws + (long long)slices * N * Cin);
-    hipLaunchKernelGGL(upconv_bwd_xprep_kernel, dim3(grid_for(NB * h * ((w + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s, x, xT, NB * h, w, Cin);
+    if (x_packed) hipLaunchKernelGGL(upconv_bwd_xprep_kernel<true>, dim3(grid_for(NB * h * ((w + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
+                                     static_cast<const void*>(x_packed), xT, NB * h, w, Cin);
+    else hipLaunchKernelGGL(upconv_bwd_xprep_kernel<false>, dim3(grid_for(NB * h * ((w + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
+                            static_cast<const void*>(x), xT, NB * h, w, Cin);
     const unsigned grid = (unsigned)(Q * slices);
     if (Cin == 64) hipLaunchKernelGGL((upconv_bwd_fused_kernel<64, 32, 4, 2, 14, 40>), dim3(grid), dim3(kSwThreads), 0, s, g_out, xT, y_lo, y_hi, x_lo, x_hi,
                                       g_P, ws, (int)NB, h, w, H, W, Q);

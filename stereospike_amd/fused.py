@@ -652,7 +652,13 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # x_packed (one-channel 3 x 3 head on a packed-only neuron output, fp32 mode): the input as a 2-bit packed spike tensor; x_cl is then a
         # data-less anchor that carries shape and autograd edge.  Projection and weight gradient read the packed form (ss_head_*_packed_f32)
         ctx.packed_in = x_packed is not None
-        if x_packed is not None:
+        if x_packed is not None and k != 3:
+            # a decoder stage on a packed-only input (deconv1 reading deconv2's output): the fused MFMA forward reads the packed form; any other form
+            # of this stage gets the dense tensor back first
+            if not (FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
+                    and _lib.upconv_fused_form(x_cl.shape[-1], weight.shape[0], k, max_window) != 0):
+                x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, x_cl.dtype), None
+        if x_packed is not None and k == 3:
             NB, h, w, Cin = x_cl.shape
             Cout, kk = weight.shape[0], k * k
             if not (k == 3 and Cout == 1 and not lowp and act_dtype is None and _lib.head_packed_supported(Cin, Cout, k)):
@@ -683,7 +689,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # P, the gather, its adjoint and every output stay fp32.
         # act_dtype (fp16 / bf16, decoder stages under 16-bit autocast): the stage output is written by the gather as 16-bit activations,
         # its gradient is read as such by the adjoint; the input may itself be a 16-bit spike tensor (exact)
-        x_cl = x_cl.contiguous()
+        if x_packed is None:
+            x_cl = x_cl.contiguous()                                 # (a packed-only input is a data-less anchor: nothing to lay out)
         ctx.x_dtype = x_cl.dtype
         half_in = x_cl.dtype in (torch.float16, torch.bfloat16)
         weight = weight.float()
@@ -721,14 +728,14 @@ class _UpConvProjectedCL(torch.autograd.Function):
             ctx.has_bias = False
             return out
         if form:
-            if ASSERT_EXACT_SPLIT:
+            if ASSERT_EXACT_SPLIT and x_packed is None:
                 assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
             Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, form), dtype=torch.bfloat16, device=x_cl.device)
             e0 = TIMER.start()
             _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout, form)
-            _lib.upconv_fused_fwd(x_cl, None, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
-            TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-            ctx.save_for_backward(x_cl, Wt, None)
+            _lib.upconv_fused_fwd(None if x_packed is not None else x_cl, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
+            TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
+            ctx.save_for_backward(x_cl, Wt, x_packed)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = True
             ctx.tables, ctx.k, ctx.n = tables, k, n
@@ -802,16 +809,22 @@ class _UpConvProjectedCL(torch.autograd.Function):
             fused_bwd = (FUSED_UPCONV_BWD and need_w and ctx.exact and not lowp and not g16 and k == 5 and x_cl.dtype == torch.float32
                          and Cin in (FUSED_UPCONV_BWD_CIN_NOGP if dgrad_fused else FUSED_UPCONV_BWD_CIN)
                          and _lib.upconv_bwd_fused_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
+            stage_pk = x_packed is not None and k == 5               # a stage whose input exists only as packed spikes
+            if stage_pk and need_w and not (fused_bwd and c0 == 0 and c1 == NB):
+                # the fused adjoint + weight-gradient kernel reads the packed form; every other weight-gradient form reads the dense tensor
+                x_cl, x_packed, stage_pk = unpack_dense(x_packed, x_cl.shape, x_cl.dtype), None, False
             if dgrad_fused:
                 _lib.upconv_bwd_dgrad(g_out[c0:c1], Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous(), y_lo, y_hi, x_lo, x_hi,
                                       g_x[c0:c1], c1 - c0, Cin, Cout, h, w, H, W)
             if dgrad_fused and (fused_bwd or not need_w):
                 g_P = None                                                        # the per-tap gradient tensor never reaches HBM
                 if fused_bwd:
-                    _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, None, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True)
+                    _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, None, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True,
+                                          x_packed=x_packed if stage_pk else None)
             elif fused_bwd:
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
-                _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True)
+                _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True,
+                                      x_packed=x_packed if stage_pk else None)
             elif lowp and k == 5:
                 # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
@@ -837,7 +850,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
             if fused_bwd:
                 pass                                                              # g_Wt accumulated by the fused kernel above
-            elif need_w and x_packed is not None:
+            elif need_w and x_packed is not None and k == 3:
                 _lib.head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=True)     # reads the 2-bit packed spikes (1/16 of the dense tensor)
             elif (need_w and ctx.exact and not lowp and EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
                     and Cin in EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
@@ -1156,6 +1169,17 @@ def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = N
 
 PACKED_HEAD = _os.environ.get('SS_PACKED_HEAD', '1') == '1'   # the full-resolution prediction head reads deconv1's output as 2-bit packed spikes (projection and weight
                                    # gradient: ss_head_*_packed_f32); the largest decoder stage then writes no dense output (4.5 instead of 8.25 B/update)
+
+
+def stage_reads_packed(Cin: int, Cout: int, k: int, max_window: int) -> bool:
+    """True when a decoder stage (NNConvUpsampling, fp32 mode) reads its input as 2-bit packed spikes in forward (fused MFMA kernel) AND in its weight
+    gradient (fused adjoint + MFMA kernel), its data gradient needing no input at all — the producer may then write packed-only.  (Should a run-time
+    condition still send the stage down another form, _UpConvProjectedCL unpacks: correct, just not free.)"""
+    return bool(PACK_SPIKES and FUSED_UPCONV_MFMA and EXACT_SPLIT_GEMM and k == 5 and _lib.upconv_fused_form(Cin, Cout, k, max_window) != 0
+                and FUSED_UPCONV_BWD and FUSED_UPCONV_DGRAD and Cin in FUSED_UPCONV_DGRAD_CIN and Cin in FUSED_UPCONV_BWD_CIN_NOGP)
+
+
+PACKED_DECONV2 = _os.environ.get('SS_PACKED_DECONV2', '1') == '1'   # deconv2's output packed-only as well (consumers: head 2 and deconv1's fused kernels)
 
 
 class _UnpackLastStep(torch.autograd.Function):

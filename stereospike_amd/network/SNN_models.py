@@ -182,6 +182,7 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             if cl:
                 cur = cur.permute(0, 1, 3, 4, 2).contiguous()          # decoder runs on NHWC arrays [T, B, h, w, C]
         last_dense = {}                                                # index into `spikes` -> the last step of a packed-only stage output, unpacked
+        prev_pk = None
         for lvl in (4, 3, 2, 1):
             stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
             if cl:
@@ -189,13 +190,19 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 # the stage output feeds the next stage and its prediction head: forked handles again
                 # the full-resolution stage feeds its prediction head only: when the head reads 2-bit packed spikes (fused.PACKED_HEAD) the stage
                 # writes no dense output at all
+                # (round 3, last: deconv2 as well — its other consumer, deconv1, reads packed spikes in its fused forward and weight-gradient kernels)
                 C_out = stage[0].up[1].out_channels
-                head_pk = bool(lvl == 1 and enc_cl and _fused.PACK_SPIKES and _fused.PACKED_HEAD and _blocks.FORK_OUTPUTS and cur.dtype == torch.float32
+                head_pk = bool(lvl in (1, 2) and enc_cl and _fused.PACK_SPIKES and _fused.PACKED_HEAD and _blocks.FORK_OUTPUTS and cur.dtype == torch.float32
                                and not torch.is_autocast_enabled('cuda') and _fused._lib.head_packed_supported(C_out, 1, 3))
+                if head_pk and lvl == 2:
+                    nxt = self.deconv1[0]
+                    hh, ww = stage[0].up[0].size[0] - 4, stage[0].up[0].size[1] - 4          # this stage's output = the next stage's input geometry
+                    head_pk = _fused.PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
                 r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_blocks.FORK_OUTPUTS,
-                                              skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else 0)
+                                              skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else 0, x_packed=prev_pk)
                 cur, cur_head = r if _blocks.FORK_OUTPUTS else (r, r)
                 out_pk = stage[2].last_packed if head_pk else None     # None: the packed kernel form did not apply, the output is dense
+                prev_pk = out_pk                                       # the next stage's input in packed form (None: dense)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
                 if out_pk is not None:
                     last_dense[len(spikes) - 1] = _fused.unpack_last_step(cur, out_pk).permute(0, 3, 1, 2)

@@ -163,12 +163,12 @@ class SpikingStage(nn.Sequential):
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, None, nnz, channels_last=True, fork=fork, pack=pack)
 
     def forward_sequence_cl(self, x_seq: torch.Tensor, skip_seq: Optional[torch.Tensor] = None, nnz=None, spikes_in: bool = False,
-                            fork: bool = False, skip_packed: Optional[torch.Tensor] = None, pack: int = 0):
+                            fork: bool = False, skip_packed: Optional[torch.Tensor] = None, pack: int = 0, x_packed: Optional[torch.Tensor] = None):
         """Channels-last decoder stage: x_seq [T, B, h, w, C] -> [T, B, H, W, C'] (NHWC arrays); the synapse must be an
         NNConvUpsampling.  spikes_in: x_seq is the output of a spiking layer (+ spike skip adds).  skip_packed: the skip operand as a
         packed spike tensor (skip_seq then carries the autograd edge only).  pack: see BaseNode.forward_sequence (`self[2].last_packed`)."""
         T, B = x_seq.shape[:2]
-        y = self[0].forward_projected_cl(x_seq.flatten(0, 1), spikes_in)
+        y = self[0].forward_projected_cl(x_seq.flatten(0, 1), spikes_in, x_packed=x_packed)     # x_packed: x_seq as packed spikes (x_seq may be an anchor)
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz, channels_last=True, fork=fork,
                                         skip_packed=skip_packed, pack=pack)

@@ -65,9 +65,9 @@ def assert_default_kernels(tags, T):
     assert sum(fwd.values()) == 13 and sum(bwd.values()) == 13, tags
     assert not any(k.endswith('+h') for k in fwd) and not any('savedh' in k for k in bwd), ('saved-h (run-time-T) kernels ran', tags)
     # packed-only outputs: the 7 encoder / bottleneck edges, the SEW block's inner layer (with its packed skip) and — its prediction head reads packed
-    # spikes (fused.PACKED_HEAD) — the full-resolution decoder stage
-    assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 2, tags
-    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 4, tags
+    # spikes (fused.PACKED_HEAD) — the two largest decoder stages (deconv2's other consumer, deconv1, reads packed spikes in its fused kernels)
+    assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 3, tags      # SEW inner layer, deconv2, deconv1
+    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 3, tags
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
     assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)
@@ -186,7 +186,8 @@ def test_packed_spike_tensors_are_in_effect():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
         assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
-    assert net.deconv2[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    assert net.deconv3[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    assert net.deconv2[2].last_packed is not None                                               # packed only: head 2 + deconv1's fused kernels read it
     # the full-resolution decoder stage: packed only (its prediction head reads the packed form); the model returns its last step unpacked
     pk1 = net.deconv1[2].last_packed
     assert pk1 is not None and pk1.dtype == torch.int32
