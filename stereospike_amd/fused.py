@@ -651,7 +651,6 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 lowrank_grad=False, x_packed=None):
         # x_packed (one-channel 3 x 3 head on a packed-only neuron output, fp32 mode): the input as a 2-bit packed spike tensor; x_cl is then a
         # data-less anchor that carries shape and autograd edge.  Projection and weight gradient read the packed form (ss_head_*_packed_f32)
-        ctx.packed_in = x_packed is not None
         if x_packed is not None and k != 3:
             # a decoder stage on a packed-only input (deconv1 reading deconv2's output): the fused MFMA forward reads the packed form; any other form
             # of this stage gets the dense tensor back first

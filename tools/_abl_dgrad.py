@@ -28,4 +28,4 @@ for name, Cin, (h, w) in [('conv1', 32, (260, 346)), ('conv2', 64, (130, 173)), 
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 4)
     out.append(f'{name} {best:6.3f}')
-print(os.environ.get('SS_LIB', 'default'), os.environ.get('SS_DGRAD_VAR', ''), ' | '.join(out), flush=True)
+print(os.environ.get('SS_LIB', 'default'), ' | '.join(out), flush=True)
