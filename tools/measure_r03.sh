@@ -3,7 +3,7 @@ set -u
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03h; mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
-SS_CONV_DGRAD_MFMA=0 SS_PACKED_HEAD=0 SS_CONV_S1_WGRAD_MFMA=0 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_second_session_kernels_only.json 2>/dev/null
+SS_CONV_DGRAD_MFMA=0 SS_PACKED_HEAD=0 SS_PACKED_DECONV2=0 SS_CONV_S1_WGRAD_MFMA=0 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_second_session_kernels_only.json 2>/dev/null
 SS_CONV_FWD_MFMA=0 SS_CONV_S1_MFMA=0 SS_FUSED_DGRAD=0 SS_CONV_DGRAD_MFMA=0 SS_PACKED_HEAD=0 SS_CONV_S1_WGRAD_MFMA=0 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_round2_kernels_only.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --dtype bf16 > $O/bench_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --dtype f16 > $O/bench_f16.json 2>/dev/null
