@@ -65,7 +65,15 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                                                                        float* __restrict__ out, int NB, int h, int w, int ho, int wo)
 {
     constexpr int NT = COUT / 32, NCH = CIN / 32;
-    constexpr int STG = 3 * NT * 1024;                                          // bytes of one weight stage (one k-step)
+#ifdef SS_SC_KPS1
+    constexpr int KPS = 1;                                                      // A/B build (tools/): one k-step per stage everywhere
+#else
+    constexpr int KPS = NT <= 2 ? 2 : 1;
+#endif
+                                        // k-steps per weight stage and barrier: a whole tap where it fits beside the window
+                                                                                // at two workgroups per CU (C_out 64: 24 KB of stages; C_out 128 would need 48)
+    constexpr int KST = 3 * NT * 1024;                                          // bytes of one k-step's weight fragments
+    constexpr int STG = KPS * KST;                                              // bytes of one weight stage
     constexpr int LPT = STG / 16 / kScThreads;                                  // whole 16-B pieces per thread and stage (+ a partial round)
     constexpr int REM = STG / 16 - LPT * kScThreads;
     __shared__ __attribute__((aligned(16))) unsigned char wnd[kScWR * kScRowB];
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                 }
             }
             // ---- weight stage 0 of this chunk
-            const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + (long long)c * 50 * STG;
+            const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + (long long)c * 50 * KST;
             stage_issue(bsrc);
             stage_commit(bst);
             __syncthreads();
@@ -197,15 +205,16 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                 for (int kx = 0; kx < 5; ++kx) {
 #pragma unroll
                     for (int gi = 0; gi < 2; ++gi) {
-                        const int s = (ky * 5 + kx) * 2 + gi;
-                        const bool more = s + 1 < 50;
-                        if (more) stage_issue(bsrc + (long long)(s + 1) * STG);
+                        const int s = (ky * 5 + kx) * 2 + gi;                   // k-step; stage = s / KPS (same MFMA order for either KPS: same result bits)
+                        const int sg = s / KPS;
+                        const bool first = s % KPS == 0, last = s % KPS == KPS - 1, more = sg + 1 < 50 / KPS;
+                        if (first && more) stage_issue(bsrc + (long long)(sg + 1) * STG);
                         if (active) {
                             const int col = 2 * tx + kx;
                             s16x8 a = *reinterpret_cast<const s16x8*>(lane_row + ky * kScRowB + col * kScPix + (((2 * gi + half) ^ ((col >> 2) & 3)) << 4));
 #pragma unroll
                             for (int e = 0; e < 8; ++e) a[e] = (short)(a[e] ^ sgn);          // -0 for a zero spike count: harmless
-                            const unsigned char* const bk = bst + (s & 1) * STG + lane * 16;
+                            const unsigned char* const bk = bst + (sg & 1) * STG + (s % KPS) * KST + lane * 16;
                             s16x8 b[3 * NT];                                    // [split][tile]
 #pragma unroll
                             for (int u = 0; u < 3 * NT; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
@@ -214,8 +223,10 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
 #pragma unroll
                                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[sp * NT + t], acc[t], 0, 0, 0);
                         }
-                        if (more) stage_commit(bst + ((s + 1) & 1) * STG);
-                        __syncthreads();
+                        if (last) {
+                            if (more) stage_commit(bst + ((sg + 1) & 1) * STG);
+                            __syncthreads();
+                        }
                     }
                 }
             }
