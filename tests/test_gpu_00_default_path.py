@@ -93,7 +93,7 @@ def test_pinned_parity_default_kernels_T5(name, C):
     check(f'pinned_T5_{name}', rep)
 
 
-@pytest.mark.parametrize('name,C,T', [('StereoSpike', 4, 10), ('PLIFNet', 4, 10), ('PLIFNetMono', 2, 1), ('StereoSpike', 4, 1)])
+@pytest.mark.parametrize('name,C,T', [('StereoSpike', 4, 10), ('PLIFNetMono', 2, 1), ('StereoSpike', 4, 1)])      # (PLIF at T = 10: tests/test_gpu_04_x16_parity.py)
 def test_pinned_parity_default_kernels_T10_T1(name, C, T):
     """The other compile-time time-step counts BASELINE names: T = 10 (config 5) and T = 1 (config 2: monocular PLIF)."""
     H, W = 64, 80
