@@ -1430,6 +1430,11 @@ def test_conv_s2_dgrad_mfma(NB, Cin, hw):
     gx2 = torch.full_like(gx, float('nan'))
     _lib.conv_s2_dgrad(g, wt, gx2, NB, Cin, Cout, h, w)
     assert torch.equal(gx, gx2)
+    if NB * h * w * Cin <= 200_000:                          # the oracle's parity-class restatement (oracle/np_conv_dgrad.py, float64): the same bound
+        from oracle import np_conv_dgrad
+        orc = torch.from_numpy(np_conv_dgrad.conv_s2_dgrad(g.cpu().numpy(), wt.cpu().numpy(), h, w)).to(DEV)
+        assert float((orc - ref).abs().max()) <= 1e-12 * float(mag.max()) + 1e-30
+        assert bool(((gx.double() - orc).abs() <= mag * 2.0 ** -21 + 1e-300).all())
     # linearity in g (size-independent property): dgrad(2 g) == 2 dgrad(g) bit for bit (powers of two commute with the bf16 split)
     _lib.conv_s2_dgrad(g * 2, wt, gx2, NB, Cin, Cout, h, w)
     assert torch.equal(gx2, gx * 2)

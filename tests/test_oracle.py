@@ -304,3 +304,26 @@ def test_winograd_dgrad_oracle_matches_autograd():
         ref = x.grad.permute(0, 2, 3, 1).numpy()
         assert np.abs(nw.dgrad_direct64(g, w) - ref).max() <= 1e-12
         assert np.abs(nw.dgrad(g, w) - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('NB,Cin,hw', [(2, 4, (9, 10)), (1, 3, (1, 7)), (2, 2, (6, 5)), (1, 8, (13, 12)), (3, 2, (4, 4))])
+def test_conv_s2_dgrad_oracle_matches_autograd(NB, Cin, hw):
+    """oracle/np_conv_dgrad.py — the parity-class form of the stride-2 5x5 data gradient that ss_conv_s2_dgrad_f32 evaluates — against torch's own
+    input gradient of conv2d(x, w, stride 2, padding 2) (the reference's autograd, /root/reference/network/SNN_models.py:80-101) in float64, and
+    against autograd through an actual forward; odd / even sizes, a one-row map."""
+    from oracle import np_conv_dgrad
+    h, w = hw
+    Cout = 2 * Cin
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    rng = np.random.default_rng(NB + h + w)
+    g = rng.standard_normal((NB, ho, wo, Cout))
+    wt = rng.standard_normal((Cout, Cin, 5, 5))
+    got = np_conv_dgrad.conv_s2_dgrad(g, wt, h, w)
+    ref = torch.nn.grad.conv2d_input((NB, Cin, h, w), torch.from_numpy(wt), torch.from_numpy(g).permute(0, 3, 1, 2), stride=2, padding=2)
+    assert np.abs(got - ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-12
+    x = torch.from_numpy(rng.standard_normal((NB, Cin, h, w))).requires_grad_()
+    y = torch.nn.functional.conv2d(x, torch.from_numpy(wt), None, 2, 2)
+    assert tuple(y.shape) == (NB, Cout, ho, wo)
+    (gx,) = torch.autograd.grad(y, x, torch.from_numpy(g).permute(0, 3, 1, 2))
+    assert np.abs(got - gx.permute(0, 2, 3, 1).numpy()).max() <= 1e-12
+    assert sum(len(v) for v in np_conv_dgrad.CLASS_TAPS.values()) == 25 and sorted(len(v) for v in np_conv_dgrad.CLASS_TAPS.values()) == [4, 6, 6, 9]
