@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_T_PROCESS_START = time.perf_counter()
 
 
 def launcher_command(gpus, argv, env):
@@ -76,9 +77,11 @@ def parse():
                          '(BASELINE.json configs 2 / 5) — reported as a separate line, never as the headline value')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    ap.add_argument('--cpu-b16-seconds', type=float, default=0.0,
-                    help='> 0: also time the CPU port at the bench batch size (SURVEY.md §8(d): B = 16): eval + 1 warm-up + >= 1 timed iteration, '
-                         '~110 s each on the GPU box host (measured 0.145 frames/s, profiles/r02/) — off by default so that the default run stays within minutes')
+    ap.add_argument('--cpu-b16', type=int, default=1,
+                    help='1 (default): also time ONE iteration of the CPU port at the bench batch size (SURVEY.md §8(d): B = 16; ~110 s on the GPU box host, '
+                         'measured 0.145 frames/s in profiles/r02/) as `cpu_baseline_B16`; 2: with evaluation pass, warm-up and >= 1 timed iteration (~6 min); 0: skip')
+    ap.add_argument('--leg-steps', type=int, default=5,
+                    help='steps of the SECOND pass that times every fused launch with HIP events (roofline legs); the headline pass runs with the timer off')
     ap.add_argument('--miopen-find', type=int, default=1,
                     help='torch.backends.cudnn.benchmark = MIOpen find mode: picks the fastest solver per conv (measured '
                          '73.8 vs 87.3 ms/step); the search costs ~3.5 min on a cold box, ~75 s with the in-tree find-db')
@@ -129,10 +132,11 @@ def build_net(model, device):
 _EVAL_REF = {}
 
 
-def cpu_baseline(model, T, budget_s, B=1, min_iters=5):
+def cpu_baseline(model, T, budget_s, B=1, min_iters=5, quick=False):
     """The oracle's eager port (oracle/ref_network.py on oracle/sj_clock_driven.py — the reference's op sequence)
     running the same training step on the host cores: B = 1, T = 5, 1 warm-up + >= 5 timed iterations (~budget_s seconds,
-    at most 6x that).  Reported, not a target."""
+    at most 6x that).  Reported, not a target.  quick: ONE timed iteration, no evaluation pass, no warm-up (the B = 16 leg of the default
+    run, SURVEY.md §8(d): ~2 min of host time on the GPU box)."""
     from oracle import ref_network as rn, sj_clock_driven as sj
     from stereospike_amd.engine import synthetic_batch
     torch.manual_seed(2021)
@@ -142,19 +146,21 @@ def cpu_baseline(model, T, budget_s, B=1, min_iters=5):
         net = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=30.)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
     x, gt = synthetic_batch(B, T, seed=2021)
-    # eval MDE on identical (seed-2021 default-init) weights and inputs, before any update: the "eval MDE" half of the metric
-    with torch.no_grad():
-        d_eval = rn.run_sequence(net, x)[0]
-        eval_mde = float(rn.mean_depth_error(d_eval[0], gt))
-        # ... and with every convolution evaluated in float64 and rounded once (oracle/ref_network.py::float64_convs): the yard-stick that does not
-        # depend on a backend's fp32 summation order.  An untrained spiking network amplifies one threshold-straddling rounding difference into a
-        # cascade (1 - 2 % of the last step's spikes, 0.4 % of the MDE: tools/diag_eval_mde.py, profiles/r03/diag_eval_mde.log), and the host's
-        # fp32 convolution is itself one such backend — so the product's eval MDE is held against THIS value, the eager fp32 one is reported beside it
-        with rn.float64_convs(net):
-            r64 = rn.run_sequence(net, x)
-            d64, s64 = r64[0], (r64[1] if len(r64) > 1 else None)
-            eval_mde64 = float(rn.mean_depth_error(d64[0], gt))
-        _EVAL_REF['spikes'] = [t.clone() for t in s64] if isinstance(s64, (list, tuple)) else None     # the last step's spike tensors (rconv, out_add4..1)
+    eval_mde = eval_mde64 = None
+    if not quick:
+        # eval MDE on identical (seed-2021 default-init) weights and inputs, before any update: the "eval MDE" half of the metric
+        with torch.no_grad():
+            d_eval = rn.run_sequence(net, x)[0]
+            eval_mde = float(rn.mean_depth_error(d_eval[0], gt))
+            # ... and with every convolution evaluated in float64 and rounded once (oracle/ref_network.py::float64_convs): the yard-stick that does not
+            # depend on a backend's fp32 summation order.  An untrained spiking network amplifies one threshold-straddling rounding difference into a
+            # cascade (1 - 2 % of the last step's spikes, 0.4 % of the MDE: tools/diag_eval_mde.py, profiles/r03/diag_eval_mde.log), and the host's
+            # fp32 convolution is itself one such backend — so the product's eval MDE is held against THIS value too, next to the eager fp32 one
+            with rn.float64_convs(net):
+                r64 = rn.run_sequence(net, x)
+                d64, s64 = r64[0], (r64[1] if len(r64) > 1 else None)
+                eval_mde64 = float(rn.mean_depth_error(d64[0], gt))
+            _EVAL_REF['spikes'] = [t.clone() for t in s64] if isinstance(s64, (list, tuple)) else None     # the last step's spike tensors (rconv, out_add4..1)
 
     def step():
         out = rn.run_sequence(net, x)
@@ -164,23 +170,24 @@ def cpu_baseline(model, T, budget_s, B=1, min_iters=5):
         opt.zero_grad()
         net.detach()
 
-    step()
+    if not quick:
+        step()
     times, t0 = [], time.perf_counter()
     while True:
         t1 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t1)
         el = time.perf_counter() - t0
-        if (len(times) >= min_iters and el >= budget_s) or len(times) >= 20 or el > 6 * budget_s:
+        if quick or (len(times) >= min_iters and el >= budget_s) or len(times) >= 20 or el > 6 * budget_s:
             break
     n = len(times)
     med = sorted(times)[n // 2]
     # the MEDIAN iteration prices the baseline (>= 5 timed iterations: single iterations on a shared 256-thread host vary 3x)
+    how = 'ONE timed training iteration, no warm-up' if quick else f'median of {n} timed training iterations after 1 warm-up'
     return dict(value=B / med, unit='frames/s', cores=torch.get_num_threads(), kind='port', eval_mde_m=eval_mde, eval_mde_m_float64_convs=eval_mde64,
                 iteration_s=dict(median=round(med, 3), min=round(min(times), 3), max=round(max(times), 3), n=n),
-                sample=f'{model} binocular T={T} 260x346 fp32, B={B}, median of {n} timed training iterations after 1 warm-up, '
-                       f'eager unfused oracle port, torch {torch.__version__} CPU, {torch.get_num_threads()} threads '
-                       f'of {os.cpu_count()} logical CPUs')
+                sample=f'{model} binocular T={T} 260x346 fp32, B={B}, {how}, eager unfused oracle port, torch {torch.__version__} CPU, '
+                       f'{torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs')
 
 
 def main():
@@ -263,19 +270,33 @@ def main():
         if rank == 0:
             print(f'[bench] warm-up step {i}: {time.perf_counter() - t_w:.2f} s (first steps include MIOpen kernel '
                   f'compilation when the in-tree cache is cold)', file=sys.stderr, flush=True)
+    # ---- headline pass: EXACTLY a.steps steps, barrier + synchronize on both sides, the per-launch HIP-event timer OFF ----
     sync()
-    TIMER.enabled = True
+    TIMER.enabled = False
     TIMER.clear()
+    t_region_start = time.perf_counter()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, pred = trainer.step(x, gt)
     sync()
     elapsed = time.perf_counter() - t0
-    TIMER.enabled = False
+    t_region_end = time.perf_counter()
     if use_dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- second, short pass for the roofline legs: the same step with a HIP-event pair around every fused launch (on the launch stream) ----
+    leg_steps = max(1, min(a.leg_steps, a.steps)) if not a.graph else 0
+    t_leg0 = time.perf_counter()
+    if leg_steps:
+        TIMER.enabled = True
+        TIMER.clear()
+        for _ in range(leg_steps):
+            trainer.step(x, gt)
+        sync()
+        TIMER.enabled = False
+    leg_elapsed = time.perf_counter() - t_leg0
+    leg_steps = max(1, leg_steps)
     summ = TIMER.summary()
     shapes = TIMER.summary(by_shape=True)
 
@@ -323,7 +344,7 @@ def main():
                         bytes_per_launch=int(d['bytes'] / max(1, d['launches'])),
                         # counter-measured HBM bytes (incl. the O(N) v_last write the per-update figure leaves out) over the same time
                         hbm_GBps_of_pmc_traffic=round(traffic / avg_us / 1e3, 1) if (traffic and avg_us > 0 and a.dtype == 'f32' and a.T == 5 and a.batch == 16) else None,
-                        ms_per_step_all_launches_of_this_kernel=round(sum(v['ms'] for k, v in summ.items() if k.startswith(which + ('_train' if which == 'neuron_fwd' else ''))) / a.steps, 3))
+                        ms_per_step_all_launches_of_this_kernel=round(sum(v['ms'] for k, v in summ.items() if k.startswith(which + ('_train' if which == 'neuron_fwd' else ''))) / leg_steps, 3))
         from stereospike_amd.network.metrics import MeanDepthError
         from stereospike_amd import fused as _fused
 
@@ -335,6 +356,13 @@ def main():
             'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if use_dp else 1, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1e3 * elapsed / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            # where the timed region sits inside this process (seconds since interpreter start): a sampler that saw no GPU activity during most of the
+            # run was looking at imports, warm-up or the CPU-baseline legs
+            'timed_region_s': round(elapsed, 4),
+            'timed_region_offsets_s': dict(start=round(t_region_start - _T_PROCESS_START, 2), end=round(t_region_end - _T_PROCESS_START, 2),
+                                           legs_pass_end=round(t_region_end - _T_PROCESS_START + leg_elapsed, 2)),
+            'per_kernel_legs': dict(steps=leg_steps, ms_per_step_with_event_timer=round(1e3 * leg_elapsed / leg_steps, 3),
+                                    note='separate pass after the timed region: fused.TIMER (one HIP-event pair per fused launch) is OFF while `value` is measured'),
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
                                    f'(reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd',
@@ -364,9 +392,9 @@ def main():
                                      else f'neuron_bwd_kernel<*, *, {a.T}, 4, {"true" if recompute_h else "false"}, false, false>')),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
-                ms_per_step=round(all_ms / a.steps, 3), algorithmic_GB_per_step=round(all_bytes / a.steps / 1e9, 3),
+                ms_per_step=round(all_ms / leg_steps, 3), algorithmic_GB_per_step=round(all_bytes / leg_steps / 1e9, 3),
                 achieved_GBps=round(all_bytes / 1e9 / (all_ms / 1e3), 1) if all_ms else 0.0,
-                share_of_step=round(all_ms / (1e3 * elapsed), 4)),
+                share_of_step=round((all_ms / leg_steps) / (1e3 * elapsed / a.steps), 4)),
             # HIP-event averages over ALL launches of each kernel instantiation, for comparison with the AverageNs column of
             # the committed `rocprofv3 --kernel-trace --stats` CSV (profiles/): events add a few us per launch
             'rocprof_check_avg_us': {
@@ -376,10 +404,10 @@ def main():
                     (f'neuron_fwd_kernel<0, {a.T}, false, false, 4, {"true" if packed_on else "false"}>', ['neuron_fwd_train', 'neuron_fwd_train+packed']),
                     (f'neuron_fwd_kernel<0, {a.T}, true, false, 4, {"true" if packed_on else "false"}>', ['neuron_fwd_train+skip', 'neuron_fwd_train+skip+packed']),
                     ('neuron_bwd_kernel<*>', [k for k in summ if k.startswith('neuron_bwd')]))},
-            'other_fused_kernels_ms_per_step': {k: round(v['ms'] / a.steps, 3) for k, v in summ.items()
+            'other_fused_kernels_ms_per_step': {k: round(v['ms'] / leg_steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
             # the up-conv stages one by one (projection GEMM + gather, resp. adjoint + dgrad / wgrad GEMMs), keyed by output elements
-            'upconv_by_stage_ms_per_step': {f'{k[0]}:{k[1]}': round(v['ms'] / a.steps, 3) for k, v in sorted(shapes.items(), key=lambda kv: -kv[0][1])
+            'upconv_by_stage_ms_per_step': {f'{k[0]}:{k[1]}': round(v['ms'] / leg_steps, 3) for k, v in sorted(shapes.items(), key=lambda kv: -kv[0][1])
                                             if k[0].startswith('upconv')},
             'roofline_upconv': _roof_upconv(shapes, a),
             'roofline_upconv_bwd': _roof_upconv_bwd(shapes, a),
@@ -388,9 +416,15 @@ def main():
         }
         # `roofline` = the dominant kernel of the path: whichever of the two fused neuron kernels took more of the timed region
         if ('fork' in bwd_tag or '+lr' in bwd_tag) and bwd['ms'] > 0 and a.dtype == 'f32':
-            # SURVEY.md §8(d) prices the backward at 12 B/update (g_out, x, g_x); the forked form also reads the second consumer's gradient
-            # (4 B/update that autograd's accumulation pass would otherwise move 3x): the same launches by that stricter definition
-            out['roofline_bwd']['frac_by_12B_per_update_definition'] = round(12 * bwd['updates'] / 1e9 / (bwd['ms'] / 1e3) / HBM_PEAK_GBS, 4)
+            # SURVEY.md §8(d) prices the backward at 12 B/update (g_out, x, g_x): THAT is `frac` / `achieved`.  The forked / low-rank form
+            # also reads the second consumer's gradient (4 resp. 36 / C B/update that autograd's accumulation pass would otherwise move 3x): the rate
+            # over the bytes the kernel really moves is kept beside it
+            rb = out['roofline_bwd']
+            rb['frac_by_bytes_moved'], rb['achieved_GBps_by_bytes_moved'], rb['bytes_moved_per_update'] = rb['frac'], rb['achieved'], bpu(bwd)
+            rb['achieved'] = round(12 * bwd['updates'] / 1e9 / (bwd['ms'] / 1e3), 1)
+            rb['frac'] = round(rb['achieved'] / HBM_PEAK_GBS, 4)
+            rb['bytes_per_launch'] = int(12 * bwd['updates'] / max(1, bwd['launches']))
+            rb['definition'] = 'SURVEY.md 8(d): 12 B per neuron update (read g_out 4, read x 4, write g_x 4) x updates of the launch / HIP-event time'
         dom_key = 'roofline_bwd' if out['roofline_bwd']['ms_per_step_all_launches_of_this_kernel'] >= \
             out['roofline_fwd']['ms_per_step_all_launches_of_this_kernel'] else 'roofline_fwd'
         out = {**{k: v for k, v in out.items() if k not in ('roofline_fwd', 'roofline_bwd')}, 'roofline': out[dom_key],
@@ -414,14 +448,14 @@ def main():
                 # against the float64-conv oracle's on the same weights and input — the number of elements that differ
                 out['eval_last_step_spikes_differing_vs_cpu'] = int(sum(int((a_ != b_).sum()) for a_, b_ in zip(s0, _EVAL_REF['spikes'])))
                 out['eval_last_step_spikes_compared'] = int(sum(a_.numel() for a_ in s0))
-            if a.cpu_b16_seconds > 0:                     # the CPU port at the bench's own batch size as well
-                out['cpu_baseline_B16'] = cpu_baseline(a.model, a.T, a.cpu_b16_seconds, B=a.batch, min_iters=1)
-            # eval MDE "at matching Mean Depth Error": against the oracle with float64 convolutions (see cpu_baseline); the eager fp32 port's own value
-            # differs from BOTH by its backend's flip cascade on some hosts and is reported next to it
-            out['eval_mde_rel_diff_vs_cpu'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m_float64_convs'])
-                                                    / out['cpu_baseline']['eval_mde_m_float64_convs'], 7)
-            out['eval_mde_rel_diff_vs_cpu_fp32_eager'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m'])
-                                                               / out['cpu_baseline']['eval_mde_m'], 6)
+            if a.cpu_b16:                                 # the CPU port at the bench's own batch size as well
+                out['cpu_baseline_B16'] = cpu_baseline(a.model, a.T, 120.0, B=a.batch, min_iters=1, quick=a.cpu_b16 == 1)
+            # eval MDE "at matching Mean Depth Error".  `eval_mde_rel_diff_vs_cpu` keeps its round-1/2 meaning — against the eager fp32 port of the reference
+            # (the reference's own fp32 arithmetic on this host) — and the float64-convolution oracle, the yard-stick that does not depend on a
+            # backend's fp32 summation order (see cpu_baseline), has its own key
+            out['eval_mde_rel_diff_vs_cpu'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m']) / out['cpu_baseline']['eval_mde_m'], 7)
+            out['eval_mde_rel_diff_vs_float64_conv_oracle'] = round(abs(out['eval_mde_m'] - out['cpu_baseline']['eval_mde_m_float64_convs'])
+                                                                    / out['cpu_baseline']['eval_mde_m_float64_convs'], 7)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
         line = json.dumps(out)
     if use_dp:

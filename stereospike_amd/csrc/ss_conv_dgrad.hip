@@ -333,10 +333,14 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     // column blocking of the (j, i) grid: 8 columns x 4 rows per wavefront wastes <= 1 / 8 of a block on any width; 32 x 1 only when it fits as well
     bool wide = ((wo + 31) / 32) * 32 <= ((wo + 7) / 8) * 8;
-    if (const char* e = getenv("SS_DGRAD_CB")) wide = e[0] == '3';              // tuning knob (tools/bench_conv_dgrad.py): 32 | 8
+    static const char* const cb_env = getenv("SS_DGRAD_CB");                    // tuning knob (tools/bench_conv_dgrad.py): 32 | 8 — read once, not per call
+    if (cb_env) wide = cb_env[0] == '3';
     const int MB = (Cin == 32 && !wide) ? 2 : 1;                                 // C_in 32 (one N tile): two M blocks per wavefront share the weight fragments
 
-    const unsigned grid = (unsigned)(2 * cus);                                   // two workgroups per CU, persistent: each draws items from its XCD's range
+    // two workgroups per CU, persistent: each draws items from the range of `blockIdx.x & 7` (its XCD as dispatched — for speed only).  The 8 ranges
+    // are drawn by 8 distinct residues, so the grid is never smaller than 8: on a device (or partition) with fewer than 4 CUs every range still
+    // has a workgroup and no part of g_x stays unwritten
+    const unsigned grid = (unsigned)(2 * cus < 8 ? 8 : 2 * cus);
 #define SS_DG(CO_, NTALL_, NT_) do { \
         if (wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 32>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, counters, (int)NB, h, w, ho, wo); \
         else hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 8>), dim3(grid), dim3(kDgThreads), 0, s, g, Bf, g_x, counters, (int)NB, h, w, ho, wo); } while (0)

@@ -199,6 +199,8 @@ class GraphedTrainer:
             # _scale / _growth_tracker) inside torch.cuda.graph, and every replay would then reset the loss scale to 2^16 — a static scale,
             # and a persistent overflow would skip every optimiser step for ever.  The warm-up iterations initialised them:
             # reset the values in place.
+            if self.scaler._scale is None:          # warmup = 0: nothing initialised them yet — do it here, still outside the capture
+                self.scaler._lazy_init_scale_growth_tracker(self.dev)
             self.scaler._scale.fill_(2.0 ** 16)
             self.scaler._growth_tracker.zero_()
         self.opt.zero_grad(set_to_none=True)    # gradients are (re)created inside the capture: every replay overwrites them

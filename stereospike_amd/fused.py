@@ -141,8 +141,12 @@ def lowrank_anchor(shape, lr_p, lr_w):
 
 
 def lowrank_of(g, rank=_LR_RANK):
-    """(lr_p [rows, rank], lr_w [rank, C]) when g is (a view of) a low-rank anchor, else None.  Raises when g has the layout of an anchor
-    but not the storage length its shape implies (an anchor that reached a layer it was not made for)."""
+    """(lr_p [rows, rank], lr_w [rank, C]) when g is (a view of) a low-rank anchor, else None.
+
+    A zero-stride gradient whose storage does not have the length the pair of ITS shape would have is not taken for a pair (e.g. the
+    gradient of `(torch.stack(terms) * w).sum()` is an expanded view of element 0 of a len(terms)-float storage) and is handled as the dense
+    gradient it is — unless its first element carries the pair buffer's NaN header, i.e. a real pair reached a layer it was not made for: that
+    RAISES (one host read, on this rare path only and never inside a stream capture; without it the NaN header still surfaces as NaN gradients)."""
     if g is None or g.dtype != torch.float32 or g.dim() == 0 or any(g.stride()) or g.storage_offset() != 0:
         return None
     st = g.untyped_storage()
@@ -153,8 +157,11 @@ def lowrank_of(g, rank=_LR_RANK):
     rows = g.numel() // C
     o_p, o_w, need = _lr_layout(rows, C, rank)
     if n != need:
-        raise _lib.SSNeuronError(f'zero-stride gradient of shape {tuple(g.shape)} over a {n}-float storage: neither an expanded scalar nor the '
-                                 f'low-rank pair of this shape ({need} floats) — a prediction head\'s gradient pair reached a layer it does not fit')
+        capturing = g.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing and bool(torch.isnan(g.reshape(-1)[:1]).item()):
+            raise _lib.SSNeuronError(f'zero-stride gradient of shape {tuple(g.shape)} over a {n}-float storage with the NaN header of a low-rank pair, but the '
+                                     f'pair of this shape has {need} floats — a prediction head\'s gradient pair reached a layer it does not fit')
+        return None
     flat = torch.empty(0, dtype=torch.float32, device=g.device).set_(st, 0, (n,), (1,))
     return flat[o_p:o_p + rows * rank].view(rows, rank), flat[o_w:o_w + rank * C].view(rank, C)
 

@@ -232,7 +232,7 @@ def narrowing_points(amp_dtype):
 
 
 def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=None, float64=True, oracle_chunk=None, loss_scale=1.0,
-                  oracle_procs=False):
+                  oracle_procs=False, penalize_spikes=False, beta=1.0):
     """Free product run (forward + Total_Loss + backward) vs the trajectory-pinned oracle.  Returns a report dict.
     amp_dtype: the product runs under torch.autocast with 16-bit activations (fp32 membranes); the oracle narrows at the same points
     (narrowing_points).  loss_scale: the product's loss is multiplied by it before backward and its gradients divided afterwards (fp16
@@ -240,7 +240,9 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
     oracle_chunk: evaluate the oracle over chunks of that many samples (the network is per-sample independent; only the loss couples the
     batch): pass 1 forward per chunk -> depths; the loss and its depth gradients on the whole batch; pass 2 forward + backward per chunk
     with those depth gradients (parameter gradients accumulate).  Bounds the CPU memory of a config-3-sized batch.
-    oracle_procs: every chunk in its own process, all at once, one forward each (the graph is kept while the parent forms the loss)."""
+    oracle_procs: every chunk in its own process, all at once, one forward each (the graph is kept while the parent forms the loss).
+    penalize_spikes / beta: Total_Loss(penalize_spikes=True, beta=...) on both sides (/root/reference/network/loss.py:96-107,126-135): the
+    loss then also reads the five RETURNED spike tensors, so a gradient enters them directly (un-chunked oracle only)."""
     from stereospike_amd import fused
     from stereospike_amd.clock_driven import functional
     from stereospike_amd.network.loss import Total_Loss
@@ -256,7 +258,7 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
             with (torch.autocast('cuda', dtype=amp_dtype) if amp_dtype is not None else contextlib.nullcontext()):
                 res = net(xg) if is_ann else net.forward_sequence(xg)
                 d, s = res if returns_spikes else (res, [])
-                L = Total_Loss()(d, gg, s)
+                L = Total_Loss(penalize_spikes=penalize_spikes, beta=beta)(d, gg, s)
             mde = MeanDepthError(d[0].detach(), gg)
             (L * loss_scale if loss_scale != 1.0 else L).backward()
             if loss_scale != 1.0:
@@ -280,13 +282,15 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
     if oracle_chunk is None or oracle_chunk >= B:
         res_o, _ = run_oracle_pinned(orc, x, z_by_node, float64=float64, stats=stats, plif=plif, narrow=narrow)
         d_o, s_o = res_o if returns_spikes else (res_o, [])
-        L_o = rn.total_loss(d_o, gt, s_o)
+        L_o = rn.total_loss(d_o, gt, s_o, penalize_spikes=penalize_spikes, beta=beta)
         mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
         L_o.backward()
     elif oracle_procs:
+        assert not penalize_spikes, 'the chunked oracle forms the loss from detached spike tensors'
         d_o, s_o, L_o = _oracle_in_processes(orc, x, gt, z_by_node, oracle_chunk, returns_spikes, float64, amp_dtype, stats, plif)
         mde_o = rn.mean_depth_error(d_o[0].detach(), gt)
     else:
+        assert not penalize_spikes, 'the chunked oracle forms the loss from detached spike tensors'
         chunks = [(c0, min(B, c0 + oracle_chunk)) for c0 in range(0, B, oracle_chunk)]
         zc = lambda c0, c1: {n: [z[c0:c1] for z in lst] for n, lst in z_by_node.items()}        # noqa: E731
         outs = []

@@ -608,8 +608,14 @@ def test_spike_conv_as_exact_bf16x3_gemm(Cin, Cout, k, s, pad, hw):
         return float((a.double() - b).abs().max())
     assert err(y.permute(0, 3, 1, 2), y64) <= 2 * err(y32, y64) + 1e-7 * float(y64.abs().max())
     assert err(gw, gw64) <= 2 * err(gw32, gw64) + 1e-7 * float(gw64.abs().max())
-    # the data gradient of the stride-2 5x5 geometries is the six-term MFMA kernel (ss_conv_s2_dgrad_f32; its own bounds: test_conv_s2_dgrad_mfma)
-    assert err(gx, gx64) <= 2 * err(gx32, gx64) + 3e-7 * float(gx64.abs().max())
+    if k == 5 and s == 2 and pad == 2 and fused.CONV_DGRAD_MFMA:
+        # the data gradient of the stride-2 5x5 geometries is the six-term MFMA kernel (ss_conv_s2_dgrad_f32): held to ITS OWN element-wise bound
+        # 2^-21 sum |g| |w| (test_conv_s2_dgrad_mfma), not to a bar relative to whatever error the library's fp32 kernel happens to have on this box
+        # (a bar of that kind failed once at 2.9e-6 vs 1.8e-6, profiles/r03/pytest_gpu_r03_clean_run3_failed_at_158.log)
+        mag = torch.autograd.grad(F.conv2d(xd.permute(0, 3, 1, 2), wd.abs(), None, s, pad), xd, gy.double().abs().permute(0, 3, 1, 2))[0]
+        assert bool(((gx.double() - gx64).abs() <= 2.0 ** -21 * mag + 1e-30).all()), float(((gx.double() - gx64).abs() / (mag + 1e-30)).max()) * 2 ** 21
+    else:
+        assert err(gx, gx64) <= 2 * err(gx32, gx64) + 3e-7 * float(gx64.abs().max())
 
 
 @pytest.mark.parametrize('kind', ['IF', 'PLIF'])

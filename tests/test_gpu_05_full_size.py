@@ -1,0 +1,293 @@
+"""GPU tests at BASELINE.json's FULL sizes through size-independent properties (the oracle cannot walk these in a test's time): config 5's
+per-GPU share (StereoSpike, T = 10, fp16 activations + fp32 membranes, B = 32, 260x346, firing-rate counters on — the ~45 GB point where
+activation memory matters) and config 2 (monocular PLIF, T = 1, bf16, B = 8, 260x346); the three scripts/ counterparts of the reference's
+train.py / test.py / calculate_firing_rates.py end to end; the N >= 2 RCCL path whenever the box has two devices.
+
+Parity at sizes the oracle finishes: tests/test_gpu_00_default_path.py (fp32) and tests/test_gpu_04_x16_parity.py (16-bit modes)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from _models import DEV, product as _product
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _count_spikes_on_device(net):
+    """Context manager: {node name: (count_nonzero of the pure spikes z, count_nonzero of the layer output z + skip)} of every fused neuron launch,
+    taken ON the device right after the launch (integers; nothing of size T x B x N leaves the GPU)."""
+    import contextlib
+    from stereospike_amd import fused
+    from stereospike_amd.clock_driven import neuron
+
+    @contextlib.contextmanager
+    def cm():
+        names = {id(m): n for n, m in net.named_modules() if isinstance(m, neuron.BaseNode)}
+        rec = {}
+        orig = neuron.BaseNode.forward_sequence
+
+        def wrapped(self, x_seq, scale=1., skip_seq=None, nnz=None, channels_last=False, fork=False, pack=0, skip_packed=None):
+            res = orig(self, x_seq, scale, skip_seq, nnz, channels_last, fork, pack, skip_packed)
+            out = (res[0] if fork else res).detach()
+            if pack and self.last_packed is not None:
+                out = fused.unpack_dense(self.last_packed, x_seq.shape)
+            skip = fused.unpack_dense(skip_packed, x_seq.shape) if skip_packed is not None else (None if skip_seq is None else skip_seq.detach())
+            n_out = int(torch.count_nonzero(out))
+            n_z = n_out if skip is None else int(torch.count_nonzero(out.float() - skip.float()))
+            rec[names[id(self)]] = (n_z, n_out, out.numel())
+            return res
+        neuron.BaseNode.forward_sequence = wrapped
+        try:
+            yield rec
+        finally:
+            neuron.BaseNode.forward_sequence = orig
+    return cm()
+
+
+def _expected_counters(rec):
+    """The 14 + 1 counters of SNN_models._run (name -> (spike count, output count)) from the per-node device counts."""
+    want = {n: rec[f'{n}.2'][:2] for n in ('bottom', 'conv1', 'conv2', 'conv3', 'conv4', 'deconv4', 'deconv3', 'deconv2', 'deconv1')}
+    want['rconv'] = rec['bottleneck.1.sn2'][:2]
+    return want
+
+
+def _train_pass(net, x, gt, amp_dtype, loss_scale):
+    """reset -> forward_sequence with the in-kernel counters -> Total_Loss -> backward, as engine.Trainer.step runs them (without the optimiser,
+    so that the gradients can be inspected)."""
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    functional.reset_net(net)
+    net.zero_grad(set_to_none=True)
+    rates = {}
+    with torch.autocast('cuda', dtype=amp_dtype):
+        out = net.forward_sequence(x, rates)
+        pred, spks = out if isinstance(out, tuple) else (out, None)
+        loss = Total_Loss()(pred, gt, spks)
+    with torch.autocast('cuda', enabled=False):
+        (loss * loss_scale).backward()
+    return loss.detach(), pred, rates
+
+
+def test_config5_per_gpu_share_fp16_T10_B32_counters_on():
+    """BASELINE.json config 5's share of ONE GPU: StereoSpike, T = 10, fp16 activations + fp32 membrane state, B = 32 (256 / 8), 260x346, firing-rate
+    counters on.  Properties: (1) the in-kernel counters equal count_nonzero of the very tensors they counted, as exact integers (9.2e8 updates in
+    the largest launch: beyond what an fp32 rate can carry, so the raw 64-bit counters are read); (2) one training pass at this size gives a finite
+    loss and finite gradients for every parameter under the loss scale engine.Trainer's GradScaler converges to; (3) the reported rates are the
+    counts / numel to fp32 rounding; (4) peak memory stays under 52 GB of the 288 (measured 45)."""
+    from stereospike_amd.engine import synthetic_batch
+    torch.manual_seed(2021)
+    net = _product('StereoSpike').to(DEV)
+    B, T = 32, 10
+    x, gt = synthetic_batch(B, T, seed=2021, device=DEV)
+    torch.cuda.reset_peak_memory_stats()
+    # (1) exact integer counters at the full launch shapes (forward only)
+    from stereospike_amd.clock_driven import functional
+    functional.reset_net(net)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16), _count_spikes_on_device(net) as rec:
+        _, _, cnt, (T_, B_) = net._run(x.transpose(0, 1), count=True)
+    assert (T_, B_) == (T, B) and len(rec) == 13
+    want = _expected_counters(rec)
+    assert rec['bottom.2'][2] == T * B * 32 * 260 * 346                      # 9.2e8 updates in one launch
+    for name, (n_z, n_out) in want.items():
+        got = [int(v) for v in cnt[name].tolist()]
+        assert 0 < n_z < rec['bottom.2'][2], name
+        if name == 'rconv':
+            assert got[1] == n_out, (name, got, n_out)                       # the reference counts out_rconv itself (SNN_models.py:214)
+        else:
+            assert got[0] == n_z, (name, got, n_z)
+            if name.startswith('deconv'):
+                assert got[1] == n_out, (name, got, n_out)
+    del cnt, rec
+    # (2) - (4) one training pass
+    loss, pred, rates = _train_pass(net, x, gt, torch.float16, loss_scale=1.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and all(torch.isfinite(p).all() for p in pred)
+    bad = [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not bad, bad
+    assert all(float(p.grad.abs().max()) > 0 for p in net.parameters())
+    assert len(rates) == 15 and all(0.0 <= float(v) <= 1.0 for v in rates.values())
+    for name, (n_z, n_out) in want.items():
+        if name != 'rconv':
+            numel = T * net.__getattr__(name)[2].v.numel()
+            assert abs(float(rates[f'out_{name}']) - n_z / numel) <= 2.0 ** -22, name
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/full_size_config5.json', 'w') as f:
+        json.dump(dict(peak_mem_GB=peak, loss=float(loss), rates={k: float(v) for k, v in rates.items()}), f, indent=1)
+    assert peak < 52.0, peak
+
+
+def test_config2_mono_plif_T1_bf16_B8_full_resolution():
+    """BASELINE.json config 2: fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike (PLIF), T = 1, bf16 activations, B = 8, 260x346.
+    Properties at full size: finite loss / depth maps / gradients (incl. the 13 PLIF dL/dw scalars), exact integer counters, sane densities, the
+    x16 kernel forms in the launch tags; the HIP-graph trainer (what the config runs on: a T = 1 step is host-bound) reproduces the eager loss."""
+    from stereospike_amd import fused
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.engine import GraphedTrainer, Trainer, synthetic_batch
+    torch.manual_seed(2021)
+    net = _product('PLIFNetMono').to(DEV)
+    B, T = 8, 1
+    x, gt = synthetic_batch(B, T, C=2, seed=2021, device=DEV, lam=0.12)
+    functional.reset_net(net)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16), _count_spikes_on_device(net) as rec:
+        _, _, cnt, _ = net._run(x.transpose(0, 1), count=True)
+    want = _expected_counters(rec)
+    for name, (n_z, n_out) in want.items():
+        got = [int(v) for v in cnt[name].tolist()]
+        assert (got[1] == n_out) if name == 'rconv' else (got[0] == n_z), (name, got, n_z, n_out)
+    dens = {n: v[0] / v[2] for n, v in rec.items()}
+    assert all(0.0 < d < 0.9 for d in dens.values()), dens
+    fused.TIMER.clear()
+    fused.TIMER.enabled = True
+    try:
+        loss, pred, rates = _train_pass(net, x, gt, torch.bfloat16, loss_scale=1.0)
+        torch.cuda.synchronize()
+        tags = {k: v['launches'] for k, v in fused.TIMER.summary().items()}
+    finally:
+        fused.TIMER.enabled = False
+        fused.TIMER.clear()
+    assert torch.isfinite(loss) and all(torch.isfinite(p).all() for p in pred) and isinstance(pred, (list, tuple)) and len(pred) == 4
+    bad = [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not bad, bad
+    assert sum(1 for n, _ in net.named_parameters() if n.endswith('.w')) == 13
+    assert sum(v for k, v in tags.items() if k.startswith('neuron_fwd')) == 13 and sum(v for k, v in tags.items() if k.startswith('neuron_bwd')) == 13, tags
+    assert not any(k.endswith('+h') or 'savedh' in k for k in tags), tags     # compile-time T = 1 recompute forms
+    # the config's own runner: whole iteration as one HIP graph; first replay == the eager trainer's first step (same weights, same batch)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    l_eager = float(Trainer(net, amp_dtype=torch.bfloat16).step(x, gt)[0])
+    net.load_state_dict(state)
+    functional.reset_net(net)
+    l_graph = float(GraphedTrainer(net, amp_dtype=torch.bfloat16, warmup=2).step(x, gt)[0])
+    assert abs(l_eager - float(loss)) <= 1e-5 * abs(l_eager) and abs(l_graph - l_eager) <= 1e-4 * abs(l_eager), (float(loss), l_eager, l_graph)
+
+
+def test_scripts_train_test_firing_rates_roundtrip(tmp_path):
+    """scripts/train_stereospike.py (/root/reference/train.py:180-356), scripts/test_stereospike.py (/root/reference/test.py:100-186) and
+    scripts/calculate_firing_rates.py (/root/reference/calculate_firing_rates.py:92-149), two iterations each, as a user runs them: the training
+    log has the reference's line format, the best-MDE checkpoint (train.py:348-352) is written with the reference's state_dict keys, loads into a
+    FRESH network (test.py:84), and the evaluation / firing-rate scripts consume it."""
+    out = str(tmp_path / 'ckpt')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+
+    def run(args):
+        r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (args, r.stdout[-2000:], r.stderr[-4000:])
+        return r.stdout
+    run(['scripts/train_stereospike.py', '--epochs', '2', '--iters', '2', '--batch', '2', '--T', '5', '--graph', '0', '--out', out])
+    log = open(os.path.join(out, 'training_logs.txt')).read()
+    for ep in (0, 1):
+        assert f'Epoch: {ep}, Training Loss: ' in log and f'Epoch: {ep}, Test Loss: ' in log and 'Training Mean Depth Error (m): ' in log, log
+    ck = os.path.join(out, 'stereospike.pth')
+    sd = torch.load(ck, map_location='cpu')
+    torch.manual_seed(1)
+    fresh = _product('StereoSpike')
+    assert list(sd.keys()) == list(fresh.state_dict().keys()) and len(sd) == 21
+    fresh.load_state_dict(sd)                                                   # strict
+    init = _product('StereoSpike')                                              # (another seed state): training moved the weights away from any init
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    assert any(not torch.equal(sd[k], init.state_dict()[k]) for k in sd)
+    txt = run(['scripts/test_stereospike.py', '--checkpoint', ck, '--samples', '2', '--T', '1', '--out', out])
+    assert 'Mean Test Loss: ' in txt and 'Mean Test MDE (m): ' in txt
+    res = open(os.path.join(out, 'test_results.txt')).read()
+    rates = json.loads(res[res.index('{'):])
+    assert len(rates) == 15 and all(0.0 <= v <= 1.0 for v in rates.values()) and rates['out_bottom'] > 0
+    run(['scripts/calculate_firing_rates.py', '--checkpoint', ck, '--samples', '2', '--T', '5', '--out', out])
+    fr = json.load(open(os.path.join(out, 'firing_rates.txt')))
+    assert set(fr) == set(rates) and fr['out_bottom'] > 0
+    # the evaluation script's numbers are the checkpoint's: the fresh network with the loaded weights reproduces its first sample
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.engine import synthetic_batch
+    from stereospike_amd.network.metrics import MeanDepthError
+    fresh = fresh.to(DEV).eval()
+    mde = 0.0
+    with torch.no_grad():
+        for i in range(2):
+            xs, lab = synthetic_batch(1, 1, seed=10 ** 6 + i, device=DEV)
+            functional.reset_net(fresh)
+            pred, _ = fresh.forward_sequence(xs)
+            mde += float(MeanDepthError(pred[0], lab)) / 2
+    got = float(res.split('Mean Test MDE (m): ')[1].split()[0])
+    assert abs(got - mde) <= 1e-4 * abs(mde), (got, mde)
+
+
+# ======================================================================================================
+# N >= 2 ranks on RCCL (runs whenever the box has two devices; the driver's 1-GPU test box skips it)
+# ======================================================================================================
+def _nccl_worker(rank, world, port, q, H, W):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from stereospike_amd.dp import GradientAllReducer
+        from stereospike_amd.engine import synthetic_batch
+        torch.manual_seed(2021)
+        net = _product('PLIFNet', input_size=(H, W)).to(dev)
+        if rank == 1:                      # ranks start from different weights: the reducer must broadcast rank 0's
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.01)
+        red = GradientAllReducer(net, bucket_bytes=8 << 20)
+        x, gt = synthetic_batch(4, 5, H=H, W=W, seed=11, device='cpu', lam=0.08)
+        sl = slice(2 * rank, 2 * rank + 2)
+        _train_pass_fp32(net, x[sl].to(dev), gt[sl].to(dev))
+        red.finish()
+        torch.cuda.synchronize()
+        q.put((rank, len(red.buckets), [p.grad.detach().cpu().numpy() for p in net.parameters()]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _train_pass_fp32(net, x, gt):
+    from stereospike_amd.clock_driven import functional
+    from stereospike_amd.network.loss import Total_Loss
+    functional.reset_net(net)
+    d, s = net.forward_sequence(x)
+    Total_Loss()(d, gt, s).backward()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 HIP devices (N >= 2 RCCL ranks)')
+def test_two_rccl_ranks_equal_shardwise_single_process():
+    """BASELINE.json config 4's path at N = 2 on the real backend: the PRODUCT network, one process per GPU, gradients in the reducer's flat buckets,
+    async all-reduce from the gradient hooks.  DP semantics as tests/test_dp_gloo.py:68 defines them (reference loss on each rank's shard, gradients
+    averaged): a single process that walks the two shards and averages must give the SAME bits — every kernel of the default path is deterministic,
+    x / 2 is exact and a two-operand sum commutes."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    from stereospike_amd.engine import synthetic_batch
+    H, W = 64, 80
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, H, W)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    torch.manual_seed(2021)
+    net = _product('PLIFNet', input_size=(H, W)).to(DEV)
+    x, gt = synthetic_batch(4, 5, H=H, W=W, seed=11, device='cpu', lam=0.08)
+    acc = None
+    for r in range(2):
+        net.zero_grad(set_to_none=True)
+        _train_pass_fp32(net, x[2 * r:2 * r + 2].to(DEV), gt[2 * r:2 * r + 2].to(DEV))
+        g = [p.grad.detach() / 2 for p in net.parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    want = [a.cpu().numpy() for a in acc]
+    for rank, nb, grads in res:
+        assert nb > 1
+        for a, b in zip(grads, want):
+            assert np.array_equal(a, b), (rank, float(np.abs(a - b).max()))

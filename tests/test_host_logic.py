@@ -240,6 +240,11 @@ def test_lowrank_pair_travels_in_a_self_describing_buffer():
     assert torch.equal(fused.lowrank_dense((p, w), (2, 3, 8)), (p @ w).view(2, 3, 8))
     with pytest.raises(_lib.SSNeuronError):
         fused.lowrank_of(a.view(6, 8)[:, :4])                                   # same storage, a shape the pair was not made for
+    # a LEGITIMATE zero-stride gradient over a longer storage — d/dterms[0] of (stack(terms) * w).sum() is an expanded view of element 0
+    # of a len(terms)-float storage — is not a pair and must come back as "dense", not raise
+    terms = torch.arange(1.0, 8.0)
+    legit = terms[0].expand(2, 3, 8)
+    assert not any(legit.stride()) and legit.untyped_storage().nbytes() // 4 == 7 and fused.lowrank_of(legit) is None
     # lifetime = the gradient's lifetime: dropping the anchor frees the pair (nothing else holds it)
     probe = weakref.ref(a)
     del a, got, v
