@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 6
+#define SS_ABI_VERSION 7
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` (8-byte aligned) to the ss_neuron_bwd_* entry points when g_k != NULL.
@@ -337,6 +337,40 @@ int ss_upconv_bwd_dgrad_supported(int Cin, int Cout, int k, int max_rows4, int m
 long long ss_upconv_bwd_dgrad_ws_floats(int Cin, int Cout);
 int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                             float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W, void* stream);
+
+/*
+ * ABI 7 — the decoder's backward on the BOX-SUM image (ss_upconv_box.hip; round 4).  Replaces, for one decoder stage, the whole autograd backward of
+ * NNConvUpsampling (/root/reference/network/blocks.py:110-132; call sites SNN_models.py:110-129) — the adjoint gather ss_upconv_cl_bwd_f32 and both
+ * contractions on its per-tap tensor g_P (ss_gemm6_f32 / ss_spike_wgrad_f32, or the fused round-3 forms ss_upconv_bwd_dgrad_f32 / ss_upconv_bwd_fused_f32):
+ *
+ *   ss_upconv_boxsum_f32    B[nb][j][i][co] = sum_{Y in VR[j]} ( sum_{X in HR[i]} g_out[nb][Y][X][co] ), rows top to bottom, columns left to right, every
+ *                           sum started from +0 (ss_upconv_cl_bwd_f32's order: g_P[nb][iy][ix][ky,kx][co] == B[nb][vmap[iy][ky]][hmap[ix][kx]][co] bit for bit),
+ *                           stored as three bf16 planes h + m + l == B (round-to-nearest split): box [NB][C_out / 8][3][NVR][NHR][8] bf16,
+ *                           ss_upconv_box_elems(NB, C_out, NVR, NHR) elements.  vr [NVR][2], hr [NHR][2]: (start, length) of the distinct vertical /
+ *                           horizontal output ranges, id 0 = the empty range.
+ *   ss_upconv_box_dgrad_f32 g_x[nb][iy][ix][ci] = sum_{ky,kx,co} B[nb][vmap[iy][ky]][hmap[ix][kx]][co] * weight[co][ci][ky][kx]: six bf16 cross terms on the
+ *                           matrix cores, |g_x - float64| <= 2^-21 sum |B| |W| element-wise.  vmap [h][5], hmap [w][5]: range ids; tile_rows [ceil(h / 4)][2],
+ *                           tile_cols [ceil(w / 32)][2]: (first id, id count) of the non-empty ranges 4 consecutive source rows / 32 consecutive source
+ *                           columns reach; ws: ss_upconv_box_dgrad_ws_floats(C_in, C_out) floats.
+ *   ss_upconv_box_wgrad_f32 g_w[co][ci][ky][kx] (+)= sum_{nb,iy,ix} x[nb][iy][ix][ci] * B[nb][vmap[iy][ky]][hmap[ix][kx]][co]: x a spike tensor (values exact
+ *                           in bf16; fp32 NHWC or the 2-bit packed form), every product exact, fp32 accumulation, fixed-order reduction (deterministic):
+ *                           |g_w - float64| <= 2^-22 sum |x| |B|.  ws: ss_upconv_box_wgrad_ws_floats(C_in, C_out, NB, h, w) floats.
+ * g_out [NB][H][W][C_out], x / g_x [NB][h][w][C_in] NHWC fp32; weight / g_w [C_out][C_in][5][5] (the Conv2d parameter's own layout).
+ * *_supported: k = 5; dgrad C_in % 64 == 0 and C_out in {32, 64, 128, 256}; wgrad C_in % 32 == 0, C_out % 8 == 0; max_rows4 <= 17 and max_cols32 <= 74
+ * (largest id span of tile_rows / tile_cols).  No g_P anywhere; HBM traffic of the three launches: g_out once, the box image (1.5 x g_out's bytes) written
+ * once and read ~twice (window halos), x once per 8 output channels in its 2-byte fragment form, g_x once.
+ */
+long long ss_upconv_box_elems(long long NB, int Cout, int NVR, int NHR);
+int ss_upconv_boxsum_f32(const float* g_out, const int* vr, const int* hr, void* box, long long NB, int Cout, int H, int W, int NVR, int NHR, void* stream);
+int ss_upconv_box_dgrad_supported(int Cin, int Cout, int k, int max_rows4, int max_cols32);
+long long ss_upconv_box_dgrad_ws_floats(int Cin, int Cout);
+int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vmap, const int* hmap, const int* tile_rows, const int* tile_cols,
+                            float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, void* stream);
+int ss_upconv_box_wgrad_supported(int Cin, int Cout, int k, int max_rows4, int max_cols32);
+long long ss_upconv_box_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w);
+int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int* x_packed, const int* vmap, const int* hmap, const int* tile_rows,
+                            const int* tile_cols, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, int accumulate,
+                            void* stream);
 
 /*
  * Dense x dense fp32 GEMM on the bf16 matrix cores with six cross terms (ABI 3) — the decoder's data gradient g_x = g_P @ W2 (autograd of

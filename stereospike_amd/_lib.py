@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1
@@ -156,6 +156,22 @@ def lib():
     L.ss_upconv_bwd_dgrad_ws_floats.restype = i64
     L.ss_upconv_bwd_dgrad_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_bwd_dgrad_f32.restype = i32
+    L.ss_upconv_box_elems.argtypes = [i64, i32, i32, i32]
+    L.ss_upconv_box_elems.restype = i64
+    L.ss_upconv_boxsum_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_boxsum_f32.restype = i32
+    L.ss_upconv_box_dgrad_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_upconv_box_dgrad_supported.restype = i32
+    L.ss_upconv_box_dgrad_ws_floats.argtypes = [i32, i32]
+    L.ss_upconv_box_dgrad_ws_floats.restype = i64
+    L.ss_upconv_box_dgrad_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_box_dgrad_f32.restype = i32
+    L.ss_upconv_box_wgrad_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_upconv_box_wgrad_supported.restype = i32
+    L.ss_upconv_box_wgrad_ws_floats.argtypes = [i32, i32, i64, i32, i32]
+    L.ss_upconv_box_wgrad_ws_floats.restype = i64
+    L.ss_upconv_box_wgrad_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_box_wgrad_f32.restype = i32
     L.ss_gemm6_supported.argtypes = [i32, i32]
     L.ss_gemm6_supported.restype = i32
     L.ss_gemm6_ws_floats.argtypes = [i32, i32]
@@ -206,6 +222,8 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
            'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
            'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
+           'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats', 'ss_upconv_box_dgrad_f32',
+           'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
@@ -401,7 +419,7 @@ def ipool_bwd(g_depth_seq, g_v_last, g_pd_seq, stride_t, stride_k, g_v_init, T, 
     _check(rc, 'ss_ipool_bwd_f32')
 
 
-def _i32(t, name, numel):
+def _i32(t, name, numel=None):
     if t.dtype != torch.int32:
         raise SSNeuronError(f'{name}: expected int32, got {t.dtype}')
     return _ptr(t, name, numel)
@@ -558,6 +576,52 @@ def upconv_bwd_dgrad(g_out, weight, y_lo, y_hi, x_lo, x_hi, g_x, NB, Cin, Cout, 
                                            _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w), _f32(g_x, 'g_x', NB * h * w * Cin),
                                            _f32(ws, 'ws'), NB, Cin, Cout, h, w, H, W, _stream(g_out))
     _check(rc, 'ss_upconv_bwd_dgrad_f32')
+
+
+def upconv_boxsum(g_out, bt, NB, Cout, H, W):
+    """g_out [NB, H, W, Cout] fp32 -> the box-sum image of the stage as three bf16 planes (int16 tensor [NB, Cout / 8, 3, NVR, NHR, 8]); bt: fused.box_tables(...)."""
+    _require_hip(g_out, 'g_out')
+    NVR, NHR = bt['NVR'], bt['NHR']
+    box = torch.empty((NB, Cout // 8, 3, NVR, NHR, 8), dtype=torch.int16, device=g_out.device)
+    assert box.numel() == int(lib().ss_upconv_box_elems(NB, int(Cout), NVR, NHR))
+    with torch.cuda.device(g_out.device):
+        rc = lib().ss_upconv_boxsum_f32(_f32(g_out, 'g_out', NB * H * W * Cout), _i32(bt['vr'], 'vr', 2 * NVR), _i32(bt['hr'], 'hr', 2 * NHR),
+                                        C.c_void_p(box.data_ptr()), NB, int(Cout), H, W, NVR, NHR, _stream(g_out))
+    _check(rc, 'ss_upconv_boxsum_f32')
+    return box
+
+
+def upconv_box_dgrad_supported(Cin, Cout, k, bt):
+    return bool(lib().ss_upconv_box_dgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_rows4']), int(bt['max_cols32'])))
+
+
+def upconv_box_wgrad_supported(Cin, Cout, k, bt):
+    return bool(lib().ss_upconv_box_wgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_rows4']), int(bt['max_cols32'])))
+
+
+def upconv_box_dgrad(box, weight, bt, g_x, NB, Cin, Cout, h, w):
+    """Decoder data gradient g_x [NB, h, w, Cin] from the box-sum planes and the Conv2d weight [Cout, Cin, 5, 5]: six-term bf16 MFMA implicit GEMM."""
+    _require_hip(box, 'box')
+    ws = torch.empty(int(lib().ss_upconv_box_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=box.device)
+    with torch.cuda.device(box.device):
+        rc = lib().ss_upconv_box_dgrad_f32(C.c_void_p(box.data_ptr()), _f32(weight, 'weight', Cout * Cin * 25), _i32(bt['vmap'], 'vmap', 5 * h),
+                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows'), _i32(bt['tile_cols'], 'tile_cols'),
+                                           _f32(g_x, 'g_x', NB * h * w * Cin), _f32(ws, 'ws'), NB, int(Cin), int(Cout), h, w, bt['NVR'], bt['NHR'], _stream(box))
+    _check(rc, 'ss_upconv_box_dgrad_f32')
+
+
+def upconv_box_wgrad(box, x, x_packed, bt, g_w, NB, Cin, Cout, h, w, accumulate=False):
+    """Decoder weight gradient g_w [Cout, Cin, 5, 5] (+)= from the box-sum planes and the stage input x [NB, h, w, Cin] (fp32 spikes, or x_packed: the 2-bit
+    packed form): exact bf16x3 MFMA contraction over the source pixels."""
+    _require_hip(box, 'box')
+    ws = torch.empty(int(lib().ss_upconv_box_wgrad_ws_floats(int(Cin), int(Cout), NB, h, w)), dtype=torch.float32, device=box.device)
+    with torch.cuda.device(box.device):
+        rc = lib().ss_upconv_box_wgrad_f32(C.c_void_p(box.data_ptr()), _f32(x, 'x', NB * h * w * Cin) if x_packed is None else None,
+                                           _i32(x_packed, 'x_packed') if x_packed is not None else None, _i32(bt['vmap'], 'vmap', 5 * h),
+                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows'), _i32(bt['tile_cols'], 'tile_cols'),
+                                           _f32(g_w, 'g_w', Cout * Cin * 25), _f32(ws, 'ws'), NB, int(Cin), int(Cout), h, w, bt['NVR'], bt['NHR'],
+                                           int(bool(accumulate)), _stream(box))
+    _check(rc, 'ss_upconv_box_wgrad_f32')
 
 
 def gemm6_supported(K, N):

@@ -609,37 +609,7 @@ __global__ __launch_bounds__(kSwThreads, CIN == 64 ? 4 : 2) void upconv_bwd_fuse
     }
 }
 
-// x [NB * h][w][C_in] fp32 spike counts (or, PACKED, the 2-bit packed spike tensor) -> xT[(source row) * KSR + k-step][ci][16 sources] bf16,
-// KSR = ceil(w / 16), zero padded
-template <bool PACKED>
-__global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const void* __restrict__ xv, unsigned short* __restrict__ xT, long long rows, int w,
-                                                                  int CIN)
-{
-    const float* x = static_cast<const float*>(xv);
-    const unsigned* xp = static_cast<const unsigned*>(xv);
-    const int KSR = (w + 15) / 16;
-    const long long total = rows * KSR * CIN;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
-        const int ci = (int)(i % CIN);
-        const long long k = i / CIN;
-        const int c = (int)(k % KSR);
-        const long long row = k / KSR;
-        u16x8 a, b;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            const int sx = 16 * c + rr;
-            const long long el = (row * w + sx) * CIN + ci;
-            unsigned short v = 0;
-            if (sx < w) {
-                if constexpr (PACKED) v = code_to_bf16((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u);
-                else v = (unsigned short)(__float_as_uint(x[el]) >> 16);
-            }
-            if (rr < 8) a[rr] = v; else b[rr - 8] = v;
-        }
-        *reinterpret_cast<u16x8*>(xT + i * 16) = a;
-        *reinterpret_cast<u16x8*>(xT + i * 16 + 8) = b;
-    }
-}
+// (upconv_bwd_xprep_kernel — the spike operand in fragment order — lives in ss_common.hpp: ss_upconv_box.hip uses it as well)
 
 // ---------------------------------------------------------------------------------------------------
 // Dense x dense fp32 GEMM on the bf16 matrix cores with SIX cross terms:  C[R][N] = A[R][K] @ B[K][N]   (decoder data gradient g_x = g_P @ W2)

@@ -644,6 +644,67 @@ def adjoint_extents(tables):
 _EXTENTS = {}
 
 
+# ----------------------------------------------------------------------------------------------------------
+# box-sum form of the decoder's backward (round 4; ss_upconv_box.hip): host-side index tables
+# ----------------------------------------------------------------------------------------------------------
+def _range_tables(lo, hi, n_out, k=5):
+    """lo, hi: inverse ranges of a resize's source-index table (python lists); n_out: output extent.  -> (ranges [(start, length)], id 0 = the empty
+    range, the others sorted; rmap[i][t] = id of [lo[i] - t, hi[i] - t) & [0, n_out)) — the distinct output ranges a (source index, tap) pair collects."""
+    pairs = []
+    for i in range(len(lo)):
+        row = []
+        for t in range(k):
+            a, b = max(lo[i] - t, 0), min(hi[i] - t, n_out)
+            row.append((a, b - a) if b > a else (0, 0))
+        pairs.append(row)
+    uniq = sorted({p for row in pairs for p in row if p[1] > 0})
+    ids = {p: n + 1 for n, p in enumerate(uniq)}
+    ids[(0, 0)] = 0
+    return [(0, 0)] + uniq, [[ids[p] for p in row] for row in pairs]
+
+
+def _tile_spans(rmap, tile):
+    """[(first id, id count)] of the non-empty ranges the maps of `tile` consecutive source indices reach, per tile."""
+    out = []
+    for a in range(0, len(rmap), tile):
+        ids = [v for row in rmap[a:a + tile] for v in row if v > 0]
+        out.append((min(ids), max(ids) - min(ids) + 1) if ids else (1, 1))
+    return out
+
+
+def register_box_tables(tables, host_tables, H, W):
+    """Called where the resize tables are built (NNConvUpsampling._tables): the range lists / maps / tile spans of the box-sum backward, from the HOST copies
+    (no device read-back, nothing that could land in a stream capture)."""
+    y_lo, y_hi, x_lo, x_hi = (host_tables[i].tolist() for i in (1, 2, 4, 5))
+    vr, vmap = _range_tables(y_lo, y_hi, H)
+    hr, hmap = _range_tables(x_lo, x_hi, W)
+    tr, tc = _tile_spans(vmap, 4), _tile_spans(hmap, 32)
+    dev = tables[1].device
+
+    def t(a):
+        return torch.tensor(a, dtype=torch.int32).reshape(-1).to(dev)
+    bt = dict(vr=t(vr), hr=t(hr), vmap=t(vmap), hmap=t(hmap), tile_rows=t(tr), tile_cols=t(tc), NVR=len(vr), NHR=len(hr),
+              max_rows4=max(n for _, n in tr), max_cols32=max(n for _, n in tc), H=H, W=W)
+    _BOX[id(tables)] = (tables, bt)
+    return bt
+
+
+def box_tables(tables, H, W):
+    """The box-sum tables of a resize-table tuple (registered by NNConvUpsampling._tables; tables built elsewhere are read back once, never during a
+    stream capture)."""
+    hit = _BOX.get(id(tables))
+    if hit is not None and hit[0] is tables and hit[1]['H'] == H and hit[1]['W'] == W:
+        return hit[1]
+    if tables[1].is_cuda and torch.cuda.is_current_stream_capturing():
+        raise _lib.SSNeuronError('box_tables: resize tables without registered box tables inside a stream capture')
+    return register_box_tables(tables, tuple(t.cpu() for t in tables), H, W)
+
+
+_BOX = {}
+BOX_BWD = _os.environ.get('SS_BOX_BWD', '1') == '1'   # decoder backward on the box-sum image: ss_upconv_boxsum_f32 + ss_upconv_box_dgrad_f32 + ss_upconv_box_wgrad_f32 (no g_P anywhere)
+BOX_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_BOX_BWD_CIN', '64,128,256,512').split(',') if c)
+
+
 class _UpConvProjectedCL(torch.autograd.Function):
     """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
     forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
@@ -681,7 +742,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _lib.head_proj_packed(x_packed, Wt, P, rows, Cin)
             _lib.upconv_cl_fwd(P, src_y, src_x, None if bias is None else bias.float(), out, NB, k, Cout, h, w, H, W)
             TIMER.stop(e0, 'upconv_cl_fwd', x_cl.numel() // 4 + 4 * out.numel(), out.numel())
-            ctx.save_for_backward(x_cl, Wt, x_packed)
+            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
             ctx.lowp, ctx.exact = False, False
             ctx.tables, ctx.k, ctx.n = tables, k, NB
             ctx.wshape = weight.shape
@@ -726,7 +787,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             e0 = TIMER.start()
             _lib.upconv_fused2_x16(x_cl, weight.contiguous(), src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
             TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-            ctx.save_for_backward(x_cl, Wt, None)
+            ctx.save_for_backward(x_cl, Wt, None, weight)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = not lowp
             ctx.tables, ctx.k, ctx.n = tables, k, n
@@ -741,7 +802,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout, form)
             _lib.upconv_fused_fwd(None if x_packed is not None else x_cl, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
             TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
-            ctx.save_for_backward(x_cl, Wt, x_packed)
+            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = True
             ctx.tables, ctx.k, ctx.n = tables, k, n
@@ -772,7 +833,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
             (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-        ctx.save_for_backward(xg, Wt, None)
+        ctx.save_for_backward(xg, Wt, None, weight)
         # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
         # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
         ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
@@ -785,7 +846,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g_out):
-        x_cl, Wt, x_packed = ctx.saved_tensors                   # x_packed: the packed-only head input (x_cl is then a data-less anchor)
+        x_cl, Wt, x_packed, weight = ctx.saved_tensors           # x_packed: the packed-only head input (x_cl is then a data-less anchor)
         k, n = ctx.k, ctx.n
         _, y_lo, y_hi, _, x_lo, x_hi = ctx.tables
         NB, h, w, Cin = x_cl.shape
@@ -799,6 +860,34 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # (anomaly detection scans every backward output for NaNs and would trip over the anchor: it gets the dense form)
         lowrank = (need_x and ctx.lowrank_grad and LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
                    and ctx.x_dtype == torch.float32 and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
+        # ---- round 4: the whole stage backward on the box-sum image (ss_upconv_box.hip): one HBM-bound box-sum launch, then both contractions as implicit
+        #      GEMMs over its three bf16 planes — no per-tap tensor g_P in HBM or on chip, no per-fragment operand arithmetic
+        box_ok = (BOX_BWD and k == 5 and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and n >= NB and not lowrank and Cin in BOX_BWD_CIN
+                  and (need_x or need_w) and (x_packed is not None or x_cl.dtype == torch.float32))
+        if box_ok:
+            bt = box_tables(ctx.tables, H, W)
+            box_ok = (not need_x or _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt)) and (not need_w or _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt))
+        if box_ok:
+            e0 = TIMER.start()                                                   # the stage's whole backward ('upconv_cl_bwd', as every other form) ...
+            e1 = TIMER.start()                                                   # ... and its three launches one by one ('box_*': inside the former, not additional)
+            box = _lib.upconv_boxsum(g_out, bt, NB, Cout, H, W)
+            TIMER.stop(e1, 'box_boxsum', 4 * g_out.numel() + 2 * box.numel(), g_out.numel())
+            g_x = g_w = None
+            wc = weight.detach().contiguous()
+            if need_x:
+                g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=g_out.device)
+                e1 = TIMER.start()
+                _lib.upconv_box_dgrad(box, wc, bt, g_x, NB, Cin, Cout, h, w)
+                TIMER.stop(e1, 'box_dgrad', 2 * box.numel() + 4 * g_x.numel(), g_x.numel())
+            if need_w:
+                g_w = torch.empty(wc.shape, dtype=torch.float32, device=g_out.device)
+                e1 = TIMER.start()
+                _lib.upconv_box_wgrad(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
+                TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()), g_out.numel())
+            TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
+            if g_x is not None and g_x.dtype != ctx.x_dtype:
+                g_x = g_x.to(ctx.x_dtype)
+            return g_x, g_w, None, None, None, None, None, None, None, None, None, None, None, None
         g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..clock_driven import neuron, surrogate
-from ..fused import nearest_tables, register_extents, upconv_projected, upconv_projected_cl
+from ..fused import nearest_tables, register_box_tables, register_extents, upconv_projected, upconv_projected_cl
 
 
 # The sequence fast path evaluates NNConvUpsampling through forward_projected (no up-sampled tensor).  Set to False to
@@ -86,6 +86,9 @@ class NNConvUpsampling(_UpConv):
             ty, tx = nearest_tables(h, Hu), nearest_tables(w, Wu)
             cache[key] = tuple(t.to(device) for t in (ty + tx))
             register_extents(cache[key], ty + tx)              # host-side, from the CPU copies: backward never reads a table back
+            k = self.up[1].kernel_size[0]
+            if k == 5:                                         # decoder stages: the index tables of the box-sum backward (ss_upconv_box.hip)
+                register_box_tables(cache[key], ty + tx, Hu - k + 1, Wu - k + 1)
         return cache[key]
 
     def forward_projected(self, x: torch.Tensor) -> torch.Tensor:

@@ -43,7 +43,10 @@ def test_header_declares_the_expected_entry_points():
                                   # ABI 6
                                   'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
                                   'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
-                                  'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32'])
+                                  'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
+                                  # ABI 7
+                                  'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats',
+                                  'ss_upconv_box_dgrad_f32', 'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -54,7 +57,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == _lib.ABI_VERSION == 6
+    assert L.ss_abi_version() == _lib.ABI_VERSION == 7
     assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
@@ -80,6 +83,14 @@ def test_argument_validation_without_a_gpu():
     assert L.ss_neuron_fwd_ex(ctypes.byref(d), None) == -22                                                # no buffers
     assert L.ss_unpack_spikes(None, None, 16, 0, 0, 1, None) == -22
     assert L.ss_im2col_cl_bf16_packed(None, None, 1, 4, 4, 8, 3, 1, 1, 4, 4, None) == -22
+    # ABI 7: the box-sum backward
+    assert L.ss_upconv_boxsum_f32(None, None, None, None, 1, 32, 8, 8, 4, 4, None) == -22
+    assert L.ss_upconv_box_dgrad_f32(None, None, None, None, None, None, None, None, 1, 64, 32, 4, 4, 4, 4, None) == -22
+    assert L.ss_upconv_box_wgrad_f32(None, None, None, None, None, None, None, None, None, 1, 64, 32, 4, 4, 4, 4, 0, None) == -22
+    assert L.ss_upconv_box_elems(2, 32, 10, 12) == 2 * 32 * 3 * 10 * 12 and L.ss_upconv_box_elems(2, 30, 10, 12) == 0
+    assert L.ss_upconv_box_dgrad_supported(64, 32, 5, 17, 74) == 1 and L.ss_upconv_box_dgrad_supported(64, 32, 5, 18, 74) == 0
+    assert L.ss_upconv_box_dgrad_supported(96, 32, 5, 12, 70) == 0 and L.ss_upconv_box_wgrad_supported(96, 40, 5, 12, 70) == 1
+    assert L.ss_upconv_box_dgrad_ws_floats(64, 32) == 1 * 4 * 13 * 6144 // 4
 
 
 def test_product_fails_loudly_on_cpu_tensors():

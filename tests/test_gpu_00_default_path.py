@@ -128,7 +128,7 @@ def test_pinned_parity_penalize_spikes_T5(name):
     # negative control — the penalty really is in the loss and in the gradients: the same run without it gives a visibly smaller loss and
     # weight gradients that differ by far more than the parity bar
     rep0 = pinned_parity(orc, net, x, gt)
-    assert rep['loss'][0] - rep0['loss'][0] > 1e-3 * abs(rep0['loss'][0]), (rep['loss'], rep0['loss'])
+    assert rep['loss'][0] - rep0['loss'][0] > 0.2, (rep['loss'], rep0['loss'])      # beta / 2 * sum of five mean(s^2): O(1) at these densities
     moved = {k: rel_l2(g_pen[k], p.grad) for k, p in net.named_parameters()}
     assert moved['deconv1.0.up.1.weight'] > 100 * TENSOR_GRAD_BAR and moved['bottleneck.1.conv2.0.weight'] > 100 * TENSOR_GRAD_BAR, moved
 

@@ -1623,3 +1623,91 @@ def test_dense_conv_s1_fwd_mfma(NB, Cin, hw):
         y2 = torch.empty_like(y)
         _lib.dense_conv_s1_fwd(x, wt, y2, NB, Cin, 32, h, w)
         assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 1), (128, 64, (65, 87), (130, 173), 2), (256, 128, (33, 44), (65, 87), 2),
+                                                (512, 256, (17, 22), (33, 44), 2), (64, 32, (32, 40), (64, 80), 3), (128, 64, (16, 20), (32, 40), 2),
+                                                (64, 64, (13, 18), (25, 35), 3), (64, 32, (4, 5), (8, 10), 2), (64, 32, (9, 11), (17, 19), 1)])
+def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
+    """The decoder's backward on the box-sum image (ss_upconv_box.hip, round 4) against oracle/np_upconv_box.py (pinned on the CPU to ss_ref_upconv_cl_bwd_f32
+    bit for bit and to torch's autograd through UpsamplingNearest2d -> Conv2d: tests/test_oracle.py):
+      ss_upconv_boxsum_f32    the three bf16 planes BIT-EQUAL to the oracle's (same rectangles, same summation order, same round-to-nearest split);
+      ss_upconv_box_dgrad_f32 |g_x - float64| <= 2^-21 sum |B| |W| element-wise (six cross terms), every element written, no coherent drift, bit-reproducible;
+      ss_upconv_box_wgrad_f32 |g_w - float64| <= 2^-22 sum |x| |B| element-wise (exact products), accumulate mode, 2-bit packed input == dense input bit
+                              for bit, bit-reproducible —
+    on the four decoder geometries of the 260x346 pyramid, the 64x80 pyramid of the parity tests, odd sizes with triple-replicated rows / columns, ragged
+    tiles, a map smaller than a tile; a resize ratio the on-chip window does not hold is refused by *_supported (the caller then keeps the g_P forms)."""
+    from oracle import np_upconv_box as nbx
+    from stereospike_amd import _lib, fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    (h, w), (H, W) = hw, HW
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
+    tables = up._tables(h, w, torch.device(DEV))
+    bt = fused.box_tables(tables, H, W)
+    vr, vmap = nbx.range_tables(tables[1].cpu().numpy(), tables[2].cpu().numpy(), H)
+    hr, hmap = nbx.range_tables(tables[4].cpu().numpy(), tables[5].cpu().numpy(), W)
+    assert np.array_equal(bt['vr'].cpu().numpy().reshape(-1, 2), vr) and np.array_equal(bt['hmap'].cpu().numpy().reshape(-1, 5), hmap)
+    assert np.array_equal(bt['hr'].cpu().numpy().reshape(-1, 2), hr) and np.array_equal(bt['vmap'].cpu().numpy().reshape(-1, 5), vmap)
+    if hw == (9, 11):      # up-sampling ratio 2.33 -> 17 x 19: more distinct ranges per 4 rows than the window holds
+        assert not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt) or bt['max_rows4'] <= 17
+    if not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt):
+        assert bt['max_rows4'] > 17 or bt['max_cols32'] > 74, bt
+        return
+    assert _lib.upconv_box_wgrad_supported(Cin, Cout, 5, bt) and not _lib.upconv_box_dgrad_supported(Cin, Cout, 3, bt)
+    gen = torch.Generator(device=DEV).manual_seed(23 + Cin + h)
+    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen) * torch.exp(2.0 * torch.randn(NB, H, W, 1, device=DEV, generator=gen))
+    g[:, : H // 5] = 0
+    weight = up.up[1].weight.detach().contiguous()
+    # ---- K1
+    box = _lib.upconv_boxsum(g, bt, NB, Cout, H, W)
+    B = nbx.boxsum(g.cpu().numpy(), vr, hr)
+    want = nbx.box_planes(B, 8)
+    got = box.cpu().numpy().view(np.uint16)
+    assert got.shape == want.shape and np.array_equal(got, want), int((got != want).sum())
+    # ---- K2
+    B64 = torch.tensor(B, dtype=torch.float64, device=DEV)
+    vm, hm = torch.tensor(vmap, device=DEV, dtype=torch.long), torch.tensor(hmap, device=DEV, dtype=torch.long)
+    w64 = weight.double()
+    ref = torch.zeros(NB, h, w, Cin, dtype=torch.float64, device=DEV)
+    mag = torch.zeros_like(ref)
+    for ky in range(5):
+        for kx in range(5):
+            gp = B64[:, vm[:, ky]][:, :, hm[:, kx]]
+            ref += gp @ w64[:, :, ky, kx]
+            mag += gp.abs() @ w64[:, :, ky, kx].abs()
+    g_x = torch.full((NB, h, w, Cin), float('nan'), device=DEV)
+    _lib.upconv_box_dgrad(box, weight, bt, g_x, NB, Cin, Cout, h, w)
+    err = (g_x.double() - ref).abs()
+    bound = mag * 2.0 ** -21 + 1e-30
+    assert bool(torch.isfinite(g_x).all()) and bool((err <= bound).all()), float((err / bound).max())
+    if g_x.numel() >= 50000:
+        assert abs(float(((g_x.double() - ref) / bound).mean())) * 2.0 ** -21 <= 1e-9          # no coherent drift (alternating accumulator sign)
+    g_x2 = torch.empty_like(g_x)
+    _lib.upconv_box_dgrad(box, weight, bt, g_x2, NB, Cin, Cout, h, w)
+    assert torch.equal(g_x, g_x2)
+    # ---- K3
+    x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float()
+         + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.02).float())
+    x64 = x.double().reshape(-1, Cin)
+    refw = torch.zeros(Cout, Cin, 5, 5, dtype=torch.float64, device=DEV)
+    magw = torch.zeros_like(refw)
+    for ky in range(5):
+        for kx in range(5):
+            gp = B64[:, vm[:, ky]][:, :, hm[:, kx]].reshape(-1, Cout)
+            refw[:, :, ky, kx] = gp.t() @ x64
+            magw[:, :, ky, kx] = gp.abs().t() @ x64
+    g_w = torch.full((Cout, Cin, 5, 5), float('nan'), device=DEV)
+    _lib.upconv_box_wgrad(box, x, None, bt, g_w, NB, Cin, Cout, h, w)
+    errw = (g_w.double() - refw).abs()
+    boundw = magw * 2.0 ** -22 + 1e-30
+    assert bool(torch.isfinite(g_w).all()) and bool((errw <= boundw).all()), float((errw / boundw).max())
+    g_w2 = g_w.clone()
+    _lib.upconv_box_wgrad(box, x, None, bt, g_w2, NB, Cin, Cout, h, w, accumulate=True)
+    assert torch.equal(g_w2, g_w + g_w)
+    if x.numel() % 16 == 0:
+        xp = torch.empty(x.numel() // 16, dtype=torch.int32, device=DEV)
+        from oracle import np_pack
+        xp.copy_(torch.from_numpy(np_pack.pack(x.cpu().numpy().reshape(1, -1)).view(np.int32).reshape(-1)))
+        g_w3 = torch.empty_like(g_w)
+        _lib.upconv_box_wgrad(box, None, xp, bt, g_w3, NB, Cin, Cout, h, w)
+        assert torch.equal(g_w3, g_w)

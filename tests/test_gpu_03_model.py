@@ -284,12 +284,11 @@ def test_dp_reducer_on_rccl_single_rank():
             results.append((losses, [p.detach().clone() for p in net.parameters()], None if red is None else len(red.buckets)))
         (l0, p0, _), (l1, p1, nb) = results
         assert nb > 1
-        # MIOpen's weight-gradient kernels use atomic split-K (run-to-run differences of ~1e-7 in the gradients), and the
-        # network amplifies them over steps, so equality is asked of the first step and closeness of the second / the weights
-        assert l0[0] == l1[0], (l0, l1)
-        assert abs(l0[1] - l1[1]) <= 1e-3 * abs(l0[1]), (l0, l1)
+        # the default fp32 step calls MIOpen nowhere and every own kernel / library GEMM in it is deterministic (three same-seed runs are bit-identical:
+        # profiles/r04/determinism.log), and with one rank the all-reduce of x / 1 is the identity: the DP path must give the SAME BITS as the plain path
+        assert l0 == l1, (l0, l1)
         for a, b in zip(p0, p1):
-            assert torch.allclose(a, b, rtol=0, atol=1e-3), float((a - b).abs().max())
+            assert torch.equal(a, b), float((a - b).abs().max())
     finally:
         dist.destroy_process_group()
 

@@ -327,3 +327,49 @@ def test_conv_s2_dgrad_oracle_matches_autograd(NB, Cin, hw):
     (gx,) = torch.autograd.grad(y, x, torch.from_numpy(g).permute(0, 3, 1, 2))
     assert np.abs(got - gx.permute(0, 2, 3, 1).numpy()).max() <= 1e-12
     assert sum(len(v) for v in np_conv_dgrad.CLASS_TAPS.values()) == 25 and sorted(len(v) for v in np_conv_dgrad.CLASS_TAPS.values()) == [4, 6, 6, 9]
+
+
+@pytest.mark.parametrize('NB,Cin,Cout,hw,up', [(2, 8, 8, (17, 22), (33, 44)), (1, 8, 16, (5, 7), (9, 13)), (2, 4, 8, (3, 3), (8, 5)), (1, 8, 8, (1, 6), (2, 11)),
+                                               (1, 4, 8, (9, 11), (9, 11))])
+def test_upconv_box_oracle_matches_the_adjoint_oracle_and_autograd(NB, Cin, Cout, hw, up):
+    """oracle/np_upconv_box.py (the box-sum form of the decoder's backward the round-4 kernels evaluate) pinned on the CPU:
+      (1) g_P gathered from the box-sum image B == ss_ref_upconv_cl_bwd_f32's g_P BIT FOR BIT (same rectangles, same summation order), on the pyramid's
+          own geometries incl. triple-replicated rows / columns, resize factors != 2, a source map of one row, and the identity resize;
+      (2) data and weight gradient through B == torch's autograd through the reference's two-op form nn.UpsamplingNearest2d -> nn.Conv2d
+          (/root/reference/network/blocks.py:124-132) in float64;
+      (3) the three bf16 planes sum back to B exactly, and the range tables are consistent (id 0 empty, maps inside the lists)."""
+    from oracle import np_upconv_box as nb
+    from stereospike_amd.fused import nearest_tables
+    h, w = hw
+    H, W = up
+    k = 5
+    rng = np.random.default_rng(h * 100 + W)
+    ty, tx = nearest_tables(h, H + k - 1), nearest_tables(w, W + k - 1)
+    y_lo, y_hi, x_lo, x_hi = (t.numpy() for t in (ty[1], ty[2], tx[1], tx[2]))
+    g = (rng.standard_normal((NB, H, W, Cout)) * np.exp(rng.uniform(-3, 3, (NB, H, W, 1)))).astype(np.float32)
+    vr, vmap = nb.range_tables(y_lo, y_hi, H, k)
+    hr, hmap = nb.range_tables(x_lo, x_hi, W, k)
+    assert tuple(vr[0]) == (0, 0) and tuple(hr[0]) == (0, 0) and vmap.max() < len(vr) and hmap.max() < len(hr)
+    assert len(vr) <= H + 2 * k + 3 * h and (np.diff(vr[1:, 0]) >= 0).all()
+    B = nb.boxsum(g, vr, hr)
+    gP = nb.g_P_from_box(B, vmap, hmap)                                                       # [NB, h, w, 25, Cout]
+    ref = c_oracle.upconv_cl_bwd(g, y_lo, y_hi, x_lo, x_hi, k).reshape(NB, h, w, k * k, Cout)
+    assert bit_equal(gP, ref)
+    hp, mp, lp = nb.split3_rn(B)
+    assert np.array_equal((nb.bf16_to_f32(hp).astype(np.float64) + nb.bf16_to_f32(mp) + nb.bf16_to_f32(lp)).astype(np.float32), B)
+    pl = nb.box_planes(B, 8)
+    assert pl.shape == (NB, Cout // 8, 3, len(vr), len(hr), 8) and np.array_equal(pl[:, Cout // 8 - 1, 2, :, :, 3], lp[..., Cout - 8 + 3])
+    # (2) autograd of the two-op form, float64
+    x = rng.integers(0, 3, (NB, h, w, Cin)).astype(np.float64)
+    wt = rng.standard_normal((Cout, Cin, k, k)) * 0.1
+    xt = torch.tensor(x).permute(0, 3, 1, 2).requires_grad_()
+    wtt = torch.tensor(wt).requires_grad_()
+    y = torch.nn.functional.conv2d(torch.nn.UpsamplingNearest2d(size=(H + k - 1, W + k - 1))(xt), wtt)
+    assert tuple(y.shape) == (NB, Cout, H, W)
+    gx_ref, gw_ref = torch.autograd.grad(y, (xt, wtt), torch.tensor(g.astype(np.float64)).permute(0, 3, 1, 2))
+    B64 = nb.boxsum(g, vr, hr).astype(np.float64)
+    gx = nb.dgrad_from_box(B64, wt, vmap, hmap)
+    gw = nb.wgrad_from_box(B64, x, vmap, hmap)
+    mag = nb.dgrad_magnitude(B64, wt, vmap, hmap)
+    assert np.abs(gx - gx_ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-6 * mag.max()         # B itself is an fp32 sum of <= 9 terms
+    assert np.abs(gw - gw_ref.numpy()).max() <= 1e-6 * np.abs(gw_ref.numpy()).max()

@@ -45,9 +45,24 @@ for name, Cin, Cout, (h, w), (H, W) in geoms:
         cases['adjoint + wgrad fused, NO g_P'] = lambda: _lib.upconv_bwd_fused(g, x, *t, None, gw_b, NB, Cin, Cout, h, w, H, W)
     if _lib.upconv_bwd_dgrad_supported(Cin, Cout, 5, ext):
         cases['adjoint + dgrad fused, NO g_P'] = lambda: _lib.upconv_bwd_dgrad(g, wt, *t, gx_b, NB, Cin, Cout, h, w, H, W)
+    # round 4: the box-sum form (ss_upconv_box.hip)
+    bt = fused.box_tables(tabs, H, W)
+    if _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt) and _lib.upconv_box_wgrad_supported(Cin, Cout, 5, bt):
+        box = _lib.upconv_boxsum(g, bt, NB, Cout, H, W)
+        gx_c, gw_c = torch.empty(NB, h, w, Cin, device=dev), torch.empty(Cout, Cin, 5, 5, device=dev)
+        cases['box: box-sum planes (HBM)'] = lambda: _lib.upconv_boxsum(g, bt, NB, Cout, H, W)
+        cases['box: dgrad on the planes'] = lambda: _lib.upconv_box_dgrad(box, wt, bt, gx_c, NB, Cin, Cout, h, w)
+        cases['box: wgrad on the planes'] = lambda: _lib.upconv_box_wgrad(box, x, None, bt, gw_c, NB, Cin, Cout, h, w)
     for f in cases.values():
         f()
     torch.cuda.synchronize()
+    if 'box: dgrad on the planes' in cases:
+        cases['dgrad: fp32 GEMM on g_P']()
+        if 'wgrad: spike_wgrad on g_P' in cases:
+            cases['wgrad: spike_wgrad on g_P']()
+        torch.cuda.synchronize()
+        print(name, 'box dgrad vs fp32 GEMM on g_P: max |diff| / max', float((gx_a - gx_c).abs().max() / gx_a.abs().max()),
+              ' box wgrad vs spike_wgrad:', float((gw_a.view(Cin, 5, 5, Cout).permute(3, 0, 1, 2) - gw_c).abs().max() / gw_c.abs().max()), flush=True)
     if 'adjoint + dgrad fused, NO g_P' in cases:
         cases['dgrad: fp32 GEMM on g_P']()
         torch.cuda.synchronize()
@@ -67,5 +82,8 @@ for name, Cin, Cout, (h, w), (H, W) in geoms:
     print(f'{name}: C_in {Cin} C_out {Cout} rows {R}  g_P {4 * R * N / 1e9:.2f} GB  stage I/O {io / 1e9:.2f} GB  MACs per contraction {macs / 1e9:.1f} G', flush=True)
     for k, ms in best.items():
         terms = 6 if 'dgrad' in k else (3 if 'wgrad' in k else 0)
+        if 'box-sum planes' in k:
+            print(f'   {k:36s} {ms:7.3f} ms  {(4 * g.numel() + 6 * NB * Cout * bt["NVR"] * bt["NHR"]) / ms / 1e6:7.1f} GB/s (g_y read + planes written)', flush=True)
+            continue
         extra = f'  {2 * terms * macs / ms / 1e9:7.1f} TFLOP/s bf16 ({2 * terms * macs / ms / 1e9 / 2500:.3f} of MFMA peak)' if terms and 'fp32' not in k else ''
         print(f'   {k:36s} {ms:7.3f} ms{extra}', flush=True)
