@@ -111,21 +111,22 @@ def parse():
     ap.add_argument('--fused-form', type=int, default=2, choices=[1, 2], help='kernel form of the fused up-conv: 2 (default) wavefront-specialised persistent workgroups, 1 the first form (A/B)')
     ap.add_argument('--fused-mfma', type=int, default=1, help='1 (default): deconv1 / deconv2 forward as ONE hand-written MFMA kernel (projection + gather, P only in LDS); 0: GEMM + gather kernel')
     ap.add_argument('--pack-spikes', type=int, default=1, help='1 (default): 2-bit packed spike tensors on the edges whose consumers read them')
+    ap.add_argument('--box-bwd', type=int, default=1, help='1 (default): decoder backward on the box-sum image (ss_upconv_box.hip); 0: the g_P forms of rounds 2 - 3 (A/B)')
     ap.add_argument('--fuse-upconv', type=int, default=1,
                     help='1: NN-upsample+conv as low-res projection + fused gather kernel; 0: two-op form on MIOpen')
     return ap.parse_args()
 
 
-def build_net(model, device):
+def build_net(model, device, config=None):
     from stereospike_amd.clock_driven import surrogate
     from stereospike_amd.network import SNN_models as S
     torch.manual_seed(2021)                                   # train.py:53
     if model == 'StereoSpike':
         net = S.StereoSpike(surrogate_function=surrogate.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
-                            multiply_factor=10.)              # gain 10 so neurons fire
+                            multiply_factor=10., config=config)   # gain 10 so neurons fire
     else:
         net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., v_threshold=1.0, v_reset=0.0,
-                                                                             use_plif=True, multiply_factor=30.)
+                                                                             use_plif=True, multiply_factor=30., config=config)
     return net.to(device)
 
 
@@ -226,26 +227,22 @@ def main():
     from stereospike_amd.fused import TIMER
     _lib.lib()                                                # fail loudly here if the HIP library is missing
 
-    from stereospike_amd.network import blocks as _blocks
-    _blocks.FUSE_UPCONV = bool(a.fuse_upconv)
-    _blocks.FORK_OUTPUTS = bool(a.fork_outputs)
-    from stereospike_amd import fused as _fused_cfg
-    _fused_cfg.RECOMPUTE_H = bool(a.recompute_h)
-    _fused_cfg.EXACT_SPLIT_GEMM = bool(a.exact_split)
-    _fused_cfg.FUSED_UPCONV_MFMA = bool(a.fused_mfma)
-    _fused_cfg.FUSED_UPCONV_FORM = int(a.fused_form)
-    _fused_cfg.PACK_SPIKES = bool(a.pack_spikes)
+    # the engine configuration of this run: the shipped default (config.EngineConfig.default(): SS_* variables seed it) with the command line's A/B
+    # switches applied — handed to the network, which owns it; nothing global is mutated
+    from stereospike_amd.config import EngineConfig
+    ov = dict(FUSE_UPCONV=bool(a.fuse_upconv), FORK_OUTPUTS=bool(a.fork_outputs), RECOMPUTE_H=bool(a.recompute_h), EXACT_SPLIT_GEMM=bool(a.exact_split),
+              FUSED_UPCONV_MFMA=bool(a.fused_mfma), FUSED_UPCONV_FORM=int(a.fused_form), PACK_SPIKES=bool(a.pack_spikes),
+              DECODER_CHANNELS_LAST=bool(a.decoder_nhwc), ENCODER_CHANNELS_LAST=bool(a.encoder_nhwc), BOX_BWD=bool(a.box_bwd))
     if a.split_wgrad_min_k is not None:
-        _fused_cfg.EXACT_SPLIT_WGRAD_MIN_K = a.split_wgrad_min_k
+        ov['EXACT_SPLIT_WGRAD_MIN_K'] = a.split_wgrad_min_k
     if a.spike_wgrad_split is not None:
-        _fused_cfg.SPIKE_CONV_WGRAD_SPLIT = a.spike_wgrad_split
+        ov['SPIKE_CONV_WGRAD_SPLIT'] = a.spike_wgrad_split
     if a.spike_conv_min_cin is not None:
-        _fused_cfg.SPIKE_CONV_MIN_CIN = a.spike_conv_min_cin
+        ov['SPIKE_CONV_MIN_CIN'] = a.spike_conv_min_cin
     if a.wgrad_split_rows:
-        _fused_cfg.WGRAD_SPLIT_ROWS = a.wgrad_split_rows
-    _blocks.DECODER_CHANNELS_LAST = bool(a.decoder_nhwc)
-    _blocks.ENCODER_CHANNELS_LAST = bool(a.encoder_nhwc)
-    net = build_net(a.model, dev)
+        ov['WGRAD_SPLIT_ROWS'] = a.wgrad_split_rows
+    engine_cfg = EngineConfig.default().replace(**ov)
+    net = build_net(a.model, dev, engine_cfg)
     if a.channels_last:
         net = net.to(memory_format=torch.channels_last)
     reducer = GradientAllReducer(net, bucket_bytes=int(a.bucket_mb * (1 << 20)), reduce_single_rank=a.force_dp) if use_dp else None
@@ -350,8 +347,8 @@ def main():
 
         def bpu(d):
             return round(d['bytes'] / d['updates'], 1) if d['updates'] else 0
-        recompute_h = bool(_fused.RECOMPUTE_H)
-        packed_on = bool(_fused.PACK_SPIKES) and a.dtype == 'f32' and recompute_h      # the PK instantiations run (2-bit packed outputs / skips)
+        recompute_h = bool(engine_cfg.RECOMPUTE_H)
+        packed_on = bool(engine_cfg.PACK_SPIKES) and a.dtype == 'f32' and recompute_h      # the PK instantiations run (2-bit packed outputs / skips)
         out = {
             'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if use_dp else 1, 'steps': a.steps, 'warmup': a.warmup,
@@ -409,8 +406,10 @@ def main():
             # the up-conv stages one by one (projection GEMM + gather, resp. adjoint + dgrad / wgrad GEMMs), keyed by output elements
             'upconv_by_stage_ms_per_step': {f'{k[0]}:{k[1]}': round(v['ms'] / leg_steps, 3) for k, v in sorted(shapes.items(), key=lambda kv: -kv[0][1])
                                             if k[0].startswith('upconv')},
-            'roofline_upconv': _roof_upconv(shapes, a),
-            'roofline_upconv_bwd': _roof_upconv_bwd(shapes, a),
+            'roofline_upconv': _roof_upconv(shapes, a, engine_cfg),
+            'roofline_upconv_bwd': _roof_upconv_bwd(shapes, a, engine_cfg),
+            # which kernel form every layer ran, per direction, as recorded at the dispatch sites (net.plan())
+            'plan': net.plan(),
             'peak_mem_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             'final_loss': round(float(loss), 5), 'train_mde_m': round(float(MeanDepthError(pred, gt)), 5),
         }
@@ -433,7 +432,7 @@ def main():
             # eval MDE of the product on the same weights (fresh seed-2021 net) and the same B = 1 input as the CPU port
             from stereospike_amd.clock_driven import functional as _F
             from stereospike_amd.engine import synthetic_batch as _sb
-            net0 = build_net(a.model, dev)
+            net0 = build_net(a.model, dev, engine_cfg)
             x0, gt0 = _sb(1, a.T, seed=2021, device=dev)
             with torch.no_grad():
                 _F.reset_net(net0)
@@ -474,7 +473,7 @@ def main():
         print(line, flush=True)
 
 
-def _roof_upconv(shapes, a):
+def _roof_upconv(shapes, a, cfg):
     """The hand-written MFMA kernel of the decoder (ss_upconv_fused_fwd_f32: projection + gather of deconv1, the largest stage) on the
     HBM roofline by its algorithmic bytes (input spikes + output + weights; P never leaves LDS) and on the bf16 MFMA roofline by the
     useful FLOPs of the minimal projection (3 exact bf16 terms); HIP-event time of its launches in the timed region (incl. the tiny
@@ -494,8 +493,7 @@ def _roof_upconv(shapes, a):
     nbytes = 4 * (src_px * cin + out_elems) + 2 * 3 * 25 * cin * cout
     flops = 2.0 * src_px * cin * 25 * cout * 3
     us = 1e3 * d['ms'] / d['launches']
-    from stereospike_amd import fused as _fused
-    form2 = getattr(_fused, 'FUSED_UPCONV_FORM', 1) == 2
+    form2 = cfg.FUSED_UPCONV_FORM == 2
     return dict(kernel=('upconv_fused2_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only; wavefront-specialised '
                         'persistent form)') if form2 else
                        'upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
@@ -509,7 +507,7 @@ def _roof_upconv(shapes, a):
                 fused=bool(a.fused_mfma))
 
 
-def _roof_upconv_bwd(shapes, a):
+def _roof_upconv_bwd(shapes, a, cfg):
     """The decoder backward of deconv1 (the largest stage; /root/reference/network/blocks.py:110-132 under autograd): every launch between the
     stage's incoming gradient and its two outgoing ones (weight preparation, adjoint + data gradient, adjoint + weight gradient, split-K
     reduce), timed with HIP events as one group.  HBM roofline by the stage's algorithmic bytes — g_y + x + g_x + weights, the per-tap tensor
@@ -528,16 +526,18 @@ def _roof_upconv_bwd(shapes, a):
     macs = src_px * cin * 25 * cout
     flops = 2.0 * macs * (6 + 3)
     us = 1e3 * d['ms'] / d['launches']
-    from stereospike_amd import fused as _fused
-    on_chip = bool(_fused.FUSED_UPCONV_DGRAD) and cin in _fused.FUSED_UPCONV_DGRAD_CIN
-    return dict(kernel=('upconv_bwd_dgrad_kernel<32> + upconv_bwd_fused_kernel<64, 32> (deconv1 backward: adjoint gather + data gradient, adjoint gather + '
+    box = bool(cfg.BOX_BWD) and cin in cfg.BOX_BWD_CIN
+    on_chip = bool(cfg.FUSED_UPCONV_DGRAD) and cin in cfg.FUSED_UPCONV_DGRAD_CIN
+    return dict(kernel=('upconv_boxsum_kernel + upconv_box_dgrad_kernel<32> + upconv_box_wgrad_kernel<2> (deconv1 backward on the box-sum image: one HBM-bound '
+                        'box-sum launch, then both contractions as implicit GEMMs over its three bf16 planes; no g_P)') if box else
+                       ('upconv_bwd_dgrad_kernel<32> + upconv_bwd_fused_kernel<64, 32> (deconv1 backward: adjoint gather + data gradient, adjoint gather + '
                         'weight gradient; g_P on chip only)') if on_chip else
                        'upconv_bwd_fused_kernel<64, 32> + fp32 GEMM (deconv1 backward: adjoint + weight gradient fused, g_P written once, read by the data-gradient GEMM)',
                 bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
                 avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=None,
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
                           note='6 bf16 cross terms per MAC (dense x dense data gradient) + 3 exact terms per MAC (spike x dense weight gradient)'),
-                g_P_in_hbm=not on_chip)
+                g_P_in_hbm=not (on_chip or box))
 
 
 def _pmc_traffic(which='neuron_fwd'):

@@ -349,7 +349,7 @@ int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* 
  *                           ss_upconv_box_elems(NB, C_out, NVR, NHR) elements.  vr [NVR][2], hr [NHR][2]: (start, length) of the distinct vertical /
  *                           horizontal output ranges, id 0 = the empty range.
  *   ss_upconv_box_dgrad_f32 g_x[nb][iy][ix][ci] = sum_{ky,kx,co} B[nb][vmap[iy][ky]][hmap[ix][kx]][co] * weight[co][ci][ky][kx]: six bf16 cross terms on the
- *                           matrix cores, |g_x - float64| <= 2^-21 sum |B| |W| element-wise.  vmap [h][5], hmap [w][5]: range ids; tile_rows [ceil(h / 4)][2],
+ *                           matrix cores, |g_x - float64| <= 2^-20 sum |B| |W| element-wise (2^-21 typical: ss_gemm6_f32's accuracy).  vmap [h][5], hmap [w][5]: range ids; tile_rows [ceil(h / 4)][2],
  *                           tile_cols [ceil(w / 32)][2]: (first id, id count) of the non-empty ranges 4 consecutive source rows / 32 consecutive source
  *                           columns reach; ws: ss_upconv_box_dgrad_ws_floats(C_in, C_out) floats.
  *   ss_upconv_box_wgrad_f32 g_w[co][ci][ky][kx] (+)= sum_{nb,iy,ix} x[nb][iy][ix][ci] * B[nb][vmap[iy][ky]][hmap[ix][kx]][co]: x a spike tensor (values exact

@@ -16,6 +16,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .config import current as _cfg, guard_module as _guard_module, note as _note, site as _site
 
 
 @dataclass(frozen=True)
@@ -75,14 +76,12 @@ TIMER = KernelTimer()
 # recomputes h inside the backward kernel: the forward launch writes 8 instead of 12 B/update, the backward reads the same 12.
 # With 16-bit activations: 4 instead of 8 B/update forward, 6 instead of 8 backward.  Applies to the compile-time time-step counts
 # (ss_neuron_bwd_rc_supported); any other T saves h.
-RECOMPUTE_H = True
 
 
 # 2-bit packed spike tensors on the edges whose consumers can read them: the im2col of the exact-split convs
 # (conv3, conv4, the bottleneck) and the skip / SEW-identity operand of a neuron launch.  A layer whose consumers are all of that kind
 # writes NO dense output (forward 4.25 instead of 8 B/update); its autograd output is then a zero-strided "anchor" of the logical shape
 # (4 bytes of storage) that only carries the graph edge — the data travels in the packed tensor next to it.
-PACK_SPIKES = True
 
 
 def spike_anchor(shape, dtype, device):
@@ -108,7 +107,6 @@ def unpack_dense(packed, shape, dtype=torch.float32):
 # layout alone (all strides 0, offset 0, storage longer than the 4-element header — an ordinary expanded scalar gradient has a 1-element
 # storage) and checks that the storage length is the one its own shape implies; a mismatch RAISES.  A consumer that knows nothing about pairs
 # and materialises the view sees NaNs everywhere.
-LOWRANK_HEAD_GRAD = _os.environ.get('SS_LOWRANK_HEAD_GRAD', '1') == '1'
 _LR_HDR = 4                                  # floats before g_P (keeps g_P and W2 16-byte aligned)
 _LR_RANK = 9
 
@@ -174,6 +172,7 @@ def lowrank_dense(lr, shape):
 class _FusedNeuron(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False, pack=0, skip_packed=None):
+        ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         """pack: 0 dense output; 1 dense + packed; 2 packed only (the returned out_seq is an anchor).  skip_packed: the skip operand as a
         packed tensor (skip_seq then only carries the autograd edge and may be an anchor)."""
         T = x_seq.shape[0]
@@ -183,7 +182,7 @@ class _FusedNeuron(torch.autograd.Function):
             v_init = v_init.contiguous()
         need_grad = any(ctx.needs_input_grad[:4])
         half = x_seq.dtype in (torch.float16, torch.bfloat16)       # 16-bit activations, fp32 membrane (configs 2 / 5)
-        recompute = need_grad and RECOMPUTE_H and _lib.neuron_bwd_rc_supported(T)
+        recompute = need_grad and _cfg().RECOMPUTE_H and _lib.neuron_bwd_rc_supported(T)
         # the packed kernel form: fp32 activations, compile-time T, whole words, no saved h
         can_pk = (not half) and N % 16 == 0 and _lib.neuron_bwd_rc_supported(T) and (recompute or not need_grad)
         if skip_packed is not None and not can_pk:
@@ -216,9 +215,10 @@ class _FusedNeuron(torch.autograd.Function):
         es = 2 if half else 4
         per = es * (1 + (0 if pack == 2 else 1)) + (0.25 if pack else 0) + (0.25 if skip_packed is not None else (es if skip_seq is not None else 0)) \
             + (4 if h_seq is not None else 0)
-        TIMER.stop(e0, ('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else '')
-                   + ('+h' if h_seq is not None else ''),      # '+h': the saved-h form (run-time T / RECOMPUTE_H off), never the benchmarked kernels
-                   int(per * T * N), T * N)
+        tag = (('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else '')
+               + ('+h' if h_seq is not None else ''))            # '+h': the saved-h form (run-time T / RECOMPUTE_H off), never the benchmarked kernels
+        TIMER.stop(e0, tag, int(per * T * N), T * N)
+        _note('neuron_fwd', tag + ('+x16' if half else ''))
         ctx.cfg = cfg
         ctx.T, ctx.N = T, N
         ctx.has_vinit = v_init is not None
@@ -284,7 +284,9 @@ class _FusedNeuron(torch.autograd.Function):
             _lib.neuron_bwd_fork_lr(g_out_seq, lr[0], lr[1], g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                                     T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
             per = 8 + 4 * lr[1].shape[0] / lr[1].shape[1] + (4 if g_out_seq is not None else 0) + (4 if g_sum is not None else 0)
-            TIMER.stop(e0, 'neuron_bwd+lr' + ('+sum' if g_sum is not None else '') if g_out_seq is not None else 'neuron_bwd+lronly', int(per * T * N), T * N)
+            tag = 'neuron_bwd+lr' + ('+sum' if g_sum is not None else '') if g_out_seq is not None else 'neuron_bwd+lronly'
+            TIMER.stop(e0, tag, int(per * T * N), T * N)
+            _note('neuron_bwd', tag, ctx.site)
             # dL/dskip: the dense sum when there was a dense first gradient, else the low-rank pair itself travels on (identity)
             g_skip = (g_sum if g_out_seq is not None else lr_anchor.view(h_seq.shape)) if want_gskip else None
             return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
@@ -301,7 +303,9 @@ class _FusedNeuron(torch.autograd.Function):
                 bwd = _lib.neuron_bwd_x16 if half else _lib.neuron_bwd
             bwd(g_out_seq, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                 T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-        TIMER.stop(e0, (('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd') + ('' if ctx.recompute else '+savedh'), (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
+        tag = (('neuron_bwd+fork+sum' if g_sum is not None else 'neuron_bwd+fork') if fuse2 else 'neuron_bwd') + ('' if ctx.recompute else '+savedh')
+        TIMER.stop(e0, tag, (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
+        _note('neuron_bwd', tag + ('+x16' if half else ''), ctx.site)
         g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
         return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
 
@@ -424,9 +428,6 @@ def nearest_tables(in_size: int, out_size: int):
 #   'auto'    : 'chunked' when a chunk holds >= 4 frames (small maps: deconv4, deconv3, the heads — few, large GEMMs),
 #               otherwise 'conv' (deconv2, deconv1: per-frame GEMMs with K = C_in <= 128 are launch/latency-bound;
 #               measured on MI355X, profiles/r01/upconv_variants.log)
-PROJECTION_IMPL = 'auto'
-P_CHUNK_BYTES = 96 << 20          # per-chunk size of P: comfortably inside the 256 MiB MALL next to x / out / g_out
-P_MAX_BYTES_CL = 16 << 30         # NHWC path: ONE GEMM over the whole batch unless P would exceed this (then the largest chunks that fit)
 
 
 class _UpConv1(torch.autograd.Function):
@@ -477,7 +478,7 @@ class _UpConvProjected(torch.autograd.Function):
         W2 = weight.permute(0, 2, 3, 1).reshape(Cout * kk, Cin).contiguous()        # rows ordered (co, ky, kx)
         src_y, _, _, src_x, _, _ = tables
         out = torch.empty((NB, Cout, H, W), dtype=x.dtype, device=x.device)
-        n = max(1, min(NB, P_CHUNK_BYTES // (Cout * kk * hw * 4)))
+        n = max(1, min(NB, _cfg().P_CHUNK_BYTES // (Cout * kk * hw * 4)))
         one_bias = bias if (bias is not None and Cout == 1) else None
         e0 = TIMER.start()
         for c0 in range(0, NB, n):
@@ -537,9 +538,9 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
     Conv2d weight [C_out, C_in, k, k]."""
     NB, Cin, h, w = x.shape
     Cout = weight.shape[0]
-    impl = PROJECTION_IMPL
+    impl = _cfg().PROJECTION_IMPL
     if impl == 'auto':
-        impl = 'chunked' if P_CHUNK_BYTES // (Cout * k * k * h * w * 4) >= 4 else 'conv'
+        impl = 'chunked' if _cfg().P_CHUNK_BYTES // (Cout * k * k * h * w * 4) >= 4 else 'conv'
     if impl == 'chunked':
         return _UpConvProjected.apply(x, weight, bias, tables, k, H, W)
     w_taps = weight.permute(0, 2, 3, 1).reshape(Cout * k * k, Cin)              # rows ordered (co, ky, kx)
@@ -557,25 +558,12 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
 # ----------------------------------------------------------------------------------------------------------
 # channels-last (NHWC) form of the same up-conv: the decoder's fast path
 # ----------------------------------------------------------------------------------------------------------
-WGRAD_SPLIT_ROWS = 8192           # split-K granularity of the weight-gradient GEMM (K = NB*h*w rows); MI355X sweep: profiles/r01/wgrad_split_sweep.log
 
 
 # Forward projection of a stage whose input is a spike tensor (values 0 / 1 / 2: exact in bf16): the fp32 weight is split into three
 # bf16 terms W = Wh + Wm + Wl (8 + 8 + 8 mantissa bits: exact), and P = [X X X](bf16) @ [Wh; Wm; Wl](bf16) runs on the bf16 MFMA
 # path with fp32 accumulation.  Every product is exact, so the result has the error profile of the fp32 GEMM (same 1e-6 relative
 # difference to a float64 reference; profiles/r01/gemm_nhwc.log) at 1.2 - 2x its speed for K >= 128.
-EXACT_SPLIT_GEMM = True
-FUSED_UPCONV_MFMA = True          # decoder stages with a compiled shape (deconv1, deconv2): projection + gather in ONE hand-written MFMA kernel, P never in HBM
-FUSED_UPCONV_X16 = True            # 16-bit autocast: deconv1 / deconv2 forward through the same fused kernel on 16-bit activations (was GEMM + gather)
-FUSED_UPCONV_FORM = 2             # 2: wavefront-specialised persistent kernel where it applies (source window <= 122); 1: always the first form (A/B)
-ACT16_GATHER = True               # 16-bit autocast: decoder gathers write / read 16-bit activations (the neuron layer then runs x16)
-EXACT_SPLIT_MIN_K = 128            # C_in below this: the GEMM is bound by writing P, nothing to gain
-EXACT_WGRAD_MFMA = True            # weight gradient of the decoder stages (C_in 64 .. 512) as the hand-written exact bf16x3 MFMA
-                                   # contraction ss_spike_wgrad_f32 (was the library's fp32 GEMM at the fp32-MFMA rate)
-EXACT_WGRAD_MFMA_CIN = tuple(int(c) for c in _os.environ.get('SS_WGRAD_MFMA_CIN', '64,128,256,512').split(',') if c)   # A/B knob (tools/)
-EXACT_SPLIT_WGRAD_MIN_K = 256      # weight gradient of the projection as bf16x3 GEMM: only the two widest stages are compute-bound enough
-                                   # to pay for the extra 10 B/element split pass over g_P (profiles/r01/split_wgrad_sweep.log)
-ASSERT_EXACT_SPLIT = False         # tests: verify (with a host sync) that the input really is bf16-exact
 
 
 def _split3_cols(Wt):
@@ -598,18 +586,8 @@ def _split3_bf16(Wt):
     return _split3_cols(Wt).view(K, 3, N).permute(1, 0, 2).reshape(3 * K, N)      # [3K, N]: rows = (term, k)
 
 
-GEMM6_DGRAD = _os.environ.get('SS_GEMM6_DGRAD', '1') == '1'   # decoder data gradient g_x = g_P @ W2 of the two wide stages as ss_gemm6_f32 (six bf16 cross terms, fp32-product accuracy)
-GEMM6_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_GEMM6_CIN', '128,256,512').split(',') if c)   # C_in 64 / 128: the library's fp32 GEMM is
-                                   # HBM-bound there and faster (profiles/r02/decoder_backward_kernels.log)
-FUSED_UPCONV_BWD = True            # deconv1 / deconv2 backward: adjoint gather + exact MFMA weight gradient in one kernel (g_P written once, read only by dgrad)
 
 
-FUSED_UPCONV_DGRAD = _os.environ.get('SS_FUSED_DGRAD', '1') == '1'   # decoder data gradient: adjoint gather + six-term MFMA contraction in ONE kernel, g_P only on chip
-FUSED_UPCONV_DGRAD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_DGRAD_CIN', '64').split(',') if c)   # deconv1 (g_P 5.76 GB at config 3): 4.17 -> 3.7 ms;
-                                   # deconv2 .. 4: the two-kernel form on g_P (2.9 / 1.5 / 0.8 GB) is faster (profiles/r03/upconv_bwd_variants.log)
-FUSED_UPCONV_BWD_CIN_NOGP = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN_NOGP', '64').split(',') if c)   # fused adjoint + weight gradient WITHOUT its g_P store
-FUSED_UPCONV_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_FUSED_BWD_CIN', '64').split(',') if c)   # C_in 128 (deconv2): the fused form is slower
-                                   # than adjoint kernel + ss_spike_wgrad_f32 (4 workgroup kinds re-load every window; profiles/r02/fused_bwd.log)
 
 
 def _extents_of(y_lo, y_hi, x_lo, x_hi):
@@ -701,8 +679,6 @@ def box_tables(tables, H, W):
 
 
 _BOX = {}
-BOX_BWD = _os.environ.get('SS_BOX_BWD', '1') == '1'   # decoder backward on the box-sum image: ss_upconv_boxsum_f32 + ss_upconv_box_dgrad_f32 + ss_upconv_box_wgrad_f32 (no g_P anywhere)
-BOX_BWD_CIN = tuple(int(c) for c in _os.environ.get('SS_BOX_BWD_CIN', '64,128,256,512').split(',') if c)
 
 
 class _UpConvProjectedCL(torch.autograd.Function):
@@ -717,12 +693,13 @@ class _UpConvProjectedCL(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
     def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0,
                 lowrank_grad=False, x_packed=None):
+        ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         # x_packed (one-channel 3 x 3 head on a packed-only neuron output, fp32 mode): the input as a 2-bit packed spike tensor; x_cl is then a
         # data-less anchor that carries shape and autograd edge.  Projection and weight gradient read the packed form (ss_head_*_packed_f32)
         if x_packed is not None and k != 3:
             # a decoder stage on a packed-only input (deconv1 reading deconv2's output): the fused MFMA forward reads the packed form; any other form
             # of this stage gets the dense tensor back first
-            if not (FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
+            if not (_cfg().FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
                     and _lib.upconv_fused_form(x_cl.shape[-1], weight.shape[0], k, max_window) != 0):
                 x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, x_cl.dtype), None
         if x_packed is not None and k == 3:
@@ -742,6 +719,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _lib.head_proj_packed(x_packed, Wt, P, rows, Cin)
             _lib.upconv_cl_fwd(P, src_y, src_x, None if bias is None else bias.float(), out, NB, k, Cout, h, w, H, W)
             TIMER.stop(e0, 'upconv_cl_fwd', x_cl.numel() // 4 + 4 * out.numel(), out.numel())
+            _note('synapse_fwd', 'head_proj_packed_mfma+gather')
             ctx.save_for_backward(x_cl, Wt, x_packed, weight)
             ctx.lowp, ctx.exact = False, False
             ctx.tables, ctx.k, ctx.n = tables, k, NB
@@ -770,23 +748,24 @@ class _UpConvProjectedCL(torch.autograd.Function):
         out = torch.empty((NB, H, W, Cout), dtype=act_dtype or torch.float32, device=x_cl.device)
         # one pass: measured on the MI355X (profiles/r01/chunk_sweep*.log) cache-sized chunks lose more in GEMM efficiency (M = n*h*w
         # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
-        n = max(1, min(NB, P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
-        exact = spikes_in and not lowp and EXACT_SPLIT_GEMM and Cin >= EXACT_SPLIT_MIN_K
+        n = max(1, min(NB, _cfg().P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
+        exact = spikes_in and not lowp and _cfg().EXACT_SPLIT_GEMM and Cin >= _cfg().EXACT_SPLIT_MIN_K
         # fused projection + gather on the bf16 matrix cores (P only in LDS): spike inputs, fp32 activations, the compiled stage shapes
         form = 0
-        if (FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and EXACT_SPLIT_GEMM and not half_in):
+        if (_cfg().FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and not half_in):
             form = _lib.upconv_fused_form(Cin, Cout, k, max_window)           # 2: wavefront-specialised persistent kernel; 1: first form
-            if form == 2 and FUSED_UPCONV_FORM == 1 and max_window <= 128:
+            if form == 2 and _cfg().FUSED_UPCONV_FORM == 1 and max_window <= 128:
                 form = 1
         # 16-bit autocast, decoder stage with 16-bit spike input and 16-bit activation output: the same kernel (form 2) on 16-bit I/O —
         # fp16: exact fp32 weights like the fp32 mode; bf16: weights rounded once to bf16, autocast's own semantics for every synapse
-        x16_fused = (FUSED_UPCONV_MFMA and FUSED_UPCONV_X16 and spikes_in and act_dtype is not None and bias is None and half_in
-                     and x_cl.dtype == act_dtype and lowp == (act_dtype == torch.bfloat16) and (lowp or EXACT_SPLIT_GEMM)
+        x16_fused = (_cfg().FUSED_UPCONV_MFMA and _cfg().FUSED_UPCONV_X16 and spikes_in and act_dtype is not None and bias is None and half_in
+                     and x_cl.dtype == act_dtype and lowp == (act_dtype == torch.bfloat16) and (lowp or _cfg().EXACT_SPLIT_GEMM)
                      and _lib.upconv_fused_form(Cin, Cout, k, max_window) == 2)
         if x16_fused:
             e0 = TIMER.start()
             _lib.upconv_fused2_x16(x_cl, weight.contiguous(), src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
             TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
+            _note('synapse_fwd', 'upconv_fused2_mfma_x16')
             ctx.save_for_backward(x_cl, Wt, None, weight)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = not lowp
@@ -795,13 +774,14 @@ class _UpConvProjectedCL(torch.autograd.Function):
             ctx.has_bias = False
             return out
         if form:
-            if ASSERT_EXACT_SPLIT and x_packed is None:
+            if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
                 assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
             Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, form), dtype=torch.bfloat16, device=x_cl.device)
             e0 = TIMER.start()
             _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout, form)
             _lib.upconv_fused_fwd(None if x_packed is not None else x_cl, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
             TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
+            _note('synapse_fwd', f'upconv_fused{form}_mfma' + ('(packed in)' if x_packed is not None else ''))
             ctx.save_for_backward(x_cl, Wt, x_packed, weight)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = True
@@ -817,7 +797,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             xg = x_cl.float()                           # 16-bit input on the plain fp32 GEMM path (narrow stages, heads)
         Wg = Wt.to(torch.bfloat16) if lowp else Wt
         if exact:
-            if ASSERT_EXACT_SPLIT:
+            if _cfg().ASSERT_EXACT_SPLIT:
                 assert bool((x_cl.to(torch.bfloat16).float() == x_cl.float()).all()), 'spikes_in=True but the input is not exact in bf16'
             W3 = _split3_bf16(Wt)
         e0 = TIMER.start()
@@ -833,6 +813,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
             (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
         TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
+        _note('synapse_fwd', ('exact_bf16x3_gemm' if exact else ('bf16_gemm' if lowp else 'fp32_gemm')) + '+gather' + ('_x16' if act_dtype else ''))
         ctx.save_for_backward(xg, Wt, None, weight)
         # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
         # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
@@ -858,11 +839,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         # one-channel 3 x 3 head on a forked neuron output: g_x = g_P [rows, 9] @ W2 [9, C_in] is left to the consumer's backward kernel
         # (anomaly detection scans every backward output for NaNs and would trip over the anchor: it gets the dense form)
-        lowrank = (need_x and ctx.lowrank_grad and LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
+        lowrank = (need_x and ctx.lowrank_grad and ctx.ecfg.LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
                    and ctx.x_dtype == torch.float32 and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
         # ---- round 4: the whole stage backward on the box-sum image (ss_upconv_box.hip): one HBM-bound box-sum launch, then both contractions as implicit
         #      GEMMs over its three bf16 planes — no per-tap tensor g_P in HBM or on chip, no per-fragment operand arithmetic
-        box_ok = (BOX_BWD and k == 5 and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and n >= NB and not lowrank and Cin in BOX_BWD_CIN
+        box_ok = (ctx.ecfg.BOX_BWD and k == 5 and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and n >= NB and not lowrank and Cin in ctx.ecfg.BOX_BWD_CIN
                   and (need_x or need_w) and (x_packed is not None or x_cl.dtype == torch.float32))
         if box_ok:
             bt = box_tables(ctx.tables, H, W)
@@ -885,6 +866,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 _lib.upconv_box_wgrad(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
                 TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()), g_out.numel())
             TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
+            _note('synapse_bwd', 'box: boxsum' + ('+dgrad6_mfma' if need_x else '') + ('+wgrad3_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
             if g_x is not None and g_x.dtype != ctx.x_dtype:
                 g_x = g_x.to(ctx.x_dtype)
             return g_x, g_w, None, None, None, None, None, None, None, None, None, None, None, None
@@ -899,10 +881,10 @@ class _UpConvProjectedCL(torch.autograd.Function):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
             # data gradient with g_P on chip only: adjoint gather + six-term MFMA contraction in one kernel (ss_upconv_bwd_dgrad_f32)
-            dgrad_fused = (FUSED_UPCONV_DGRAD and need_x and not lowrank and not lowp and not g16 and k == 5 and g_out.dtype == torch.float32
-                           and Cin in FUSED_UPCONV_DGRAD_CIN and _lib.upconv_bwd_dgrad_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
-            fused_bwd = (FUSED_UPCONV_BWD and need_w and ctx.exact and not lowp and not g16 and k == 5 and x_cl.dtype == torch.float32
-                         and Cin in (FUSED_UPCONV_BWD_CIN_NOGP if dgrad_fused else FUSED_UPCONV_BWD_CIN)
+            dgrad_fused = (ctx.ecfg.FUSED_UPCONV_DGRAD and need_x and not lowrank and not lowp and not g16 and k == 5 and g_out.dtype == torch.float32
+                           and Cin in ctx.ecfg.FUSED_UPCONV_DGRAD_CIN and _lib.upconv_bwd_dgrad_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
+            fused_bwd = (ctx.ecfg.FUSED_UPCONV_BWD and need_w and ctx.exact and not lowp and not g16 and k == 5 and x_cl.dtype == torch.float32
+                         and Cin in (ctx.ecfg.FUSED_UPCONV_BWD_CIN_NOGP if dgrad_fused else ctx.ecfg.FUSED_UPCONV_BWD_CIN)
                          and _lib.upconv_bwd_fused_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
             stage_pk = x_packed is not None and k == 5               # a stage whose input exists only as packed spikes
             if stage_pk and need_w and not (fused_bwd and c0 == 0 and c1 == NB):
@@ -937,7 +919,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
             elif dgrad_fused:
                 pass                                                              # g_x written by the fused kernel above
-            elif need_x and not lowp and GEMM6_DGRAD and Cin in GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
+            elif need_x and not lowp and ctx.ecfg.GEMM6_DGRAD and Cin in ctx.ecfg.GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
                 # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy): the fp32 GEMM is compute-bound here
                 _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
             elif need_x:
@@ -947,17 +929,17 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 pass                                                              # g_Wt accumulated by the fused kernel above
             elif need_w and x_packed is not None and k == 3:
                 _lib.head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=True)     # reads the 2-bit packed spikes (1/16 of the dense tensor)
-            elif (need_w and ctx.exact and not lowp and EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
-                    and Cin in EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
+            elif (need_w and ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
+                    and Cin in ctx.ecfg.EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
                 # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
                 _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)
-            elif need_w and ctx.exact and not lowp and Cin >= EXACT_SPLIT_WGRAD_MIN_K:
+            elif need_w and ctx.exact and not lowp and Cin >= ctx.ecfg.EXACT_SPLIT_WGRAD_MIN_K:
                 # x is a spike tensor: g_Wt = x^T @ (gh + gm + gl) with exact products on the bf16 MFMA path (one extra 10 B/element pass
                 # over g_P for the split — pays only where the GEMM is compute-bound, i.e. the widest stage)
                 g3 = torch.empty((rows, 3 * kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
                 _lib.split3_bf16(g_P, g3, rows, kk * Cout)
                 xb = x_cl[c0:c1].view(rows, Cin).to(torch.bfloat16)
-                S = next(d for d in (SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if rows % d == 0)
+                S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if rows % d == 0)
                 gw3 = torch.bmm(xb.view(S, rows // S, Cin).transpose(1, 2), g3.view(S, rows // S, 3 * kk * Cout),
                                 out_dtype=torch.float32).sum(0) if S > 1 else torch.mm(xb.t(), g3, out_dtype=torch.float32)
                 g_Wt += gw3.view(Cin, 3, kk * Cout).sum(1)
@@ -968,7 +950,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                     xs = xs.to(torch.bfloat16)                                    # spikes: exact
                 elif not lowp and xs.dtype != torch.float32:
                     xs = xs.float()
-                S = max(1, rows // WGRAD_SPLIT_ROWS)
+                S = max(1, rows // ctx.ecfg.WGRAD_SPLIT_ROWS)
                 L = rows // S
                 if S > 1:
                     g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout), **f32).sum(0)
@@ -977,6 +959,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 else:
                     g_Wt += torch.mm(xs.t(), g_P, **f32)
         TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
+        how_x = 'none' if not need_x else ('lowrank_pair' if lowrank else ('fused_adjoint+dgrad6_mfma' if dgrad_fused else ('adjoint+gemm6' if (
+            not lowp and ctx.ecfg.GEMM6_DGRAD and Cin in ctx.ecfg.GEMM6_DGRAD_CIN and _lib.gemm6_supported(kk * Cout, Cin)) else 'adjoint+library_gemm')))
+        how_w = 'none' if not need_w else ('fused_adjoint+wgrad3_mfma' if fused_bwd else ('head_wgrad_packed_mfma' if (x_packed is not None and k == 3) else (
+            'spike_wgrad_mfma' if (ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and Cin in ctx.ecfg.EXACT_WGRAD_MFMA_CIN) else 'library_gemm')))
+        _note('synapse_bwd', f'g_x: {how_x}; g_w: {how_w}' + ('; 16-bit' if (lowp or g16) else ''), ctx.site)
         g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
         g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if g_x is not None and g_x.dtype != ctx.x_dtype:
@@ -995,6 +982,7 @@ class _SpikeConvCL(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x_cl, weight, stride, pad, x_packed=None):
+        ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         # x_packed: the same input as a 2-bit packed spike tensor (x_cl then only carries shape and autograd edge; it may be an anchor)
         if x_packed is None:
             x_cl = x_cl.contiguous()
@@ -1002,7 +990,7 @@ class _SpikeConvCL(torch.autograd.Function):
         Cout, _, k, _ = weight.shape
         ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
         M, K = NB * ho * wo, k * k * Cin
-        if ASSERT_EXACT_SPLIT and x_packed is None:
+        if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
             assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
         A = torch.empty((M, K), dtype=torch.bfloat16, device=x_cl.device)
         if x_packed is not None:
@@ -1012,6 +1000,7 @@ class _SpikeConvCL(torch.autograd.Function):
         Wt = weight.permute(2, 3, 1, 0).reshape(K, Cout)                          # row index = (ky, kx, c): the im2col column order
         y3 = torch.mm(A, _split3_cols(Wt.float()), out_dtype=torch.float32)       # [M, 3*Cout] = A @ [Wh | Wm | Wl]
         y = y3.view(M, 3, Cout).sum(1).view(NB, ho, wo, Cout)
+        _note('synapse_fwd', 'im2col' + ('(packed in)' if x_packed is not None else '') + '+exact_bf16x3_gemm')
         ctx.save_for_backward(A, weight)
         ctx.geom = (NB, h, w, Cin, Cout, k, stride, pad, ho, wo)
         return y
@@ -1027,17 +1016,21 @@ class _SpikeConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g3 = torch.empty((M, 3 * Cout), dtype=torch.bfloat16, device=g.device)
             _lib.split3_bf16(g, g3, M, Cout)
-            S = next(d for d in (SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)   # split-K: the output is only K x 3*Cout
+            S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)   # split-K: the output is only K x 3*Cout
             if S > 1:
                 gw3 = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g3.view(S, M // S, 3 * Cout), out_dtype=torch.float32).sum(0)
             else:
                 gw3 = torch.mm(A.t(), g3, out_dtype=torch.float32)                # [K, 3*Cout]
             g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
-        if ctx.needs_input_grad[0] and WINOGRAD_DGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 4 == 0 and Cout % 4 == 0:
-            g_x = winograd_dgrad_cl(g, weight)
-        elif ctx.needs_input_grad[0] and CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, k, stride, pad):
+        how_x = 'none'
+        if ctx.needs_input_grad[0] and ctx.ecfg.WINOGRAD_DGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 4 == 0 and Cout % 4 == 0:
+            g_x = winograd_dgrad_cl(g, weight, ctx.ecfg.WINOGRAD_GEMM6)
+            how_x = 'winograd_f2x2_3x3+batched_gemm'
+        elif ctx.needs_input_grad[0] and ctx.ecfg.CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, k, stride, pad):
             g_x = conv_s2_dgrad_cl(g, weight, h, w)
+            how_x = 'conv_s2_dgrad6_mfma'
         elif ctx.needs_input_grad[0]:
+            how_x = 'miopen'
             x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
             g_x = torch.ops.aten.convolution_backward(
                 g.permute(0, 3, 1, 2), x_meta, weight.contiguous(memory_format=torch.channels_last), None,
@@ -1045,15 +1038,12 @@ class _SpikeConvCL(torch.autograd.Function):
             g_x = g_x.permute(0, 2, 3, 1)
             if not g_x.is_contiguous():
                 g_x = g_x.contiguous()
+        _note('synapse_bwd', f'g_x: {how_x}; g_w: ' + ('split3+exact_bf16x3_gemm' if ctx.needs_input_grad[1] else 'none'), ctx.site)
         return g_x, g_w, None, None, None
 
 
-WINOGRAD_DGRAD = True              # data gradient of the 3x3 / stride 1 convs (the four bottleneck convs) as Winograd F(2x2, 3x3): hand-written
-                                   # transforms around one batched fp32 GEMM, 2.25x fewer multiplications (1.14 -> 0.7 ms per layer at config 3)
 
 
-CONV_DGRAD_MFMA = _os.environ.get('SS_CONV_DGRAD_MFMA', '1') == '1'   # data gradient of conv1 .. conv4 (5x5, stride 2: dense x dense) as the six-term bf16 MFMA implicit GEMM
-                                   # ss_conv_s2_dgrad_f32 (was MIOpen's fp32 igemm_bwd at the fp32-MFMA rate: 7.1 -> 4.4 ms per step at config 3, profiles/r03/conv_dgrad.log)
 
 
 def conv_s2_dgrad_cl(g: torch.Tensor, weight: torch.Tensor, h: int, w: int) -> torch.Tensor:
@@ -1068,12 +1058,9 @@ def conv_s2_dgrad_cl(g: torch.Tensor, weight: torch.Tensor, h: int, w: int) -> t
     return g_x
 
 
-WINOGRAD_GEMM6 = _os.environ.get('SS_WINOGRAD_GEMM6', '0') == '1'   # the transform-domain products as ss_gemm6_batched_f32 instead of the library's fp32 batched
-                                   # GEMM: 0.70 -> 0.63 ms per layer, but Winograd + six-term error reaches 2.4x the direct fp32 convolution's on tiny maps
-                                   # (the test bar is 2x) — off by default, accuracy first
 
 
-def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor, gemm6: Optional[bool] = None) -> torch.Tensor:
     """Data gradient of conv2d(x, weight, stride 1, padding 1), weight [C_out, C_in, 3, 3]: g [NB, H, W, C_out] (contiguous NHWC array, fp32)
     -> g_x [NB, H, W, C_in].  The autograd backward of the reference's SEWResBlock convs (/root/reference/network/blocks.py:146-159) w.r.t.
     their input, as ss_wino_dgrad_{weights,input,output}_f32 around torch.bmm (fp32)."""
@@ -1084,7 +1071,7 @@ def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     V = torch.empty((16, T, Cout), dtype=torch.float32, device=g.device)
     _lib.wino_dgrad_weights(weight.detach().float().contiguous(), U, Cout, Cin)
     _lib.wino_dgrad_input(g, V, NB, H, W, Cout)
-    if WINOGRAD_GEMM6 and _lib.gemm6_supported(Cout, Cin) and (T * Cout) % 4 == 0:
+    if (_cfg().WINOGRAD_GEMM6 if gemm6 is None else gemm6) and _lib.gemm6_supported(Cout, Cin) and (T * Cout) % 4 == 0:
         M = torch.empty((16, T, Cin), dtype=torch.float32, device=g.device)          # the 16 products on the bf16 matrix cores, six cross terms
         _lib.gemm6_batched(V, U, M, 16, T, Cout, Cin)
     else:
@@ -1095,10 +1082,6 @@ def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return g_x
 
 
-SPIKE_CONV_FWD_MFMA = _os.environ.get('SS_CONV_FWD_MFMA', '1') == '1'     # conv1 / conv2 FORWARD as the exact bf16x3 implicit-GEMM kernel ss_spike_conv_fwd_f32 (was MIOpen fp32:
-                                   # 1.42 ms each at config 3, at the fp32-MFMA rate); reads the 2-bit packed spikes, so bottom / conv1 write no dense output
-SPIKE_CONV_WGRAD_MFMA = _os.environ.get('SS_CONV_WGRAD_MFMA', '1') == '1'   # conv1 / conv2 (5x5, stride 2, spike inputs): forward and data gradient on
-                                   # MIOpen, weight gradient as the hand-written exact bf16x3 MFMA contraction ss_spike_conv_wgrad_f32
 
 
 class _SpikeConvWgradCL(torch.autograd.Function):
@@ -1109,21 +1092,24 @@ class _SpikeConvWgradCL(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x_cl, weight, x_packed=None):
+        ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         NB, h, w, Cin = x_cl.shape
         Cout = weight.shape[0]
-        if SPIKE_CONV_FWD_MFMA and _lib.spike_conv_fwd_supported(Cin, Cout, 5, 2, 2):
+        if _cfg().SPIKE_CONV_FWD_MFMA and _lib.spike_conv_fwd_supported(Cin, Cout, 5, 2, 2):
             # forward as the exact bf16x3 implicit GEMM on the matrix cores, reading the packed spikes when the producer wrote them
             # (x_cl may then be a data-less anchor)
             if x_packed is None:
                 x_cl = x_cl.contiguous()
-                if ASSERT_EXACT_SPLIT:
+                if _cfg().ASSERT_EXACT_SPLIT:
                     assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spike_conv: the input is not exact in bf16'
             y = torch.empty((NB, (h - 1) // 2 + 1, (w - 1) // 2 + 1, Cout), dtype=torch.float32, device=x_cl.device)
             e0 = TIMER.start()
             _lib.spike_conv_fwd(None if x_packed is not None else x_cl, None if x_packed is None else x_packed.contiguous(),
                                 weight.detach().float().contiguous(), y, NB, Cin, Cout, h, w)
             TIMER.stop(e0, 'spike_conv_fwd', 4 * y.numel() + (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()), y.numel())
+            _note('synapse_fwd', 'spike_conv_fwd3_mfma' + ('(packed in)' if x_packed is not None else ''))
         else:
+            _note('synapse_fwd', 'miopen')
             if x_cl.stride(-1) == 0:
                 raise RuntimeError('packed-only spike tensor handed to a convolution that reads dense activations')
             x_cl = x_cl.contiguous()
@@ -1145,22 +1131,26 @@ class _SpikeConvWgradCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g_w = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
             _lib.spike_conv_wgrad(g, x_cl, g_w, NB, Cin, Cout, h, w, x_packed=None if x_packed is None else x_packed.contiguous())
-        if ctx.needs_input_grad[0] and CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, 5, 2, 2):
+        how_x = 'none'
+        if ctx.needs_input_grad[0] and ctx.ecfg.CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, 5, 2, 2):
             g_x = conv_s2_dgrad_cl(g, weight, h, w)
+            how_x = 'conv_s2_dgrad6_mfma'
         elif ctx.needs_input_grad[0]:
+            how_x = 'miopen'
             x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
             g_x = torch.ops.aten.convolution_backward(
                 g.permute(0, 3, 1, 2), x_meta, weight.contiguous(memory_format=torch.channels_last), None,
                 [2, 2], [2, 2], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
             if not g_x.is_contiguous():
                 g_x = g_x.contiguous()
+        _note('synapse_bwd', f'g_x: {how_x}; g_w: ' + ('spike_conv_wgrad3_mfma' if ctx.needs_input_grad[1] else 'none'), ctx.site)
         return g_x, g_w, None
 
 
 def spike_conv_fwd_applies(conv, device, dtype=torch.float32) -> bool:
     """True when `conv` on a spike NHWC array runs its FORWARD through ss_spike_conv_fwd_f32 (and can therefore take a packed-only input)."""
     import torch.nn as nn
-    return bool(SPIKE_CONV_FWD_MFMA and SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and device.type == 'cuda' and dtype == torch.float32
+    return bool(_cfg().SPIKE_CONV_FWD_MFMA and _cfg().SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and device.type == 'cuda' and dtype == torch.float32
                 and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
                 and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2)
                 and _lib.spike_conv_fwd_supported(conv.in_channels, conv.out_channels, 5, 2, 2)
@@ -1170,7 +1160,7 @@ def spike_conv_fwd_applies(conv, device, dtype=torch.float32) -> bool:
 def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """conv on a spike NHWC array through _SpikeConvWgradCL, or None when it does not apply (caller then uses the plain MIOpen convolution)."""
     import torch.nn as nn
-    if not (SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
+    if not (_cfg().SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
             and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
             and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2)
             and (x_cl.stride(-1) == 1 or (x_packed is not None and spike_conv_fwd_applies(conv, x_cl.device, x_cl.dtype)))   # anchor: packed-only input
@@ -1179,8 +1169,6 @@ def spike_conv_wgrad_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tenso
     return _SpikeConvWgradCL.apply(x_cl, conv.weight, x_packed)
 
 
-DENSE_CONV_S1_WGRAD_MFMA = _os.environ.get('SS_CONV_S1_WGRAD_MFMA', '1') == '1'   # ... and its WEIGHT gradient as ss_dense_conv_s1_wgrad_f32 (was MIOpen's igemm_wrw)
-DENSE_CONV_S1_MFMA = _os.environ.get('SS_CONV_S1_MFMA', '1') == '1'   # first encoder layer (C_in 4 | 2 -> 32, 5x5, stride 1) FORWARD as ss_dense_conv_s1_fwd_f32
 
 
 class _DenseConvS1CL(torch.autograd.Function):
@@ -1191,6 +1179,7 @@ class _DenseConvS1CL(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x_cl, weight):
+        ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         x_cl = x_cl.contiguous()
         NB, h, w, Cin = x_cl.shape
         Cout = weight.shape[0]
@@ -1198,6 +1187,7 @@ class _DenseConvS1CL(torch.autograd.Function):
         e0 = TIMER.start()
         _lib.dense_conv_s1_fwd(x_cl, weight.detach().float().contiguous(), y, NB, Cin, Cout, h, w)
         TIMER.stop(e0, 'dense_conv_s1_fwd', 4 * (y.numel() + x_cl.numel()), y.numel())
+        _note('synapse_fwd', 'dense_conv_s1_fwd6_mfma')
         ctx.save_for_backward(x_cl, weight)
         return y
 
@@ -1207,7 +1197,7 @@ class _DenseConvS1CL(torch.autograd.Function):
         x_cl, weight = ctx.saved_tensors
         g = g.float().contiguous()
         NB, h, w, Cin = x_cl.shape
-        own_w = bool(ctx.needs_input_grad[1]) and DENSE_CONV_S1_WGRAD_MFMA and _lib.dense_conv_s1_wgrad_supported(Cin, weight.shape[0], 5, 1, 2)
+        own_w = bool(ctx.needs_input_grad[1]) and ctx.ecfg.DENSE_CONV_S1_WGRAD_MFMA and _lib.dense_conv_s1_wgrad_supported(Cin, weight.shape[0], 5, 1, 2)
         gw_own = None
         if own_w:                                            # six-term MFMA contraction over the pixels (was MIOpen's igemm_wrw: the step's last MIOpen call)
             gw_own = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
@@ -1215,12 +1205,14 @@ class _DenseConvS1CL(torch.autograd.Function):
             _lib.dense_conv_s1_wgrad(g, x_cl, gw_own, NB, Cin, weight.shape[0], h, w)
             TIMER.stop(e0, 'dense_conv_s1_wgrad', 4 * (g.numel() + x_cl.numel()), g.numel())
             if not ctx.needs_input_grad[0]:
+                _note('synapse_bwd', 'g_x: none; g_w: dense_conv_s1_wgrad6_mfma', ctx.site)
                 return None, gw_own
         gx, gw, _ = torch.ops.aten.convolution_backward(
             g.permute(0, 3, 1, 2), x_cl.permute(0, 3, 1, 2), weight.contiguous(memory_format=torch.channels_last), None,
             [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]) and not own_w, False])
         if own_w:
             gw = gw_own
+        _note('synapse_bwd', 'g_x: ' + ('miopen' if ctx.needs_input_grad[0] else 'none') + '; g_w: ' + ('dense_conv_s1_wgrad6_mfma' if own_w else 'miopen'), ctx.site)
         if gx is not None:
             gx = gx.permute(0, 2, 3, 1)
             gx = gx if gx.is_contiguous() else gx.contiguous()
@@ -1230,7 +1222,7 @@ class _DenseConvS1CL(torch.autograd.Function):
 def dense_conv_s1_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
     """conv (the first encoder layer's geometry) on a dense NHWC array through _DenseConvS1CL, or None when it does not apply."""
     import torch.nn as nn
-    if not (DENSE_CONV_S1_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
+    if not (_cfg().DENSE_CONV_S1_MFMA and isinstance(conv, nn.Conv2d) and x_cl.is_cuda and x_cl.dtype == torch.float32
             and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
             and conv.kernel_size == (5, 5) and conv.stride == (1, 1) and conv.padding == (2, 2)
             and _lib.dense_conv_s1_fwd_supported(conv.in_channels, conv.out_channels, 5, 1, 2)):
@@ -1238,8 +1230,6 @@ def dense_conv_s1_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
     return _DenseConvS1CL.apply(x_cl, conv.weight)
 
 
-SPIKE_CONV_WGRAD_SPLIT = 8         # profiles/r01/wgrad_splitk.log
-SPIKE_CONV_MIN_CIN = 128           # conv3 (128), conv4 (256), bottleneck (512); below: im2col traffic outweighs the MFMA gain
 
 
 def spike_conv_applies(conv, device, dtype=torch.float32) -> bool:
@@ -1248,10 +1238,10 @@ def spike_conv_applies(conv, device, dtype=torch.float32) -> bool:
     if not isinstance(conv, nn.Conv2d):
         return False
     k = conv.kernel_size[0]
-    return bool(EXACT_SPLIT_GEMM and device.type == 'cuda' and dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
+    return bool(_cfg().EXACT_SPLIT_GEMM and device.type == 'cuda' and dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
                 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size == (k, k)
                 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and not isinstance(conv.padding, str)
-                and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= SPIKE_CONV_MIN_CIN)
+                and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= _cfg().SPIKE_CONV_MIN_CIN)
 
 
 def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -1262,19 +1252,16 @@ def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = N
     return _SpikeConvCL.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0], x_packed)
 
 
-PACKED_HEAD = _os.environ.get('SS_PACKED_HEAD', '1') == '1'   # the full-resolution prediction head reads deconv1's output as 2-bit packed spikes (projection and weight
-                                   # gradient: ss_head_*_packed_f32); the largest decoder stage then writes no dense output (4.5 instead of 8.25 B/update)
 
 
 def stage_reads_packed(Cin: int, Cout: int, k: int, max_window: int) -> bool:
     """True when a decoder stage (NNConvUpsampling, fp32 mode) reads its input as 2-bit packed spikes in forward (fused MFMA kernel) AND in its weight
     gradient (fused adjoint + MFMA kernel), its data gradient needing no input at all — the producer may then write packed-only.  (Should a run-time
     condition still send the stage down another form, _UpConvProjectedCL unpacks: correct, just not free.)"""
-    return bool(PACK_SPIKES and FUSED_UPCONV_MFMA and EXACT_SPLIT_GEMM and k == 5 and _lib.upconv_fused_form(Cin, Cout, k, max_window) != 0
-                and FUSED_UPCONV_BWD and FUSED_UPCONV_DGRAD and Cin in FUSED_UPCONV_DGRAD_CIN and Cin in FUSED_UPCONV_BWD_CIN_NOGP)
+    return bool(_cfg().PACK_SPIKES and _cfg().FUSED_UPCONV_MFMA and _cfg().EXACT_SPLIT_GEMM and k == 5 and _lib.upconv_fused_form(Cin, Cout, k, max_window) != 0
+                and _cfg().FUSED_UPCONV_BWD and _cfg().FUSED_UPCONV_DGRAD and Cin in _cfg().FUSED_UPCONV_DGRAD_CIN and Cin in _cfg().FUSED_UPCONV_BWD_CIN_NOGP)
 
 
-PACKED_DECONV2 = _os.environ.get('SS_PACKED_DECONV2', '1') == '1'   # deconv2's output packed-only as well (consumers: head 2 and deconv1's fused kernels)
 
 
 class _UnpackLastStep(torch.autograd.Function):
@@ -1310,6 +1297,9 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
     lowp = amp and adt == torch.bfloat16
     lowp_bwd = amp and adt in (torch.bfloat16, torch.float16)
     # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
-    act_dtype = adt if (lowp_bwd and k == 5 and ACT16_GATHER) else None
+    act_dtype = adt if (lowp_bwd and k == 5 and _cfg().ACT16_GATHER) else None
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
         return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad, x_packed)
+
+
+_guard_module(__name__, 'fused')

@@ -21,7 +21,9 @@ returns what the last of T successive `net(...)` calls would return.
 import torch
 import torch.nn as nn
 
+from .. import config as _config
 from ..clock_driven import layer, neuron, surrogate
+from ..config import EngineConfig, current as _cfg
 from ..fused import ipool
 from . import blocks as _blocks
 from .blocks import MultiplyBy, NNConvUpsampling, SEWResBlock, SpikingStage
@@ -49,6 +51,33 @@ class NeuromorphicNet(nn.Module):
         self.v_rst = v_reset
         self.max_test_accuracy = float('inf')
         self.epoch = 0
+        # the engine configuration this network runs with (config.EngineConfig: which kernel form every layer takes).  Captured at construction from the
+        # configuration in effect (the shipped default unless built inside `config.engine_config(...)` / handed `config=`); NOT part of state_dict
+        self.config = _cfg()
+        self._plan = {}
+
+    # -- engine configuration (build-side addition; the reference has no such thing) -------------------
+    def configured(self, **overrides):
+        """Context manager: this network with `overrides` applied to its configuration, e.g. `with net.configured(BOX_BWD=False): ...`."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self.config = self.config, self.config.replace(**overrides)
+            try:
+                yield self
+            finally:
+                self.config = prev
+        return cm()
+
+    def plan(self, as_text=False):
+        """The dispatch plan of the LAST forward (and, once it has run, backward) pass: {layer: {'synapse_fwd', 'neuron_fwd', 'synapse_bwd', 'neuron_bwd': kernel
+        form}} for the 13 spiking layers and the 4 prediction heads, recorded at the dispatch sites themselves (not re-derived)."""
+        import copy
+        if not as_text:
+            return copy.deepcopy(self._plan)
+        keys = ('synapse_fwd', 'neuron_fwd', 'neuron_bwd', 'synapse_bwd')
+        return '\n'.join(f'{name:22s} ' + ' | '.join(f'{k}: {d.get(k, "-")}' for k in keys) for name, d in self._plan.items())
 
     # -- state utilities (SNN_models.py:22-48) ------------------------------------------------------
     def detach(self):
@@ -114,7 +143,13 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
 
     # -- the engine --------------------------------------------------------------------------------------
     def _run(self, x_seq: torch.Tensor, count: bool = False):
-        """x_seq [T, B, C, H, W] -> (depth_seq [T, 4, B, 1, H, W], last-step spike tensors, counters)."""
+        """x_seq [T, B, C, H, W] -> (depth_seq [T, 4, B, 1, H, W], last-step spike tensors, counters), under THIS network's configuration; the kernel
+        form every layer takes is recorded into the dispatch plan (`plan()`), the backward adds its half when it runs."""
+        self._plan.clear()
+        with _config.use_config(self.config), _config.recording(self._plan):
+            return self._run_impl(x_seq, count)
+
+    def _run_impl(self, x_seq: torch.Tensor, count: bool = False):
         T, B = x_seq.shape[:2]          # x_seq may be a transposed view of [B, T, ...]: the NHWC path below copies it once, into its own layout
         cnt = {}
 
@@ -124,12 +159,12 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             cnt[name] = torch.zeros(2, dtype=torch.int64, device=x_seq.device)
             return cnt[name]
 
-        cl = _blocks.FUSE_UPCONV and _blocks.DECODER_CHANNELS_LAST
-        enc_cl = cl and _blocks.ENCODER_CHANNELS_LAST and all(
+        cl = _cfg().FUSE_UPCONV and _cfg().DECODER_CHANNELS_LAST
+        enc_cl = cl and _cfg().ENCODER_CHANNELS_LAST and all(
             getattr(b, 'connect_function', 'ADD') == 'ADD' for b in self.bottleneck)
         if enc_cl:          # whole network on NHWC arrays [T, B, h, w, C]: no layout copies anywhere
             # every encoder output has two consumers (next conv + decoder skip): forked handles, gradients summed in the neuron backward
-            fork = _blocks.FORK_OUTPUTS
+            fork = _cfg().FORK_OUTPUTS
 
             def two(r):
                 return r if fork else (r, r)
@@ -137,7 +172,7 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             # the decoder are read packed; a layer whose next synapse is an exact-split conv (reads packed through its im2col) writes
             # no dense output at all.  dense=1, packed-only=2, off=0.
             from .. import fused as _fused
-            pk_on = _fused.PACK_SPIKES and x_seq.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and x_seq.is_cuda
+            pk_on = _cfg().PACK_SPIKES and x_seq.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and x_seq.is_cuda
 
             def mode(next_conv):
                 if not pk_on:
@@ -149,32 +184,41 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                     return None
                 if _fused.spike_conv_applies(conv, x_seq.device):
                     return packed
-                wg = (_fused.SPIKE_CONV_WGRAD_MFMA and getattr(conv, 'kernel_size', None) == (5, 5) and conv.stride == (2, 2)
+                wg = (_cfg().SPIKE_CONV_WGRAD_MFMA and getattr(conv, 'kernel_size', None) == (5, 5) and conv.stride == (2, 2)
                       and conv.in_channels in (32, 64))
                 return packed if wg else None
-            a, b = two(self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'), fork=fork,
-                                                            pack=mode(self.conv1[0])))
+            with _config.layer('bottom'):
+                a, b = two(self.bottom.forward_sequence_conv_cl(x_seq.permute(0, 1, 3, 4, 2).contiguous(), nnz('bottom'), fork=fork,
+                                                                pack=mode(self.conv1[0])))
             enc, enc_skip, enc_pk = [a], [b], [self.bottom[2].last_packed]
             for i in range(1, 4):
                 st, nxt = getattr(self, f'conv{i}'), getattr(self, f'conv{i + 1}')
-                a, b = two(st.forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True, fork=fork,
-                                                       x_packed=packed_in(st[0], enc_pk[-1]), pack=mode(nxt[0])))
+                with _config.layer(f'conv{i}'):
+                    a, b = two(st.forward_sequence_conv_cl(enc[-1], nnz(f'conv{i}'), spikes_in=True, fork=fork,
+                                                           x_packed=packed_in(st[0], enc_pk[-1]), pack=mode(nxt[0])))
                 enc.append(a)
                 enc_skip.append(b)
                 enc_pk.append(st[2].last_packed)
             bn0, bn1 = self.bottleneck[0], self.bottleneck[1]
-            enc.append(self.conv4.forward_sequence_conv_cl(enc[-1], nnz('conv4'), spikes_in=True, x_packed=packed_in(self.conv4[0], enc_pk[-1]),
-                                                           pack=mode(bn0.conv1[0])))
-            cur = bn0.forward_sequence_cl(enc[4], spikes_in=True, x_packed=self.conv4[2].last_packed, pack_out=mode(bn1.conv1[0]))   # enc[*], cur: spike tensors
-            cur = bn1.forward_sequence_cl(cur, nnz('rconv'), spikes_in=True, x_packed=bn0.sn2.last_packed)
+            with _config.layer('conv4'):
+                enc.append(self.conv4.forward_sequence_conv_cl(enc[-1], nnz('conv4'), spikes_in=True, x_packed=packed_in(self.conv4[0], enc_pk[-1]),
+                                                               pack=mode(bn0.conv1[0])))
+            with _config.layer('bottleneck.0'):
+                cur = bn0.forward_sequence_cl(enc[4], spikes_in=True, x_packed=self.conv4[2].last_packed, pack_out=mode(bn1.conv1[0]))   # enc[*], cur: spike tensors
+            with _config.layer('bottleneck.1'):
+                cur = bn1.forward_sequence_cl(cur, nnz('rconv'), spikes_in=True, x_packed=bn0.sn2.last_packed)
             spikes, heads = [cur.permute(0, 1, 4, 2, 3)], []
         else:
             x_seq = x_seq.contiguous()
-            enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]
+            with _config.layer('bottom'):
+                enc = [self.bottom.forward_sequence(x_seq, None, nnz('bottom'))]
             for i in range(1, 5):
-                enc.append(getattr(self, f'conv{i}').forward_sequence(enc[-1], None, nnz(f'conv{i}')))
-            cur = self.bottleneck[0].forward_sequence(enc[4])
-            cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
+                with _config.layer(f'conv{i}'):
+                    enc.append(getattr(self, f'conv{i}').forward_sequence(enc[-1], None, nnz(f'conv{i}')))
+            with _config.layer('bottleneck.0'):
+                cur = self.bottleneck[0].forward_sequence(enc[4])
+            with _config.layer('bottleneck.1'):
+                cur = self.bottleneck[1].forward_sequence(cur, nnz('rconv'))
             if count and getattr(self.bottleneck[1], 'connect_function', 'ADD') != 'ADD':
                 # the in-kernel counter saw sn2's output BEFORE the (unfused) connect function; the reference counts out_rconv itself
                 cnt['rconv'] = torch.stack((cnt['rconv'][0], torch.count_nonzero(cur)))
@@ -192,15 +236,16 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 # writes no dense output at all
                 # (round 3, last: deconv2 as well — its other consumer, deconv1, reads packed spikes in its fused forward and weight-gradient kernels)
                 C_out = stage[0].up[1].out_channels
-                head_pk = bool(lvl in (1, 2) and enc_cl and _fused.PACK_SPIKES and _fused.PACKED_HEAD and _blocks.FORK_OUTPUTS and cur.dtype == torch.float32
+                head_pk = bool(lvl in (1, 2) and enc_cl and _cfg().PACK_SPIKES and _cfg().PACKED_HEAD and _cfg().FORK_OUTPUTS and cur.dtype == torch.float32
                                and not torch.is_autocast_enabled('cuda') and _fused._lib.head_packed_supported(C_out, 1, 3))
                 if head_pk and lvl == 2:
                     nxt = self.deconv1[0]
                     hh, ww = stage[0].up[0].size[0] - 4, stage[0].up[0].size[1] - 4          # this stage's output = the next stage's input geometry
-                    head_pk = _fused.PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
-                r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_blocks.FORK_OUTPUTS,
-                                              skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else 0, x_packed=prev_pk)
-                cur, cur_head = r if _blocks.FORK_OUTPUTS else (r, r)
+                    head_pk = _cfg().PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
+                with _config.layer(f'deconv{lvl}'):
+                    r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_cfg().FORK_OUTPUTS,
+                                                  skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else 0, x_packed=prev_pk)
+                cur, cur_head = r if _cfg().FORK_OUTPUTS else (r, r)
                 out_pk = stage[2].last_packed if head_pk else None     # None: the packed kernel form did not apply, the output is dense
                 prev_pk = out_pk                                       # the next stage's input in packed form (None: dense)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
@@ -209,13 +254,16 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 # the head is the only consumer of its forked handle: its input gradient travels as a rank-9 pair into the stage's neuron backward.
                 # The full-resolution stage has no other gradient, so there the pair itself travels on as dL/dskip — which only another fused
                 # neuron layer (the forked NHWC encoder output) can take
-                lr_ok = bool(_blocks.FORK_OUTPUTS) and (enc_cl or lvl != 1)
-                pd = head[0].forward_projected_cl(cur_head.flatten(0, 1), lowrank_grad=lr_ok, x_packed=out_pk)  # [T*B, H, W, 1]: one channel, NHWC == NCHW
+                lr_ok = bool(_cfg().FORK_OUTPUTS) and (enc_cl or lvl != 1)
+                with _config.layer(f'predict_depth{lvl}'):
+                    pd = head[0].forward_projected_cl(cur_head.flatten(0, 1), lowrank_grad=lr_ok, x_packed=out_pk)  # [T*B, H, W, 1]: one channel, NHWC == NCHW
             else:
-                cur = stage.forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
+                with _config.layer(f'deconv{lvl}'):
+                    cur = stage.forward_sequence(cur, enc[lvl - 1], nnz(f'deconv{lvl}'))
                 spikes.append(cur)
-                synapse = head[0].forward_projected if _blocks.FUSE_UPCONV else head[0]
-                pd = synapse(cur.flatten(0, 1))
+                synapse = head[0].forward_projected if _cfg().FUSE_UPCONV else head[0]
+                with _config.layer(f'predict_depth{lvl}'):
+                    pd = synapse(cur.flatten(0, 1))
             heads.append(pd.view(T, B, 1, *self.input_size))
         # shared I-neuron pool: v += gain * head, heads charged in the order 4,3,2,1 every step (:172-188)
         gains = [h[1].scale_value for h in (self.predict_depth4, self.predict_depth3, self.predict_depth2,
@@ -281,8 +329,10 @@ class StereoSpike(_SpikingEncoderDecoder):
     whatever `surrogate_function` is — quirks kept on purpose, they are part of numerical parity."""
 
     def __init__(self, surrogate_function=None, detach_reset=True, v_threshold=1.0, v_reset=0.0, multiply_factor=1.,
-                 input_size=(260, 346)):
+                 input_size=(260, 346), config: EngineConfig = None):
         super().__init__(surrogate_function=surrogate_function, detach_reset=detach_reset)
+        if config is not None:
+            self.config = config
 
         def node():
             return neuron.IFNode(v_threshold=self.v_th, v_reset=self.v_rst, surrogate_function=self.surrogate_fct,
@@ -303,9 +353,11 @@ class fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(_SpikingEncode
     _in_channels = 4
 
     def __init__(self, use_plif=False, detach_reset=True, tau=10., v_threshold=1.0, v_reset=0.0, multiply_factor=1.,
-                 input_size=(260, 346)):
+                 input_size=(260, 346), config: EngineConfig = None):
         super().__init__(detach_reset=detach_reset)
         self.is_cext_model = False
+        if config is not None:
+            self.config = config
 
         def node():
             if use_plif:
@@ -330,7 +382,7 @@ class fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike(
     _returns_spikes = False
 
     def __init__(self, use_plif=False, detach_reset=True, tau=10., v_threshold=1.0, v_reset=0.0,
-                 final_activation=nn.Identity, multiply_factor=1., input_size=(260, 346)):
+                 final_activation=nn.Identity, multiply_factor=1., input_size=(260, 346), config: EngineConfig = None):
         super().__init__(use_plif=use_plif, detach_reset=detach_reset, tau=tau, v_threshold=v_threshold,
-                         v_reset=v_reset, multiply_factor=multiply_factor, input_size=input_size)
+                         v_reset=v_reset, multiply_factor=multiply_factor, input_size=input_size, config=config)
         self.final_activation = final_activation

@@ -11,22 +11,19 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from .. import config as _config
 from ..clock_driven import neuron, surrogate
+from ..config import current as _cfg
 from ..fused import nearest_tables, register_box_tables, register_extents, upconv_projected, upconv_projected_cl
 
 
-# The sequence fast path evaluates NNConvUpsampling through forward_projected (no up-sampled tensor).  Set to False to
-# fall back to the reference's two-op form on MIOpen (used by bench.py --no-fuse-upconv for A/B measurements).
-FUSE_UPCONV = True
-# Keep the decoder (deconv4..1, their skip adds, the predict_depth heads) in NHWC memory: the projection is then ONE
-# row-major GEMM per stage and the gather kernels read/write 16-B channel vectors (no MIOpen layout transposes, no
-# per-image batched GEMMs).  The neuron kernels are layout-agnostic.  False = NCHW decoder (bench.py --decoder-nhwc 0).
-DECODER_CHANNELS_LAST = True
-# Also keep the encoder / bottleneck activations in NHWC memory (torch channels_last): MIOpen then runs its NHWC-native
-# implicit-GEMM kernels without layout transposes and the decoder's skip tensors need no NCHW->NHWC copies.
-ENCODER_CHANNELS_LAST = True
-# outputs with two consumers (next synapse + skip / head) are handed out as two handles; the neuron backward adds the two gradients on load
-FORK_OUTPUTS = True
+# Execution layout (fields of config.EngineConfig; reads of `blocks.<NAME>` answer with the configuration in effect, assignments are refused):
+#   FUSE_UPCONV            the sequence fast path evaluates NNConvUpsampling through forward_projected (no up-sampled tensor); False = the reference's
+#                          two-op form on MIOpen (bench.py --fuse-upconv 0 for A/B measurements)
+#   DECODER_CHANNELS_LAST  decoder (deconv4..1, their skip adds, the predict_depth heads) in NHWC memory: the projection is then ONE row-major GEMM per
+#                          stage and the gather kernels read / write 16-B channel vectors; the neuron kernels are layout-agnostic
+#   ENCODER_CHANNELS_LAST  encoder / bottleneck activations in NHWC memory as well: no layout copies anywhere
+#   FORK_OUTPUTS           outputs with two consumers are handed out as two handles; the neuron backward adds the two gradients on load
 
 
 class MultiplyBy(nn.Module):
@@ -147,7 +144,7 @@ class SpikingStage(nn.Sequential):
         for a feed-forward synapse), the neuron kernel then walks t = 0..T-1 with v in registers."""
         T, B = x_seq.shape[:2]
         syn = self[0]
-        y = syn.forward_projected(x_seq.flatten(0, 1)) if (FUSE_UPCONV and isinstance(syn, NNConvUpsampling)) \
+        y = syn.forward_projected(x_seq.flatten(0, 1)) if (_cfg().FUSE_UPCONV and isinstance(syn, NNConvUpsampling)) \
             else syn(x_seq.flatten(0, 1))
         y, scale = _fold_gain(self[1], y)
         return self[2].forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip_seq, nnz)
@@ -222,8 +219,11 @@ def _conv_cl(conv: nn.Module, x_arr: torch.Tensor, spikes_in: bool = False, x_pa
         w = conv.weight.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x_arr.permute(0, 3, 1, 2), w, conv.bias, conv.stride, conv.padding,
                                        conv.dilation, conv.groups)
+        _config.note('synapse_fwd', 'miopen')
+        _config.note('synapse_bwd', 'g_x: miopen; g_w: miopen')
     else:
         y = conv(x_arr.permute(0, 3, 1, 2))
+        _config.note('synapse_fwd', 'torch module (MIOpen)')
     y = y.permute(0, 2, 3, 1)
     return y if y.is_contiguous() else y.contiguous()
 
@@ -272,8 +272,10 @@ class SEWResBlock(nn.Module):
         T, B = x_seq.shape[:2]
 
         def half(conv, sn, inp, skip, cnt):
-            y, scale = _fold_gain(conv[1], conv[0](inp.flatten(0, 1)))
-            return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt)
+            with _config.sublayer('.conv1' if conv is self.conv1 else '.conv2'):
+                y, scale = _fold_gain(conv[1], conv[0](inp.flatten(0, 1)))
+                _config.note('synapse_fwd', 'torch module (MIOpen)')
+                return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt)
 
         out = half(self.conv1, self.sn1, x_seq, None, None)
         if self.connect_function == 'ADD':
@@ -292,13 +294,17 @@ class SEWResBlock(nn.Module):
         T, B = x_seq.shape[:2]
 
         def half(conv, sn, inp, skip, cnt, spk, inp_packed, skip_packed, pack):
-            y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1), spk, inp_packed))
-            return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt, channels_last=True, pack=pack, skip_packed=skip_packed)
+            with _config.sublayer('.conv1' if conv is self.conv1 else '.conv2'):           # the block's two halves are two layers of the dispatch plan
+                y, scale = _fold_gain(conv[1], _conv_cl(conv[0], inp.flatten(0, 1), spk, inp_packed))
+                return sn.forward_sequence(y.view(T, B, *y.shape[1:]), scale, skip, cnt, channels_last=True, pack=pack, skip_packed=skip_packed)
 
         exact1 = fused.spike_conv_applies(self.conv1[0], x_seq.device, x_seq.dtype)
-        exact2 = fused.PACK_SPIKES and fused.spike_conv_applies(self.conv2[0], x_seq.device, x_seq.dtype)
+        exact2 = _cfg().PACK_SPIKES and fused.spike_conv_applies(self.conv2[0], x_seq.device, x_seq.dtype)
         out = half(self.conv1, self.sn1, x_seq, None, None, spikes_in, x_packed if (exact1 and spikes_in) else None, None, 2 if exact2 else 0)
         return half(self.conv2, self.sn2, out, x_seq, nnz, True, self.sn1.last_packed, x_packed, pack_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_sequence(x.unsqueeze(0))[0]
+
+
+_config.guard_module(__name__, 'blocks')

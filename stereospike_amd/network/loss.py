@@ -10,6 +10,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import config as _config
+from ..config import current as _cfg
+
 
 def _residual(predicted, groundtruth):
     mask = ~torch.isnan(groundtruth)
@@ -76,7 +79,7 @@ def SpikePenalization_Loss(intermediary_spike_tensors):
 
 # On the MI355X the two terms of every scale come from one statistics kernel (+ one stencil kernel backward) instead of ~25
 # element-wise / reduction / convolution launches per scale; the functions above stay as the definition (and the CPU form).
-FUSED_LOSS = True
+# (EngineConfig.FUSED_LOSS; reads of `loss.FUSED_LOSS` answer with the configuration in effect.)
 
 
 def _on_device(t):
@@ -84,7 +87,7 @@ def _on_device(t):
 
 
 def _fusable(pred, gt):
-    return FUSED_LOSS and _on_device(pred) and pred.dim() == 4 and pred.shape[1] == 1 and pred.shape == gt.shape \
+    return _cfg().FUSED_LOSS and _on_device(pred) and pred.dim() == 4 and pred.shape[1] == 1 and pred.shape == gt.shape \
         and pred.dtype == torch.float32 and gt.dtype == torch.float32
 
 
@@ -124,3 +127,6 @@ class Total_Loss(nn.Module):
         if self.penalize_spikes:
             loss = loss + self.beta * SpikePenalization_Loss(intermediary_spike_tensors)
         return loss
+
+
+_config.guard_module(__name__, 'loss')

@@ -326,7 +326,7 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
         loss=[float(L.detach()), float(L_o.detach())], loss_rel=abs(float(L.detach()) - float(L_o.detach())) / abs(float(L_o.detach())),
         mde=[float(mde), float(mde_o)], mde_rel=abs(float(mde) - float(mde_o)) / abs(float(mde_o)),
         product_spike_density=[float(t.count_nonzero()) / t.numel() for t in s],
-        grad_rel_l2=grad_rel_l2, plif_w=plif_w, launch_tags=tags)
+        grad_rel_l2=grad_rel_l2, plif_w=plif_w, launch_tags=tags, plan=net.plan() if hasattr(net, 'plan') else {})
     rep['flip_frac_max'] = max([v['flip_frac'] for v in rep['layers'].values()] or [0.0])
     rep['margin_max'] = max([v['max_margin'] for v in rep['layers'].values()] or [0.0])
     rep['grad_rel_l2_max'] = max(rep['grad_rel_l2'].values())

@@ -56,6 +56,36 @@ def check(tag, rep, margin=MARGIN_DEFAULT, depth_bar=1e-5, tensor_bar=TENSOR_GRA
     assert rep['plif_w_err_over_magnitude_max'] <= plif_bar, (tag, rep['plif_w'])
 
 
+DEFAULT_PLAN = {
+    # layer: (synapse forward, synapse backward) kernel forms of the shipped fp32 configuration, as the dispatch sites record them (net.plan())
+    'bottom': ('dense_conv_s1_fwd6_mfma', 'g_x: none; g_w: dense_conv_s1_wgrad6_mfma'),
+    'conv1': ('spike_conv_fwd3_mfma(packed in)', 'g_x: conv_s2_dgrad6_mfma; g_w: spike_conv_wgrad3_mfma'),
+    'conv2': ('spike_conv_fwd3_mfma(packed in)', 'g_x: conv_s2_dgrad6_mfma; g_w: spike_conv_wgrad3_mfma'),
+    'conv3': ('im2col(packed in)+exact_bf16x3_gemm', 'g_x: conv_s2_dgrad6_mfma; g_w: split3+exact_bf16x3_gemm'),
+    'conv4': ('im2col(packed in)+exact_bf16x3_gemm', 'g_x: conv_s2_dgrad6_mfma; g_w: split3+exact_bf16x3_gemm'),
+    **{f'bottleneck.{b}.conv{c}': ('im2col(packed in)+exact_bf16x3_gemm', 'g_x: winograd_f2x2_3x3+batched_gemm; g_w: split3+exact_bf16x3_gemm') for b in (0, 1) for c in (1, 2)},
+    'predict_depth1': ('head_proj_packed_mfma+gather', 'g_x: lowrank_pair; g_w: head_wgrad_packed_mfma'),
+    'predict_depth2': ('head_proj_packed_mfma+gather', 'g_x: lowrank_pair; g_w: head_wgrad_packed_mfma'),
+    'predict_depth3': ('fp32_gemm+gather', 'g_x: lowrank_pair; g_w: library_gemm'),
+    'predict_depth4': ('fp32_gemm+gather', 'g_x: lowrank_pair; g_w: library_gemm'),
+}
+
+
+def assert_default_plan(plan, geometry_full=True):
+    """The dispatch plan of a default fp32 run (`assert_default_kernels` checks the plan as well as the launch tags): every encoder /
+    bottleneck / head layer on the kernel form named above; the decoder stages on the fused MFMA forward where the geometry is compiled (deconv1 / deconv2)
+    and — every stage whose window the box-sum kernels hold — on the box-sum backward."""
+    for name, (fwd, bwd) in DEFAULT_PLAN.items():
+        assert plan[name]['synapse_fwd'] == fwd and plan[name]['synapse_bwd'] == bwd, (name, plan[name])
+    for lvl in (1, 2):
+        assert plan[f'deconv{lvl}']['synapse_fwd'].startswith('upconv_fused2_mfma'), plan[f'deconv{lvl}']
+    for lvl in (3, 4):
+        assert plan[f'deconv{lvl}']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan[f'deconv{lvl}']
+    box = [lvl for lvl in (1, 2, 3, 4) if plan[f'deconv{lvl}']['synapse_bwd'].startswith('box: boxsum+dgrad6_mfma+wgrad3_mfma')]
+    assert set(box) >= {1, 2}, {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
+    assert len(plan) == 17 and all('neuron_fwd' in v and 'neuron_bwd' in v for k, v in plan.items() if not k.startswith('predict'))
+
+
 def assert_default_kernels(tags, T, penalized=False):
     """The launch tags of one forward + backward of a 13-layer spiking network in the shipped default configuration at a compile-time T:
     packed-only outputs on the seven edges into exact-split / implicit-GEMM convs, packed skip operands, forked gradients on conv1..3, the four heads'
@@ -96,6 +126,7 @@ def test_pinned_parity_default_kernels_T5(name, C):
     rep = pinned_parity(orc, net, x, gt, returns_spikes=name != 'PLIFNetMono')
     assert len(rep['layers']) == 13 and len(rep['plif_w']) == {'StereoSpike': 0, 'LIFNet': 4}.get(name, 13)
     assert_default_kernels(rep['launch_tags'], T)
+    assert_default_plan(rep['plan'])
     check(f'pinned_T5_{name}', rep)
 
 
@@ -113,7 +144,7 @@ def test_pinned_parity_default_kernels_T10_T1(name, C, T):
 
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
 def test_pinned_parity_penalize_spikes_T5(name):
-    """Total_Loss(penalize_spikes=True, beta=0.5) at network level (/root/reference/network/loss.py:96-107,126-135; train.py:125): the loss reads the five
+    """Total_Loss(penalize_spikes=True, beta=20) at network level (/root/reference/network/loss.py:96-107,126-135; train.py:125): the loss reads the five
     RETURNED spike tensors, so a gradient enters out_rconv / out_add4..1 directly — two of them (out_add2, out_add1) are fused.unpack_last_step views of
     packed-only anchors that also carry a forked and a low-rank gradient.  Same pinned protocol and bars as the default loss; the default (packed /
     forked / low-rank) launch tags are asserted in the form this loss gives them."""
@@ -121,16 +152,18 @@ def test_pinned_parity_penalize_spikes_T5(name):
     orc, net = pair(name, H, W)
     x = synth_input(2, T, 4, 81, H, W, lam=0.08)
     gt = synth_label(2, 82, H, W)
-    rep = pinned_parity(orc, net, x, gt, penalize_spikes=True, beta=0.5)
+    # beta = 20: on this untrained network the depth terms are ~9000 and their gradients dwarf the penalty's; at beta = 0.5 the penalty moves the bottleneck's
+    # weight gradients by 8e-5 — BELOW the parity bar, i.e. invisible to it (measured, profiles/r04/) — at 20 by >= 30 x the bar (negative control below)
+    rep = pinned_parity(orc, net, x, gt, penalize_spikes=True, beta=20.0)
     assert_default_kernels(rep['launch_tags'], T, penalized=True)
     check(f'pinned_T5_{name}_penalize_spikes', rep)
     g_pen = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
     # negative control — the penalty really is in the loss and in the gradients: the same run without it gives a visibly smaller loss and
     # weight gradients that differ by far more than the parity bar
     rep0 = pinned_parity(orc, net, x, gt)
-    assert rep['loss'][0] - rep0['loss'][0] > 0.2, (rep['loss'], rep0['loss'])      # beta / 2 * sum of five mean(s^2): O(1) at these densities
+    assert rep['loss'][0] - rep0['loss'][0] > 10.0, (rep['loss'], rep0['loss'])     # beta / 2 * sum of five mean(s^2): 2.5 * beta at these densities
     moved = {k: rel_l2(g_pen[k], p.grad) for k, p in net.named_parameters()}
-    assert moved['deconv1.0.up.1.weight'] > 100 * TENSOR_GRAD_BAR and moved['bottleneck.1.conv2.0.weight'] > 100 * TENSOR_GRAD_BAR, moved
+    assert moved['deconv1.0.up.1.weight'] > 10 * TENSOR_GRAD_BAR and moved['bottleneck.1.conv2.0.weight'] > 10 * TENSOR_GRAD_BAR, moved
 
 
 def test_pinned_parity_ann():
@@ -164,6 +197,7 @@ def test_pinned_parity_full_resolution_stereospike_T5():
     assert state_sha(orc) == str(z['state_sha'])
     rep = pinned_parity(orc, net, x, gt)
     assert_default_kernels(rep['launch_tags'], 5)
+    assert_default_plan(rep['plan'])
     check('pinned_full_stereospike_T5', rep)
     # statistics of the free-running product against the reference's fixture (chaotic per neuron, stable in the mean)
     for nm, dens in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), rep['product_spike_density']):
@@ -183,6 +217,7 @@ def test_pinned_parity_config3_step_B16_T5():
     gt = synth_label(16, 2022)
     rep = pinned_parity(orc, net, x, gt, oracle_chunk=2, oracle_procs=True)
     assert_default_kernels(rep['launch_tags'], 5)
+    assert_default_plan(rep['plan'])
     check('pinned_config3_B16_T5', rep)
 
 
@@ -225,24 +260,20 @@ def test_packed_spike_tensors_are_in_effect():
     assert rec['anchor']                                                                        # bottom's dense output is a data-less anchor
     packed_only = fused.unpack_dense(net.bottom[2].last_packed, rec['shape'])
     # with conv1's forward back on MIOpen (which reads dense activations) bottom writes BOTH forms in one launch: unpack(packed) == dense
-    fused.SPIKE_CONV_FWD_MFMA = False
-    try:
+    with net.configured(SPIKE_CONV_FWD_MFMA=False):
         functional.reset_net(net)
         with torch.no_grad():
             net.forward_sequence(x)
         assert not rec['anchor'] and torch.equal(fused.unpack_dense(net.bottom[2].last_packed, rec['shape']), rec['bottom_out'])
         assert torch.equal(rec['bottom_out'], packed_only)
-    finally:
-        fused.SPIKE_CONV_FWD_MFMA = True
+        assert net.plan()['conv1']['synapse_fwd'] == 'miopen'
     assert 0.02 < float(rec['bottom_out'].mean()) < 0.9
-    fused.PACK_SPIKES = False
-    try:
+    with net.configured(PACK_SPIKES=False):
         functional.reset_net(net)
         with torch.no_grad():
             net.forward_sequence(x)
         assert net.conv3[2].last_packed is None and net.bottom[2].last_packed is None
-    finally:
-        fused.PACK_SPIKES = True
+    assert net.config.PACK_SPIKES and net.config.SPIKE_CONV_FWD_MFMA          # the context managers restored the network's own configuration
 
 
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
@@ -260,20 +291,20 @@ def test_low_rank_head_gradients_are_in_effect_and_equal_the_dense_form(name):
     gt = synth_label(2, 8, H, W).to(DEV)
 
     def grads(on):
-        fused.LOWRANK_HEAD_GRAD = on
         fused.TIMER.clear()
         fused.TIMER.enabled = True
         try:
-            functional.reset_net(net)
-            for p in net.parameters():
-                p.grad = None
-            out = net.forward_sequence(x)
-            d, s = out if isinstance(out, tuple) else (out, None)
-            Total_Loss()(d, gt, s).backward()
+            with net.configured(LOWRANK_HEAD_GRAD=on):
+                functional.reset_net(net)
+                for p in net.parameters():
+                    p.grad = None
+                out = net.forward_sequence(x)
+                d, s = out if isinstance(out, tuple) else (out, None)
+                L = Total_Loss()(d, gt, s)
+            L.backward()                  # outside the context on purpose: the backward dispatches from the configuration its forward captured
             torch.cuda.synchronize()
             tags = {k: v['launches'] for k, v in fused.TIMER.summary().items() if k.startswith('neuron_bwd')}
         finally:
-            fused.LOWRANK_HEAD_GRAD = True
             fused.TIMER.enabled = False
         return {n: p.grad.detach().double().clone() for n, p in net.named_parameters()}, tags
     g_on, t_on = grads(True)

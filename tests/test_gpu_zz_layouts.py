@@ -33,34 +33,33 @@ EXACT = ('all_nhwc_exact_split', 'exact_split_dense_spikes', 'saved_h_no_fork')
 LAYOUTS = ['all_nhwc_exact_split', 'exact_split_dense_spikes', 'saved_h_no_fork', 'all_nhwc', 'decoder_nhwc', 'nchw', 'two_op_miopen']
 
 
-def _configure(layout, setattr_):
-    from stereospike_amd import fused
-    from stereospike_amd.network import blocks
-    setattr_(blocks, 'FUSE_UPCONV', layout != 'two_op_miopen')
-    setattr_(blocks, 'DECODER_CHANNELS_LAST', layout in ('decoder_nhwc', 'all_nhwc') + EXACT)
-    setattr_(blocks, 'ENCODER_CHANNELS_LAST', layout in ('all_nhwc',) + EXACT)
-    setattr_(fused, 'EXACT_SPLIT_GEMM', layout in EXACT)
-    setattr_(fused, 'PACK_SPIKES', layout != 'exact_split_dense_spikes')
-    setattr_(fused, 'ASSERT_EXACT_SPLIT', True)
+def _layout_config(layout):
+    """The engine-configuration overrides (config.EngineConfig fields) of one execution layout."""
+    ov = dict(FUSE_UPCONV=layout != 'two_op_miopen',
+              DECODER_CHANNELS_LAST=layout in ('decoder_nhwc', 'all_nhwc') + EXACT,
+              ENCODER_CHANNELS_LAST=layout in ('all_nhwc',) + EXACT,
+              EXACT_SPLIT_GEMM=layout in EXACT,
+              PACK_SPIKES=layout != 'exact_split_dense_spikes',
+              ASSERT_EXACT_SPLIT=True)
     if layout == 'saved_h_no_fork':
-        setattr_(fused, 'RECOMPUTE_H', False)
-        setattr_(blocks, 'FORK_OUTPUTS', False)
+        ov.update(RECOMPUTE_H=False, FORK_OUTPUTS=False)
+    return ov
 
 
 def _run(layout, T):
     H, W = 64, 80
     orc, net = pair('PLIFNet', H, W)
+    net.config = net.config.replace(**_layout_config(layout))          # the network owns its configuration: nothing global is touched
     x = synth_input(2, T, 4, 77, H, W, lam=0.08)
     gt = synth_label(2, 78, H, W)
     return pinned_parity(orc, net, x, gt)
 
 
 @pytest.mark.parametrize('layout,T', [(lay, 5) for lay in LAYOUTS] + [('nchw', 3)])        # (one run-time-T case; the default path has its own: test_gpu_00)
-def test_pinned_parity_every_execution_layout(layout, T, monkeypatch):
+def test_pinned_parity_every_execution_layout(layout, T):
     """The same network through every execution variant of the synapses / neuron kernels: the shipped default; dense instead of packed
     spikes; saved-h backward without forked gradients; NHWC with plain fp32 GEMMs; NHWC decoder only; projected NCHW; the reference's
     two-op up-convs on MIOpen — at T = 5 (compile-time-T kernels), three of them also at T = 3 (run-time-T kernels)."""
-    _configure(layout, monkeypatch.setattr)
     rep = _run(layout, T)
     try:
         check(f'pinned_layout_{layout}_T{T}', rep, MARGIN_DEFAULT if layout in EXACT else MARGIN_MIOPEN)
@@ -85,6 +84,5 @@ if __name__ == '__main__':            # the logging re-run of _dump_miopen_comma
     from stereospike_amd import gemm_tuning
     gemm_tuning.enable(0)
     lay, T = os.environ['SS_LAYOUT'], int(os.environ['SS_LAYOUT_T'])
-    _configure(lay, setattr)
     rep = _run(lay, T)
     print(json.dumps({k: rep[k] for k in ('grad_rel_l2', 'plif_w', 'layers', 'depth_max_abs_rel')}, indent=1))

@@ -16,8 +16,9 @@ layers = [('deconv4', 512, 256, 5, (17, 22), (33, 44)), ('deconv3', 256, 128, 5,
           ('pd2', 64, 1, 3, (130, 173), (260, 346)), ('pd1', 32, 1, 3, (260, 346), (260, 346))]
 which = os.environ.get('WHICH', 'projected,miopen').split(',')
 from stereospike_amd import fused
-fused.PROJECTION_IMPL = os.environ.get('PROJ', 'auto')
-fused.P_CHUNK_BYTES = int(os.environ.get('CHUNK_MB', fused.P_CHUNK_BYTES >> 20)) << 20
+from stereospike_amd import config as _config
+_cm = _config.engine_config(PROJECTION_IMPL=os.environ.get('PROJ', 'auto'), P_CHUNK_BYTES=int(os.environ.get('CHUNK_MB', fused.P_CHUNK_BYTES >> 20)) << 20)
+_cm.__enter__()                # a one-off diagnostic script: the ambient configuration for the rest of the process
 only = os.environ.get('LAYERS')
 if only:
     layers = [l for l in layers if l[0] in only.split(',')]
