@@ -349,26 +349,28 @@ int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* 
  *                           ss_upconv_box_elems(NB, C_out, NVR, NHR) elements.  vr [NVR][2], hr [NHR][2]: (start, length) of the distinct vertical /
  *                           horizontal output ranges, id 0 = the empty range.
  *   ss_upconv_box_dgrad_f32 g_x[nb][iy][ix][ci] = sum_{ky,kx,co} B[nb][vmap[iy][ky]][hmap[ix][kx]][co] * weight[co][ci][ky][kx]: six bf16 cross terms on the
- *                           matrix cores, |g_x - float64| <= 2^-20 sum |B| |W| element-wise (2^-21 typical: ss_gemm6_f32's accuracy).  vmap [h][5], hmap [w][5]: range ids; tile_rows [ceil(h / 4)][2],
- *                           tile_cols [ceil(w / 32)][2]: (first id, id count) of the non-empty ranges 4 consecutive source rows / 32 consecutive source
- *                           columns reach; ws: ss_upconv_box_dgrad_ws_floats(C_in, C_out) floats.
+ *                           matrix cores, |g_x - float64| <= 2^-20 sum |B| |W| element-wise (2^-21 typical: ss_gemm6_f32's accuracy).  vmap [h][5], hmap [w][5]: range ids;
+ *                           tile_rows [n_row_tiles][4]: (first source row, rows <= 4, first id, id count <= 13) — the caller cuts the source rows into tiles whose
+ *                           non-empty vertical ranges fit the on-chip window (a triple-replicated row shortens its tile); tile_cols [ceil(w / 32)][2]: (first id,
+ *                           id count <= 78) of 32 consecutive source columns; ws: ss_upconv_box_dgrad_ws_floats(C_in, C_out) floats.
  *   ss_upconv_box_wgrad_f32 g_w[co][ci][ky][kx] (+)= sum_{nb,iy,ix} x[nb][iy][ix][ci] * B[nb][vmap[iy][ky]][hmap[ix][kx]][co]: x a spike tensor (values exact
  *                           in bf16; fp32 NHWC or the 2-bit packed form), every product exact, fp32 accumulation, fixed-order reduction (deterministic):
  *                           |g_w - float64| <= 2^-22 sum |x| |B|.  ws: ss_upconv_box_wgrad_ws_floats(C_in, C_out, NB, h, w) floats.
  * g_out [NB][H][W][C_out], x / g_x [NB][h][w][C_in] NHWC fp32; weight / g_w [C_out][C_in][5][5] (the Conv2d parameter's own layout).
- * *_supported: k = 5; dgrad C_in % 64 == 0 and C_out in {32, 64, 128, 256}; wgrad C_in % 32 == 0, C_out % 8 == 0; max_rows4 <= 17 and max_cols32 <= 74
- * (largest id span of tile_rows / tile_cols).  No g_P anywhere; HBM traffic of the three launches: g_out once, the box image (1.5 x g_out's bytes) written
+ * *_supported: k = 5; dgrad C_in % 64 == 0, C_out % 8 == 0; wgrad C_in % 32 == 0, C_out % 8 == 0; largest id span of tile_rows <= 13 and of tile_cols <= 78
+ * (ss_upconv_box_window).  No g_P anywhere; HBM traffic of the three launches: g_out once, the box image (1.5 x g_out's bytes) written
  * once and read ~twice (window halos), x once per 8 output channels in its 2-byte fragment form, g_x once.
  */
 long long ss_upconv_box_elems(long long NB, int Cout, int NVR, int NHR);
 int ss_upconv_boxsum_f32(const float* g_out, const int* vr, const int* hr, void* box, long long NB, int Cout, int H, int W, int NVR, int NHR, void* stream);
-int ss_upconv_box_dgrad_supported(int Cin, int Cout, int k, int max_rows4, int max_cols32);
+int ss_upconv_box_window(int* max_tile_rows, int* max_cols32);   /* returns the most source rows of a row tile (4); the id spans a tile may reach */
+int ss_upconv_box_dgrad_supported(int Cin, int Cout, int k, int max_tile_rows, int max_cols32);
 long long ss_upconv_box_dgrad_ws_floats(int Cin, int Cout);
-int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vmap, const int* hmap, const int* tile_rows, const int* tile_cols,
+int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles, const int* tile_cols,
                             float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, void* stream);
-int ss_upconv_box_wgrad_supported(int Cin, int Cout, int k, int max_rows4, int max_cols32);
+int ss_upconv_box_wgrad_supported(int Cin, int Cout, int k, int max_tile_rows, int max_cols32);
 long long ss_upconv_box_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w);
-int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int* x_packed, const int* vmap, const int* hmap, const int* tile_rows,
+int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int* x_packed, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles,
                             const int* tile_cols, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, int accumulate,
                             void* stream);
 

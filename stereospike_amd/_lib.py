@@ -164,13 +164,15 @@ def lib():
     L.ss_upconv_box_dgrad_supported.restype = i32
     L.ss_upconv_box_dgrad_ws_floats.argtypes = [i32, i32]
     L.ss_upconv_box_dgrad_ws_floats.restype = i64
-    L.ss_upconv_box_dgrad_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_box_window.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ss_upconv_box_window.restype = i32
+    L.ss_upconv_box_dgrad_f32.argtypes = [p, p, p, p, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_box_dgrad_f32.restype = i32
     L.ss_upconv_box_wgrad_supported.argtypes = [i32, i32, i32, i32, i32]
     L.ss_upconv_box_wgrad_supported.restype = i32
     L.ss_upconv_box_wgrad_ws_floats.argtypes = [i32, i32, i64, i32, i32]
     L.ss_upconv_box_wgrad_ws_floats.restype = i64
-    L.ss_upconv_box_wgrad_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_box_wgrad_f32.argtypes = [p, p, p, p, p, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_box_wgrad_f32.restype = i32
     L.ss_gemm6_supported.argtypes = [i32, i32]
     L.ss_gemm6_supported.restype = i32
@@ -222,7 +224,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
            'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
            'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
-           'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats', 'ss_upconv_box_dgrad_f32',
+           'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_window', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats', 'ss_upconv_box_dgrad_f32',
            'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
@@ -591,12 +593,19 @@ def upconv_boxsum(g_out, bt, NB, Cout, H, W):
     return box
 
 
+def upconv_box_window():
+    """(most source rows of a row tile, largest vertical id span of a tile, largest horizontal id span of 32 source columns) the box kernels hold on chip."""
+    r, c = C.c_int(0), C.c_int(0)
+    n = lib().ss_upconv_box_window(C.byref(r), C.byref(c))
+    return int(n), int(r.value), int(c.value)
+
+
 def upconv_box_dgrad_supported(Cin, Cout, k, bt):
-    return bool(lib().ss_upconv_box_dgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_rows4']), int(bt['max_cols32'])))
+    return bool(lib().ss_upconv_box_dgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_tile_rows']), int(bt['max_cols32'])))
 
 
 def upconv_box_wgrad_supported(Cin, Cout, k, bt):
-    return bool(lib().ss_upconv_box_wgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_rows4']), int(bt['max_cols32'])))
+    return bool(lib().ss_upconv_box_wgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_tile_rows']), int(bt['max_cols32'])))
 
 
 def upconv_box_dgrad(box, weight, bt, g_x, NB, Cin, Cout, h, w):
@@ -605,7 +614,7 @@ def upconv_box_dgrad(box, weight, bt, g_x, NB, Cin, Cout, h, w):
     ws = torch.empty(int(lib().ss_upconv_box_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=box.device)
     with torch.cuda.device(box.device):
         rc = lib().ss_upconv_box_dgrad_f32(C.c_void_p(box.data_ptr()), _f32(weight, 'weight', Cout * Cin * 25), _i32(bt['vmap'], 'vmap', 5 * h),
-                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows'), _i32(bt['tile_cols'], 'tile_cols'),
+                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows', 4 * bt['n_row_tiles']), bt['n_row_tiles'], _i32(bt['tile_cols'], 'tile_cols'),
                                            _f32(g_x, 'g_x', NB * h * w * Cin), _f32(ws, 'ws'), NB, int(Cin), int(Cout), h, w, bt['NVR'], bt['NHR'], _stream(box))
     _check(rc, 'ss_upconv_box_dgrad_f32')
 
@@ -618,7 +627,7 @@ def upconv_box_wgrad(box, x, x_packed, bt, g_w, NB, Cin, Cout, h, w, accumulate=
     with torch.cuda.device(box.device):
         rc = lib().ss_upconv_box_wgrad_f32(C.c_void_p(box.data_ptr()), _f32(x, 'x', NB * h * w * Cin) if x_packed is None else None,
                                            _i32(x_packed, 'x_packed') if x_packed is not None else None, _i32(bt['vmap'], 'vmap', 5 * h),
-                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows'), _i32(bt['tile_cols'], 'tile_cols'),
+                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows', 4 * bt['n_row_tiles']), bt['n_row_tiles'], _i32(bt['tile_cols'], 'tile_cols'),
                                            _f32(g_w, 'g_w', Cout * Cin * 25), _f32(ws, 'ws'), NB, int(Cin), int(Cout), h, w, bt['NVR'], bt['NHR'],
                                            int(bool(accumulate)), _stream(box))
     _check(rc, 'ss_upconv_box_wgrad_f32')

@@ -650,19 +650,41 @@ def _tile_spans(rmap, tile):
     return out
 
 
+def _row_tiles(vmap, max_rows, max_span):
+    """Cut the source rows into tiles of <= max_rows rows whose non-empty vertical range ids span <= max_span: [(first row, rows, first id, id count)].  A tile
+    with a triple-replicated row reaches more distinct ranges than the on-chip window holds and is cut short (a single row always fits: <= 5 ranges... its
+    ids are consecutive taps of one row)."""
+    out, a = [], 0
+    while a < len(vmap):
+        n = 1
+        while n < max_rows and a + n < len(vmap):
+            ids = [v for row in vmap[a:a + n + 1] for v in row if v > 0]
+            if ids and max(ids) - min(ids) + 1 > max_span:
+                break
+            n += 1
+        ids = [v for row in vmap[a:a + n] for v in row if v > 0]
+        out.append((a, n, min(ids), max(ids) - min(ids) + 1) if ids else (a, n, 1, 1))
+        a += n
+    return out
+
+
 def register_box_tables(tables, host_tables, H, W):
-    """Called where the resize tables are built (NNConvUpsampling._tables): the range lists / maps / tile spans of the box-sum backward, from the HOST copies
+    """Called where the resize tables are built (NNConvUpsampling._tables): the range lists / maps / tiles of the box-sum backward, from the HOST copies
     (no device read-back, nothing that could land in a stream capture)."""
     y_lo, y_hi, x_lo, x_hi = (host_tables[i].tolist() for i in (1, 2, 4, 5))
     vr, vmap = _range_tables(y_lo, y_hi, H)
     hr, hmap = _range_tables(x_lo, x_hi, W)
-    tr, tc = _tile_spans(vmap, 4), _tile_spans(hmap, 32)
     dev = tables[1].device
+    if dev.type == 'cuda':
+        max_rows, max_span, _ = _lib.upconv_box_window()
+    else:
+        max_rows, max_span = 4, 13
+    tr, tc = _row_tiles(vmap, max_rows, max_span), _tile_spans(hmap, 32)
 
     def t(a):
         return torch.tensor(a, dtype=torch.int32).reshape(-1).to(dev)
-    bt = dict(vr=t(vr), hr=t(hr), vmap=t(vmap), hmap=t(hmap), tile_rows=t(tr), tile_cols=t(tc), NVR=len(vr), NHR=len(hr),
-              max_rows4=max(n for _, n in tr), max_cols32=max(n for _, n in tc), H=H, W=W)
+    bt = dict(vr=t(vr), hr=t(hr), vmap=t(vmap), hmap=t(hmap), tile_rows=t(tr), tile_cols=t(tc), NVR=len(vr), NHR=len(hr), n_row_tiles=len(tr),
+              max_tile_rows=max(n for _, _, _, n in tr), max_cols32=max(n for _, n in tc), H=H, W=W)
     _BOX[id(tables)] = (tables, bt)
     return bt
 

@@ -45,7 +45,7 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
                                   'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
                                   # ABI 7
-                                  'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats',
+                                  'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_window', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats',
                                   'ss_upconv_box_dgrad_f32', 'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32'])
 
 
@@ -85,12 +85,12 @@ def test_argument_validation_without_a_gpu():
     assert L.ss_im2col_cl_bf16_packed(None, None, 1, 4, 4, 8, 3, 1, 1, 4, 4, None) == -22
     # ABI 7: the box-sum backward
     assert L.ss_upconv_boxsum_f32(None, None, None, None, 1, 32, 8, 8, 4, 4, None) == -22
-    assert L.ss_upconv_box_dgrad_f32(None, None, None, None, None, None, None, None, 1, 64, 32, 4, 4, 4, 4, None) == -22
-    assert L.ss_upconv_box_wgrad_f32(None, None, None, None, None, None, None, None, None, 1, 64, 32, 4, 4, 4, 4, 0, None) == -22
+    assert L.ss_upconv_box_dgrad_f32(None, None, None, None, None, 1, None, None, None, 1, 64, 32, 4, 4, 4, 4, None) == -22
+    assert L.ss_upconv_box_wgrad_f32(None, None, None, None, None, None, 1, None, None, None, 1, 64, 32, 4, 4, 4, 4, 0, None) == -22
     assert L.ss_upconv_box_elems(2, 32, 10, 12) == 2 * 32 * 3 * 10 * 12 and L.ss_upconv_box_elems(2, 30, 10, 12) == 0
-    assert L.ss_upconv_box_dgrad_supported(64, 32, 5, 17, 74) == 1 and L.ss_upconv_box_dgrad_supported(64, 32, 5, 18, 74) == 0
+    assert L.ss_upconv_box_dgrad_supported(64, 32, 5, 13, 78) == 1 and L.ss_upconv_box_dgrad_supported(64, 32, 5, 14, 78) == 0
     assert L.ss_upconv_box_dgrad_supported(96, 32, 5, 12, 70) == 0 and L.ss_upconv_box_wgrad_supported(96, 40, 5, 12, 70) == 1
-    assert L.ss_upconv_box_dgrad_ws_floats(64, 32) == 1 * 4 * 13 * 6144 // 4
+    assert L.ss_upconv_box_dgrad_ws_floats(64, 32) == 2 * 4 * 13 * 3072 // 4 and _lib.upconv_box_window() == (4, 13, 78)
 
 
 def test_product_fails_loudly_on_cpu_tensors():

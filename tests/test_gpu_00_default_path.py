@@ -71,7 +71,7 @@ DEFAULT_PLAN = {
 }
 
 
-def assert_default_plan(plan, geometry_full=True):
+def assert_default_plan(plan, full_resolution=False):
     """The dispatch plan of a default fp32 run (`assert_default_kernels` checks the plan as well as the launch tags): every encoder /
     bottleneck / head layer on the kernel form named above; the decoder stages on the fused MFMA forward where the geometry is compiled (deconv1 / deconv2)
     and — every stage whose window the box-sum kernels hold — on the box-sum backward."""
@@ -82,7 +82,8 @@ def assert_default_plan(plan, geometry_full=True):
     for lvl in (3, 4):
         assert plan[f'deconv{lvl}']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan[f'deconv{lvl}']
     box = [lvl for lvl in (1, 2, 3, 4) if plan[f'deconv{lvl}']['synapse_bwd'].startswith('box: boxsum+dgrad6_mfma+wgrad3_mfma')]
-    assert set(box) >= {1, 2}, {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
+    # (64x80 frames: deconv1's 32 source columns reach 84 horizontal ranges, more than the on-chip window's 78 — that stage keeps the round-3 fused forms)
+    assert set(box) == ({1, 2, 3, 4} if full_resolution else {2, 3, 4}), {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
     assert len(plan) == 17 and all('neuron_fwd' in v and 'neuron_bwd' in v for k, v in plan.items() if not k.startswith('predict'))
 
 
@@ -197,7 +198,7 @@ def test_pinned_parity_full_resolution_stereospike_T5():
     assert state_sha(orc) == str(z['state_sha'])
     rep = pinned_parity(orc, net, x, gt)
     assert_default_kernels(rep['launch_tags'], 5)
-    assert_default_plan(rep['plan'])
+    assert_default_plan(rep['plan'], full_resolution=True)
     check('pinned_full_stereospike_T5', rep)
     # statistics of the free-running product against the reference's fixture (chaotic per neuron, stable in the mean)
     for nm, dens in zip(('out_rconv', 'out_add4', 'out_add3', 'out_add2', 'out_add1'), rep['product_spike_density']):
@@ -217,7 +218,7 @@ def test_pinned_parity_config3_step_B16_T5():
     gt = synth_label(16, 2022)
     rep = pinned_parity(orc, net, x, gt, oracle_chunk=2, oracle_procs=True)
     assert_default_kernels(rep['launch_tags'], 5)
-    assert_default_plan(rep['plan'])
+    assert_default_plan(rep['plan'], full_resolution=True)
     check('pinned_config3_B16_T5', rep)
 
 

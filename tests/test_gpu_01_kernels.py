@@ -1632,10 +1632,12 @@ def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
     hr, hmap = nbx.range_tables(tables[4].cpu().numpy(), tables[5].cpu().numpy(), W)
     assert np.array_equal(bt['vr'].cpu().numpy().reshape(-1, 2), vr) and np.array_equal(bt['hmap'].cpu().numpy().reshape(-1, 5), hmap)
     assert np.array_equal(bt['hr'].cpu().numpy().reshape(-1, 2), hr) and np.array_equal(bt['vmap'].cpu().numpy().reshape(-1, 5), vmap)
-    if hw == (9, 11):      # up-sampling ratio 2.33 -> 17 x 19: more distinct ranges per 4 rows than the window holds
-        assert not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt) or bt['max_rows4'] <= 17
+    # the host cuts the source rows into tiles of <= 4 rows whose vertical ranges fit the on-chip window (13 ids): every geometry's ROWS fit by construction;
+    # a resize whose 32 source columns reach more than 78 horizontal ranges is refused (the caller then keeps the g_P forms)
+    tr = bt['tile_rows'].cpu().numpy().reshape(-1, 4)
+    assert tr[0, 0] == 0 and (tr[1:, 0] == tr[:-1, 0] + tr[:-1, 1]).all() and tr[-1, 0] + tr[-1, 1] == h and tr[:, 1].max() <= 4 and tr[:, 3].max() <= 13
     if not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt):
-        assert bt['max_rows4'] > 17 or bt['max_cols32'] > 74, bt
+        assert bt['max_cols32'] > 78, bt
         return
     assert _lib.upconv_box_wgrad_supported(Cin, Cout, 5, bt) and not _lib.upconv_box_dgrad_supported(Cin, Cout, 3, bt)
     gen = torch.Generator(device=DEV).manual_seed(23 + Cin + h)
