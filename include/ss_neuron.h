@@ -350,14 +350,14 @@ int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* 
  *                           horizontal output ranges, id 0 = the empty range.
  *   ss_upconv_box_dgrad_f32 g_x[nb][iy][ix][ci] = sum_{ky,kx,co} B[nb][vmap[iy][ky]][hmap[ix][kx]][co] * weight[co][ci][ky][kx]: six bf16 cross terms on the
  *                           matrix cores, |g_x - float64| <= 2^-20 sum |B| |W| element-wise (2^-21 typical: ss_gemm6_f32's accuracy).  vmap [h][5], hmap [w][5]: range ids;
- *                           tile_rows [n_row_tiles][4]: (first source row, rows <= 4, first id, id count <= 13) — the caller cuts the source rows into tiles whose
+ *                           tile_rows [n_row_tiles][4]: (first source row, rows <= 4, first id, id count <= 15) — the caller cuts the source rows into tiles whose
  *                           non-empty vertical ranges fit the on-chip window (a triple-replicated row shortens its tile); tile_cols [ceil(w / 32)][2]: (first id,
- *                           id count <= 78) of 32 consecutive source columns; ws: ss_upconv_box_dgrad_ws_floats(C_in, C_out) floats.
+ *                           id count <= 76) of 32 consecutive source columns; ws: ss_upconv_box_dgrad_ws_floats(C_in, C_out) floats.
  *   ss_upconv_box_wgrad_f32 g_w[co][ci][ky][kx] (+)= sum_{nb,iy,ix} x[nb][iy][ix][ci] * B[nb][vmap[iy][ky]][hmap[ix][kx]][co]: x a spike tensor (values exact
  *                           in bf16; fp32 NHWC or the 2-bit packed form), every product exact, fp32 accumulation, fixed-order reduction (deterministic):
- *                           |g_w - float64| <= 2^-22 sum |x| |B|.  ws: ss_upconv_box_wgrad_ws_floats(C_in, C_out, NB, h, w) floats.
+ *                           |g_w - float64| <= 2^-20 sum |x| |B| (fp32 accumulation over up to 1.8 M source pixels; measured <= 2^-21).  ws: ss_upconv_box_wgrad_ws_floats(C_in, C_out, NB, h, w) floats.
  * g_out [NB][H][W][C_out], x / g_x [NB][h][w][C_in] NHWC fp32; weight / g_w [C_out][C_in][5][5] (the Conv2d parameter's own layout).
- * *_supported: k = 5; dgrad C_in % 64 == 0, C_out % 8 == 0; wgrad C_in % 32 == 0, C_out % 8 == 0; largest id span of tile_rows <= 13 and of tile_cols <= 78
+ * *_supported: k = 5; dgrad C_in % 64 == 0, C_out % 8 == 0; wgrad C_in % 32 == 0, C_out % 8 == 0; largest id span of tile_rows <= 15 and of tile_cols <= 76
  * (ss_upconv_box_window).  No g_P anywhere; HBM traffic of the three launches: g_out once, the box image (1.5 x g_out's bytes) written
  * once and read ~twice (window halos), x once per 8 output channels in its 2-byte fragment form, g_x once.
  */

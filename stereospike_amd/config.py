@@ -46,7 +46,8 @@ class EngineConfig:
     PACKED_DECONV2: bool = True         # deconv2's output packed-only   [SS_PACKED_DECONV2]
     # ---- decoder backward -----------------------------------------------------------------------------------------------------------------------------
     BOX_BWD: bool = True                # round 4: the stage backward on the box-sum image (ss_upconv_box.hip), no g_P anywhere   [SS_BOX_BWD]
-    BOX_BWD_CIN: Tuple[int, ...] = (64, 128, 256, 512)                           # [SS_BOX_BWD_CIN]
+    BOX_BWD_CIN: Tuple[int, ...] = (64, 128)     # deconv1 / deconv2; the wide stages' 33x44 / 17x22 maps fill 4 x 32-pixel tiles to 57 / 47 % and stay on
+                                                 # adjoint -> g_P -> ss_gemm6_f32 + ss_spike_wgrad_f32 (profiles/r04/bench_box_bwd_v5.log)   [SS_BOX_BWD_CIN]
     WGRAD_SPLIT_ROWS: int = 8192
     EXACT_WGRAD_MFMA: bool = True
     EXACT_WGRAD_MFMA_CIN: Tuple[int, ...] = (64, 128, 256, 512)                  # [SS_WGRAD_MFMA_CIN]
@@ -87,7 +88,7 @@ class EngineConfig:
             return tuple(int(c) for c in e.get(name, default).split(',') if c)
         return EngineConfig(
             LOWRANK_HEAD_GRAD=flag('SS_LOWRANK_HEAD_GRAD', True), PACKED_HEAD=flag('SS_PACKED_HEAD', True), PACKED_DECONV2=flag('SS_PACKED_DECONV2', True),
-            BOX_BWD=flag('SS_BOX_BWD', True), BOX_BWD_CIN=ints('SS_BOX_BWD_CIN', '64,128,256,512'),
+            BOX_BWD=flag('SS_BOX_BWD', True), BOX_BWD_CIN=ints('SS_BOX_BWD_CIN', '64,128'),
             EXACT_WGRAD_MFMA_CIN=ints('SS_WGRAD_MFMA_CIN', '64,128,256,512'), GEMM6_DGRAD=flag('SS_GEMM6_DGRAD', True),
             GEMM6_DGRAD_CIN=ints('SS_GEMM6_CIN', '128,256,512'), FUSED_UPCONV_DGRAD=flag('SS_FUSED_DGRAD', True),
             FUSED_UPCONV_DGRAD_CIN=ints('SS_FUSED_DGRAD_CIN', '64'), FUSED_UPCONV_BWD_CIN_NOGP=ints('SS_FUSED_BWD_CIN_NOGP', '64'),

@@ -113,24 +113,24 @@ __global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __re
 // Window of the box planes in LDS, shared by the two contraction kernels
 // ---------------------------------------------------------------------------------------------------
 // A tile is <= 4 source rows (cut shorter by the host where a triple-replicated row would need more than 13 distinct vertical ranges) x 32 source columns.
-// Per 8-channel chunk of C_out its window of the three planes sits in LDS as 16-byte pixels: [plane][WR rows][WC columns]; row 0 and columns 0, 1 are zeros
-// (= the empty range, and what a phantom tap reads), data rows 1 .. nj, data columns 2 .. ni + 1.  Column slot = c ^ ((r >> 1) & 1): a wavefront's lanes are
-// 4 rows x 8 columns of source pixels = every second window row / column, and with this swizzle the 16 lanes of each ds_read_b128 group hit 16 distinct
-// 16-byte bank groups (tools/r04 brute force: conflict-free for WC = 80 at every offset).
+// Per 8-channel chunk of C_out its window of the three planes sits in LDS as 16-byte pixels: [plane][WR rows][WC columns] + ONE zero pixel per plane behind
+// them (= the empty range, and what a phantom tap reads: a lane's address is either a window slot or the zero pixel).  Column slot = c ^ ((r >> 1) & 1): a
+// wavefront's lanes are 4 rows x 8 columns of source pixels = every second window row / column, and with this swizzle the 16 lanes of each ds_read_b128
+// group hit 16 distinct 16-byte bank groups (brute force over all offsets: conflict-free for WC = 76 and 80).
 constexpr int kB2Threads = 256;
 constexpr int kB2TR = 4, kB2TC = 32;
-constexpr int kB2WR = 14, kB2WC = 80;          // window rows (1 zero + <= 13 ranges) x columns (2 zero + <= 78 ranges)
-constexpr int kB2Plane = kB2WR * kB2WC * 16;   // bytes of one plane of the window (17920)
+constexpr int kB2WR = 15, kB2WC = 76;          // window rows x columns = the most distinct vertical / horizontal ranges a tile may reach
+constexpr int kB2Zero = kB2WR * kB2WC * 16;    // byte offset of the zero pixel inside a plane
+constexpr int kB2Plane = kB2Zero + 16;         // bytes of one plane of the window (18256)
 constexpr int kB2KS = 13;                      // k-steps per chunk: 25 taps in pairs (the 26th is a zero-weight phantom)
 
-__device__ __forceinline__ int bx_slot(int rw, int cw) { return (rw * kB2WC + (cw ^ ((rw >> 1) & 1))) * 16; }
+__device__ __forceinline__ int bx_slot(int rw, int cw) { return (rw * kB2WC + (cw ^ ((rw >> 1) & 1))) * 16; }      // rw, cw: window row / column (0-based)
+// byte offset (inside a plane) of the pixel of range ids (jv, iv); either id 0 = the empty range -> the zero pixel
+__device__ __forceinline__ int bx_addr(int jv, int iv, int j0, int i0) { return (jv && iv) ? bx_slot(jv - j0, iv - i0) : kB2Zero; }
 
 __device__ __forceinline__ void bx_zero_borders(unsigned char* wnd)
 {
-    for (int i = threadIdx.x; i < 3 * kB2WR * kB2WC; i += kB2Threads) {
-        const int r = (i / kB2WC) % kB2WR, cc = i % kB2WC;
-        if (r == 0 || cc < 2) *reinterpret_cast<f4*>(wnd + i * 16) = (f4){0.f, 0.f, 0.f, 0.f};
-    }
+    if (threadIdx.x < 3) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB2Plane + kB2Zero) = (f4){0.f, 0.f, 0.f, 0.f};
 }
 
 // 3 planes x nj rows x ni granules of chunk c, HBM rows contiguous -> LDS; the loads of a thread are issued in batches before its stores
@@ -155,7 +155,7 @@ __device__ __forceinline__ void bx_stage_window(unsigned char* wnd, const unsign
             const int idx = threadIdx.x + kB2Threads * (u0 + v);
             const int rp = idx / kPerRow, cc = idx - rp * kPerRow;
             const int p = rp / nj, r = rp - p * nj;
-            if (rp < rows3 && cc < ni) *reinterpret_cast<f4*>(wnd + p * kB2Plane + bx_slot(r + 1, cc + 2)) = buf[v];
+            if (rp < rows3 && cc < ni) *reinterpret_cast<f4*>(wnd + p * kB2Plane + bx_slot(r, cc)) = buf[v];
         }
     }
 }
@@ -233,26 +233,26 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
         // ---- this lane's pixel and its 13 A-fragment addresses (bytes inside a plane of the window)
         const int m = lane & 31;
         const int sy = min(sy0 + min(m >> 3, nrow - 1), h - 1), sx = min(sx0 + 8 * wv + (m & 7), w - 1);
-        int rofs[5], cofs[5];
+        int jvq[5], ivq[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int jv = vmap[sy * 5 + q], iv = hmap[sx * 5 + q];
-            rofs[q] = jv ? jv - j0 + 1 : 0;
-            cofs[q] = iv ? iv - i0 + 2 : 0;
-        }
+        for (int q = 0; q < 5; ++q) { jvq[q] = vmap[sy * 5 + q]; ivq[q] = hmap[sx * 5 + q]; }
         int addr[kB2KS];
 #pragma unroll
         for (int s = 0; s < kB2KS; ++s) {
             const int t0 = 2 * s, t1 = 2 * s + 1;                               // tap = 2 s + (lane >> 5): both candidates are compile-time, the lane half selects
-            const int r0 = rofs[t0 / 5], c0 = cofs[t0 % 5];
-            const int r1 = t1 < 25 ? rofs[t1 / 5] : 0, c1 = t1 < 25 ? cofs[t1 % 5] : 0;
-            addr[s] = (lane >> 5) ? bx_slot(r1, c1) : bx_slot(r0, c0);
+            const int a0 = bx_addr(jvq[t0 / 5], ivq[t0 % 5], j0, i0);
+            const int a1 = t1 < 25 ? bx_addr(jvq[t1 / 5], ivq[t1 % 5], j0, i0) : kB2Zero;
+            addr[s] = (lane >> 5) ? a1 : a0;
         }
-        f32x16 acc[NT];
+        // KPS accumulator sets (one per k-step of a stage): with NT = 2 that makes 4 independent MFMA chains per wavefront instead of 2 (a dependent
+        // v_mfma_f32_32x32x16_bf16 can issue every ~64 cycles only); the sets are added once per tile
+        f32x16 acc[KPS][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int a = 0; a < KPS; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window and of the stages are done
@@ -267,9 +267,11 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
             __syncthreads();
             if (c > 0) {                                                        // sign of the running sum alternates per chunk (odd chunks' weights are negated)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int a = 0; a < KPS; ++a)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = -acc[t][r];
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][t][r] = -acc[a][t][r];
             }
 #pragma unroll
             for (int sg = 0; sg < kNS; ++sg) {
@@ -283,33 +285,36 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                         if (sg + 2 < kNS || off < kLastBytes) st[u] = *reinterpret_cast<const f4*>(bsrc + (long long)(sg + 1) * kStage + off);
                     }
                 }
+                // hipcc sinks these loads down to their first use — the LDS stores at the END of the stage — and then waits for them at once: the whole L2
+                // latency exposed per stage (0.29 of the MFMA peak: profiles/r04/bench_box_bwd_v2.log).  The scheduling barrier keeps them up here.
+                __builtin_amdgcn_sched_barrier(0);
+                // all operand fragments of the stage are read up front (the second k-step's are in flight while the first multiplies) ...
+                s16x8 fa[KPS][3], fb[KPS][3][NT];
 #pragma unroll
                 for (int ks = 0; ks < KPS; ++ks) {
                     const int s = sg * KPS + ks;
                     if (s < kB2KS) {
                         const unsigned char* const ap = wnd + addr[s];
-                        const s16x8 ah = *reinterpret_cast<const s16x8*>(ap), am = *reinterpret_cast<const s16x8*>(ap + kB2Plane),
-                                    al = *reinterpret_cast<const s16x8*>(ap + 2 * kB2Plane);
                         const unsigned char* const bk = bst + (sg & 1) * kStage + ks * kKB + lane * 16;
-                        s16x8 bh[NT], bm[NT], bl[NT];
 #pragma unroll
-                        for (int u = 0; u < NT; ++u) {
-                            bh[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
-                            bm[u] = *reinterpret_cast<const s16x8*>(bk + (NT + u) * 1024);
-                            bl[u] = *reinterpret_cast<const s16x8*>(bk + (2 * NT + u) * 1024);
+                        for (int p = 0; p < 3; ++p) {
+                            fa[ks][p] = *reinterpret_cast<const s16x8*>(ap + p * kB2Plane);
+#pragma unroll
+                            for (int u = 0; u < NT; ++u) fb[ks][p][u] = *reinterpret_cast<const s16x8*>(bk + (p * NT + u) * 1024);
                         }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ... then the six cross terms, smallest first: (h, l) (m, m) (l, h) (h, m) (m, h) (h, h)
 #pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[u], acc[u], 0, 0, 0);
+                for (int ks = 0; ks < KPS; ++ks) {
+                    const int s = sg * KPS + ks;
+                    if (s < kB2KS) {
+                        constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[u], acc[u], 0, 0, 0);
+                        for (int q = 0; q < 6; ++q)
 #pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[u], acc[u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[u], acc[u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[u], acc[u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[u], acc[u], 0, 0, 0);
+                            for (int u = 0; u < NT; ++u) acc[ks][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][pa[q]], fb[ks][pb[q]][u], acc[ks][u], 0, 0, 0);
                     }
                 }
                 if (more) {
@@ -331,7 +336,9 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
             for (int r = 0; r < 16; ++r) {
                 const int pm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int py = sy0 + (pm >> 3), px = sx0 + 8 * wv + (pm & 7);
-                if ((pm >> 3) < nrow && px < w) store_out(gx + (((long long)nb * h + py) * w + px) * CIN + 32 * NT * blk + 32 * t + (lane & 31), acc[t][r] * fin);
+                float v = acc[0][t][r];
+                if constexpr (KPS > 1) v += acc[1][t][r];
+                if ((pm >> 3) < nrow && px < w) store_out(gx + (((long long)nb * h + py) * w + px) * CIN + 32 * NT * blk + 32 * t + (lane & 31), v * fin);
             }
     }
 }
@@ -348,23 +355,21 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
 // the group's lanes address INDIVIDUALLY (measured: out[i][r] = in[lane 4 r + i / 4][element i % 4], profiles/r04/tr16.log), so each source lane points at
 // "its" pixel through the two index maps and the gather along k costs nothing.  The main loop is branch-free: rows / columns beyond the tile meet a zeroed
 // spike fragment, phantom taps and quads read the window's zero row.  Partials -> ws[slice][co][tap][ci] -> upconv_box_wgrad_reduce_kernel (fixed order).
-template <int NT>                              // input-channel tiles per kind (1 | 2); a wavefront owns ci tile wv % NT and the tap quads q = wv / NT + (4 / NT) u
+template <int NT>                              // input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of them,
+                                               // so every transposed A fragment feeds NT MFMAs (v2 had one ci tile per wavefront: LDS-read bound at 0.17 of the peak)
 __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const unsigned short* __restrict__ Bp, const unsigned short* __restrict__ xT,
                                                                          const int* __restrict__ vmap, const int* __restrict__ hmap,
                                                                          const int* __restrict__ tr, const int* __restrict__ tc,
                                                                          float* __restrict__ ws, int NB, int h, int w, int NVR, int NHR, int CIN, int COUT, int KINDS,
                                                                          int RG, int CG)
 {
-    constexpr int QS = 4 / NT;                                                  // stride of a wavefront's tap quads
-    constexpr int NQ = (7 + QS - 1) / QS;                                       // quads a wavefront walks (4 | 2); those beyond the 7th are phantoms (zero row)
+    constexpr int NQ = 2;                                                       // tap quads per wavefront: wv, wv + 4 (the 8th is a phantom: zero row)
     __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * kB2Plane];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NCH = COUT / kBxCo, CIB = CIN / (32 * NT);
     const int kind = (int)(blockIdx.x % KINDS), slice = (int)(blockIdx.x / KINDS), slices = (int)(gridDim.x / KINDS);
     const int c = kind / CIB, cib = kind - c * CIB;                              // chunk of C_out, block of input channels
-    const int cit = cib * NT + wv % NT;                                          // this wavefront's ci tile (of CIN / 32)
-    const int q0 = wv / NT;                                                      // first tap quad; then q0 + QS, ...
     const int KSR = (w + 15) / 16;
     const long long n_tiles = (long long)NB * RG * CG;
     const long long t_begin = n_tiles * slice / slices, t_end = n_tiles * (slice + 1) / slices;
@@ -377,18 +382,33 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
     bool real[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-        const int t = 4 * (q0 + QS * u) + tq4;
+        const int t = 4 * (wv + 4 * u) + tq4;
         real[u] = t < 25;
         kyq[u] = real[u] ? t / 5 : 0;
         kxq[u] = real[u] ? t - 5 * (t / 5) : 0;
     }
-    f32x16 acc[NQ];
+    f32x16 acc[NQ][NT];
 #pragma unroll
     for (int u = 0; u < NQ; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
     const unsigned xoffT = (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * 8u;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const unsigned short* const xbase = xT + (long long)(cib * NT) * (32 * 16) + xoffT;
+    // the spike fragments of k-step sidx = (row sidx >> 1, half sidx & 1) of the tile (NT ci tiles); rows / halves outside the map are zeroed
+    auto load_x = [&](s16x8 (&xf)[NT], int nb, int sy0, int nrow, int sx0, int sidx) {
+        const int r = sidx >> 1, half = sidx & 1;
+        const bool ok = r < nrow && sx0 + 16 * half < w;
+        const long long srow = (long long)nb * h + min(sy0 + r, h - 1);
+        const int ks = min((sx0 >> 4) + half, KSR - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xf[t] = *reinterpret_cast<const s16x8*>(xbase + (srow * KSR + ks) * ((long long)CIN * 16) + t * (32 * 16));
+            if (!ok) xf[t] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
 #pragma unroll 1
     for (long long tl = t_begin; tl < t_end; ++tl) {
         const int cg = (int)(tl % CG);
@@ -396,75 +416,86 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         const int rg = (int)(rr % RG), nb = (int)(rr / RG);
         const int sy0 = tr[4 * rg], nrow = tr[4 * rg + 1], j0 = tr[4 * rg + 2], nj = tr[4 * rg + 3];
         const int sx0 = kB2TC * cg, i0 = tc[2 * cg], ni = tc[2 * cg + 1];
-        // ---- the spike fragments of the tile's 8 k-steps (row r, half): in flight while the window is staged; k-steps outside the map are zeroed
-        s16x8 xf[kB2TR][2];
-#pragma unroll
-        for (int r = 0; r < kB2TR; ++r)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const bool ok = r < nrow && sx0 + 16 * half < w;
-                const long long srow = (long long)nb * h + min(sy0 + r, h - 1);
-                const int ks = min((sx0 >> 4) + half, KSR - 1);
-                xf[r][half] = *reinterpret_cast<const s16x8*>(xT + (srow * KSR + ks) * ((long long)CIN * 16) + (long long)cit * (32 * 16) + xoffT);
-                if (!ok) xf[r][half] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        // ---- address parts of this lane: rowp[row][quad] = byte offset of the window row, swizzle bit in bit 4;  colp[half * 2 + rd][quad] = byte offset of the column
+        s16x8 xa[NT], xb[NT];
+        load_x(xa, nb, sy0, nrow, sx0, 0);                                      // in flight while the window is staged
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- this lane's read addresses in two halves: rowp[row][quad] = byte offset of the window row | swizzle bit in bit 4, colp[half * 2 + rd][quad] = byte
+        //      offset of "its" pixel's column (+ 8 for the odd channel quad); negative = the empty range (-> the zero pixel)
         int rowp[kB2TR][NQ], colp[4][NQ];
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
 #pragma unroll
             for (int r = 0; r < kB2TR; ++r) {
-                const int sy = min(sy0 + min(r, nrow - 1), h - 1);
-                const int jv = real[u] ? vmap[sy * 5 + kyq[u]] : 0;
-                const int rw = jv ? jv - j0 + 1 : 0;
-                rowp[r][u] = rw * (kB2WC * 16) | (((rw >> 1) & 1) << 4);
+                const int jv = real[u] ? vmap[min(sy0 + min(r, nrow - 1), h - 1) * 5 + kyq[u]] : 0;
+                const int rw = jv - j0;
+                rowp[r][u] = jv ? (rw * (kB2WC * 16) | (((rw >> 1) & 1) << 4)) : -1;
             }
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
-                const int sx = min(sx0 + 16 * (jx >> 1) + 8 * oct + 4 * (jx & 1) + (L >> 2), w - 1);
-                const int iv = real[u] ? hmap[sx * 5 + kxq[u]] : 0;
-                const int cw = iv ? iv - i0 + 2 : 0;
-                colp[jx][u] = cw * 16 + 8 * coq;
+                const int iv = real[u] ? hmap[min(sx0 + 16 * (jx >> 1) + 8 * oct + 4 * (jx & 1) + (L >> 2), w - 1) * 5 + kxq[u]] : 0;
+                colp[jx][u] = iv ? (iv - i0) * 16 : -1;
             }
         }
+        auto addr_of = [&](int r, int jx, int u) {
+            const int rp = rowp[r][u], cp = colp[jx][u];
+            const int a = (rp & ~16) + (cp ^ (rp & 16));
+            return ((rp | cp) < 0 ? kB2Zero : a) + 8 * coq;
+        };
         __syncthreads();                                                        // the previous tile's readers of the window are done
         bx_stage_window(wnd, Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)j0 * NHR + i0) * kBxCo, plane_g, NHR, nj, ni);
         __syncthreads();
+        // k-step s = (row s >> 1, half s & 1): its A fragments (2 quads x 3 planes x 2 transpose reads) are fetched one k-step AHEAD of its MFMAs
+        auto read_a = [&](int sidx, s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3]) {
+            const int r = sidx >> 1, half = sidx & 1;
+            int a0[NQ], a1[NQ];
 #pragma unroll
-        for (int r = 0; r < kB2TR; ++r)
+            for (int u = 0; u < NQ; ++u) { a0[u] = addr_of(r, 2 * half, u); a1[u] = addr_of(r, 2 * half + 1, u); }
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                s16x4 lo[NQ][3], hi[NQ][3];
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    lo[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB2Plane + a0[u]));
+                    hi[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB2Plane + a1[u]));
+                }
+        };
+        auto mma = [&](s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3], s16x8 (&xf)[NT]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int u = 0; u < NQ; ++u) {
-                    const int rp = rowp[r][u] & ~16, sb = rowp[r][u] & 16;
-                    const int a0 = rp + (colp[2 * half][u] ^ sb), a1 = rp + (colp[2 * half + 1][u] ^ sb);
+                    const s16x8 af = {lo[u][p][0], lo[u][p][1], lo[u][p][2], lo[u][p][3], hi[u][p][0], hi[u][p][1], hi[u][p][2], hi[u][p][3]};
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        lo[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB2Plane + a0));
-                        hi[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB2Plane + a1));
-                    }
+                    for (int t = 0; t < NT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xf[t], acc[u][t], 0, 0, 0);
                 }
+        };
+        s16x4 la[NQ][3], ha[NQ][3], lb[NQ][3], hb[NQ][3];
+        read_a(0, la, ha);
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-#pragma unroll
-                    for (int u = 0; u < NQ; ++u) {
-                        const s16x8 af = {lo[u][p][0], lo[u][p][1], lo[u][p][2], lo[u][p][3], hi[u][p][0], hi[u][p][1], hi[u][p][2], hi[u][p][3]};
-                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xf[r][half], acc[u], 0, 0, 0);
-                    }
+        for (int sidx = 0; sidx < 2 * kB2TR; sidx += 2) {                       // two k-steps per trip: the buffers alternate statically
+            read_a(sidx + 1, lb, hb);
+            load_x(xb, nb, sy0, nrow, sx0, sidx + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(la, ha, xa);
+            if (sidx + 2 < 2 * kB2TR) {
+                read_a(sidx + 2, la, ha);
+                load_x(xa, nb, sy0, nrow, sx0, sidx + 2);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(lb, hb, xb);
+        }
     }
     // ---- partials: D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31], m = 8 (tap - 4 quad) + channel  ->  ws[slice][co][tap][ci]
     float* const wsl = ws + (long long)slice * COUT * 25 * CIN;
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
+    for (int u = 0; u < NQ; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int tap = 4 * (q0 + QS * u) + (mm >> 3), co = kBxCo * c + (mm & 7);
-            if (tap < 25) wsl[((long long)co * 25 + tap) * CIN + 32 * cit + (lane & 31)] = acc[u][r];
-        }
-    }
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int tap = 4 * (wv + 4 * u) + (mm >> 3), co = kBxCo * c + (mm & 7);
+                if (tap < 25) wsl[((long long)co * 25 + tap) * CIN + 32 * (cib * NT + t) + (lane & 31)] = acc[u][t][r];
+            }
 }
 
 // g_W [C_out][C_in][25] (+)= sum over slices of ws[slice][co][tap][ci], slices in ascending order
@@ -511,8 +542,8 @@ int ss_upconv_boxsum_f32(const float* g_out, const int* vr, const int* hr, void*
 
 int ss_upconv_box_window(int* max_rows, int* max_cols)
 {
-    if (max_rows) *max_rows = kB2WR - 1;                                        // distinct vertical range ids (span) a tile of <= 4 source rows may reach
-    if (max_cols) *max_cols = kB2WC - 2;                                        // ... and horizontal ones 32 source columns may reach
+    if (max_rows) *max_rows = kB2WR;                                            // distinct vertical range ids (span) a tile of <= 4 source rows may reach
+    if (max_cols) *max_cols = kB2WC;                                        // ... and horizontal ones 32 source columns may reach
     return kB2TR;
 }
 
@@ -520,7 +551,7 @@ int ss_upconv_box_dgrad_supported(int Cin, int Cout, int k, int max_tile_rows, i
 {
     // max_tile_rows / max_cols32: largest id span of the caller's row tiles (fused.box_tables cuts them so that they fit) / of 32 consecutive source columns
     if (k != 5 || Cin < 64 || Cin % 64 != 0 || Cout < kBxCo || Cout % kBxCo != 0) return 0;
-    return max_tile_rows > 0 && max_tile_rows <= kB2WR - 1 && max_cols32 > 0 && max_cols32 <= kB2WC - 2;
+    return max_tile_rows > 0 && max_tile_rows <= kB2WR && max_cols32 > 0 && max_cols32 <= kB2WC;
 }
 
 long long ss_upconv_box_dgrad_ws_floats(int Cin, int Cout)
@@ -558,7 +589,7 @@ static int box_wgrad_plan(int Cin, int Cout, int* NT, int* kinds, int* slices)
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
-    *NT = Cin % 64 == 0 ? 2 : 1;                                               // (a kind of 4 ci tiles would need 7 tap quads per wavefront: 256 registers + spills)
+    *NT = Cin % 128 == 0 ? 4 : (Cin % 64 == 0 ? 2 : 1);                        // input-channel tiles per kind (= per wavefront)
     *kinds = (Cout / kBxCo) * (Cin / (32 * *NT));
     int sl = (2 * cus) / *kinds;                                                // two workgroups per CU
     if (sl < 1) sl = 1;
@@ -569,7 +600,7 @@ static int box_wgrad_plan(int Cin, int Cout, int* NT, int* kinds, int* slices)
 int ss_upconv_box_wgrad_supported(int Cin, int Cout, int k, int max_tile_rows, int max_cols32)
 {
     if (k != 5 || Cin < 32 || Cin % 32 != 0 || Cout < kBxCo || Cout % kBxCo != 0) return 0;
-    return max_tile_rows > 0 && max_tile_rows <= kB2WR - 1 && max_cols32 > 0 && max_cols32 <= kB2WC - 2;
+    return max_tile_rows > 0 && max_tile_rows <= kB2WR && max_cols32 > 0 && max_cols32 <= kB2WC;
 }
 
 long long ss_upconv_box_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w)
@@ -602,7 +633,7 @@ int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int*
     const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
 #define SS_BW(NT_) hipLaunchKernelGGL((upconv_box_wgrad_kernel<NT_>), dim3(grid), dim3(kB2Threads), 0, s, Bp, xT, vmap, hmap, tile_rows, tile_cols, ws, \
                                       (int)NB, h, w, NVR, NHR, Cin, Cout, kinds, RG, CG)
-    if (NT == 2) SS_BW(2); else SS_BW(1);
+    if (NT == 4) SS_BW(4); else if (NT == 2) SS_BW(2); else SS_BW(1);
 #undef SS_BW
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(upconv_box_wgrad_reduce_kernel, dim3(grid_for((long long)Cout * 25 * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cout, Cin, accumulate);

@@ -678,7 +678,7 @@ def register_box_tables(tables, host_tables, H, W):
     if dev.type == 'cuda':
         max_rows, max_span, _ = _lib.upconv_box_window()
     else:
-        max_rows, max_span = 4, 13
+        max_rows, max_span = 4, 15
     tr, tc = _row_tiles(vmap, max_rows, max_span), _tile_spans(hmap, 32)
 
     def t(a):

@@ -88,9 +88,9 @@ def test_argument_validation_without_a_gpu():
     assert L.ss_upconv_box_dgrad_f32(None, None, None, None, None, 1, None, None, None, 1, 64, 32, 4, 4, 4, 4, None) == -22
     assert L.ss_upconv_box_wgrad_f32(None, None, None, None, None, None, 1, None, None, None, 1, 64, 32, 4, 4, 4, 4, 0, None) == -22
     assert L.ss_upconv_box_elems(2, 32, 10, 12) == 2 * 32 * 3 * 10 * 12 and L.ss_upconv_box_elems(2, 30, 10, 12) == 0
-    assert L.ss_upconv_box_dgrad_supported(64, 32, 5, 13, 78) == 1 and L.ss_upconv_box_dgrad_supported(64, 32, 5, 14, 78) == 0
+    assert L.ss_upconv_box_dgrad_supported(64, 32, 5, 15, 76) == 1 and L.ss_upconv_box_dgrad_supported(64, 32, 5, 16, 76) == 0
     assert L.ss_upconv_box_dgrad_supported(96, 32, 5, 12, 70) == 0 and L.ss_upconv_box_wgrad_supported(96, 40, 5, 12, 70) == 1
-    assert L.ss_upconv_box_dgrad_ws_floats(64, 32) == 2 * 4 * 13 * 3072 // 4 and _lib.upconv_box_window() == (4, 13, 78)
+    assert L.ss_upconv_box_dgrad_ws_floats(64, 32) == 2 * 4 * 13 * 3072 // 4 and _lib.upconv_box_window() == (4, 15, 76)
 
 
 def test_product_fails_loudly_on_cpu_tensors():

@@ -74,7 +74,7 @@ DEFAULT_PLAN = {
 def assert_default_plan(plan, full_resolution=False):
     """The dispatch plan of a default fp32 run (`assert_default_kernels` checks the plan as well as the launch tags): every encoder /
     bottleneck / head layer on the kernel form named above; the decoder stages on the fused MFMA forward where the geometry is compiled (deconv1 / deconv2)
-    and — every stage whose window the box-sum kernels hold — on the box-sum backward."""
+    and — deconv1 / deconv2 (EngineConfig.BOX_BWD_CIN), where the box-sum kernels' window holds the geometry — on the box-sum backward."""
     for name, (fwd, bwd) in DEFAULT_PLAN.items():
         assert plan[name]['synapse_fwd'] == fwd and plan[name]['synapse_bwd'] == bwd, (name, plan[name])
     for lvl in (1, 2):
@@ -82,8 +82,8 @@ def assert_default_plan(plan, full_resolution=False):
     for lvl in (3, 4):
         assert plan[f'deconv{lvl}']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan[f'deconv{lvl}']
     box = [lvl for lvl in (1, 2, 3, 4) if plan[f'deconv{lvl}']['synapse_bwd'].startswith('box: boxsum+dgrad6_mfma+wgrad3_mfma')]
-    # (64x80 frames: deconv1's 32 source columns reach 84 horizontal ranges, more than the on-chip window's 78 — that stage keeps the round-3 fused forms)
-    assert set(box) == ({1, 2, 3, 4} if full_resolution else {2, 3, 4}), {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
+    # (64x80 frames: deconv1's 32 source columns reach 84 horizontal ranges, more than the on-chip window's 76 — that stage keeps the round-3 fused forms)
+    assert set(box) == ({1, 2} if full_resolution else {2}), {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
     assert len(plan) == 17 and all('neuron_fwd' in v and 'neuron_bwd' in v for k, v in plan.items() if not k.startswith('predict'))
 
 

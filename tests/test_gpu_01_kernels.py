@@ -1617,7 +1617,7 @@ def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
       ss_upconv_boxsum_f32    the three bf16 planes BIT-EQUAL to the oracle's (same rectangles, same summation order, same round-to-nearest split);
       ss_upconv_box_dgrad_f32 |g_x - float64| <= 2^-20 sum |B| |W| element-wise and <= 1.5 x ss_gemm6_f32's own worst element on the same operands (six
                               cross terms), every element written, no coherent drift, bit-reproducible;
-      ss_upconv_box_wgrad_f32 |g_w - float64| <= 2^-22 sum |x| |B| element-wise (exact products), accumulate mode, 2-bit packed input == dense input bit
+      ss_upconv_box_wgrad_f32 |g_w - float64| <= 2^-20 sum |x| |B| element-wise (exact products, fp32 accumulation) and <= 1.5 x ss_spike_wgrad_f32's, accumulate mode, 2-bit packed input == dense input bit
                               for bit, bit-reproducible —
     on the four decoder geometries of the 260x346 pyramid, the 64x80 pyramid of the parity tests, odd sizes with triple-replicated rows / columns, ragged
     tiles, a map smaller than a tile; a resize ratio the on-chip window does not hold is refused by *_supported (the caller then keeps the g_P forms)."""
@@ -1632,12 +1632,12 @@ def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
     hr, hmap = nbx.range_tables(tables[4].cpu().numpy(), tables[5].cpu().numpy(), W)
     assert np.array_equal(bt['vr'].cpu().numpy().reshape(-1, 2), vr) and np.array_equal(bt['hmap'].cpu().numpy().reshape(-1, 5), hmap)
     assert np.array_equal(bt['hr'].cpu().numpy().reshape(-1, 2), hr) and np.array_equal(bt['vmap'].cpu().numpy().reshape(-1, 5), vmap)
-    # the host cuts the source rows into tiles of <= 4 rows whose vertical ranges fit the on-chip window (13 ids): every geometry's ROWS fit by construction;
-    # a resize whose 32 source columns reach more than 78 horizontal ranges is refused (the caller then keeps the g_P forms)
+    # the host cuts the source rows into tiles of <= 4 rows whose vertical ranges fit the on-chip window (15 ids): every geometry's ROWS fit by construction;
+    # a resize whose 32 source columns reach more than 76 horizontal ranges is refused (the caller then keeps the g_P forms)
     tr = bt['tile_rows'].cpu().numpy().reshape(-1, 4)
-    assert tr[0, 0] == 0 and (tr[1:, 0] == tr[:-1, 0] + tr[:-1, 1]).all() and tr[-1, 0] + tr[-1, 1] == h and tr[:, 1].max() <= 4 and tr[:, 3].max() <= 13
+    assert tr[0, 0] == 0 and (tr[1:, 0] == tr[:-1, 0] + tr[:-1, 1]).all() and tr[-1, 0] + tr[-1, 1] == h and tr[:, 1].max() <= 4 and tr[:, 3].max() <= 15
     if not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt):
-        assert bt['max_cols32'] > 78, bt
+        assert bt['max_cols32'] > 76, bt
         return
     assert _lib.upconv_box_wgrad_supported(Cin, Cout, 5, bt) and not _lib.upconv_box_dgrad_supported(Cin, Cout, 3, bt)
     gen = torch.Generator(device=DEV).manual_seed(23 + Cin + h)
@@ -1694,7 +1694,16 @@ def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
     _lib.upconv_box_wgrad(box, x, None, bt, g_w, NB, Cin, Cout, h, w)
     errw = (g_w.double() - refw).abs()
     boundw = magw * 2.0 ** -22 + 1e-30
-    assert bool(torch.isfinite(g_w).all()) and bool((errw <= boundw).all()), float((errw / boundw).max())
+    # every product is exact; what is left is the fp32 accumulation over the source pixels (22 000 - 60 000 per element here, 1.8 M at config 3, in <= 128
+    # fixed-order slices): measured <= 1.8 x 2^-22 of the magnitude sum, asserted at 2^-20 and against ss_spike_wgrad_f32 (the same exact products in
+    # another order) on the materialised g_P
+    assert bool(torch.isfinite(g_w).all()) and bool((errw <= 4.0 * boundw).all()), float((errw / boundw).max())
+    if _lib.spike_wgrad_supported(Cin, 25 * Cout):
+        gPm = B64[:, vm][:, :, :, hm].permute(0, 1, 3, 2, 4, 5).reshape(NB * h * w, 25 * Cout).float().contiguous()
+        gw_sp = torch.empty(Cin, 25 * Cout, device=DEV)
+        _lib.spike_wgrad(gPm, x.view(NB * h * w, Cin), gw_sp, NB * h * w, Cin, 25 * Cout)
+        e_sp = (gw_sp.view(Cin, 5, 5, Cout).permute(3, 0, 1, 2).double() - refw).abs()
+        assert float((errw / boundw).max()) <= 1.5 * float((e_sp / boundw).max()) + 0.5, (float((errw / boundw).max()), float((e_sp / boundw).max()))
     g_w2 = g_w.clone()
     _lib.upconv_box_wgrad(box, x, None, bt, g_w2, NB, Cin, Cout, h, w, accumulate=True)
     assert torch.equal(g_w2, g_w + g_w)
