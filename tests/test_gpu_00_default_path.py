@@ -164,7 +164,7 @@ def test_pinned_parity_penalize_spikes_T5(name):
     rep0 = pinned_parity(orc, net, x, gt)
     assert rep['loss'][0] - rep0['loss'][0] > 10.0, (rep['loss'], rep0['loss'])     # beta / 2 * sum of five mean(s^2): 2.5 * beta at these densities
     moved = {k: rel_l2(g_pen[k], p.grad) for k, p in net.named_parameters()}
-    assert moved['deconv1.0.up.1.weight'] > 10 * TENSOR_GRAD_BAR and moved['bottleneck.1.conv2.0.weight'] > 10 * TENSOR_GRAD_BAR, moved
+    assert moved['deconv1.0.up.1.weight'] > 10 * TENSOR_GRAD_BAR and moved['bottleneck.1.conv2.0.weight'] > 3 * TENSOR_GRAD_BAR, moved
 
 
 def test_pinned_parity_ann():
