@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef SS_BX_ABLATE
+#define SS_BX_ABLATE 0                        // development aid (make variant DEFS=-DSS_BX_ABLATE=mask): data-gradient kernel without 1 window traffic,
+#endif                                       // 2 weight stream, 4 MFMAs, 8 per-stage barriers — wrong results, timing only (profiles/r04/box_dgrad_ablations.log)
 constexpr int kBxCo = 8;                       // output channels per chunk of the plane layout (= half a k-step: a k-step is 2 taps x 8 channels)
 
 __device__ __forceinline__ void bx_split3(const float (&v)[8], u16x8& h, u16x8& m, u16x8& l)
@@ -133,31 +136,60 @@ __device__ __forceinline__ void bx_zero_borders(unsigned char* wnd)
     if (threadIdx.x < 3) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB2Plane + kB2Zero) = (f4){0.f, 0.f, 0.f, 0.f};
 }
 
-// 3 planes x nj rows x ni granules of chunk c, HBM rows contiguous -> LDS; the loads of a thread are issued in batches before its stores
-__device__ __forceinline__ void bx_stage_window(unsigned char* wnd, const unsigned short* __restrict__ src, long long plane_g, int NHR, int nj, int ni)
+// The window of (frame nb, chunk c) — 3 planes x nj rows x ni granules, HBM rows contiguous — travels HBM -> registers -> LDS in two halves so that the
+// NEXT window's loads are in flight while the current one is multiplied.  Thread t < 228 owns plane t / 76 and window column t % 76 and walks the 15 rows:
+// the per-row address arithmetic is scalar (uniform row base + one per-thread 32-bit offset; LDS: one per-thread base + an immediate per row), so a
+// staging costs ~15 loads + 15 stores per thread and next to no VALU work (the first form spent ~600 VALU instructions per window on index math —
+// 6 per MFMA of the item: profiles/r04/pmc_box_v3).
+constexpr int kWinRegs = kB2WR;
+
+struct BxLane { unsigned voff_plane; int cc; int lds0, lds1; bool act; };
+
+__device__ __forceinline__ BxLane bx_lane(long long plane_g)
 {
-    const int rows3 = 3 * nj;
-    constexpr int kPerRow = 80, kBatch = 8;                                     // idx / 80 by multiply-shift
-    const int total = rows3 * kPerRow;
-#pragma unroll 1
-    for (int u0 = 0; u0 * kB2Threads < total; u0 += kBatch) {
-        f4 buf[kBatch];
+    BxLane L;
+    const int t = threadIdx.x, p = t / kB2WC;
+    L.cc = t - p * kB2WC;
+    L.act = p < 3;
+    L.voff_plane = (unsigned)((L.act ? p : 0) * plane_g + L.cc * kBxCo);       // elements from the window's first granule (row 0)
+    L.lds0 = (L.act ? p : 0) * kB2Plane + L.cc * 16;                            // rows with swizzle bit 0
+    L.lds1 = (L.act ? p : 0) * kB2Plane + (L.cc ^ 1) * 16;                      // rows with swizzle bit 1 ((r >> 1) & 1)
+    return L;
+}
+
+__device__ __forceinline__ void bx_win_load(f4 (&buf)[kWinRegs], const BxLane& L, const unsigned short* __restrict__ src, int NHR, int nj, int ni)
+{
+    // (an execution-mask-free form — clamped column, scalar row branch only — measured SLOWER: 1.27 -> 1.53 ms on deconv1, profiles/r04/bench_box_bwd_v6.log)
+    const bool on = L.act && L.cc < ni;
 #pragma unroll
-        for (int v = 0; v < kBatch; ++v) {
-            const int idx = threadIdx.x + kB2Threads * (u0 + v);
-            const int rp = idx / kPerRow, cc = idx - rp * kPerRow;
-            const int p = rp / nj, r = rp - p * nj;
-            buf[v] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (rp < rows3 && cc < ni) buf[v] = *reinterpret_cast<const f4*>(src + (long long)p * plane_g + ((long long)r * NHR + cc) * kBxCo);
-        }
+    for (int r = 0; r < kB2WR; ++r) {
+        buf[r] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (on && r < nj) buf[r] = *reinterpret_cast<const f4*>(src + (long long)r * NHR * kBxCo + L.voff_plane);
+    }
+}
+
+// rows [R0, R1) only: the contraction kernels issue a window a few rows per weight stage, BEHIND that stage's weight loads — the vector-memory counter
+// retires in issue order, so a window fetched in one piece ahead of the weight stream makes the first weight wait of the item wait for all of HBM's latency
+// (ablations, profiles/r04/box_dgrad_ablations.log: window traffic 0.28 ms of deconv1's 1.29 ms although every load was "in flight" for a whole item)
+__device__ __forceinline__ void bx_win_load_rows(f4 (&buf)[kWinRegs], const BxLane& L, const unsigned short* __restrict__ src, int NHR, int nj, int ni,
+                                                 int R0, int R1)            // R0, R1: compile-time after the callers' loops are unrolled
+{
+    const bool on = L.act && L.cc < ni;
 #pragma unroll
-        for (int v = 0; v < kBatch; ++v) {
-            const int idx = threadIdx.x + kB2Threads * (u0 + v);
-            const int rp = idx / kPerRow, cc = idx - rp * kPerRow;
-            const int p = rp / nj, r = rp - p * nj;
-            if (rp < rows3 && cc < ni) *reinterpret_cast<f4*>(wnd + p * kB2Plane + bx_slot(r, cc)) = buf[v];
+    for (int r = R0; r < R1; ++r) {
+        if (r < kB2WR) {
+            buf[r] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (on && r < nj) buf[r] = *reinterpret_cast<const f4*>(src + (long long)r * NHR * kBxCo + L.voff_plane);
         }
     }
+}
+
+__device__ __forceinline__ void bx_win_store(unsigned char* wnd, const f4 (&buf)[kWinRegs], const BxLane& L, int nj, int ni)
+{
+    const bool on = L.act && L.cc < ni;
+#pragma unroll
+    for (int r = 0; r < kB2WR; ++r)
+        if (on && r < nj) *reinterpret_cast<f4*>(wnd + (((r >> 1) & 1) ? L.lds1 : L.lds0) + r * (kB2WC * 16)) = buf[r];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -213,133 +245,175 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
     static_assert(kStage % (16 * kB2Threads) == 0, "stage size");
     __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * kB2Plane];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kStage];
+    __shared__ int tiles[4 * 64 + 2 * 16];                                       // the row / column tile tables (<= 64 row tiles, <= 16 column tiles: checked by the host)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NBLK = CIN / (32 * NT);
     const long long n_tiles = (long long)NB * RG * CG * NBLK;
     bx_zero_borders(wnd);
+    for (int i = threadIdx.x; i < 4 * RG; i += kB2Threads) tiles[i] = tr[i];
+    for (int i = threadIdx.x; i < 2 * CG; i += kB2Threads) tiles[256 + i] = tc[i];
+    __syncthreads();
     const unsigned g = xcd_remap(blockIdx.x, gridDim.x);
     const long long t_begin = n_tiles * g / gridDim.x, t_end = n_tiles * (g + 1) / gridDim.x;
     const long long plane_g = (long long)NVR * NHR * kBxCo;                    // elements of one plane of one chunk in HBM
+    // work items = (tile, chunk) pairs in tile-major order; item -> (frame, row tile, column tile, ci block, chunk) and its window in HBM
+    struct Item { int nb, rg, cg, blk, c, j0, nj, i0, ni; };
+    auto extents = [&](Item& d) {
+        d.j0 = tiles[4 * d.rg + 2]; d.nj = tiles[4 * d.rg + 3];
+        d.i0 = tiles[256 + 2 * d.cg]; d.ni = tiles[256 + 2 * d.cg + 1];
+    };
+    auto decode = [&](long long item) {                                         // (64-bit divisions: once per workgroup; the loop advances incrementally)
+        Item d;
+        d.c = (int)(item % NCH);
+        long long tl = item / NCH;
+        d.blk = (int)(tl % NBLK); tl /= NBLK;
+        d.cg = (int)(tl % CG); tl /= CG;
+        d.rg = (int)(tl % RG);
+        d.nb = (int)(tl / RG);
+        extents(d);
+        return d;
+    };
+    auto advance = [&](Item& d) {
+        if (++d.c == NCH) { d.c = 0; if (++d.blk == NBLK) { d.blk = 0; if (++d.cg == CG) { d.cg = 0; if (++d.rg == RG) { d.rg = 0; ++d.nb; } } } }
+        extents(d);
+    };
+    const BxLane bl = bx_lane(plane_g);
+    auto win_src = [&](const Item& d) { return Bp + (((long long)d.nb * NCH + d.c) * 3) * plane_g + ((long long)d.j0 * NHR + d.i0) * kBxCo; };
+    const long long it_begin = t_begin * NCH, it_end = t_end * NCH;
+    if (it_begin >= it_end) return;
+    f4 wbuf[kWinRegs];
+    Item cur = decode(it_begin);
+    bx_win_load(wbuf, bl, win_src(cur), NHR, cur.nj, cur.ni);                   // the first window: the only one whose latency is exposed
+    bx_win_store(wnd, wbuf, bl, cur.nj, cur.ni);
+    int addr[kB2KS];
+    // KPS accumulator sets (one per k-step of a stage): with NT = 2 that makes 4 independent MFMA chains per wavefront instead of 2; added once per tile
+    f32x16 acc[KPS][NT];
+    static_assert(kNS & 1, "the stage double buffer's parity flips per item");
+    constexpr int kWR = (kB2WR + kNS - 3) / (kNS - 2);                          // window rows fetched per stage (3 | 2): done two stages before the item ends
+    auto wsrc = [&](const Item& d) { return reinterpret_cast<const unsigned char*>(Wf) + ((long long)d.blk * NCH + d.c) * kB2KS * kKB; };
+    f4 st[kF4];
+    {   // weight stage 0 of the first item (every later one arrives during its predecessor's last stage)
+        const unsigned char* const b0 = wsrc(cur);
+#pragma unroll
+        for (int u = 0; u < kF4; ++u) st[u] = *reinterpret_cast<const f4*>(b0 + (threadIdx.x + kB2Threads * u) * 16);
+#pragma unroll
+        for (int u = 0; u < kF4; ++u) *reinterpret_cast<f4*>(bst + (threadIdx.x + kB2Threads * u) * 16) = st[u];
+    }
+    int par = 0;                                                                // half of the stage buffer that holds stage 0 of the current item
 #pragma unroll 1
-    for (long long tl = t_begin; tl < t_end; ++tl) {
-        const int blk = (int)(tl % NBLK);
-        long long rr = tl / NBLK;
-        const int cg = (int)(rr % CG); rr /= CG;
-        const int rg = (int)(rr % RG);
-        const int nb = (int)(rr / RG);
-        const int sy0 = tr[4 * rg], nrow = tr[4 * rg + 1], j0 = tr[4 * rg + 2], nj = tr[4 * rg + 3];
-        const int sx0 = kB2TC * cg, i0 = tc[2 * cg], ni = tc[2 * cg + 1];
-        // ---- this lane's pixel and its 13 A-fragment addresses (bytes inside a plane of the window)
-        const int m = lane & 31;
-        const int sy = min(sy0 + min(m >> 3, nrow - 1), h - 1), sx = min(sx0 + 8 * wv + (m & 7), w - 1);
-        int jvq[5], ivq[5];
+    for (long long item = it_begin; item < it_end; ++item) {
+        const bool has_next = item + 1 < it_end;
+        Item nxt = cur;
+        if (has_next) advance(nxt);
+        const unsigned short* const wn = win_src(nxt);
+        const int sy0 = tiles[4 * cur.rg], nrow = tiles[4 * cur.rg + 1], sx0 = kB2TC * cur.cg;
+        if (cur.c == 0) {
+            // ---- a new tile: this lane's pixel and its 13 A-fragment addresses (bytes inside a plane of the window)
+            const int m = lane & 31;
+            const int sy = min(sy0 + min(m >> 3, nrow - 1), h - 1), sx = min(sx0 + 8 * wv + (m & 7), w - 1);
+            int jvq[5], ivq[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { jvq[q] = vmap[sy * 5 + q]; ivq[q] = hmap[sx * 5 + q]; }
-        int addr[kB2KS];
+            for (int q = 0; q < 5; ++q) { jvq[q] = vmap[sy * 5 + q]; ivq[q] = hmap[sx * 5 + q]; }
 #pragma unroll
-        for (int s = 0; s < kB2KS; ++s) {
-            const int t0 = 2 * s, t1 = 2 * s + 1;                               // tap = 2 s + (lane >> 5): both candidates are compile-time, the lane half selects
-            const int a0 = bx_addr(jvq[t0 / 5], ivq[t0 % 5], j0, i0);
-            const int a1 = t1 < 25 ? bx_addr(jvq[t1 / 5], ivq[t1 % 5], j0, i0) : kB2Zero;
-            addr[s] = (lane >> 5) ? a1 : a0;
-        }
-        // KPS accumulator sets (one per k-step of a stage): with NT = 2 that makes 4 independent MFMA chains per wavefront instead of 2 (a dependent
-        // v_mfma_f32_32x32x16_bf16 can issue every ~64 cycles only); the sets are added once per tile
-        f32x16 acc[KPS][NT];
-#pragma unroll
-        for (int a = 0; a < KPS; ++a)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            __syncthreads();                                                    // the previous chunk's / tile's readers of the window and of the stages are done
-            bx_stage_window(wnd, Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)j0 * NHR + i0) * kBxCo, plane_g, NHR, nj, ni);
-            // ---- weight stage 0 of this (ci block, chunk)
-            const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Wf) + ((long long)blk * NCH + c) * kB2KS * kKB;
-            f4 st[kF4];
-#pragma unroll
-            for (int u = 0; u < kF4; ++u) st[u] = *reinterpret_cast<const f4*>(bsrc + (threadIdx.x + kB2Threads * u) * 16);
-#pragma unroll
-            for (int u = 0; u < kF4; ++u) *reinterpret_cast<f4*>(bst + (threadIdx.x + kB2Threads * u) * 16) = st[u];
-            __syncthreads();
-            if (c > 0) {                                                        // sign of the running sum alternates per chunk (odd chunks' weights are negated)
-#pragma unroll
-                for (int a = 0; a < KPS; ++a)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[a][t][r] = -acc[a][t][r];
+            for (int s2 = 0; s2 < kB2KS; ++s2) {
+                const int t0 = 2 * s2, t1 = 2 * s2 + 1;                         // tap = 2 s + (lane >> 5): both candidates are compile-time, the lane half selects
+                const int a0 = bx_addr(jvq[t0 / 5], ivq[t0 % 5], cur.j0, cur.i0);
+                const int a1 = t1 < 25 ? bx_addr(jvq[t1 / 5], ivq[t1 % 5], cur.j0, cur.i0) : kB2Zero;
+                addr[s2] = (lane >> 5) ? a1 : a0;
             }
 #pragma unroll
-            for (int sg = 0; sg < kNS; ++sg) {
-                const bool more = sg + 1 < kNS;
-                // the last stage of a chunk may hold fewer k-steps (13 = 6 x 2 + 1): only what exists is fetched
-                constexpr int kLastBytes = (kB2KS - (kNS - 1) * KPS) * kKB;
+            for (int a2 = 0; a2 < KPS; ++a2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a2][t][r] = 0.f;
+        } else {                                                                // sign of the running sum alternates per chunk (odd chunks' weights are negated)
+#pragma unroll
+            for (int a2 = 0; a2 < KPS; ++a2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a2][t][r] = -acc[a2][t][r];
+        }
+        const unsigned char* const bsrc = wsrc(cur);
+        const unsigned char* const bnxt = wsrc(nxt);
+        __syncthreads();                                                        // stage 0 and this item's window (stored at the end of the previous item) are visible
+#pragma unroll
+        for (int sg = 0; sg < kNS; ++sg) {
+            const bool more = sg + 1 < kNS;
+            // the last stage of a chunk may hold fewer k-steps (13 = 6 x 2 + 1): only what exists is fetched
+            constexpr int kLastBytes = (kB2KS - (kNS - 1) * KPS) * kKB;
+            if (!(SS_BX_ABLATE & 2)) {
                 if (more) {
 #pragma unroll
                     for (int u = 0; u < kF4; ++u) {
                         const int off = (threadIdx.x + kB2Threads * u) * 16;
                         if (sg + 2 < kNS || off < kLastBytes) st[u] = *reinterpret_cast<const f4*>(bsrc + (long long)(sg + 1) * kStage + off);
                     }
+                } else if (has_next) {                                          // stage 0 of the NEXT item, into the half this item's last stage does not read
+#pragma unroll
+                    for (int u = 0; u < kF4; ++u) st[u] = *reinterpret_cast<const f4*>(bnxt + (threadIdx.x + kB2Threads * u) * 16);
                 }
-                // hipcc sinks these loads down to their first use — the LDS stores at the END of the stage — and then waits for them at once: the whole L2
-                // latency exposed per stage (0.29 of the MFMA peak: profiles/r04/bench_box_bwd_v2.log).  The scheduling barrier keeps them up here.
-                __builtin_amdgcn_sched_barrier(0);
-                // all operand fragments of the stage are read up front (the second k-step's are in flight while the first multiplies) ...
-                s16x8 fa[KPS][3], fb[KPS][3][NT];
+            }
+            if (has_next && !(SS_BX_ABLATE & 1)) {                              // the next window, kWR rows per stage, issued behind the weight loads
+                bx_win_load_rows(wbuf, bl, wn, NHR, nxt.nj, nxt.ni, sg * kWR, (sg + 1) * kWR);
+            }
+            // hipcc sinks these loads down to their first use — the LDS stores at the END of the stage — and then waits for them at once: the whole L2
+            // latency exposed per stage.  The scheduling barrier keeps them up here.
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < KPS; ++ks) {
-                    const int s = sg * KPS + ks;
-                    if (s < kB2KS) {
-                        const unsigned char* const ap = wnd + addr[s];
-                        const unsigned char* const bk = bst + (sg & 1) * kStage + ks * kKB + lane * 16;
+            for (int ks = 0; ks < KPS; ++ks) {
+                const int s2 = sg * KPS + ks;
+                if (s2 < kB2KS) {
+                    const unsigned char* const ap = wnd + addr[s2];
+                    const unsigned char* const bk = bst + ((sg & 1) ^ par) * kStage + ks * kKB + lane * 16;
+                    s16x8 fa[3], fb[3][NT];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            fa[ks][p] = *reinterpret_cast<const s16x8*>(ap + p * kB2Plane);
+                    for (int p2 = 0; p2 < 3; ++p2) {
+                        fa[p2] = *reinterpret_cast<const s16x8*>(ap + p2 * kB2Plane);
 #pragma unroll
-                            for (int u = 0; u < NT; ++u) fb[ks][p][u] = *reinterpret_cast<const s16x8*>(bk + (p * NT + u) * 1024);
+                        for (int u = 0; u < NT; ++u) fb[p2][u] = *reinterpret_cast<const s16x8*>(bk + (p2 * NT + u) * 1024);
+                    }
+                    // the six cross terms, smallest first: (h, l) (m, m) (l, h) (h, m) (m, h) (h, h)
+                    constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) {
+                            if (SS_BX_ABLATE & 4) acc[ks][u][q] += (float)(fa[pa[q]][0] + fb[pb[q]][u][1]);
+                            else acc[ks][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa[q]], fb[pb[q]][u], acc[ks][u], 0, 0, 0);
                         }
-                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                // ... then the six cross terms, smallest first: (h, l) (m, m) (l, h) (h, m) (m, h) (h, h)
+            }
+            if (more || has_next) {
+                unsigned char* const dst = bst + (((sg + 1) & 1) ^ par) * kStage;
 #pragma unroll
-                for (int ks = 0; ks < KPS; ++ks) {
-                    const int s = sg * KPS + ks;
-                    if (s < kB2KS) {
-                        constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-                        for (int q = 0; q < 6; ++q)
-#pragma unroll
-                            for (int u = 0; u < NT; ++u) acc[ks][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][pa[q]], fb[ks][pb[q]][u], acc[ks][u], 0, 0, 0);
-                    }
+                for (int u = 0; u < kF4; ++u) {
+                    const int off = (threadIdx.x + kB2Threads * u) * 16;
+                    if (!(SS_BX_ABLATE & 2) && (!more || sg + 2 < kNS || off < kLastBytes)) *reinterpret_cast<f4*>(dst + off) = st[u];
                 }
-                if (more) {
-                    unsigned char* const dst = bst + ((sg + 1) & 1) * kStage;
-#pragma unroll
-                    for (int u = 0; u < kF4; ++u) {
-                        const int off = (threadIdx.x + kB2Threads * u) * 16;
-                        if (sg + 2 < kNS || off < kLastBytes) *reinterpret_cast<f4*>(dst + off) = st[u];
-                    }
-                    __syncthreads();
-                }
+                if (more && !(SS_BX_ABLATE & 8)) __syncthreads();
             }
         }
-        // ---- tile epilogue: D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31]; the sum carries the sign of the last chunk
-        const float fin = ((NCH - 1) & 1) ? -1.f : 1.f;
+        par ^= 1;
+        __syncthreads();                                                        // every reader of this item's window and stages is done
+        if (has_next && !(SS_BX_ABLATE & 1)) bx_win_store(wnd, wbuf, bl, nxt.nj, nxt.ni);
+        if (cur.c == NCH - 1) {
+            // ---- tile epilogue: D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31]; the sum carries the sign of the last chunk
+            const float fin = ((NCH - 1) & 1) ? -1.f : 1.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int py = sy0 + (pm >> 3), px = sx0 + 8 * wv + (pm & 7);
-                float v = acc[0][t][r];
-                if constexpr (KPS > 1) v += acc[1][t][r];
-                if ((pm >> 3) < nrow && px < w) store_out(gx + (((long long)nb * h + py) * w + px) * CIN + 32 * NT * blk + 32 * t + (lane & 31), v * fin);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int pm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int py = sy0 + (pm >> 3), px = sx0 + 8 * wv + (pm & 7);
+                    float v = acc[0][t][r];
+                    if constexpr (KPS > 1) v += acc[1][t][r];
+                    if ((pm >> 3) < nrow && px < w) store_out(gx + (((long long)cur.nb * h + py) * w + px) * CIN + 32 * NT * cur.blk + 32 * t + (lane & 31), v * fin);
+                }
+        }
+        cur = nxt;
     }
 }
 
@@ -355,8 +429,9 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
 // the group's lanes address INDIVIDUALLY (measured: out[i][r] = in[lane 4 r + i / 4][element i % 4], profiles/r04/tr16.log), so each source lane points at
 // "its" pixel through the two index maps and the gather along k costs nothing.  The main loop is branch-free: rows / columns beyond the tile meet a zeroed
 // spike fragment, phantom taps and quads read the window's zero row.  Partials -> ws[slice][co][tap][ci] -> upconv_box_wgrad_reduce_kernel (fixed order).
-template <int NT>                              // input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of them,
-                                               // so every transposed A fragment feeds NT MFMAs (v2 had one ci tile per wavefront: LDS-read bound at 0.17 of the peak)
+template <int NT, bool PF>                     // NT: input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of
+                                               // them, so every transposed A fragment feeds NT MFMAs.  PF: the next tile's window is fetched into registers while this
+                                               // tile multiplies (14 x 16 B per thread: NT <= 2 only — NT = 4 holds 128 accumulator registers)
 __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const unsigned short* __restrict__ Bp, const unsigned short* __restrict__ xT,
                                                                          const int* __restrict__ vmap, const int* __restrict__ hmap,
                                                                          const int* __restrict__ tr, const int* __restrict__ tc,
@@ -409,15 +484,35 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
             if (!ok) xf[t] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
+    __shared__ int tiles[4 * 64 + 2 * 16];                                       // the row / column tile tables (<= 64 row tiles, <= 16 column tiles: checked by the host)
+    for (int i = threadIdx.x; i < 4 * RG; i += kB2Threads) tiles[i] = tr[i];
+    for (int i = threadIdx.x; i < 2 * CG; i += kB2Threads) tiles[256 + i] = tc[i];
+    __syncthreads();
+    const BxLane bl = bx_lane(plane_g);
+    auto win_src = [&](int nb, int rg, int cg) { return Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)tiles[4 * rg + 2] * NHR + tiles[256 + 2 * cg]) * kBxCo; };
+    // tile -> (frame, row tile, column tile): one 64-bit division per workgroup, then incremental
+    int cg = (int)(t_begin % CG), rg = (int)((t_begin / CG) % RG), nb = (int)(t_begin / ((long long)CG * RG));
+    f4 wbuf[kWinRegs];                                                          // (a slice without tiles still writes its — zero — partials below)
+    if constexpr (PF) {
+        if (t_begin < t_end) {
+            bx_win_load(wbuf, bl, win_src(nb, rg, cg), NHR, tiles[4 * rg + 3], tiles[256 + 2 * cg + 1]);     // the first window: the only latency exposed
+            bx_win_store(wnd, wbuf, bl, tiles[4 * rg + 3], tiles[256 + 2 * cg + 1]);
+        }
+    }
 #pragma unroll 1
     for (long long tl = t_begin; tl < t_end; ++tl) {
-        const int cg = (int)(tl % CG);
-        const long long rr = tl / CG;
-        const int rg = (int)(rr % RG), nb = (int)(rr / RG);
-        const int sy0 = tr[4 * rg], nrow = tr[4 * rg + 1], j0 = tr[4 * rg + 2], nj = tr[4 * rg + 3];
-        const int sx0 = kB2TC * cg, i0 = tc[2 * cg], ni = tc[2 * cg + 1];
+        const int sy0 = tiles[4 * rg], nrow = tiles[4 * rg + 1], j0 = tiles[4 * rg + 2], nj = tiles[4 * rg + 3];
+        const int sx0 = kB2TC * cg, i0 = tiles[256 + 2 * cg], ni = tiles[256 + 2 * cg + 1];
+        int cgn = cg + 1, rgn = rg, nbn = nb;                                   // the next tile
+        if (cgn == CG) { cgn = 0; if (++rgn == RG) { rgn = 0; ++nbn; } }
+        const int njn = tiles[4 * rgn + 3], nin = tiles[256 + 2 * cgn + 1];
+        // PF: the next tile's window is fetched two rows per k-step, each pair issued BEHIND that k-step's spike loads (in-order vector-memory counter: see
+        // bx_win_load_rows)
+        const bool pf_next = PF && tl + 1 < t_end;
+        const unsigned short* const wn = win_src(nbn, rgn, cgn);
         s16x8 xa[NT], xb[NT];
         load_x(xa, nb, sy0, nrow, sx0, 0);                                      // in flight while the window is staged
+        if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- this lane's read addresses in two halves: rowp[row][quad] = byte offset of the window row | swizzle bit in bit 4, colp[half * 2 + rd][quad] = byte
         //      offset of "its" pixel's column (+ 8 for the odd channel quad); negative = the empty range (-> the zero pixel)
@@ -441,9 +536,12 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
             const int a = (rp & ~16) + (cp ^ (rp & 16));
             return ((rp | cp) < 0 ? kB2Zero : a) + 8 * coq;
         };
-        __syncthreads();                                                        // the previous tile's readers of the window are done
-        bx_stage_window(wnd, Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)j0 * NHR + i0) * kBxCo, plane_g, NHR, nj, ni);
-        __syncthreads();
+        if constexpr (!PF) {
+            __syncthreads();                                                    // the previous tile's readers of the window are done
+            bx_win_load(wbuf, bl, win_src(nb, rg, cg), NHR, nj, ni);
+            bx_win_store(wnd, wbuf, bl, nj, ni);
+        }
+        __syncthreads();                                                        // this tile's window (PF: stored at the end of the previous tile) is visible
         // k-step s = (row s >> 1, half s & 1): its A fragments (2 quads x 3 planes x 2 transpose reads) are fetched one k-step AHEAD of its MFMAs
         auto read_a = [&](int sidx, s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3]) {
             const int r = sidx >> 1, half = sidx & 1;
@@ -474,15 +572,22 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         for (int sidx = 0; sidx < 2 * kB2TR; sidx += 2) {                       // two k-steps per trip: the buffers alternate statically
             read_a(sidx + 1, lb, hb);
             load_x(xb, nb, sy0, nrow, sx0, sidx + 1);
+            if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 1), 2 * (sidx + 1) + 2);
             __builtin_amdgcn_sched_barrier(0);
             mma(la, ha, xa);
             if (sidx + 2 < 2 * kB2TR) {
                 read_a(sidx + 2, la, ha);
                 load_x(xa, nb, sy0, nrow, sx0, sidx + 2);
+                if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 2), 2 * (sidx + 2) + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
             mma(lb, hb, xb);
         }
+        if constexpr (PF) {
+            __syncthreads();                                                    // every reader of this tile's window is done
+            if (tl + 1 < t_end) bx_win_store(wnd, wbuf, bl, njn, nin);
+        }
+        cg = cgn; rg = rgn; nb = nbn;
     }
     // ---- partials: D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31], m = 8 (tap - 4 quad) + channel  ->  ws[slice][co][tap][ci]
     float* const wsl = ws + (long long)slice * COUT * 25 * CIN;
@@ -565,6 +670,7 @@ int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vma
 {
     if (!box || !weight || !vmap || !hmap || !tile_rows || !tile_cols || !g_x || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
     if (!ss_upconv_box_dgrad_supported(Cin, Cout, 5, 1, 1)) return SS_EINVAL;                    // shape only: the caller checked the extents
+    if (n_row_tiles > 64 || (w + kB2TC - 1) / kB2TC > 16) return SS_EINVAL;                      // the tile tables live in LDS (maps up to ~250 x 512 source pixels)
     if (!aligned16(box) || !aligned16(ws) || !aligned16(g_x) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
@@ -617,6 +723,7 @@ int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int*
     if (x_packed && (NB * h * (long long)w * Cin) % 16 != 0) return SS_EINVAL;
     if (!box || (!x && !x_packed) || !vmap || !hmap || !tile_rows || !tile_cols || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
     if (!ss_upconv_box_wgrad_supported(Cin, Cout, 5, 1, 1) || !aligned16(box) || !aligned16(ws) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
+    if (n_row_tiles > 64 || (w + kB2TC - 1) / kB2TC > 16) return SS_EINVAL;                      // the tile tables live in LDS
     int NT = 0, kinds = 0, slices = 0;
     if (!box_wgrad_plan(Cin, Cout, &NT, &kinds, &slices)) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -631,9 +738,9 @@ int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int*
     const unsigned grid = (unsigned)(kinds * slices);
     const unsigned short* Bp = static_cast<const unsigned short*>(box);
     const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
-#define SS_BW(NT_) hipLaunchKernelGGL((upconv_box_wgrad_kernel<NT_>), dim3(grid), dim3(kB2Threads), 0, s, Bp, xT, vmap, hmap, tile_rows, tile_cols, ws, \
+#define SS_BW(NT_, PF_) hipLaunchKernelGGL((upconv_box_wgrad_kernel<NT_, PF_>), dim3(grid), dim3(kB2Threads), 0, s, Bp, xT, vmap, hmap, tile_rows, tile_cols, ws, \
                                       (int)NB, h, w, NVR, NHR, Cin, Cout, kinds, RG, CG)
-    if (NT == 4) SS_BW(4); else if (NT == 2) SS_BW(2); else SS_BW(1);
+    if (NT == 4) SS_BW(4, false); else if (NT == 2) SS_BW(2, true); else SS_BW(1, true);
 #undef SS_BW
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(upconv_box_wgrad_reduce_kernel, dim3(grid_for((long long)Cout * 25 * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cout, Cin, accumulate);
