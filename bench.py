@@ -498,7 +498,10 @@ def _roof_upconv(shapes, a, cfg):
                         'persistent form)') if form2 else
                        'upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
                 bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=None,
+                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=traffic,
+                traffic_note=('sum of the three launches; the three bf16 planes of the box-sum image (1.55 GB at deconv1) are written once and read by both '
+                              'contractions with their window halos — 4.8 x the stage\'s algorithmic I/O; round 3\'s g_P-on-chip pair moved 7.0 GB in 3.7 ms, this group 8.9 GB in 3.0 ms: '
+                              'neither is HBM-bound, the contractions sit on the LDS / MFMA issue limits (profiles/r04/box_dgrad_ablations.log)') if box else None,
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
                           note='useful FLOPs of the minimal projection x 3 exact bf16 terms; the kernel issues ~1.9x that (source-window halo)'),
                 note=('issue bound: the MFMAs of the 4 producer wavefronts and the LDS / VALU instructions of the 4 gathering wavefronts share each '
@@ -528,16 +531,27 @@ def _roof_upconv_bwd(shapes, a, cfg):
     us = 1e3 * d['ms'] / d['launches']
     box = bool(cfg.BOX_BWD) and cin in cfg.BOX_BWD_CIN
     on_chip = bool(cfg.FUSED_UPCONV_DGRAD) and cin in cfg.FUSED_UPCONV_DGRAD_CIN
+    # counter-measured HBM bytes of the group (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes on tools/pmc_target.py)
+    parts = [_pmc_traffic(kk) for kk in (('upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad') if box_on(cfg, cin) else
+                                         ('upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp') if on_chip else ())]
+    traffic = int(sum(parts)) if parts and all(p is not None for p in parts) else None
     return dict(kernel=('upconv_boxsum_kernel + upconv_box_dgrad_kernel<32> + upconv_box_wgrad_kernel<2> (deconv1 backward on the box-sum image: one HBM-bound '
                         'box-sum launch, then both contractions as implicit GEMMs over its three bf16 planes; no g_P)') if box else
                        ('upconv_bwd_dgrad_kernel<32> + upconv_bwd_fused_kernel<64, 32> (deconv1 backward: adjoint gather + data gradient, adjoint gather + '
                         'weight gradient; g_P on chip only)') if on_chip else
                        'upconv_bwd_fused_kernel<64, 32> + fp32 GEMM (deconv1 backward: adjoint + weight gradient fused, g_P written once, read by the data-gradient GEMM)',
                 bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=None,
+                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=traffic,
+                traffic_note=('sum of the three launches; the three bf16 planes of the box-sum image (1.55 GB at deconv1) are written once and read by both '
+                              'contractions with their window halos — 4.8 x the stage\'s algorithmic I/O; round 3\'s g_P-on-chip pair moved 7.0 GB in 3.7 ms, this group 8.9 GB in 3.0 ms: '
+                              'neither is HBM-bound, the contractions sit on the LDS / MFMA issue limits (profiles/r04/box_dgrad_ablations.log)') if box else None,
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
                           note='6 bf16 cross terms per MAC (dense x dense data gradient) + 3 exact terms per MAC (spike x dense weight gradient)'),
                 g_P_in_hbm=not (on_chip or box))
+
+
+def box_on(cfg, cin):
+    return bool(cfg.BOX_BWD) and cin in cfg.BOX_BWD_CIN
 
 
 def _pmc_traffic(which='neuron_fwd'):

@@ -1250,7 +1250,9 @@ def test_decoder_stage_backward_keeps_g_P_on_chip(monkeypatch):
     gx0, gw0, peak0 = run(BOX_BWD=False, FUSED_UPCONV_DGRAD=False)        # g_P in HBM
     gx2, gw2, peak2 = run()                                               # round 4 default: the box-sum image (1.5 x g_y's bytes), no g_P
     gp_bytes = NB * h * w * 25 * Cout * 4
-    assert peak0 >= gp_bytes and peak1 < gp_bytes // 2 and peak2 < gp_bytes // 2, (peak0, peak1, peak2, gp_bytes)
+    # (the box path's peak: three bf16 planes of ~(H + 4)(W + 4) pixels + the weight gradient's per-slice partials, 2 CUs / kinds slices of
+    #  [C_out, 25, C_in] floats whatever the number of rows — 26 MB here)
+    assert peak0 >= gp_bytes and peak1 < gp_bytes // 2 and peak2 < gp_bytes * 2 // 3, (peak0, peak1, peak2, gp_bytes)
     assert torch.equal(gw1, gw0)
     assert float((gx1 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max())
     assert float((gx2 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max()) and float((gw2 - gw0).abs().max()) <= 1e-5 * float(gw0.abs().max())

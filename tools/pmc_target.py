@@ -82,5 +82,15 @@ if mode == 'rc':
         _lib.head_proj_packed(xbp, Wh, Ph, rows, 32)
         _lib.head_wgrad_packed(xbp, gPh, gWh, rows, 32)
         _lib.neuron_fwd_ex(x, None, None, xbp.view(T, -1), None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+if mode == 'rc':
+    # round 4: the decoder backward of deconv1 on the box-sum image (ss_upconv_boxsum_f32 -> ss_upconv_box_dgrad_f32 + ss_upconv_box_wgrad_f32), what the default path runs
+    from stereospike_amd import fused
+    bt = fused.box_tables(tabs, H, W)
+    gxs2, gw2 = torch.empty(NB, h, w, Cin, device=dev), torch.empty(Cout, Cin, 5, 5, device=dev)
+    for _ in range(5):
+        box = _lib.upconv_boxsum(gy, bt, NB, Cout, H, W)
+        _lib.upconv_box_dgrad(box, wt, bt, gxs2, NB, Cin, Cout, h, w)
+        _lib.upconv_box_wgrad(box, xs, None, bt, gw2, NB, Cin, Cout, h, w)
+    print('box planes', tuple(box.shape), box.dtype, 'bytes', box.numel() * box.element_size())
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
