@@ -498,10 +498,7 @@ def _roof_upconv(shapes, a, cfg):
                         'persistent form)') if form2 else
                        'upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
                 bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=traffic,
-                traffic_note=('sum of the three launches; the three bf16 planes of the box-sum image (1.55 GB at deconv1) are written once and read by both '
-                              'contractions with their window halos — 4.8 x the stage\'s algorithmic I/O; round 3\'s g_P-on-chip pair moved 7.0 GB in 3.7 ms, this group 8.9 GB in 3.0 ms: '
-                              'neither is HBM-bound, the contractions sit on the LDS / MFMA issue limits (profiles/r04/box_dgrad_ablations.log)') if box else None,
+                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=_pmc_traffic('upconv_fused2' if form2 else 'upconv_fused'),
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
                           note='useful FLOPs of the minimal projection x 3 exact bf16 terms; the kernel issues ~1.9x that (source-window halo)'),
                 note=('issue bound: the MFMAs of the 4 producer wavefronts and the LDS / VALU instructions of the 4 gathering wavefronts share each '

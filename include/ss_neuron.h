@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 7
+#define SS_ABI_VERSION 8
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` (8-byte aligned) to the ss_neuron_bwd_* entry points when g_k != NULL.
@@ -411,6 +411,9 @@ int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* 
  * accuracy); out [NB][ho][wo][C_out] fp32, ho = (h - 1) / 2 + 1.  ws: ss_spike_conv_fwd_ws_floats floats.  Compiled shapes: (32 -> 64), (64 -> 128).
  */
 int ss_spike_conv_fwd_supported(int Cin, int Cout, int k, int stride, int pad);
+/* (ABI 8) the wide shapes of conv3 / conv4 (128 -> 256, 256 -> 512; /root/reference/network/SNN_models.py:91-101) that ss_spike_conv_fwd_f32 ALSO accepts,
+ * in output-channel slices of 128 per workgroup: an A/B against the im2col + library-GEMM path, which the network keeps (profiles/r04/conv34_ab.log) */
+int ss_spike_conv_fwd_wide_supported(int Cin, int Cout, int k, int stride, int pad);
 long long ss_spike_conv_fwd_ws_floats(int Cin, int Cout);
 int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const float* weight, float* out, float* ws,
                           long long NB, int Cin, int Cout, int h, int w, void* stream);
@@ -571,6 +574,10 @@ int ss_voxelize_f64(const double* events, long long E, const double* start, cons
  */
 int ss_im2col_cl_bf16(const float* x, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, void* stream);
 int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream);
+/*   ss_wgrad_reduce3_f32 (ABI 8): epilogue of that weight-gradient GEMM (autograd's Conv2d weight gradient, /root/reference/network/SNN_models.py:91-101,
+ *                      blocks.py:146-159): parts fp32 [S][k*k*C_in rows (ky, kx, ci)][3][C_out] — S split-K slices of A^T @ [g_hi | g_mid | g_lo] —
+ *                      -> g_w fp32 [C_out][C_in][k][k] = sum over slices (ascending) of ((hi + mid) + lo).  C_in % 8 == 0, C_out % 32 == 0, k <= 7. */
+int ss_wgrad_reduce3_f32(const float* parts, float* g_w, int S, int k, int Cin, int Cout, void* stream);
 
 /*
  * Fused per-scale loss statistics — the step AFTER the path: /root/reference/network/loss.py:7-24

@@ -37,3 +37,14 @@ def im2col_cl(x, k, stride, pad):
         for kx in range(k):
             A[:, :, :, ky, kx] = xp[:, ky:ky + stride * ho:stride, kx:kx + stride * wo:stride]
     return bf16_round(A.reshape(NB * ho * wo, k * k * C)), (ho, wo)
+
+
+def wgrad_reduce3(parts, k, Cin, Cout):
+    """Epilogue of the exact bf16x3 weight-gradient GEMM (ss_wgrad_reduce3_f32; autograd's Conv2d weight gradient of the reference's encoder / bottleneck
+    convs, /root/reference/network/SNN_models.py:91-101, blocks.py:146-159): parts fp32 [S, k*k*Cin rows (ky, kx, ci), 3, Cout] -> g_w [Cout, Cin, k, k],
+    slices added in ascending order, inside a slice ((hi + mid) + lo), every addition rounded to fp32."""
+    parts = np.asarray(parts, np.float32).reshape(-1, k * k * Cin, 3, Cout)
+    acc = np.zeros((k * k * Cin, Cout), np.float32)
+    for s in range(parts.shape[0]):
+        acc = acc + ((parts[s, :, 0] + parts[s, :, 1]) + parts[s, :, 2])
+    return np.ascontiguousarray(acc.reshape(k, k, Cin, Cout).transpose(3, 2, 0, 1))

@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1
@@ -72,6 +72,8 @@ def lib():
     L.ss_split3_bf16.argtypes = [p, p, i64, i32, p]
     L.ss_im2col_cl_bf16.restype = i32
     L.ss_split3_bf16.restype = i32
+    L.ss_wgrad_reduce3_f32.argtypes = [p, p, i32, i32, i32, i32, p]
+    L.ss_wgrad_reduce3_f32.restype = i32
     L.ss_loss_stats_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
     L.ss_loss_grad_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     L.ss_loss_stats_f32.restype = i32
@@ -122,6 +124,8 @@ def lib():
     L.ss_upconv_bwd_fused_f32.restype = i32
     L.ss_spike_conv_fwd_supported.argtypes = [i32, i32, i32, i32, i32]
     L.ss_spike_conv_fwd_supported.restype = i32
+    L.ss_spike_conv_fwd_wide_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.ss_spike_conv_fwd_wide_supported.restype = i32
     L.ss_spike_conv_fwd_ws_floats.argtypes = [i32, i32]
     L.ss_spike_conv_fwd_ws_floats.restype = i64
     L.ss_spike_conv_fwd_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, p]
@@ -210,7 +214,7 @@ def lib():
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
-           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_wgrad_reduce3_f32', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
            'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed',
            'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
            'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32',
@@ -219,7 +223,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
            'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
-           'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
+           'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_wide_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
            'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
@@ -519,6 +523,13 @@ def im2col_cl_bf16(x, A, NB, h, w, C, k, stride, pad, ho, wo):
     _check(rc, 'ss_im2col_cl_bf16')
 
 
+def wgrad_reduce3(parts, g_w, S, k, Cin, Cout):
+    """parts fp32 [S, k*k*Cin, 3, Cout] (split-K slices x bf16 terms) -> g_w fp32 [Cout, Cin, k, k] (ss_wgrad_reduce3_f32)."""
+    with torch.cuda.device(parts.device):
+        rc = lib().ss_wgrad_reduce3_f32(_f32(parts, 'parts', S * k * k * Cin * 3 * Cout), _f32(g_w, 'g_w', Cout * Cin * k * k), S, k, Cin, Cout, _stream(parts))
+    _check(rc, 'ss_wgrad_reduce3_f32')
+
+
 def split3_bf16(g, g3, M, N):
     _require_hip(g, 'g')
     with torch.cuda.device(g.device):
@@ -658,6 +669,10 @@ def gemm6_batched(A, B, C_, batch, R, K, N):
 
 def spike_conv_fwd_supported(Cin, Cout, k, stride, pad):
     return bool(lib().ss_spike_conv_fwd_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def spike_conv_fwd_wide_supported(Cin, Cout, k, stride, pad):
+    return bool(lib().ss_spike_conv_fwd_wide_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
 
 
 def spike_conv_fwd(x, x_packed, weight, out, NB, Cin, Cout, h, w):

@@ -62,6 +62,7 @@ class EngineConfig:
     # ---- encoder / bottleneck convolutions ----------------------------------------------------------------------------------------------------------------
     WINOGRAD_DGRAD: bool = True
     WINOGRAD_GEMM6: bool = False        # [SS_WINOGRAD_GEMM6]
+    WGRAD_REDUCE3: bool = True          # encoder / bottleneck weight-gradient GEMM: slices + terms summed and laid out by ss_wgrad_reduce3_f32
     CONV_DGRAD_MFMA: bool = True        # [SS_CONV_DGRAD_MFMA]
     SPIKE_CONV_FWD_MFMA: bool = True    # [SS_CONV_FWD_MFMA]
     SPIKE_CONV_WGRAD_MFMA: bool = True  # [SS_CONV_WGRAD_MFMA]

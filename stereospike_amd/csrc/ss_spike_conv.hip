@@ -60,11 +60,15 @@ __global__ __launch_bounds__(kBlock) void spike_conv_fwd_prep_kernel(const float
     }
 }
 
-template <int CIN, int COUT, bool PACKED>
+// NTW: 32-channel output tiles per workgroup.  NTW == C_out / 32 for the shipped shapes (conv1, conv2); the wide shapes of conv3 / conv4 (C_out 256 / 512)
+// run C_out / (32 NTW) workgroup SLICES per tile (slice = blockIdx.x % slices), each re-staging the window — built for the A/B against the library path
+// (profiles/r04/conv34_ab.log), not dispatched by the network
+template <int CIN, int COUT, bool PACKED, int NTW = COUT / 32>
 __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Bf,
                                                                        float* __restrict__ out, int NB, int h, int w, int ho, int wo)
 {
-    constexpr int NT = COUT / 32, NCH = CIN / 32;
+    constexpr int NTG = COUT / 32, NT = NTW, NCH = CIN / 32, NSL = NTG / NTW;
+    static_assert(NTG % NTW == 0, "slices");
 #ifdef SS_SC_KPS1
     constexpr int KPS = 1;                                                      // A/B build (tools/): one k-step per stage everywhere
 #else
@@ -72,7 +76,8 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
 #endif
                                         // k-steps per weight stage and barrier: a whole tap where it fits beside the window
                                                                                 // at two workgroups per CU (C_out 64: 24 KB of stages; C_out 128 would need 48)
-    constexpr int KST = 3 * NT * 1024;                                          // bytes of one k-step's weight fragments
+    constexpr int KST = 3 * NT * 1024;                                          // bytes of one k-step's weight fragments (of this slice: the LDS stage)
+    constexpr int KSTG = 3 * NTG * 1024;                                        // ... of all of C_out: the stride in Bf
     constexpr int STG = KPS * KST;                                              // bytes of one weight stage
     constexpr int LPT = STG / 16 / kScThreads;                                  // whole 16-B pieces per thread and stage (+ a partial round)
     constexpr int REM = STG / 16 - LPT * kScThreads;
@@ -82,14 +87,24 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
     const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // wavefront = output row of the tile
     const int RG = (ho + kScTR - 1) / kScTR, CG = (wo + kScTC - 1) / kScTC;
     const long long n_tiles = (long long)NB * RG * CG;
-    const unsigned g = xcd_remap(blockIdx.x, gridDim.x);                        // contiguous tile ranges, neighbours on one XCD (halo rows in its L2)
-    const long long t_begin = n_tiles * g / gridDim.x, t_end = n_tiles * (g + 1) / gridDim.x;
+    const int slice = NSL > 1 ? (int)(blockIdx.x % NSL) : 0;
+    const unsigned gdim = gridDim.x / NSL;
+    const unsigned g = xcd_remap(blockIdx.x / NSL, gdim);                       // contiguous tile ranges, neighbours on one XCD (halo rows in its L2)
+    const long long t_begin = n_tiles * g / gdim, t_end = n_tiles * (g + 1) / gdim;
     const int tx = lane & 31, half = lane >> 5;
     f4 st[LPT + 1];
+    // byte offset inside Bf's k-steps of 16-byte piece p of a stage (slices: NTW KB of each split term of each k-step)
+    auto piece = [&](int p) -> long long {
+        if constexpr (NSL == 1) return (long long)p * 16;
+        else {
+            const int ks = p / (3 * NT * 64), rem = p - ks * (3 * NT * 64), sp = rem / (NT * 64), q = rem - sp * (NT * 64);
+            return (long long)ks * KSTG + (sp * NTG + NT * slice) * 1024 + q * 16;
+        }
+    };
     auto stage_issue = [&](const unsigned char* src) {
 #pragma unroll
-        for (int u = 0; u < LPT; ++u) st[u] = *reinterpret_cast<const f4*>(src + (threadIdx.x + kScThreads * u) * 16);
-        if (REM && (int)threadIdx.x < REM) st[LPT] = *reinterpret_cast<const f4*>(src + (threadIdx.x + kScThreads * LPT) * 16);
+        for (int u = 0; u < LPT; ++u) st[u] = *reinterpret_cast<const f4*>(src + piece(threadIdx.x + kScThreads * u));
+        if (REM && (int)threadIdx.x < REM) st[LPT] = *reinterpret_cast<const f4*>(src + piece(threadIdx.x + kScThreads * LPT));
     };
     auto stage_commit = [&](unsigned char* dst) {
 #pragma unroll
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                 }
             }
             // ---- weight stage 0 of this chunk
-            const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + (long long)c * 50 * KST;
+            const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + (long long)c * 50 * KSTG;
             stage_issue(bsrc);
             stage_commit(bst);
             __syncthreads();
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                         const int s = (ky * 5 + kx) * 2 + gi;                   // k-step; stage = s / KPS (same MFMA order for either KPS: same result bits)
                         const int sg = s / KPS;
                         const bool first = s % KPS == 0, last = s % KPS == KPS - 1, more = sg + 1 < 50 / KPS;
-                        if (first && more) stage_issue(bsrc + (long long)(sg + 1) * STG);
+                        if (first && more) stage_issue(bsrc + (long long)(sg + 1) * KPS * KSTG);
                         if (active) {
                             const int col = 2 * tx + kx;
                             s16x8 a = *reinterpret_cast<const s16x8*>(lane_row + ky * kScRowB + col * kScPix + (((2 * gi + half) ^ ((col >> 2) & 3)) << 4));
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (ox < wo) store_out(out + (rowbase + ox) * COUT + 32 * t + tx, neg ? -acc[t][r] : acc[t][r]);
+                    if (ox < wo) store_out(out + (rowbase + ox) * COUT + 32 * (NT * slice + t) + tx, neg ? -acc[t][r] : acc[t][r]);
                 }
         }
     }
@@ -372,6 +387,13 @@ int ss_spike_conv_fwd_supported(int Cin, int Cout, int k, int stride, int pad)
     return k == 5 && stride == 2 && pad == 2 && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128));
 }
 
+/* 1 for the shapes ss_spike_conv_fwd_f32 runs in output-channel SLICES (conv3: 128 -> 256, conv4: 256 -> 512 — 2 / 4 workgroup slices of 128 channels per
+   tile).  Measured slower than the library path there (profiles/r04/conv34_ab.log): kept for that comparison, not dispatched by the network. */
+int ss_spike_conv_fwd_wide_supported(int Cin, int Cout, int k, int stride, int pad)
+{
+    return k == 5 && stride == 2 && pad == 2 && ((Cin == 128 && Cout == 256) || (Cin == 256 && Cout == 512));
+}
+
 long long ss_spike_conv_fwd_ws_floats(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
@@ -382,7 +404,8 @@ int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const fl
                           long long NB, int Cin, int Cout, int h, int w, void* stream)
 {
     if ((!x && !x_packed) || !weight || !out || !ws || NB <= 0 || h <= 0 || w <= 0) return SS_EINVAL;
-    if (!ss_spike_conv_fwd_supported(Cin, Cout, 5, 2, 2) || !aligned16(out) || !aligned16(ws) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
+    const bool wide = ss_spike_conv_fwd_wide_supported(Cin, Cout, 5, 2, 2) != 0;
+    if ((!wide && !ss_spike_conv_fwd_supported(Cin, Cout, 5, 2, 2)) || !aligned16(out) || !aligned16(ws) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
     const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
     if (NB * h * (long long)w * Cin > 0x7fffffffffLL || (x_packed && (NB * h * (long long)w * Cin) % 16 != 0)) return SS_EINVAL;
     int dev = 0, cus = 0;
@@ -392,12 +415,18 @@ int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const fl
     hipLaunchKernelGGL(spike_conv_fwd_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const long long n_tiles = NB * ((ho + kScTR - 1) / kScTR) * ((wo + kScTC - 1) / kScTC);
-    const unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);     // two workgroups per CU, persistent over their tile ranges
+    unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);           // two workgroups per CU, persistent over their tile ranges
 #define SS_SC(CI, CO) do { if (x_packed) hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, true>), dim3(grid), dim3(kScThreads), 0, s, \
                                static_cast<const void*>(x_packed), Bf, out, (int)NB, h, w, ho, wo); \
                            else hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, false>), dim3(grid), dim3(kScThreads), 0, s, \
                                static_cast<const void*>(x), Bf, out, (int)NB, h, w, ho, wo); } while (0)
-    if (Cin == 32) SS_SC(32, 64); else SS_SC(64, 128);
+#define SS_SCW(CI, CO) do { const unsigned tg = (unsigned)(n_tiles * (CO / 128) < 2 * cus ? n_tiles : 2 * cus / (CO / 128)); grid = tg * (CO / 128); \
+                           if (x_packed) hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, true, 4>), dim3(grid), dim3(kScThreads), 0, s, \
+                               static_cast<const void*>(x_packed), Bf, out, (int)NB, h, w, ho, wo); \
+                           else hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, false, 4>), dim3(grid), dim3(kScThreads), 0, s, \
+                               static_cast<const void*>(x), Bf, out, (int)NB, h, w, ho, wo); } while (0)
+    if (Cin == 32) SS_SC(32, 64); else if (Cin == 64) SS_SC(64, 128); else if (Cin == 128) SS_SCW(128, 256); else SS_SCW(256, 512);
+#undef SS_SCW
 #undef SS_SC
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }

@@ -59,6 +59,37 @@ __global__ __launch_bounds__(kBlock) void split3_bf16_kernel(const float* __rest
     }
 }
 
+// Epilogue of the exact bf16x3 weight-gradient GEMM of an encoder / bottleneck convolution (fused._SpikeConvCL.backward): the library GEMM leaves
+// parts[S][K = (ky, kx, ci)][3 terms][C_out] (split-K slices x the three bf16 terms of the output gradient); this kernel sums slices and terms in a fixed
+// order (slice-major, terms hi, mid, lo inside) and writes the Conv2d layout g_W[C_out][C_in][k][k] — one launch instead of two torch reductions and a
+// permuting copy.  A workgroup owns 32 output channels x 8 input channels x all taps: reads are 128-byte rows along C_out, the LDS tile turns them into
+// the 4 kk * 8-byte contiguous runs of the output.
+constexpr int kWr3Co = 32, kWr3Ci = 8;
+__global__ __launch_bounds__(kBlock) void wgrad_reduce3_kernel(const float* __restrict__ parts, float* __restrict__ gw, int S, int kk, int Cin, int Cout)
+{
+    extern __shared__ float wr3_tile[];                                       // [co 32][ci 8 * kk + 1]
+    const int cib = Cin / kWr3Ci;
+    const int co0 = (int)(blockIdx.x / cib) * kWr3Co, ci0 = (int)(blockIdx.x % cib) * kWr3Ci;
+    const int row = kWr3Ci * kk + 1;
+    const long long slice = (long long)kk * Cin * 3 * Cout;
+    for (int it = threadIdx.x; it < kk * kWr3Ci * kWr3Co; it += kBlock) {
+        const int co = it % kWr3Co, r = it / kWr3Co, ci = r % kWr3Ci, tap = r / kWr3Ci;
+        const float* src = parts + ((long long)(tap * Cin + ci0 + ci) * 3) * Cout + co0 + co;
+        float a = 0.f;
+        for (int sl = 0; sl < S; ++sl) {
+            const float* q = src + sl * slice;
+            a += (q[0] + q[Cout]) + q[2 * Cout];
+        }
+        wr3_tile[co * row + ci * kk + tap] = a;
+    }
+    __syncthreads();
+    const int run = kWr3Ci * kk;                                             // contiguous floats per output channel
+    for (int it = threadIdx.x; it < kWr3Co * run; it += kBlock) {
+        const int co = it / run, e = it - co * run;
+        gw[((long long)(co0 + co) * Cin + ci0) * kk + e] = wr3_tile[co * row + e];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 2-bit packed spike tensors: readers for the consumers of a packed neuron output
 // ---------------------------------------------------------------------------------------------------
@@ -834,6 +865,16 @@ int ss_split3_bf16(const float* g, void* g3, long long M, int N, void* stream)
     if (!g || !g3 || M <= 0 || N <= 0 || N % 4 != 0 || !aligned16(g) || !aligned16(g3)) return SS_EINVAL;
     hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(M * (N / 4), kMaxGridBwd)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        g, static_cast<unsigned short*>(g3), M, N);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_wgrad_reduce3_f32(const float* parts, float* g_w, int S, int k, int Cin, int Cout, void* stream)
+{
+    if (!parts || !g_w || S < 1 || k < 1 || k > 7 || Cin <= 0 || Cout <= 0 || Cin % kWr3Ci != 0 || Cout % kWr3Co != 0) return SS_EINVAL;
+    const int kk = k * k;
+    const size_t lds = (size_t)kWr3Co * (kWr3Ci * kk + 1) * sizeof(float);
+    hipLaunchKernelGGL(wgrad_reduce3_kernel, dim3((unsigned)((Cout / kWr3Co) * (Cin / kWr3Ci))), dim3(kBlock), lds, static_cast<hipStream_t>(stream),
+                       parts, g_w, S, kk, Cin, Cout);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -1040,10 +1040,17 @@ class _SpikeConvCL(torch.autograd.Function):
             _lib.split3_bf16(g, g3, M, Cout)
             S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)   # split-K: the output is only K x 3*Cout
             if S > 1:
-                gw3 = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g3.view(S, M // S, 3 * Cout), out_dtype=torch.float32).sum(0)
+                gw3 = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g3.view(S, M // S, 3 * Cout), out_dtype=torch.float32)      # [S, K, 3*Cout]
             else:
                 gw3 = torch.mm(A.t(), g3, out_dtype=torch.float32)                # [K, 3*Cout]
-            g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
+            if ctx.ecfg.WGRAD_REDUCE3 and Cin % 8 == 0 and Cout % 32 == 0 and k <= 7:
+                # slices and terms summed and the Conv2d layout written by one kernel (instead of two torch reductions and a permuting copy)
+                g_w = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=g.device)
+                _lib.wgrad_reduce3(gw3, g_w, S, k, Cin, Cout)
+            else:
+                if S > 1:
+                    gw3 = gw3.sum(0)
+                g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
         how_x = 'none'
         if ctx.needs_input_grad[0] and ctx.ecfg.WINOGRAD_DGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 4 == 0 and Cout % 4 == 0:
             g_x = winograd_dgrad_cl(g, weight, ctx.ecfg.WINOGRAD_GEMM6)

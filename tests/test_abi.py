@@ -46,7 +46,9 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
                                   # ABI 7
                                   'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_window', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats',
-                                  'ss_upconv_box_dgrad_f32', 'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32'])
+                                  'ss_upconv_box_dgrad_f32', 'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
+                                  # ABI 8
+                                  'ss_wgrad_reduce3_f32', 'ss_spike_conv_fwd_wide_supported'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -57,7 +59,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == _lib.ABI_VERSION == 7
+    assert L.ss_abi_version() == _lib.ABI_VERSION == 8
     assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
@@ -91,6 +93,9 @@ def test_argument_validation_without_a_gpu():
     assert L.ss_upconv_box_dgrad_supported(64, 32, 5, 15, 76) == 1 and L.ss_upconv_box_dgrad_supported(64, 32, 5, 16, 76) == 0
     assert L.ss_upconv_box_dgrad_supported(96, 32, 5, 12, 70) == 0 and L.ss_upconv_box_wgrad_supported(96, 40, 5, 12, 70) == 1
     assert L.ss_upconv_box_dgrad_ws_floats(64, 32) == 2 * 4 * 13 * 3072 // 4 and _lib.upconv_box_window() == (4, 15, 76)
+    # ABI 8
+    assert L.ss_wgrad_reduce3_f32(None, None, 4, 5, 128, 256, None) == -22
+    assert L.ss_spike_conv_fwd_wide_supported(128, 256, 5, 2, 2) == 1 and L.ss_spike_conv_fwd_wide_supported(64, 128, 5, 2, 2) == 0
 
 
 def test_product_fails_loudly_on_cpu_tensors():

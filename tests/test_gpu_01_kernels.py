@@ -861,6 +861,21 @@ def test_unpack_copies_and_packed_im2col_vs_oracle():
         assert np.array_equal(A1.float().cpu().numpy(), ref.reshape(A1.shape))
 
 
+def test_wgrad_reduce3_vs_oracle():
+    """ss_wgrad_reduce3_f32 (slices + bf16 terms of the encoder weight-gradient GEMM summed, Conv2d layout written) == oracle/np_operands.wgrad_reduce3
+    bit for bit; the network's geometries (conv3, conv4, a bottleneck conv) and ragged ones."""
+    from oracle import np_operands
+    from stereospike_amd import _lib
+    rng = np.random.default_rng(11)
+    for (S, k, Cin, Cout) in ((4, 5, 128, 256), (4, 5, 256, 512), (2, 3, 512, 512), (1, 3, 8, 32), (3, 7, 16, 64), (5, 1, 24, 96)):
+        parts = (rng.standard_normal((S, k * k * Cin, 3, Cout)) * np.array([1.0, 2.0 ** -8, 2.0 ** -16]).reshape(1, 1, 3, 1)).astype(np.float32)
+        g_w = torch.full((Cout, Cin, k, k), float('nan'), device=DEV)
+        _lib.wgrad_reduce3(torch.from_numpy(parts).to(DEV), g_w, S, k, Cin, Cout)
+        assert np.array_equal(g_w.cpu().numpy(), np_operands.wgrad_reduce3(parts, k, Cin, Cout)), (S, k, Cin, Cout)
+    with pytest.raises(_lib.SSNeuronError):
+        _lib.wgrad_reduce3(torch.zeros(1, 25 * 12, 3, 32, device=DEV), torch.zeros(32, 12, 5, 5, device=DEV), 1, 5, 12, 32)      # C_in % 8 != 0
+
+
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('kind', ['IF', 'PLIF'])
 @pytest.mark.parametrize('T,N', [(5, 4096 * 3), (5, 1003), (10, 8192), (1, 64)])
@@ -1345,7 +1360,8 @@ def test_spike_conv_wgrad_mfma(NB, Cin, Cout, hw):
 # exact MFMA FORWARD of the stride-2 5x5 encoder convs on spike inputs (ss_spike_conv_fwd_f32)
 # ======================================================================================================
 @pytest.mark.parametrize('NB,Cin,Cout,hw', [(2, 32, 64, (64, 80)), (3, 64, 128, (33, 45)), (1, 32, 64, (7, 9)), (5, 64, 128, (130, 173)), (4, 32, 64, (260, 346)),
-                                            (2, 32, 64, (50, 70))])
+                                            (2, 32, 64, (50, 70)),
+                                            (3, 128, 256, (65, 87)), (2, 256, 512, (33, 44)), (1, 128, 256, (9, 7))])     # the wide (sliced, A/B-only) shapes
 def test_spike_conv_fwd_mfma(NB, Cin, Cout, hw):
     """== conv2d(x, w, stride 2, padding 2) evaluated in float64 within fp32 accumulation error of EXACT products (element-wise bound 2^-21 of
     the magnitude sum sum |x||w| over K = 800 / 1600 terms: the exact 3-way bf16 split of the weight times spike counts, fp32 accumulation in the MFMA); within 4x (worst element) / 2x (rms) of
@@ -1358,7 +1374,7 @@ def test_spike_conv_fwd_mfma(NB, Cin, Cout, hw):
          + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.03).float())                      # values 0 .. 3
     wt = torch.randn(Cout, Cin, 5, 5, device=DEV, generator=gen) * 0.05
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    assert _lib.spike_conv_fwd_supported(Cin, Cout, 5, 2, 2) and not _lib.spike_conv_fwd_supported(Cin, Cout, 3, 1, 1)
+    assert (_lib.spike_conv_fwd_supported(Cin, Cout, 5, 2, 2) != _lib.spike_conv_fwd_wide_supported(Cin, Cout, 5, 2, 2)) and not _lib.spike_conv_fwd_supported(Cin, Cout, 3, 1, 1)
     y = torch.full((NB, ho, wo, Cout), float('nan'), device=DEV)
     _lib.spike_conv_fwd(x, None, wt, y, NB, Cin, Cout, h, w)
 

@@ -290,6 +290,21 @@ def test_exact_split_operand_oracle_identities():
         assert np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max() <= 1e-12      # exact products, float64 accumulation on both sides
 
 
+def test_wgrad_reduce3_oracle_is_the_two_reductions_and_the_permute():
+    """oracle/np_operands.wgrad_reduce3 (checker of ss_wgrad_reduce3_f32) == the torch expression it replaces in fused._SpikeConvCL.backward —
+    parts.sum(0).view(K, 3, C_out).sum(1) permuted to the Conv2d layout — to fp32 summation-order accuracy, and exactly when every partial sum is
+    representable."""
+    from oracle import np_operands as no
+    rng = np.random.default_rng(3)
+    for (S, k, Cin, Cout) in ((4, 5, 8, 32), (1, 3, 16, 32), (3, 1, 8, 64)):
+        parts = rng.standard_normal((S, k * k * Cin, 3, Cout)).astype(np.float32)
+        ref = torch.tensor(parts).double().sum(0).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).numpy()
+        got = no.wgrad_reduce3(parts, k, Cin, Cout)
+        assert got.shape == (Cout, Cin, k, k) and np.abs(got - ref).max() <= 2e-6 * np.abs(parts).sum((0, 2)).max()
+        ints = rng.integers(-8, 9, parts.shape).astype(np.float32)                   # small integers: every order gives the same fp32 value
+        assert np.array_equal(no.wgrad_reduce3(ints, k, Cin, Cout), torch.tensor(ints).sum(0).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).numpy())
+
+
 def test_winograd_dgrad_oracle_matches_autograd():
     """oracle/np_winograd.py: the float64 direct form == torch autograd's conv data gradient; the fp32 Winograd restatement is within fp32
     accumulation error of it (odd sizes, ragged last tile)."""
