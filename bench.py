@@ -493,6 +493,20 @@ def _roof_upconv(shapes, a, cfg):
     nbytes = 4 * (src_px * cin + out_elems) + 2 * 3 * 25 * cin * cout
     flops = 2.0 * src_px * cin * 25 * cout * 3
     us = 1e3 * d['ms'] / d['launches']
+    if cfg.SUB_FWD and cin in cfg.SUB_FWD_CIN:
+        # round 4: the sub-pixel (merged tap) implicit GEMM on the packed input — 9 instead of 6.25 multiply-adds per output element and input channel
+        # (1.44 x the projection's minimum), no P, no gather, no halo
+        nbytes = src_px * cin // 4 + 4 * out_elems + 2 * 25 * 27 * 512 * (cin // 16) * (cout // 32)
+        issued = 2.0 * (out_elems // cout) * 9 * cin * cout * 3
+        return dict(kernel='upconv_sub_fwd_kernel<packed> (deconv1 forward: UpsamplingNearest2d + Conv2d(5) as ONE implicit GEMM over the output pixels with the '
+                           'taps that read one source pixel merged — 3 x 3 taps per pixel class; 2-bit packed spikes in, fp32 out, exact bf16x3 products)',
+                    bound='hbm', achieved=round(nbytes / us_of(d) / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us_of(d) / 1e3 / HBM_PEAK_GBS, 4),
+                    avg_launch_us=round(us_of(d), 1), bytes_per_launch=int(nbytes), traffic=_pmc_traffic('upconv_sub'),
+                    mfma=dict(achieved_TFLOPs=round(flops / us_of(d) / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us_of(d) / 1e6 / 2500.0, 4),
+                              issued_frac=round(issued / us_of(d) / 1e6 / 2500.0, 4),
+                              note='frac: useful FLOPs of the minimal projection x 3 exact bf16 terms; issued_frac: what the kernel issues (9 merged taps per output pixel)'),
+                    note='latency / issue bound at 3 workgroups per CU (profiles/r04/sub_fwd_ablations.log); replaces upconv_fused2_fwd_kernel (1.9 x halo MFMAs, gather wavefronts)',
+                    fused=True)
     form2 = cfg.FUSED_UPCONV_FORM == 2
     return dict(kernel=('upconv_fused2_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only; wavefront-specialised '
                         'persistent form)') if form2 else
@@ -545,6 +559,10 @@ def _roof_upconv_bwd(shapes, a, cfg):
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
                           note='6 bf16 cross terms per MAC (dense x dense data gradient) + 3 exact terms per MAC (spike x dense weight gradient)'),
                 g_P_in_hbm=not (on_chip or box))
+
+
+def us_of(d):
+    return 1e3 * d['ms'] / d['launches']
 
 
 def box_on(cfg, cin):

@@ -602,6 +602,34 @@ int ss_loss_stats_f32(const float* pred, const float* gt, double* sums, double* 
 int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, const float* coef, float* g_pred,
                      long long B, int H, int W, void* stream);
 
+/*
+ * ABI 8 — decoder stage FORWARD in the sub-pixel ("merged tap") form (stereospike_amd/csrc/ss_upconv_sub.hip).  Replaces, for spike inputs,
+ * NNConvUpsampling.forward (/root/reference/network/blocks.py:110-132: UpsamplingNearest2d(size = up + 4) -> Conv2d(k = 5, bias=False)) at the decoder
+ * call sites /root/reference/network/SNN_models.py:110-129:
+ *     y[nb][Y][X][co] = sum_{ky, kx, ci} W[co][ci][ky][kx] * x[nb][src_y[Y + ky]][src_x[X + kx]][ci]
+ * evaluated as  sum_{r, c < 3, ci} Wm[class(Y)][class(X)][co][ci][r][c] * x[nb][src_y[Y + k0_r]][src_x[X + k0_c]][ci]  with the taps that read one source
+ * pixel added first (9 instead of 25 multiply-adds per output element and input channel; no per-tap tensor, no gather).  Host tables (fused.sub_tables;
+ * restated in oracle/np_upconv_sub.py), all int32:
+ *   vcls [NVC][8] / hcls [NHC][8]   : per class of output rows / columns: number of runs, first tap of run 0..2, tap count of run 0..2, 0
+ *   vblk [NVB][vrec_ints]            : per block of <= block_rows output rows of ONE class: class, n_out, n_src, out[block_rows] (output rows),
+ *                                      src[window_rows] (the distinct source rows they read), slot[block_rows][3] (index into src of run r's source row)
+ *   hblk [NHB][hrec_ints]            : the same for columns (block_cols, window_cols)
+ * Every output row belongs to exactly one row block, every column to one column block; a (row block, column block) pair is one tile.
+ *   ss_upconv_sub_geometry : block_rows 16, block_cols 32, window_rows 20, window_cols 36, record sizes 88 / 168; returns the runs per class (3).
+ *   ss_upconv_sub_prep_f32 : weight [C_out][C_in][5][5] fp32 -> wm (ss_upconv_sub_wm_elems bf16 elements, 16-byte aligned): the merged taps, added in fp32
+ *                            (ky outer, kx inner, from +0), exactly split into three bf16 terms, in MFMA fragment order.  Once per weight update.
+ *   ss_upconv_sub_fwd_f32  : x fp32 NHWC [NB][h][w][C_in] spike counts exact in bf16 (or x_packed: the 2-bit packed tensor; x may then be NULL) ->
+ *                            out fp32 NHWC [NB][H][W][C_out], every element written.  C_in % 16 == 0, C_out % 32 == 0, NB h w C_in < 2^32.
+ * Accuracy: exact products; |out - float64| <= 2^-21 sum |x||W| element-wise (fp32 rounding of the <= 9-term weight sums + fp32 accumulation over
+ * 9 C_in products).  Deterministic; not bit-identical to ss_upconv_fused_fwd (different association of the same sum).
+ */
+int ss_upconv_sub_geometry(int* block_rows, int* block_cols, int* window_rows, int* window_cols, int* vrec_ints, int* hrec_ints);
+int ss_upconv_sub_supported(int Cin, int Cout, int k);
+long long ss_upconv_sub_wm_elems(int Cin, int Cout, int NVC, int NHC);
+int ss_upconv_sub_prep_f32(const float* weight, const int* vcls, const int* hcls, void* wm, int Cin, int Cout, int NVC, int NHC, void* stream);
+int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* vcls, const int* hcls,
+                          float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

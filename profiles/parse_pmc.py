@@ -37,6 +37,8 @@ def key_of(name):
         return 'spike_conv_fwd'
     if 'dense_conv_s1_fwd_kernel' in name:
         return 'dense_conv_s1_fwd'
+    if 'upconv_sub_fwd_kernel' in name:
+        return 'upconv_sub'
     if 'upconv_boxsum_kernel' in name:
         return 'upconv_boxsum'
     if 'upconv_box_dgrad_kernel' in name:
@@ -102,8 +104,9 @@ planes = 80 * 4 * 3 * 278 * 364 * 8 * 2
 alg['upconv_boxsum'] = 4 * 80 * 260 * 346 * 32 + planes                                               # g_y in, planes out
 alg['upconv_box_dgrad'] = planes + 4 * 80 * 130 * 173 * 64 + 2 * 3 * 26 * 64 * 32                     # planes in, g_x out, split weights
 alg['upconv_box_wgrad'] = planes + 2 * 80 * 130 * 176 * 64 + 4 * 128 * 25 * 32 * 64                   # planes + bf16 transposed spikes in, 128 slices of partials out
+alg['upconv_sub'] = 80 * 130 * 173 * 64 // 4 + 4 * 80 * 260 * 346 * 32 + 2 * 25 * 27 * 512 * 4            # deconv1 forward: packed spikes in, fp32 out, merged weights
 res['algorithmic_bytes_per_launch'] = alg
-for k in ('upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad', 'conv_s2_dgrad', 'dense_conv_s1_wgrad', 'head_proj_packed', 'head_wgrad_packed', 'neuron_fwd_skip_packed', 'spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
+for k in ('upconv_sub', 'upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad', 'conv_s2_dgrad', 'dense_conv_s1_wgrad', 'head_proj_packed', 'head_wgrad_packed', 'neuron_fwd_skip_packed', 'spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
     if k in fetch and k in write:
         hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],

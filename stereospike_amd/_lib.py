@@ -168,6 +168,16 @@ def lib():
     L.ss_upconv_box_dgrad_supported.restype = i32
     L.ss_upconv_box_dgrad_ws_floats.argtypes = [i32, i32]
     L.ss_upconv_box_dgrad_ws_floats.restype = i64
+    L.ss_upconv_sub_geometry.argtypes = [C.POINTER(C.c_int)] * 6
+    L.ss_upconv_sub_geometry.restype = i32
+    L.ss_upconv_sub_supported.argtypes = [i32, i32, i32]
+    L.ss_upconv_sub_supported.restype = i32
+    L.ss_upconv_sub_wm_elems.argtypes = [i32, i32, i32, i32]
+    L.ss_upconv_sub_wm_elems.restype = i64
+    L.ss_upconv_sub_prep_f32.argtypes = [p, p, p, p, i32, i32, i32, i32, p]
+    L.ss_upconv_sub_prep_f32.restype = i32
+    L.ss_upconv_sub_fwd_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_sub_fwd_f32.restype = i32
     L.ss_upconv_box_window.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ss_upconv_box_window.restype = i32
     L.ss_upconv_box_dgrad_f32.argtypes = [p, p, p, p, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
@@ -223,6 +233,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
            'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
+           'ss_upconv_sub_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32',
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_wide_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
@@ -602,6 +613,45 @@ def upconv_boxsum(g_out, bt, NB, Cout, H, W):
                                         C.c_void_p(box.data_ptr()), NB, int(Cout), H, W, NVR, NHR, _stream(g_out))
     _check(rc, 'ss_upconv_boxsum_f32')
     return box
+
+
+def upconv_sub_geometry():
+    """dict(block_rows, block_cols, window_rows, window_cols, vrec_ints, hrec_ints, runs) of the sub-pixel forward kernel (ss_upconv_sub_geometry)."""
+    v = [C.c_int(0) for _ in range(6)]
+    runs = lib().ss_upconv_sub_geometry(*[C.byref(a) for a in v])
+    return dict(zip(('block_rows', 'block_cols', 'window_rows', 'window_cols', 'vrec_ints', 'hrec_ints'), (int(a.value) for a in v)), runs=int(runs))
+
+
+def upconv_sub_supported(Cin, Cout, k):
+    return bool(lib().ss_upconv_sub_supported(int(Cin), int(Cout), int(k)))
+
+
+def upconv_sub_prep(weight, st, Cin, Cout):
+    """weight [Cout, Cin, 5, 5] fp32 -> the merged-tap weight fragments of the sub-pixel forward (bf16 tensor; ss_upconv_sub_prep_f32)."""
+    _require_hip(weight, 'weight')
+    n = int(lib().ss_upconv_sub_wm_elems(int(Cin), int(Cout), int(st['NVC']), int(st['NHC'])))
+    if n <= 0:
+        raise SSNeuronError(f'ss_upconv_sub_wm_elems: unsupported C_in {Cin} / C_out {Cout}')
+    wm = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib().ss_upconv_sub_prep_f32(_f32(weight, 'weight', Cout * Cin * 25), _i32(st['vcls'], 'vcls', 8 * st['NVC']), _i32(st['hcls'], 'hcls', 8 * st['NHC']),
+                                          _x16(wm, 'wm', n, torch.bfloat16), Cin, Cout, st['NVC'], st['NHC'], _stream(weight))
+    _check(rc, 'ss_upconv_sub_prep_f32')
+    return wm
+
+
+def upconv_sub_fwd(x, x_packed, wm, st, out, NB, Cin, Cout, h, w):
+    """out [NB, H, W, Cout] = Conv2d(5)(UpsamplingNearest2d(x)) of a spike input (dense fp32 NHWC x, or the 2-bit packed x_packed) in the sub-pixel form."""
+    _require_hip(out, 'out')
+    H, W = st['H'], st['W']
+    with torch.cuda.device(out.device):
+        rc = lib().ss_upconv_sub_fwd_f32(None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
+                                         _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                                         _x16(wm, 'wm', int(lib().ss_upconv_sub_wm_elems(int(Cin), int(Cout), int(st['NVC']), int(st['NHC']))), torch.bfloat16),
+                                         _i32(st['vblk'], 'vblk', st['NVB'] * st['vrec_ints']), _i32(st['hblk'], 'hblk', st['NHB'] * st['hrec_ints']),
+                                         _i32(st['vcls'], 'vcls', 8 * st['NVC']), _i32(st['hcls'], 'hcls', 8 * st['NHC']),
+                                         _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W, st['NVB'], st['NHB'], st['NHC'], _stream(out))
+    _check(rc, 'ss_upconv_sub_fwd_f32')
 
 
 def upconv_box_window():

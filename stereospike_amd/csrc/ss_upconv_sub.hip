@@ -1,0 +1,394 @@
+// ss_upconv_sub.hip — the decoder stage's FORWARD in the sub-pixel ("merged tap") form (round 4; include/ss_neuron.h: ss_upconv_sub_prep_f32,
+// ss_upconv_sub_fwd_f32).
+//
+// Reference: NNConvUpsampling (/root/reference/network/blocks.py:110-132: UpsamplingNearest2d(size = up + k - 1) -> Conv2d(k = 5, bias=False)) at the
+// decoder call sites /root/reference/network/SNN_models.py:110-129, input = a spike tensor:
+//
+//     y[nb][Y][X][co] = sum_{ky, kx, ci} W[co][ci][ky][kx] * x[nb][src_y[Y + ky]][src_x[X + kx]][ci]
+//
+// The projected form of ss_upconv.hip multiplies at SOURCE resolution (P = x W: 25 C_out products per source pixel and input channel — the minimum) and
+// then gathers 25 taps of P per output pixel; fused in one kernel (upconv_fused2_fwd_kernel) P stays in LDS but every 16 x 16 output tile recomputes the
+// projection of its 122-pixel source window, 1.9 x the minimum, and half the wavefronts spend their issue slots on the gather.  A nearest resize by ~2
+// lets the taps be merged instead: the five rows src_y[Y .. Y + 4] take only 2 - 3 distinct values, in runs — (2, 2, 1) / (1, 2, 2) on the regular
+// lattice, (3, 2) / (2, 3) / (1, 3, 1) where the resize repeats a row three times — so with the run structure of an output row (its vertical CLASS) and
+// column (horizontal class)
+//
+//     Wm[cv][ch][co][ci][r][c] = sum_{ky in run r of cv} sum_{kx in run c of ch} W[co][ci][ky][kx]                 (ss_upconv_sub_prep_f32, every step)
+//     y[nb][Y][X][co]          = sum_{r, c < 3} sum_ci Wm[class(Y)][class(X)][co][ci][r][c] * x[nb][src_y[Y + k0_r]][src_x[X + k0_c]][ci]
+//
+// is a plain implicit GEMM — 9 C_in multiply-adds per output element (1.44 x the minimum), no per-tap tensor, no gather, no halo recomputation, the
+// output written once.  Pixels of one class pair share their weights: M = 32 of them (4 lattice rows x 8 lattice columns) per MFMA tile.  Host side
+// (fused.sub_tables, restated in oracle/np_upconv_sub.py): the classes, and per class BLOCKS of <= 16 output rows / <= 32 output columns with the
+// distinct source rows / columns they read (<= 20 / 36) — the few irregular rows and columns form small blocks of their own, so every output pixel belongs
+// to exactly one (row block, column block) TILE and nothing is special-cased in the kernel.
+//
+// Numerics: spike counts are exact in bf16; Wm is added in fp32 (ky outer, kx inner, from +0) and split into three bf16 terms (exact), so every product
+// is exact and y differs from the float64 value of the reference formula by the fp32 rounding of the <= 9-term weight sums and the fp32 accumulation of
+// the MFMA over 9 C_in products (terms lo, mid, hi per k-step; the running sum's sign alternates per 16-channel group against the bf16 MFMA's downward
+// drift).  Tolerance class of every fp32 convolution; NOT bit-identical to the projected kernels (different association).
+#include "ss_common.hpp"
+
+namespace {
+
+#ifndef SS_SB_ABLATE
+#define SS_SB_ABLATE 0                        // development aid (timing only, wrong results): 1 no window traffic after a tile's first group, 2 no weight
+#endif                                       // stream, 4 no MFMAs, 8 no per-stage barriers (profiles/r04/sub_fwd_ablations.log)
+#ifndef SS_SB_WGS
+#define SS_SB_WGS 3                           // workgroups per CU of the packed-input kernel: 3 (168 registers, 44 B of scratch) measured 12 % faster than 2
+#endif                                       // (profiles/r04/bench_sub_fwd_v4*.log); the dense-input fallback keeps 2 (its staging needs the registers)
+constexpr int kSbThreads = 256;
+constexpr int kSbBR = 16, kSbBC = 32;           // output rows / columns of a tile (4 M-blocks of 4 rows per wavefront; 4 wavefronts of 8 columns)
+constexpr int kSbWR = 20, kSbWC = 36;           // distinct source rows / columns a block may read (the on-chip window)
+constexpr int kSbVRec = 88, kSbHRec = 168;      // ints per row-block / column-block record: cls, n_out, n_src, out[BR | BC], src[WR | WC], slot[BR | BC][3]
+constexpr int kSbPix = 32;                      // window bytes per source pixel: 16 input channels (one k-step) as bf16
+constexpr int kSbStage = 9 * 1024;              // weight stage: the 3 merged taps of one run row x 3 split terms, 1 KB fragments (32 output channels)
+constexpr int kSbWnd = kSbWR * kSbWC * kSbPix;  // 23040 B
+
+// W [C_out][C_in][5][5] fp32 -> Wm fragments [pair = cv * NHC + ch][C_out / 32][g = C_in / 16][r 3][c 3][term 3][lane 64][8] bf16: element e of a lane =
+// split term of (-1)^g * sum of W[co = 32 cot + (lane & 31)][ci = 16 g + 8 (lane >> 5) + e] over the taps of run (r, c); zero where the class has no such run
+__global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __restrict__ W, const int* __restrict__ vcls, const int* __restrict__ hcls,
+                                                                 unsigned short* __restrict__ Wm, int Cin, int Cout, int NVC, int NHC)
+{
+    const int NCOT = Cout / 32, G = Cin / 16;
+    const long long total = (long long)NVC * NHC * NCOT * G * 9 * 64;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
+        const int lane = (int)(i & 63);
+        long long q = i >> 6;
+        const int c = (int)(q % 3); q /= 3;
+        const int r = (int)(q % 3); q /= 3;
+        const int g = (int)(q % G); q /= G;
+        const int cot = (int)(q % NCOT); q /= NCOT;
+        const int ch = (int)(q % NHC), cv = (int)(q / NHC);
+        const int ky0 = vcls[cv * 8 + 1 + r], kyn = vcls[cv * 8 + 4 + r], kx0 = hcls[ch * 8 + 1 + c], kxn = hcls[ch * 8 + 4 + c];
+        const int co = 32 * cot + (lane & 31);
+        u16x8 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 16 * g + 8 * (lane >> 5) + e;
+            const float* wp = W + ((long long)co * Cin + ci) * 25;
+            float a = 0.f;
+            for (int ky = ky0; ky < ky0 + kyn; ++ky)
+                for (int kx = kx0; kx < kx0 + kxn; ++kx) a += wp[ky * 5 + kx];
+            if (g & 1) a = -a;
+            const unsigned short h1 = narrow<SS_DT_BF16>(a);
+            const float r1 = a - widen<SS_DT_BF16>(h1);
+            const unsigned short h2 = narrow<SS_DT_BF16>(r1);
+            const float r2 = r1 - widen<SS_DT_BF16>(h2);
+            ph[e] = h1; pm[e] = h2; pl[e] = narrow<SS_DT_BF16>(r2);
+        }
+        // [.. r][c][term][lane][8]: this thread's three fragments sit 1 KB apart
+        unsigned short* o = Wm + ((i >> 6) * 3 * 64 + lane) * 8;
+        *reinterpret_cast<u16x8*>(o) = ph;
+        *reinterpret_cast<u16x8*>(o + 64 * 8) = pm;
+        *reinterpret_cast<u16x8*>(o + 2 * 64 * 8) = pl;
+    }
+}
+
+// A workgroup (4 wavefronts, two workgroups per CU) takes tiles round-robin.  Per tile and per 32-channel slice of C_out the accumulators (4 M-blocks of
+// 32 pixels per wavefront) stay in registers while the kernel walks the C_in / 16 input-channel groups: the group's window — the tile's distinct source
+// rows x columns, 16 channels as bf16 — is staged HBM / L2 -> registers -> LDS (the next group's loads are issued under the current group's last weight
+// stage), the merged weights stream L2 -> registers -> LDS double-buffered in stages of one run row (<= 3 taps x 3 terms = 9 KB, 36 MFMAs per wavefront
+// between two barriers).  A k-step is one merged tap x 16 channels: the lane's A fragment is ONE 16-byte LDS read at (row slot, column slot) of its pixel,
+// each weight fragment is read once per wavefront and feeds all 4 M-blocks: 7 KB of LDS reads per 12 MFMAs.
+template <bool PACKED>
+__global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wm,
+                                                                       const int* __restrict__ vblk, const int* __restrict__ hblk,
+                                                                       const int* __restrict__ vcls, const int* __restrict__ hcls,
+                                                                       float* __restrict__ out, int NB, int h, int w, int H, int W, int CIN, int COUT,
+                                                                       int NVB, int NHB, int NHC)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[kSbWnd];
+    __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kSbStage];
+    __shared__ int vrec[kSbVRec], hrec[kSbHRec];
+    const int lane = threadIdx.x & 63, m = lane & 31, half = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = CIN / 16, NCOT = COUT / 32;
+    const long long n_tiles = (long long)NB * NVB * NHB;
+    constexpr int kWItems = PACKED ? 3 : 6;                                     // window items per thread: PACKED (pixel) = one 32-bit word of 16 codes;
+                                                                                // dense (pixel, half) = 8 fp32 channels
+    constexpr int kSt = (kSbStage / 16 + kSbThreads - 1) / kSbThreads;          // 16-byte pieces per thread and weight stage (3; the last partial)
+#pragma unroll 1
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int hb = (int)(tile % NHB);
+        const long long t2 = tile / NHB;
+        const int vb = (int)(t2 % NVB), nb = (int)(t2 / NVB);
+        __syncthreads();                                                        // the previous tile's readers of the records are done
+        for (int i = threadIdx.x; i < kSbVRec; i += kSbThreads) vrec[i] = vblk[vb * kSbVRec + i];
+        for (int i = threadIdx.x; i < kSbHRec; i += kSbThreads) hrec[i] = hblk[hb * kSbHRec + i];
+        __syncthreads();
+        const int cv = vrec[0], nv = vrec[1], nsv = vrec[2], ch = hrec[0], nh = hrec[1], nsh = hrec[2];
+        const int ngv = vcls[cv * 8], ngh = hcls[ch * 8];
+        const int nblk = (nv + 3) >> 2;
+        const bool active = 8 * wv < nh;                                        // wave-uniform: this wavefront has columns in the tile
+        // this lane's pixel in M-block b: row 4 b + (m >> 3), column 8 wv + (m & 7); byte offsets of its source row / column per run
+        int rs[4][3], cs[3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ri = min(4 * b + (m >> 3), nv - 1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) rs[b][r] = vrec[3 + kSbBR + kSbWR + 3 * ri + r] * (kSbWC * kSbPix);
+        }
+        {
+            const int cj = min(8 * wv + (m & 7), nh - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cs[c] = hrec[3 + kSbBC + kSbWC + 3 * cj + c] * kSbPix + 16 * half;
+        }
+        const int npix = nsv * nsh;
+        const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(Wm) + (long long)(cv * NHC + ch) * NCOT * G * (3 * kSbStage);
+        // ---- the window of group g: loads into registers | conversion + LDS stores
+        unsigned wreg_p[PACKED ? kWItems : 1];
+        // (dense fp32 input — the fallback for inputs nobody packed — is staged synchronously at the group boundary, 3 items at a time: prefetching its
+        //  48 registers across the MFMA region spilled)
+        unsigned xoff[kWItems];                                                 // element index of the item's first channel in group 0 (< 2^32: checked by the host)
+        int loff[kWItems];                                                      // its byte offset in the window (-1: no such item)
+#pragma unroll
+        for (int u = 0; u < kWItems; ++u) {
+            const int it = threadIdx.x + kSbThreads * u;
+            const int pix = PACKED ? it : (it >> 1);
+            xoff[u] = 0u; loff[u] = -1;
+            if (pix < npix) {
+                const int wy = pix / nsh, wx = pix - wy * nsh;
+                xoff[u] = (unsigned)(((((long long)nb * h + vrec[3 + kSbBR + wy]) * w) + hrec[3 + kSbBC + wx]) * CIN + (PACKED ? 0 : 8 * (it & 1)));
+                loff[u] = (wy * kSbWC + wx) * kSbPix + (PACKED ? 0 : 16 * (it & 1));
+            }
+        }
+        auto win_issue = [&](int g) {
+#pragma unroll
+            for (int u = 0; u < kWItems; ++u) {
+                if (loff[u] >= 0) {
+                    if constexpr (PACKED) wreg_p[u] = static_cast<const unsigned*>(xin)[(xoff[u] >> 4) + g];
+                }
+            }
+        };
+        auto win_commit = [&]([[maybe_unused]] int g) {
+            if constexpr (PACKED) {
+#pragma unroll
+                for (int u = 0; u < kWItems; ++u) {
+                    if (loff[u] >= 0) {
+                        unsigned char* const pp = wnd + loff[u];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            u16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = code_to_bf16((wreg_p[u] >> (2 * (8 * q + e))) & 3u);
+                            *reinterpret_cast<u16x8*>(pp + 16 * q) = o;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u0 = 0; u0 < kWItems; u0 += 3) {
+                    f4 d[3][2];
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        if (loff[u0 + v] >= 0) {
+                            const float* xp = static_cast<const float*>(xin) + xoff[u0 + v] + 16 * g;
+                            d[v][0] = *reinterpret_cast<const f4*>(xp);
+                            d[v][1] = *reinterpret_cast<const f4*>(xp + 4);
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        if (loff[u0 + v] >= 0) {
+                            u16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {                       // spike counts: exact in bf16 (the high half of the fp32 pattern)
+                                o[e] = (unsigned short)(__float_as_uint(d[v][0][e]) >> 16);
+                                o[4 + e] = (unsigned short)(__float_as_uint(d[v][1][e]) >> 16);
+                            }
+                            *reinterpret_cast<u16x8*>(wnd + loff[u0 + v]) = o;
+                        }
+                    }
+                }
+            }
+        };
+        // ---- weight stages: stage r of (cot, g) = ngh taps x 3 terms, contiguous in Wm
+        f4 st[kSt];
+        const int stage_bytes = ngh * 3 * 1024;
+        auto stage_issue = [&](const unsigned char* src) {
+#pragma unroll
+            for (int u = 0; u < kSt; ++u) {
+                const int off = (threadIdx.x + kSbThreads * u) * 16;
+                if (off < stage_bytes) st[u] = *reinterpret_cast<const f4*>(src + off);
+            }
+        };
+        auto stage_commit = [&](unsigned char* dst) {
+#pragma unroll
+            for (int u = 0; u < kSt; ++u) {
+                const int off = (threadIdx.x + kSbThreads * u) * 16;
+                if (off < stage_bytes) *reinterpret_cast<f4*>(dst + off) = st[u];
+            }
+        };
+        auto stage_src = [&](int cot, int g, int r) { return wbase + (((long long)cot * G + g) * 3 + r) * kSbStage; };
+
+        // The (cot, g) loop is compiled once per (runs per row class, runs per column class, all four M-blocks present): with these three as run-time
+        // values hipcc guarded every MFMA with a branch and shuttled the accumulators through v_mov_b64 (10 VALU instructions per MFMA:
+        // profiles/r04/pmc_sub_v1.txt); the tile picks its instance with one switch.
+        auto run_tile = [&](auto ngv_c, auto ngh_c, auto full_c) {
+            constexpr int NGV = decltype(ngv_c)::value, NGH = decltype(ngh_c)::value;
+            constexpr bool FULL = decltype(full_c)::value;
+            // the first (cot, g) of the tile: its latency is exposed
+            win_issue(0);
+            stage_issue(stage_src(0, 0, 0));
+            win_commit(0);
+            stage_commit(bst);
+            f32x16 acc[4];
+            int par = 0;                                                        // half of the stage buffer that holds the current stage
+#pragma unroll 1
+            for (int cot = 0; cot < NCOT; ++cot) {
+#pragma unroll 1
+                for (int g = 0; g < G; ++g) {
+                    if (g == 0) {
+#pragma unroll
+                        for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[b2][r] = 0.f;
+                    } else {                                                    // the running sum's sign alternates per group (odd groups' weights are negated)
+#pragma unroll
+                        for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[b2][r] = -acc[b2][r];
+                    }
+                    const bool last_g = g + 1 == G;
+                    const bool has_next = !(last_g && cot + 1 == NCOT);
+                    const int gn = last_g ? 0 : g + 1, cotn = last_g ? cot + 1 : cot;
+                    __syncthreads();                                            // this group's window and first stage are visible
+#pragma unroll
+                    for (int r = 0; r < NGV; ++r) {
+                        const bool more = r + 1 < NGV;
+                        if (!(SS_SB_ABLATE & 2)) {
+                            if (more) stage_issue(stage_src(cot, g, r + 1));
+                            else if (has_next) stage_issue(stage_src(cotn, gn, 0));
+                        }
+                        // the next group's window: its (HBM) loads are issued under the FIRST stage — three stages of MFMAs to land; the weights (L2) one stage ahead
+                        if (r == 0 && has_next && !(SS_SB_ABLATE & 1)) win_issue(gn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (active) {
+                            const unsigned char* const bk = bst + par * kSbStage + lane * 16;
+#pragma unroll
+                            for (int c = 0; c < NGH; ++c) {
+                                s16x8 bp[3];
+#pragma unroll
+                                for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const s16x8*>(bk + (c * 3 + p) * 1024);
+                                s16x8 a[4];
+#pragma unroll
+                                for (int b2 = 0; b2 < 4; ++b2) a[b2] = *reinterpret_cast<const s16x8*>(wnd + rs[b2][r] + cs[c]);
+#pragma unroll
+                                for (int p = 2; p >= 0; --p)                    // smallest terms first
+#pragma unroll
+                                    for (int b2 = 0; b2 < 4; ++b2)
+                                        if (FULL || b2 == 0) {                  // (partial tiles: the irregular row blocks hold <= 4 rows = one M-block)
+                                            if (SS_SB_ABLATE & 4) acc[b2][p] += (float)(a[b2][0] + bp[p][1]);
+                                            else acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[b2], bp[p], acc[b2], 0, 0, 0);
+                                        }
+                            }
+                        }
+                        if (more) {
+                            if (!(SS_SB_ABLATE & 2)) stage_commit(bst + (par ^ 1) * kSbStage);
+                            if (!(SS_SB_ABLATE & 8)) __syncthreads();
+                            par ^= 1;
+                        }
+                    }
+                    if (has_next) {
+                        __syncthreads();                                        // every reader of this group's window is done
+                        if (!(SS_SB_ABLATE & 1)) win_commit(gn);
+                        if (!(SS_SB_ABLATE & 2)) stage_commit(bst + (par ^ 1) * kSbStage);
+                        par ^= 1;
+                    }
+                }
+                // ---- D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][co = lane & 31]; the sum carries the sign of the last group
+                if (active) {
+                    const float fin = ((G - 1) & 1) ? -1.f : 1.f;
+                    float* const ob = out + (long long)nb * H * W * COUT + 32 * cot + m;
+                    // pixel pm of M-block b2: row 4 b2 + (r >> 2), column 8 wv + (r & 3) + 4 half
+                    int co4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int cj = 8 * wv + q + 4 * half; co4[q] = cj < nh ? hrec[3 + cj] * COUT : -1; }
+#pragma unroll
+                    for (int b2 = 0; b2 < (FULL ? 4 : 1); ++b2)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int ri = 4 * b2 + rr;
+                            if (ri < nv) {
+                                float* const orow = ob + (long long)vrec[3 + ri] * W * COUT;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    if (co4[q] >= 0) store_out(orow + co4[q], acc[b2][4 * rr + q] * fin);
+                            }
+                        }
+                }
+            }
+        };
+        using std::integral_constant;
+        const int sel = (ngv == 3 ? 4 : 0) + (ngh == 3 ? 2 : 0) + (nblk > 1 ? 1 : 0);        // (classes have 2 or 3 runs: checked where the host tables are built)
+        switch (sel) {
+        case 0: run_tile(integral_constant<int, 2>{}, integral_constant<int, 2>{}, std::false_type{}); break;
+        case 1: run_tile(integral_constant<int, 2>{}, integral_constant<int, 2>{}, std::true_type{}); break;
+        case 2: run_tile(integral_constant<int, 2>{}, integral_constant<int, 3>{}, std::false_type{}); break;
+        case 3: run_tile(integral_constant<int, 2>{}, integral_constant<int, 3>{}, std::true_type{}); break;
+        case 4: run_tile(integral_constant<int, 3>{}, integral_constant<int, 2>{}, std::false_type{}); break;
+        case 5: run_tile(integral_constant<int, 3>{}, integral_constant<int, 2>{}, std::true_type{}); break;
+        case 6: run_tile(integral_constant<int, 3>{}, integral_constant<int, 3>{}, std::false_type{}); break;
+        case 7: run_tile(integral_constant<int, 3>{}, integral_constant<int, 3>{}, std::true_type{}); break;
+        default: break;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* tile geometry the host tables must respect: rows / columns per block, distinct source rows / columns per block, ints per block record */
+int ss_upconv_sub_geometry(int* block_rows, int* block_cols, int* window_rows, int* window_cols, int* vrec_ints, int* hrec_ints)
+{
+    if (block_rows) *block_rows = kSbBR;
+    if (block_cols) *block_cols = kSbBC;
+    if (window_rows) *window_rows = kSbWR;
+    if (window_cols) *window_cols = kSbWC;
+    if (vrec_ints) *vrec_ints = kSbVRec;
+    if (hrec_ints) *hrec_ints = kSbHRec;
+    return 3;                                  /* runs per class */
+}
+
+int ss_upconv_sub_supported(int Cin, int Cout, int k)
+{
+    return k == 5 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 32 == 0;
+}
+
+long long ss_upconv_sub_wm_elems(int Cin, int Cout, int NVC, int NHC)
+{
+    if (!ss_upconv_sub_supported(Cin, Cout, 5) || NVC < 1 || NHC < 1) return 0;
+    return (long long)NVC * NHC * (Cout / 32) * (Cin / 16) * 27 * 512;      /* bf16 elements */
+}
+
+int ss_upconv_sub_prep_f32(const float* weight, const int* vcls, const int* hcls, void* wm, int Cin, int Cout, int NVC, int NHC, void* stream)
+{
+    if (!weight || !vcls || !hcls || !wm || !ss_upconv_sub_supported(Cin, Cout, 5) || NVC < 1 || NHC < 1 || !aligned16(wm)) return SS_EINVAL;
+    const long long total = (long long)NVC * NHC * (Cout / 32) * (Cin / 16) * 9 * 64;
+    hipLaunchKernelGGL(upconv_sub_prep_kernel, dim3(grid_for(total, 4096)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       weight, vcls, hcls, static_cast<unsigned short*>(wm), Cin, Cout, NVC, NHC);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* vcls, const int* hcls,
+                          float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, void* stream)
+{
+    if ((!x && !x_packed) || !wm || !vblk || !hblk || !vcls || !hcls || !out || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || NVB < 1 || NHB < 1 || NHC < 1)
+        return SS_EINVAL;
+    if (!ss_upconv_sub_supported(Cin, Cout, 5) || !aligned16(out) || !aligned16(wm) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
+    if (NB * NVB * (long long)NHB > 0x7fffffffLL || NB * h * (long long)w * Cin > 0xffffffffLL) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    const long long n_tiles = NB * NVB * (long long)NHB;
+    const long long wgs = (long long)(x_packed ? SS_SB_WGS : 2) * cus;
+    const unsigned grid = (unsigned)(n_tiles < wgs ? n_tiles : wgs);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x_packed) hipLaunchKernelGGL((upconv_sub_fwd_kernel<true>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x_packed),
+                                     static_cast<const unsigned short*>(wm), vblk, hblk, vcls, hcls, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
+    else hipLaunchKernelGGL((upconv_sub_fwd_kernel<false>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x),
+                            static_cast<const unsigned short*>(wm), vblk, hblk, vcls, hcls, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+}  // extern "C"

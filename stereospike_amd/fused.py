@@ -215,7 +215,7 @@ class _FusedNeuron(torch.autograd.Function):
         es = 2 if half else 4
         per = es * (1 + (0 if pack == 2 else 1)) + (0.25 if pack else 0) + (0.25 if skip_packed is not None else (es if skip_seq is not None else 0)) \
             + (4 if h_seq is not None else 0)
-        tag = (('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else '')
+        tag = (('neuron_fwd_train' if need_grad else 'neuron_fwd_infer') + ('+skip' if has_skip else '') + ('+packed' if pack == 2 else ('+pkcopy' if pack == 1 else ''))
                + ('+h' if h_seq is not None else ''))            # '+h': the saved-h form (run-time T / RECOMPUTE_H off), never the benchmarked kernels
         TIMER.stop(e0, tag, int(per * T * N), T * N)
         _note('neuron_fwd', tag + ('+x16' if half else ''))
@@ -703,6 +703,86 @@ def box_tables(tables, H, W):
 _BOX = {}
 
 
+# ---- sub-pixel ("merged tap") forward of a decoder stage (ss_upconv_sub.hip): classes of output rows / columns by the run structure of the five source
+#      indices under their 5-tap window, and per class blocks of output positions with the distinct source positions they read
+def _axis_classes(src, n_out, k=5):
+    per = []
+    for Y in range(n_out):
+        runs, start = [], 0
+        for t in range(1, k + 1):
+            if t == k or src[Y + t] != src[Y + start]:
+                runs.append(t - start)
+                start = t
+        per.append(tuple(runs))
+    keys = sorted(set(per))
+    if any(len(key) not in (2, 3) for key in keys):
+        return None                                   # (a resize factor far from 2: the kernel is compiled for 2 or 3 distinct source positions per window)
+    ids = {key: n for n, key in enumerate(keys)}
+    table = []
+    for key in keys:
+        k0, a = [], 0
+        for ln in key:
+            k0.append(a)
+            a += ln
+        table.append([len(key)] + (k0 + [0, 0, 0])[:3] + (list(key) + [0, 0, 0])[:3] + [0])
+    return [ids[p] for p in per], table
+
+
+def _axis_blocks(src, cls, table, max_out, max_src, rec_ints):
+    recs = []
+    for c, row in enumerate(table):
+        ng, k0 = row[0], row[1:4]
+        pos = [Y for Y, cc in enumerate(cls) if cc == c]
+        a = 0
+        while a < len(pos):
+            n, need = 0, set()
+            while a + n < len(pos) and n < max_out:
+                more = need | {src[pos[a + n] + k0[r]] for r in range(ng)}
+                if len(more) > max_src:
+                    break
+                need, n = more, n + 1
+            srcs = sorted(need)
+            where = {sv: i for i, sv in enumerate(srcs)}
+            rec = [c, n, len(srcs)] + (pos[a:a + n] + [0] * max_out)[:max_out] + (srcs + [0] * max_src)[:max_src]
+            for i in range(max_out):
+                rec += [where[src[pos[a + i] + k0[r]]] if (i < n and r < ng) else 0 for r in range(3)]
+            recs.append((rec + [0] * rec_ints)[:rec_ints])
+            a += n
+    return recs
+
+
+def register_sub_tables(tables, host_tables, H, W):
+    """Called where the resize tables are built (NNConvUpsampling._tables), from the HOST copies: class / block tables of the sub-pixel forward, or None
+    when the geometry has more than 3 runs per window (the stage then keeps the projected form)."""
+    src_y, src_x = host_tables[0].tolist(), host_tables[3].tolist()
+    dev = tables[0].device
+    geo = _lib.upconv_sub_geometry() if dev.type == 'cuda' else dict(block_rows=16, block_cols=32, window_rows=20, window_cols=36, vrec_ints=88, hrec_ints=168, runs=3)
+    cv, ch = _axis_classes(src_y, H), _axis_classes(src_x, W)
+    st = None
+    if cv is not None and ch is not None:
+        vblk = _axis_blocks(src_y, cv[0], cv[1], geo['block_rows'], geo['window_rows'], geo['vrec_ints'])
+        hblk = _axis_blocks(src_x, ch[0], ch[1], geo['block_cols'], geo['window_cols'], geo['hrec_ints'])
+
+        def t(a):
+            return torch.tensor(a, dtype=torch.int32).reshape(-1).to(dev)
+        st = dict(vcls=t(cv[1]), hcls=t(ch[1]), vblk=t(vblk), hblk=t(hblk), NVC=len(cv[1]), NHC=len(ch[1]), NVB=len(vblk), NHB=len(hblk),
+                  vrec_ints=geo['vrec_ints'], hrec_ints=geo['hrec_ints'], H=H, W=W)
+    _SUB[id(tables)] = (tables, st, H, W)
+    return st
+
+
+def sub_tables(tables, H, W):
+    hit = _SUB.get(id(tables))
+    if hit is not None and hit[0] is tables and hit[2] == H and hit[3] == W:
+        return hit[1]
+    if tables[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        raise _lib.SSNeuronError('sub_tables: resize tables without registered sub-pixel tables inside a stream capture')
+    return register_sub_tables(tables, tuple(t.cpu() for t in tables), H, W)
+
+
+_SUB = {}
+
+
 class _UpConvProjectedCL(torch.autograd.Function):
     """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
     forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
@@ -721,9 +801,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
         if x_packed is not None and k != 3:
             # a decoder stage on a packed-only input (deconv1 reading deconv2's output): the fused MFMA forward reads the packed form; any other form
             # of this stage gets the dense tensor back first
-            if not (_cfg().FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
-                    and _lib.upconv_fused_form(x_cl.shape[-1], weight.shape[0], k, max_window) != 0):
-                x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, x_cl.dtype), None
+            sub_ok = (_cfg().SUB_FWD and k == 5 and x_cl.shape[-1] in _cfg().SUB_FWD_CIN and _lib.upconv_sub_supported(x_cl.shape[-1], weight.shape[0], k)
+                      and sub_tables(tables, H, W) is not None)
+            if not (spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
+                    and (sub_ok or (_cfg().FUSED_UPCONV_MFMA and _lib.upconv_fused_form(x_cl.shape[-1], weight.shape[0], k, max_window) != 0))):
+                x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None     # (a dense copy came along: use it)
         if x_packed is not None and k == 3:
             NB, h, w, Cin = x_cl.shape
             Cout, kk = weight.shape[0], k * k
@@ -791,6 +873,27 @@ class _UpConvProjectedCL(torch.autograd.Function):
             ctx.save_for_backward(x_cl, Wt, None, weight)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = not lowp
+            ctx.tables, ctx.k, ctx.n = tables, k, n
+            ctx.wshape = weight.shape
+            ctx.has_bias = False
+            return out
+        # round 4: the sub-pixel (merged tap) implicit GEMM — 9 instead of 25 multiply-adds per output element and channel, no P, no gather, no halo
+        st = None
+        if (_cfg().SUB_FWD and k == 5 and spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and not half_in
+                and x_cl.dtype == torch.float32 and Cin in _cfg().SUB_FWD_CIN and x_cl.is_cuda and _lib.upconv_sub_supported(Cin, Cout, k)
+                and NB * h * w * Cin < 2 ** 32):
+            st = sub_tables(tables, H, W)
+        if st is not None:
+            if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
+                assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
+            e0 = TIMER.start()
+            wm = _lib.upconv_sub_prep(weight.contiguous(), st, Cin, Cout)
+            _lib.upconv_sub_fwd(None if x_packed is not None else x_cl, x_packed, wm, st, out, NB, Cin, Cout, h, w)
+            TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
+            _note('synapse_fwd', 'upconv_sub_mfma' + ('(packed in)' if x_packed is not None else ''))
+            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
+            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+            ctx.exact = True
             ctx.tables, ctx.k, ctx.n = tables, k, n
             ctx.wshape = weight.shape
             ctx.has_bias = False
@@ -1291,6 +1394,13 @@ def stage_reads_packed(Cin: int, Cout: int, k: int, max_window: int) -> bool:
                 and _cfg().FUSED_UPCONV_BWD and _cfg().FUSED_UPCONV_DGRAD and Cin in _cfg().FUSED_UPCONV_DGRAD_CIN and Cin in _cfg().FUSED_UPCONV_BWD_CIN_NOGP)
 
 
+
+
+def stage_takes_packed_copy(Cin: int, Cout: int, k: int) -> bool:
+    """True when a decoder stage's sub-pixel forward (ss_upconv_sub_fwd_f32) and box-sum weight gradient read their input as 2-bit packed spikes when they
+    are given them: the producer then writes the packed form BESIDE its dense output (pack = 1: 0.25 B per element more) and the stage never touches the
+    dense tensor (32 x fewer input bytes, no fp32 -> bf16 conversion while staging)."""
+    return bool(_cfg().PACK_SPIKES and _cfg().SUB_FWD and _cfg().EXACT_SPLIT_GEMM and k == 5 and Cin in _cfg().SUB_FWD_CIN and _lib.upconv_sub_supported(Cin, Cout, k))
 
 
 class _UnpackLastStep(torch.autograd.Function):

@@ -242,12 +242,17 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                     nxt = self.deconv1[0]
                     hh, ww = stage[0].up[0].size[0] - 4, stage[0].up[0].size[1] - 4          # this stage's output = the next stage's input geometry
                     head_pk = _cfg().PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
+                # (round 4) a stage whose head needs the dense tensor still hands the next stage a packed COPY when that stage's sub-pixel forward reads one
+                copy_pk = False
+                if not head_pk and lvl > 1 and enc_cl and cur.dtype == torch.float32 and not torch.is_autocast_enabled('cuda'):
+                    nxt = getattr(self, f'deconv{lvl - 1}')[0]
+                    copy_pk = _fused.stage_takes_packed_copy(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0])
                 with _config.layer(f'deconv{lvl}'):
                     r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_cfg().FORK_OUTPUTS,
-                                                  skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else 0, x_packed=prev_pk)
+                                                  skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else (1 if copy_pk else 0), x_packed=prev_pk)
                 cur, cur_head = r if _cfg().FORK_OUTPUTS else (r, r)
                 out_pk = stage[2].last_packed if head_pk else None     # None: the packed kernel form did not apply, the output is dense
-                prev_pk = out_pk                                       # the next stage's input in packed form (None: dense)
+                prev_pk = stage[2].last_packed if (head_pk or copy_pk) else None       # the next stage's input in packed form (None: dense only)
                 spikes.append(cur.permute(0, 1, 4, 2, 3))              # logical [T, B, C, H, W] view
                 if out_pk is not None:
                     last_dense[len(spikes) - 1] = _fused.unpack_last_step(cur, out_pk).permute(0, 3, 1, 2)

@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import config as _config
 from ..clock_driven import neuron, surrogate
 from ..config import current as _cfg
-from ..fused import nearest_tables, register_box_tables, register_extents, upconv_projected, upconv_projected_cl
+from ..fused import nearest_tables, register_box_tables, register_extents, register_sub_tables, upconv_projected, upconv_projected_cl
 
 
 # Execution layout (fields of config.EngineConfig; reads of `blocks.<NAME>` answer with the configuration in effect, assignments are refused):
@@ -86,6 +86,7 @@ class NNConvUpsampling(_UpConv):
             k = self.up[1].kernel_size[0]
             if k == 5:                                         # decoder stages: the index tables of the box-sum backward (ss_upconv_box.hip)
                 register_box_tables(cache[key], ty + tx, Hu - k + 1, Wu - k + 1)
+                register_sub_tables(cache[key], ty + tx, Hu - k + 1, Wu - k + 1)      # ... and of the sub-pixel forward (ss_upconv_sub.hip)
         return cache[key]
 
     def forward_projected(self, x: torch.Tensor) -> torch.Tensor:

@@ -77,8 +77,8 @@ def assert_default_plan(plan, full_resolution=False):
     and — deconv1 / deconv2 (EngineConfig.BOX_BWD_CIN), where the box-sum kernels' window holds the geometry — on the box-sum backward."""
     for name, (fwd, bwd) in DEFAULT_PLAN.items():
         assert plan[name]['synapse_fwd'] == fwd and plan[name]['synapse_bwd'] == bwd, (name, plan[name])
-    for lvl in (1, 2):
-        assert plan[f'deconv{lvl}']['synapse_fwd'].startswith('upconv_fused2_mfma'), plan[f'deconv{lvl}']
+    for lvl in (1, 2):                                                     # round 4: the sub-pixel (merged tap) implicit GEMM on the packed spikes
+        assert plan[f'deconv{lvl}']['synapse_fwd'] == 'upconv_sub_mfma(packed in)', plan[f'deconv{lvl}']
     for lvl in (3, 4):
         assert plan[f'deconv{lvl}']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan[f'deconv{lvl}']
     box = [lvl for lvl in (1, 2, 3, 4) if plan[f'deconv{lvl}']['synapse_bwd'].startswith('box: boxsum+dgrad6_mfma+wgrad3_mfma')]
@@ -98,7 +98,8 @@ def assert_default_kernels(tags, T, penalized=False):
     # packed-only outputs: the 7 encoder / bottleneck edges, the SEW block's inner layer (with its packed skip) and — its prediction head reads packed
     # spikes (fused.PACKED_HEAD) — the two largest decoder stages (deconv2's other consumer, deconv1, reads packed spikes in its fused kernels)
     assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 3, tags      # SEW inner layer, deconv2, deconv1
-    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 3, tags
+    # (round 4: deconv3 writes a packed COPY beside its dense output — its head reads the dense tensor, deconv2's sub-pixel forward the packed one)
+    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 2 and fwd.get('neuron_fwd_train+skip+pkcopy', 0) == 1, tags
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
     assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)

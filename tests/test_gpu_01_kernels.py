@@ -1626,6 +1626,64 @@ def test_dense_conv_s1_fwd_mfma(NB, Cin, hw):
         assert torch.equal(y, y2)
 
 
+# ======================================================================================================
+# decoder stage forward in the sub-pixel (merged tap) form (ss_upconv_sub_prep_f32 / ss_upconv_sub_fwd_f32)
+# ======================================================================================================
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 1), (128, 64, (65, 87), (130, 173), 2), (256, 128, (33, 44), (65, 87), 2),
+                                                (64, 32, (17, 22), (33, 44), 3), (16, 32, (13, 9), (26, 18), 2), (32, 96, (5, 7), (10, 13), 2),
+                                                (64, 32, (8, 8), (15, 17), 1), (64, 64, (32, 40), (64, 80), 2)])
+def test_upconv_sub_forward(Cin, Cout, hw, HW, NB):
+    """The merged weights are the oracle's fp32 tap sums, split exactly (hi + mid + lo == the sum, sign flipped on odd channel groups); the output is the
+    reference formula evaluated in float64 to within 2^-21 sum |x||W| element-wise and within 2e-6 (max norm) of today's projected kernel; packed input ==
+    dense input bit for bit; every element written; deterministic."""
+    from oracle import np_pack, np_upconv_sub as ns
+    from stereospike_amd import _lib, fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    (h, w), (H, W) = hw, HW
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
+    tabs = up._tables(h, w, torch.device(DEV))
+    st = fused.sub_tables(tabs, H, W)
+    assert st is not None and _lib.upconv_sub_supported(Cin, Cout, 5) and not _lib.upconv_sub_supported(Cin, Cout, 3) and not _lib.upconv_sub_supported(24, Cout, 5)
+    gen = torch.Generator(device=DEV).manual_seed(NB + h)
+    x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float()
+         + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.03).float())                      # values 0 .. 3
+    wt = torch.randn(Cout, Cin, 5, 5, device=DEV, generator=gen) * 0.05
+    wm = _lib.upconv_sub_prep(wt, st, Cin, Cout)
+    # ---- the merged weights
+    vc, hc = st['vcls'].view(-1, 8).cpu().numpy(), st['hcls'].view(-1, 8).cpu().numpy()
+    Wm = ns.merged_weights(wt.cpu().numpy(), vc[:, 1:4], vc[:, 4:7], hc[:, 1:4], hc[:, 4:7], np.float32)          # [cv, ch, co, ci, r, c]
+    terms = wm.view(st['NVC'], st['NHC'], Cout // 32, Cin // 16, 3, 3, 3, 64, 8).float().cpu().numpy().astype(np.float64)
+    got = terms.sum(6)                                                                                          # [cv, ch, cot, g, r, c, lane, e]
+    lane, e = np.arange(64)[:, None], np.arange(8)[None, :]
+    for cot in range(Cout // 32):
+        for g in range(Cin // 16):
+            ref = Wm[:, :, 32 * cot + (lane & 31), 16 * g + 8 * (lane >> 5) + e]                                # [cv, ch, lane, e, r, c]
+            assert np.array_equal(got[:, :, cot, g], (-1.0) ** g * ref.transpose(0, 1, 4, 5, 2, 3).astype(np.float64)), (cot, g)
+    # ---- the forward
+    y = torch.full((NB, H, W, Cout), float('nan'), device=DEV)
+    _lib.upconv_sub_fwd(x, None, wm, st, y, NB, Cin, Cout, h, w)
+    sy, sx = tabs[0].cpu().numpy(), tabs[3].cpu().numpy()
+    xd, wd = x.cpu().numpy(), wt.cpu().numpy()
+    ref = ns.forward_direct(xd, wd, sy, sx, H, W)
+    mag = ns.magnitude(xd, wd, sy, sx, H, W)
+    err = np.abs(y.double().cpu().numpy() - ref)
+    assert bool(torch.isfinite(y).all()) and (err <= 2.0 ** -21 * mag + 1e-30).all(), float((err / (2.0 ** -21 * mag + 1e-30)).max())
+    from stereospike_amd import config
+    with torch.no_grad(), config.engine_config(SUB_FWD=False):                    # today's projected form (fused projection + gather, or GEMM + gather)
+        up.up[1].weight.copy_(wt)
+        assert up.up[1].bias is None
+        y_old = up.forward_projected_cl(x, spikes_in=True)
+    assert float((y - y_old).abs().max()) <= 2e-6 * float(y_old.abs().max())
+    y2 = torch.empty_like(y)
+    _lib.upconv_sub_fwd(x, None, wm, st, y2, NB, Cin, Cout, h, w)
+    assert torch.equal(y, y2)
+    if (NB * h * w * Cin) % 16 == 0:
+        xp = torch.from_numpy(np_pack.pack(xd.reshape(-1)).view(np.int32)).to(DEV)
+        y3 = torch.full_like(y, float('nan'))
+        _lib.upconv_sub_fwd(None, xp, wm, st, y3, NB, Cin, Cout, h, w)
+        assert torch.equal(y, y3)
+
+
 @pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 1), (128, 64, (65, 87), (130, 173), 2), (256, 128, (33, 44), (65, 87), 2),
                                                 (512, 256, (17, 22), (33, 44), 2), (64, 32, (32, 40), (64, 80), 3), (128, 64, (16, 20), (32, 40), 2),
                                                 (64, 64, (13, 18), (25, 35), 3), (64, 32, (4, 5), (8, 10), 2), (64, 32, (9, 11), (17, 19), 1)])

@@ -344,6 +344,45 @@ def test_conv_s2_dgrad_oracle_matches_autograd(NB, Cin, hw):
     assert sum(len(v) for v in np_conv_dgrad.CLASS_TAPS.values()) == 25 and sorted(len(v) for v in np_conv_dgrad.CLASS_TAPS.values()) == [4, 6, 6, 9]
 
 
+@pytest.mark.parametrize('NB,Cin,Cout,hw,up', [(2, 8, 4, (17, 22), (33, 44)), (1, 8, 8, (13, 9), (26, 18)), (1, 4, 4, (33, 44), (65, 87)), (2, 4, 4, (5, 7), (10, 13)),
+                                               (1, 4, 4, (8, 8), (15, 17))])
+def test_upconv_sub_oracle_is_the_reference_formula_and_the_product_tables(NB, Cin, Cout, hw, up):
+    """oracle/np_upconv_sub.py (checker of ss_upconv_sub_*): (1) forward_direct == torch's UpsamplingNearest2d -> Conv2d in float64 (the reference's two ops,
+    /root/reference/network/blocks.py:110-132); (2) the merged-tap form with float64 weight sums is the SAME function (<= 1e-12: it only re-associates the
+    weight additions); (3) with the weight sums rounded to fp32 (what the kernel's preparation does) it stays within 2^-24 sum |x||W| per element;
+    (4) the product's host tables (fused.register_sub_tables) are the oracle's classes and blocks, every output row / column in exactly one block."""
+    from oracle import np_upconv_sub as ns
+    from stereospike_amd import fused
+    (h, w), (H, W) = hw, up
+    rng = np.random.default_rng(NB + h)
+    tabs = fused.nearest_tables(h, H + 4) + fused.nearest_tables(w, W + 4)
+    sy, sx = tabs[0].numpy(), tabs[3].numpy()
+    x = rng.integers(0, 4, (NB, h, w, Cin)).astype(np.float32)
+    Wt = (rng.standard_normal((Cout, Cin, 5, 5)) * 0.1).astype(np.float32)
+    yd = ns.forward_direct(x, Wt, sy, sx, H, W)
+    xt = torch.tensor(x).permute(0, 3, 1, 2).double()
+    ref = torch.nn.functional.conv2d(torch.nn.UpsamplingNearest2d(size=(H + 4, W + 4))(xt), torch.tensor(Wt).double()).permute(0, 2, 3, 1).numpy()
+    assert np.abs(yd - ref).max() <= 1e-12
+    assert np.abs(ns.forward_merged(x, Wt, sy, sx, H, W, merge_dtype=np.float64) - yd).max() <= 1e-12
+    mag = ns.magnitude(x, Wt, sy, sx, H, W)
+    assert (np.abs(ns.forward_merged(x, Wt, sy, sx, H, W, merge_dtype=np.float32) - yd) <= 2.0 ** -24 * mag + 1e-30).all()
+    st = fused.register_sub_tables(tabs, tabs, H, W)
+    for src, n_out, cls_t, blk_t, rec, mo, ms in ((sy, H, st['vcls'], st['vblk'], 88, 16, 20), (sx, W, st['hcls'], st['hblk'], 168, 32, 36)):
+        keys, cls, k0, kn = ns.axis_classes(src, n_out)
+        ct = cls_t.view(-1, 8).numpy()
+        assert np.array_equal(ct[:, 0], (kn > 0).sum(1)) and np.array_equal(ct[:, 1:4], k0) and np.array_equal(ct[:, 4:7], kn)
+        blocks = ns.axis_blocks(src, n_out, cls, k0, kn, mo, ms)
+        bt = blk_t.view(-1, rec).numpy()
+        assert len(blocks) == bt.shape[0]
+        seen = []
+        for b, r in zip(blocks, bt):
+            n, m = len(b['out']), len(b['src'])
+            assert (r[0], r[1], r[2]) == (b['cls'], n, m) and np.array_equal(r[3:3 + n], b['out']) and np.array_equal(r[3 + mo:3 + mo + m], b['src'])
+            assert np.array_equal(r[3 + mo + ms:3 + mo + ms + 3 * n].reshape(n, 3), b['slot'])
+            seen += list(b['out'])
+        assert sorted(seen) == list(range(n_out))
+
+
 @pytest.mark.parametrize('NB,Cin,Cout,hw,up', [(2, 8, 8, (17, 22), (33, 44)), (1, 8, 16, (5, 7), (9, 13)), (2, 4, 8, (3, 3), (8, 5)), (1, 8, 8, (1, 6), (2, 11)),
                                                (1, 4, 8, (9, 11), (9, 11))])
 def test_upconv_box_oracle_matches_the_adjoint_oracle_and_autograd(NB, Cin, Cout, hw, up):

@@ -92,5 +92,11 @@ if mode == 'rc':
         _lib.upconv_box_dgrad(box, wt, bt, gxs2, NB, Cin, Cout, h, w)
         _lib.upconv_box_wgrad(box, xs, None, bt, gw2, NB, Cin, Cout, h, w)
     print('box planes', tuple(box.shape), box.dtype, 'bytes', box.numel() * box.element_size())
+    # round 4: deconv1's forward as the sub-pixel (merged tap) implicit GEMM on the packed spikes (ss_upconv_sub_fwd_f32)
+    st = fused.sub_tables(tabs, H, W)
+    xsp = torch.from_numpy(np_pack.pack(xs.cpu().numpy().reshape(-1)).view(np.int32)).to(dev)
+    for _ in range(5):
+        wm = _lib.upconv_sub_prep(wt, st, Cin, Cout)
+        _lib.upconv_sub_fwd(None, xsp, wm, st, o, NB, Cin, Cout, h, w)
 torch.cuda.synchronize()
 print('mode', mode, 'algorithmic bytes per launch: fwd', (8 if mode == 'rc' else 12) * T * N, 'bwd', (16 if mode == 'rc' else 12) * T * N)
