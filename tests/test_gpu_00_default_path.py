@@ -236,6 +236,7 @@ def test_packed_spike_tensors_are_in_effect():
     _, net = pair('StereoSpike', H, W)
     x = synth_input(2, 5, 4, 7, H, W, lam=0.08).to(DEV)
     gt = synth_label(2, 8, H, W).to(DEV)
+    T0 = 5
     rec = {}
     orig = net.bottom[2].forward_sequence
 
@@ -251,7 +252,11 @@ def test_packed_spike_tensors_are_in_effect():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
         assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
-    assert net.deconv3[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    assert net.deconv4[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    # deconv3: dense (its head reads it) + a packed COPY for deconv2's sub-pixel forward / weight gradient (round 4), bit-identical contents
+    pk3 = net.deconv3[2].last_packed
+    assert pk3 is not None and pk3.dtype == torch.int32 and tuple(s[2].shape) == (2, 128, H // 4, W // 4) and any(s[2].stride())
+    assert torch.equal(fused.unpack_dense(pk3[T0 - 1:T0], (1, 2, H // 4, W // 4, 128))[0].permute(0, 3, 1, 2), s[2])
     assert net.deconv2[2].last_packed is not None                                               # packed only: head 2 + deconv1's fused kernels read it
     # the full-resolution decoder stage: packed only (its prediction head reads the packed form); the model returns its last step unpacked
     pk1 = net.deconv1[2].last_packed

@@ -522,8 +522,9 @@ def test_exact_bf16x3_projection_has_fp32_gemm_accuracy(Cin, Cout, hw, HW):
     outs = {}
     from stereospike_amd import config
     for exact in (True, False):
-        # (BOX_BWD off: this test is about the g_P forms of the backward, which share their data gradient between the two projection forms)
-        with config.engine_config(EXACT_SPLIT_GEMM=exact, ASSERT_EXACT_SPLIT=True, BOX_BWD=False):
+        # (BOX_BWD off: this test is about the g_P forms of the backward, which share their data gradient between the two projection forms; SUB_FWD off: it is
+        #  about the PROJECTION forms of the forward — the sub-pixel kernel has its own element-wise bound in test_upconv_sub_forward)
+        with config.engine_config(EXACT_SPLIT_GEMM=exact, ASSERT_EXACT_SPLIT=True, BOX_BWD=False, SUB_FWD=False):
             xin = x.clone().requires_grad_()
             y = m.forward_projected_cl(xin, spikes_in=True)
             gx, gw = torch.autograd.grad(y, (xin, m.up[1].weight), g)
@@ -542,8 +543,9 @@ def test_exact_bf16x3_projection_has_fp32_gemm_accuracy(Cin, Cout, hw, HW):
     assert ew_exact <= 1.5 * ew_fp32 + 1e-7 * float(gw_ref.abs().max()), (ew_exact, ew_fp32)
     if Cin < fused.EXACT_SPLIT_WGRAD_MIN_K and Cin not in fused.EXACT_WGRAD_MFMA_CIN:       # C_in 64 / 128: hand-written exact MFMA contraction
         assert torch.equal(outs[True][2], outs[False][2])
-    with config.engine_config(ASSERT_EXACT_SPLIT=True), pytest.raises(AssertionError):
-        m.forward_projected_cl(x + 0.3, spikes_in=True)
+    for sub in (False, True):                                       # checking mode refuses a non-spike input on either forward form
+        with config.engine_config(ASSERT_EXACT_SPLIT=True, SUB_FWD=sub), pytest.raises(AssertionError):
+            m.forward_projected_cl(x + 0.3, spikes_in=True)
 
 
 @pytest.mark.parametrize('Cin,Cout,k,s,pad,hw', [(512, 512, 3, 1, 1, (17, 22)), (256, 512, 5, 2, 2, (33, 44)), (128, 256, 5, 2, 2, (21, 30)),
@@ -958,11 +960,11 @@ def test_upconv_fused_mfma_forward(Cin, Cout, hw, HW, NB):
     assert err <= 2e-6, err                                                                # fp32 accumulation of exact products
     # unfused product path on the same operands
     from stereospike_amd import config
-    with config.engine_config(FUSED_UPCONV_MFMA=False), torch.no_grad():
+    with config.engine_config(FUSED_UPCONV_MFMA=False, SUB_FWD=False), torch.no_grad():
         unf = up.forward_projected_cl(x_cl, spikes_in=True)
     assert float((unf - out).abs().max()) / scale <= 2e-6
-    with torch.no_grad():                                                                  # and through the module (fused on by default)
-        via = up.forward_projected_cl(x_cl, spikes_in=True)
+    with config.engine_config(SUB_FWD=False), torch.no_grad():                             # and through the module (the sub-pixel form of round 4 off: this
+        via = up.forward_projected_cl(x_cl, spikes_in=True)                                # test is about the fused projection + gather kernels)
     assert torch.equal(via, out)
     # packed spike input
     xp = torch.from_numpy(np_pack.pack(x_cl.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
