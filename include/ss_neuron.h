@@ -612,7 +612,8 @@ int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, con
  * restated in oracle/np_upconv_sub.py), all int32:
  *   vcls [NVC][8] / hcls [NHC][8]   : per class of output rows / columns: number of runs, first tap of run 0..2, tap count of run 0..2, 0
  *   vblk [NVB][vrec_ints]            : per block of <= block_rows output rows of ONE class: class, n_out, n_src, out[block_rows] (output rows),
- *                                      src[window_rows] (the distinct source rows they read), slot[block_rows][3] (index into src of run r's source row)
+ *                                      src[window_rows] (the distinct source rows they read), slot[block_rows][3] (index into src of run r's source row),
+ *                                      last word of the record: the class's number of runs
  *   hblk [NHB][hrec_ints]            : the same for columns (block_cols, window_cols)
  * Every output row belongs to exactly one row block, every column to one column block; a (row block, column block) pair is one tile.
  *   ss_upconv_sub_geometry : block_rows 16, block_cols 32, window_rows 20, window_cols 36, record sizes 88 / 168; returns the runs per class (3).

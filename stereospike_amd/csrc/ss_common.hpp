@@ -214,6 +214,15 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries an s_waitcnt vmcnt(0) whenever vector-memory loads are in flight, i.e. it DRAINS every
+// prefetch a kernel has issued across it (guide: cdna_hip_programming.md "Pipelining across barriers") — a window fetched three stages ahead is waited for at
+// the very next stage barrier.  This one waits for the wavefront's own LDS operations (lgkmcnt) and leaves vmcnt alone.  Loads whose registers are consumed
+// before the barrier are still waited for where they are used (the compiler's own partial vmcnt(N)).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // code (0..3) of a 2-bit packed spike -> bf16 bit pattern of the same small integer: 0x0000, 0x3F80, 0x4000, 0x4040
 #define SS_CODE_LUT 0x404040003F800000ull
 __device__ __forceinline__ unsigned short code_to_bf16(unsigned c) { return (unsigned short)((SS_CODE_LUT >> (16 * c)) & 0xFFFFu); }

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
         }
         const unsigned char* const bsrc = wsrc(cur);
         const unsigned char* const bnxt = wsrc(nxt);
-        __syncthreads();                                                        // stage 0 and this item's window (stored at the end of the previous item) are visible
+        lds_barrier();                                                          // stage 0 and this item's window (stored at the end of the previous item) are visible
+                                                                                // (LDS-only barriers in the item loop: __syncthreads() would drain the prefetches, ss_common.hpp)
 #pragma unroll
         for (int sg = 0; sg < kNS; ++sg) {
             const bool more = sg + 1 < kNS;
@@ -393,11 +394,11 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                     const int off = (threadIdx.x + kB2Threads * u) * 16;
                     if (!(SS_BX_ABLATE & 2) && (!more || sg + 2 < kNS || off < kLastBytes)) *reinterpret_cast<f4*>(dst + off) = st[u];
                 }
-                if (more && !(SS_BX_ABLATE & 8)) __syncthreads();
+                if (more && !(SS_BX_ABLATE & 8)) lds_barrier();
             }
         }
         par ^= 1;
-        __syncthreads();                                                        // every reader of this item's window and stages is done
+        lds_barrier();                                                          // every reader of this item's window and stages is done
         if (has_next && !(SS_BX_ABLATE & 1)) bx_win_store(wnd, wbuf, bl, nxt.nj, nxt.ni);
         if (cur.c == NCH - 1) {
             // ---- tile epilogue: D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31]; the sum carries the sign of the last chunk
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
             bx_win_load(wbuf, bl, win_src(nb, rg, cg), NHR, nj, ni);
             bx_win_store(wnd, wbuf, bl, nj, ni);
         }
-        __syncthreads();                                                        // this tile's window (PF: stored at the end of the previous tile) is visible
+        if constexpr (PF) lds_barrier(); else __syncthreads();                  // this tile's window (PF: stored at the end of the previous tile) is visible
         // k-step s = (row s >> 1, half s & 1): its A fragments (2 quads x 3 planes x 2 transpose reads) are fetched one k-step AHEAD of its MFMAs
         auto read_a = [&](int sidx, s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3]) {
             const int r = sidx >> 1, half = sidx & 1;
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
             mma(lb, hb, xb);
         }
         if constexpr (PF) {
-            __syncthreads();                                                    // every reader of this tile's window is done
+            lds_barrier();                                                      // every reader of this tile's window is done
             if (tl + 1 < t_end) bx_win_store(wnd, wbuf, bl, njn, nin);
         }
         cg = cgn; rg = rgn; nb = nbn;

@@ -36,6 +36,15 @@ namespace {
 #ifndef SS_SB_WGS
 #define SS_SB_WGS 3                           // workgroups per CU of the packed-input kernel: 3 (168 registers, 44 B of scratch) measured 12 % faster than 2
 #endif                                       // (profiles/r04/bench_sub_fwd_v4*.log); the dense-input fallback keeps 2 (its staging needs the registers)
+#ifndef SS_SB_TRACE
+#define SS_SB_TRACE 0                         // development aid: wavefront 0 of workgroup 0 records s_memtime stamps of its first (cot, g) iterations (ss_debug_sub_trace)
+#endif
+#if SS_SB_TRACE
+__device__ unsigned long long sb_trace[96][8];
+#define SB_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && titer < 96) sb_trace[titer][slot] = clock64(); } while (0)
+#else
+#define SB_STAMP(slot) do { } while (0)
+#endif
 constexpr int kSbThreads = 256;
 constexpr int kSbBR = 16, kSbBC = 32;           // output rows / columns of a tile (4 M-blocks of 4 rows per wavefront; 4 wavefronts of 8 columns)
 constexpr int kSbWR = 20, kSbWC = 36;           // distinct source rows / columns a block may read (the on-chip window)
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = CIN / 16, NCOT = COUT / 32;
     const long long n_tiles = (long long)NB * NVB * NHB;
+    [[maybe_unused]] int titer = 0;
     constexpr int kWItems = PACKED ? 3 : 6;                                     // window items per thread: PACKED (pixel) = one 32-bit word of 16 codes;
                                                                                 // dense (pixel, half) = 8 fp32 channels
     constexpr int kSt = (kSbStage / 16 + kSbThreads - 1) / kSbThreads;          // 16-byte pieces per thread and weight stage (3; the last partial)
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
         for (int i = threadIdx.x; i < kSbHRec; i += kSbThreads) hrec[i] = hblk[hb * kSbHRec + i];
         __syncthreads();
         const int cv = vrec[0], nv = vrec[1], nsv = vrec[2], ch = hrec[0], nh = hrec[1], nsh = hrec[2];
-        const int ngv = vcls[cv * 8], ngh = hcls[ch * 8];
+        const int ngv = vrec[kSbVRec - 1], ngh = hrec[kSbHRec - 1];                   // runs per class (copied into the records' last word by the host)
         const int nblk = (nv + 3) >> 2;
         const bool active = 8 * wv < nh;                                        // wave-uniform: this wavefront has columns in the tile
         // this lane's pixel in M-block b: row 4 b + (m >> 3), column 8 wv + (m & 7); byte offsets of its source row / column per run
@@ -126,12 +136,18 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
         for (int b = 0; b < 4; ++b) {
             const int ri = min(4 * b + (m >> 3), nv - 1);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) rs[b][r] = vrec[3 + kSbBR + kSbWR + 3 * ri + r] * (kSbWC * kSbPix);
+            for (int r = 0; r < 3; ++r) {
+                // the two 16-byte halves of a pixel (channels 0-7 | 8-15) swap places on odd window rows: the 16 lanes of a ds_read_b128 group are two lattice
+                // rows x 8 columns — without the swap both rows hit the even 16-byte bank groups (2-way conflict on every A read: SQ_LDS_BANK_CONFLICT
+                // 5.3e7 cycles against 4.4e7 active, profiles/r04/pmc_sub_v1.txt)
+                const int sl = vrec[3 + kSbBR + kSbWR + 3 * ri + r];
+                rs[b][r] = sl * (kSbWC * kSbPix) + 16 * ((sl & 1) ^ half);
+            }
         }
         {
             const int cj = min(8 * wv + (m & 7), nh - 1);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) cs[c] = hrec[3 + kSbBC + kSbWC + 3 * cj + c] * kSbPix + 16 * half;
+            for (int c = 0; c < 3; ++c) cs[c] = hrec[3 + kSbBC + kSbWC + 3 * cj + c] * kSbPix;
         }
         const int npix = nsv * nsh;
         const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(Wm) + (long long)(cv * NHC + ch) * NCOT * G * (3 * kSbStage);
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
             if (pix < npix) {
                 const int wy = pix / nsh, wx = pix - wy * nsh;
                 xoff[u] = (unsigned)(((((long long)nb * h + vrec[3 + kSbBR + wy]) * w) + hrec[3 + kSbBC + wx]) * CIN + (PACKED ? 0 : 8 * (it & 1)));
-                loff[u] = (wy * kSbWC + wx) * kSbPix + (PACKED ? 0 : 16 * (it & 1));
+                loff[u] = (wy * kSbWC + wx) * kSbPix + (PACKED ? 16 * (wy & 1) : 16 * ((it & 1) ^ (wy & 1)));      // (PACKED: where channels 0-7 go)
             }
         }
         auto win_issue = [&](int g) {
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                             u16x8 o;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = code_to_bf16((wreg_p[u] >> (2 * (8 * q + e))) & 3u);
-                            *reinterpret_cast<u16x8*>(pp + 16 * q) = o;
+                            *reinterpret_cast<u16x8*>(q == 0 ? pp : wnd + (loff[u] ^ 16)) = o;
                         }
                     }
                 }
@@ -252,7 +268,9 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                     const bool last_g = g + 1 == G;
                     const bool has_next = !(last_g && cot + 1 == NCOT);
                     const int gn = last_g ? 0 : g + 1, cotn = last_g ? cot + 1 : cot;
-                    __syncthreads();                                            // this group's window and first stage are visible
+                    SB_STAMP(0);
+                    lds_barrier();                                              // this group's window and first stage are visible (LDS only: loads stay in flight)
+                    SB_STAMP(1);
 #pragma unroll
                     for (int r = 0; r < NGV; ++r) {
                         const bool more = r + 1 < NGV;
@@ -283,18 +301,27 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                                         }
                             }
                         }
+#if SS_SB_TRACE
+                        if (acc[0][0] == 12345.f && acc[1][1] == 1.f && acc[2][2] == 2.f && acc[3][3] == 3.f) sb_trace[95][7] = 1;   // waits for the MFMAs
+#endif
+                        SB_STAMP(2 + 2 * r);
                         if (more) {
                             if (!(SS_SB_ABLATE & 2)) stage_commit(bst + (par ^ 1) * kSbStage);
-                            if (!(SS_SB_ABLATE & 8)) __syncthreads();
+                            if (!(SS_SB_ABLATE & 8)) lds_barrier();
                             par ^= 1;
                         }
+                        SB_STAMP(3 + 2 * r);
                     }
                     if (has_next) {
-                        __syncthreads();                                        // every reader of this group's window is done
+                        lds_barrier();                                          // every reader of this group's window is done
                         if (!(SS_SB_ABLATE & 1)) win_commit(gn);
                         if (!(SS_SB_ABLATE & 2)) stage_commit(bst + (par ^ 1) * kSbStage);
                         par ^= 1;
                     }
+#if SS_SB_TRACE
+                    if (blockIdx.x == 0 && threadIdx.x == 0 && titer < 96) { sb_trace[titer][7] = ((unsigned long long)(tile & 0xffff) << 32) | (unsigned)(cot * 256 + g) | ((unsigned long long)(NGV * 16 + NGH * 4 + (FULL ? 1 : 0)) << 48); }
+                    ++titer;
+#endif
                 }
                 // ---- D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][co = lane & 31]; the sum carries the sign of the last group
                 if (active) {
@@ -338,6 +365,13 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
 }  // namespace
 
 extern "C" {
+
+#if SS_SB_TRACE
+int ss_debug_sub_trace(unsigned long long* host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sb_trace), sizeof(unsigned long long) * 96 * 8) == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+#endif
 
 /* tile geometry the host tables must respect: rows / columns per block, distinct source rows / columns per block, ints per block record */
 int ss_upconv_sub_geometry(int* block_rows, int* block_cols, int* window_rows, int* window_cols, int* vrec_ints, int* hrec_ints)

@@ -746,7 +746,9 @@ def _axis_blocks(src, cls, table, max_out, max_src, rec_ints):
             rec = [c, n, len(srcs)] + (pos[a:a + n] + [0] * max_out)[:max_out] + (srcs + [0] * max_src)[:max_src]
             for i in range(max_out):
                 rec += [where[src[pos[a + i] + k0[r]]] if (i < n and r < ng) else 0 for r in range(3)]
-            recs.append((rec + [0] * rec_ints)[:rec_ints])
+            rec = (rec + [0] * rec_ints)[:rec_ints]
+            rec[-1] = ng                                  # the kernel reads the class's run count from the record (no dependent class-table load)
+            recs.append(rec)
             a += n
     return recs
 

@@ -983,7 +983,7 @@ def test_upconv_fused_mfma_forward(Cin, Cout, hw, HW, NB):
         _lib.upconv_fused_fwd(xd, xpk, Wf2, tables[0], tables[3], o2, NB, Cin, Cout, h, w, H, W, win, 2)
         assert torch.equal(o2, out), float((o2 - out).abs().max())
     for form in (1, 2):
-        with config.engine_config(FUSED_UPCONV_FORM=form), torch.no_grad():
+        with config.engine_config(FUSED_UPCONV_FORM=form, SUB_FWD=False), torch.no_grad():
             assert torch.equal(up.forward_projected_cl(x_cl, spikes_in=True), out)
 
 

@@ -379,6 +379,7 @@ def test_upconv_sub_oracle_is_the_reference_formula_and_the_product_tables(NB, C
             n, m = len(b['out']), len(b['src'])
             assert (r[0], r[1], r[2]) == (b['cls'], n, m) and np.array_equal(r[3:3 + n], b['out']) and np.array_equal(r[3 + mo:3 + mo + m], b['src'])
             assert np.array_equal(r[3 + mo + ms:3 + mo + ms + 3 * n].reshape(n, 3), b['slot'])
+            assert r[-1] == (kn[b['cls']] > 0).sum()                         # the record's last word: runs of its class
             seen += list(b['out'])
         assert sorted(seen) == list(range(n_out))
 
