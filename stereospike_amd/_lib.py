@@ -644,12 +644,13 @@ def upconv_sub_fwd(x, x_packed, wm, st, out, NB, Cin, Cout, h, w):
     """out [NB, H, W, Cout] = Conv2d(5)(UpsamplingNearest2d(x)) of a spike input (dense fp32 NHWC x, or the 2-bit packed x_packed) in the sub-pixel form."""
     _require_hip(out, 'out')
     H, W = st['H'], st['W']
+    counter = torch.empty(1, dtype=torch.int32, device=out.device)           # the launch's tile counter (zeroed by the entry point on the launch stream)
     with torch.cuda.device(out.device):
         rc = lib().ss_upconv_sub_fwd_f32(None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
                                          _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
                                          _x16(wm, 'wm', int(lib().ss_upconv_sub_wm_elems(int(Cin), int(Cout), int(st['NVC']), int(st['NHC']))), torch.bfloat16),
                                          _i32(st['vblk'], 'vblk', st['NVB'] * st['vrec_ints']), _i32(st['hblk'], 'hblk', st['NHB'] * st['hrec_ints']),
-                                         _i32(st['vcls'], 'vcls', 8 * st['NVC']), _i32(st['hcls'], 'hcls', 8 * st['NHC']),
+                                         _i32(st['order'], 'order', st['NVB'] * st['NHB']), _i32(counter, 'counter', 1),
                                          _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W, st['NVB'], st['NHB'], st['NHC'], _stream(out))
     _check(rc, 'ss_upconv_sub_fwd_f32')
 

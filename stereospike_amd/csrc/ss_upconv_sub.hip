@@ -41,9 +41,12 @@ namespace {
 #endif
 #if SS_SB_TRACE
 __device__ unsigned long long sb_trace[96][8];
+__device__ unsigned long long sb_trace2[32][8];       // per tile: 0 loop top (after the barrier), 1 records in LDS, 2 per-lane setup done, 3 first window + stage committed, 4 last MFMA, 5 epilogue issued
+#define SB_STAMP2(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && ttile < 32) sb_trace2[ttile][slot] = clock64(); } while (0)
 #define SB_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && titer < 96) sb_trace[titer][slot] = clock64(); } while (0)
 #else
 #define SB_STAMP(slot) do { } while (0)
+#define SB_STAMP2(slot) do { } while (0)
 #endif
 constexpr int kSbThreads = 256;
 constexpr int kSbBR = 16, kSbBC = 32;           // output rows / columns of a tile (4 M-blocks of 4 rows per wavefront; 4 wavefronts of 8 columns)
@@ -102,30 +105,42 @@ __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __
 template <bool PACKED>
 __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wm,
                                                                        const int* __restrict__ vblk, const int* __restrict__ hblk,
-                                                                       const int* __restrict__ vcls, const int* __restrict__ hcls,
+                                                                       const int* __restrict__ order, unsigned* __restrict__ counter,
                                                                        float* __restrict__ out, int NB, int h, int w, int H, int W, int CIN, int COUT,
                                                                        int NVB, int NHB, int NHC)
 {
     __shared__ __attribute__((aligned(16))) unsigned char wnd[kSbWnd];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kSbStage];
     __shared__ int vrec[kSbVRec], hrec[kSbHRec];
+    __shared__ long long s_next;
     const int lane = threadIdx.x & 63, m = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = CIN / 16, NCOT = COUT / 32;
     const long long n_tiles = (long long)NB * NVB * NHB;
     [[maybe_unused]] int titer = 0;
+    [[maybe_unused]] int ttile = 0;
     constexpr int kWItems = PACKED ? 3 : 6;                                     // window items per thread: PACKED (pixel) = one 32-bit word of 16 codes;
                                                                                 // dense (pixel, half) = 8 fp32 channels
     constexpr int kSt = (kSbStage / 16 + kSbThreads - 1) / kSbThreads;          // 16-byte pieces per thread and weight stage (3; the last partial)
+    // Tiles are drawn from a counter (the first one is the workgroup's index): a frame's 285 tiles cost between 1 / 16 and 1 of a full one, and with 10 - 30
+    // tiles per workgroup a static round-robin left the last workgroups running alone (deconv2: 0.88 -> 0.82 ms, profiles/r04/bench_sub_fwd_v7.log).  Tile t
+    // = (class-pair block order[t / NB], frame t % NB): the host sorts the blocks by cost, the expensive ones first, so the tail is made of small tiles; the
+    // frames of one block run together (its weights stay in L2).
+    if (threadIdx.x == 0) s_next = blockIdx.x;
+    long long drawn = 0;                                                        // thread 0: the tile after this one, drawn while this one runs
 #pragma unroll 1
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int hb = (int)(tile % NHB);
-        const long long t2 = tile / NHB;
-        const int vb = (int)(t2 % NVB), nb = (int)(t2 / NVB);
-        __syncthreads();                                                        // the previous tile's readers of the records are done
+    for (;;) {
+        __syncthreads();                                                        // the previous tile's readers of the records are done; s_next is written
+        const long long tile = s_next;
+        if (tile >= n_tiles) break;
+        SB_STAMP2(0);
+        const int pair = order[tile / NB], nb = (int)(tile % NB);
+        const int vb = pair / NHB, hb = pair - vb * NHB;
+        if (threadIdx.x == 0) drawn = (long long)atomicAdd(counter, 1u) + gridDim.x;
         for (int i = threadIdx.x; i < kSbVRec; i += kSbThreads) vrec[i] = vblk[vb * kSbVRec + i];
         for (int i = threadIdx.x; i < kSbHRec; i += kSbThreads) hrec[i] = hblk[hb * kSbHRec + i];
         __syncthreads();
+        SB_STAMP2(1);
         const int cv = vrec[0], nv = vrec[1], nsv = vrec[2], ch = hrec[0], nh = hrec[1], nsh = hrec[2];
         const int ngv = vrec[kSbVRec - 1], ngh = hrec[kSbHRec - 1];                   // runs per class (copied into the records' last word by the host)
         const int nblk = (nv + 3) >> 2;
@@ -244,10 +259,12 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
             constexpr int NGV = decltype(ngv_c)::value, NGH = decltype(ngh_c)::value;
             constexpr bool FULL = decltype(full_c)::value;
             // the first (cot, g) of the tile: its latency is exposed
+            SB_STAMP2(2);
             win_issue(0);
             stage_issue(stage_src(0, 0, 0));
             win_commit(0);
             stage_commit(bst);
+            SB_STAMP2(3);
             f32x16 acc[4];
             int par = 0;                                                        // half of the stage buffer that holds the current stage
 #pragma unroll 1
@@ -323,6 +340,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                     ++titer;
 #endif
                 }
+                SB_STAMP2(4);
                 // ---- D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][co = lane & 31]; the sum carries the sign of the last group
                 if (active) {
                     const float fin = ((G - 1) & 1) ? -1.f : 1.f;
@@ -359,6 +377,12 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
         case 7: run_tile(integral_constant<int, 3>{}, integral_constant<int, 3>{}, std::true_type{}); break;
         default: break;
         }
+        SB_STAMP2(5);
+#if SS_SB_TRACE
+        ++ttile;
+#endif
+        __syncthreads();                                                        // every reader of s_next is past it
+        if (threadIdx.x == 0) s_next = drawn;
     }
 }
 
@@ -370,6 +394,10 @@ extern "C" {
 int ss_debug_sub_trace(unsigned long long* host_dst)
 {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sb_trace), sizeof(unsigned long long) * 96 * 8) == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+int ss_debug_sub_trace2(unsigned long long* host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sb_trace2), sizeof(unsigned long long) * 32 * 8) == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 #endif
 
@@ -405,10 +433,10 @@ int ss_upconv_sub_prep_f32(const float* weight, const int* vcls, const int* hcls
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
-int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* vcls, const int* hcls,
+int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* order, unsigned int* counter,
                           float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, void* stream)
 {
-    if ((!x && !x_packed) || !wm || !vblk || !hblk || !vcls || !hcls || !out || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || NVB < 1 || NHB < 1 || NHC < 1)
+    if ((!x && !x_packed) || !wm || !vblk || !hblk || !order || !counter || !out || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || NVB < 1 || NHB < 1 || NHC < 1)
         return SS_EINVAL;
     if (!ss_upconv_sub_supported(Cin, Cout, 5) || !aligned16(out) || !aligned16(wm) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
     if (NB * NVB * (long long)NHB > 0x7fffffffLL || NB * h * (long long)w * Cin > 0xffffffffLL) return SS_EINVAL;
@@ -418,10 +446,11 @@ int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const vo
     const long long wgs = (long long)(x_packed ? SS_SB_WGS : 2) * cus;
     const unsigned grid = (unsigned)(n_tiles < wgs ? n_tiles : wgs);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess) return SS_ELAUNCH;       // the tile counter of this launch
     if (x_packed) hipLaunchKernelGGL((upconv_sub_fwd_kernel<true>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x_packed),
-                                     static_cast<const unsigned short*>(wm), vblk, hblk, vcls, hcls, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
+                                     static_cast<const unsigned short*>(wm), vblk, hblk, order, counter, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
     else hipLaunchKernelGGL((upconv_sub_fwd_kernel<false>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x),
-                            static_cast<const unsigned short*>(wm), vblk, hblk, vcls, hcls, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
+                            static_cast<const unsigned short*>(wm), vblk, hblk, order, counter, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

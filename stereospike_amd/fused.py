@@ -767,7 +767,12 @@ def register_sub_tables(tables, host_tables, H, W):
 
         def t(a):
             return torch.tensor(a, dtype=torch.int32).reshape(-1).to(dev)
-        st = dict(vcls=t(cv[1]), hcls=t(ch[1]), vblk=t(vblk), hblk=t(hblk), NVC=len(cv[1]), NHC=len(ch[1]), NVB=len(vblk), NHB=len(hblk),
+        # tile order: (row block, column block) pairs by cost — runs x runs x (4 M-blocks | 1) MFMA rounds per wavefront — most expensive first
+        def cost(pair):
+            v, hh = vblk[pair // len(hblk)], hblk[pair % len(hblk)]
+            return v[-1] * hh[-1] * (4 if v[1] > 4 else 1)
+        order = sorted(range(len(vblk) * len(hblk)), key=lambda pr: (-cost(pr), pr))
+        st = dict(vcls=t(cv[1]), hcls=t(ch[1]), vblk=t(vblk), hblk=t(hblk), order=t(order), NVC=len(cv[1]), NHC=len(ch[1]), NVB=len(vblk), NHB=len(hblk),
                   vrec_ints=geo['vrec_ints'], hrec_ints=geo['hrec_ints'], H=H, W=W)
     _SUB[id(tables)] = (tables, st, H, W)
     return st

@@ -382,6 +382,11 @@ def test_upconv_sub_oracle_is_the_reference_formula_and_the_product_tables(NB, C
             assert r[-1] == (kn[b['cls']] > 0).sum()                         # the record's last word: runs of its class
             seen += list(b['out'])
         assert sorted(seen) == list(range(n_out))
+    order = st['order'].numpy()
+    assert sorted(order.tolist()) == list(range(st['NVB'] * st['NHB']))                 # every (row block, column block) pair once, most expensive first
+    vb, hb = st['vblk'].view(-1, 88).numpy(), st['hblk'].view(-1, 168).numpy()
+    costs = [vb[p // st['NHB']][-1] * hb[p % st['NHB']][-1] * (4 if vb[p // st['NHB']][1] > 4 else 1) for p in order]
+    assert costs == sorted(costs, reverse=True)
 
 
 @pytest.mark.parametrize('NB,Cin,Cout,hw,up', [(2, 8, 8, (17, 22), (33, 44)), (1, 8, 16, (5, 7), (9, 13)), (2, 4, 8, (3, 3), (8, 5)), (1, 8, 8, (1, 6), (2, 11)),

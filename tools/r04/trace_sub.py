@@ -36,3 +36,12 @@ for i in range(60):
     d = lambda a, c: (b[c] - b[a]) if b[a] and b[c] else -1
     nxt = int(buf[i + 1, 0]) - b[0] if buf[i + 1, 0] else -1
     print(f'{i:3d} {tile:6d} {cg >> 8:3d} {cg & 255:2d} {inst:4d} | {b[0] - t0:8d} {d(0, 1):5d} | {d(1, 2):7d} {d(2, 3):6d} | {d(3, 4):7d} {d(4, 5):6d} | {d(5, 6):7d} {d(6, 7) if False else 0:6d} | {nxt:7d}')
+
+buf2 = np.zeros((32, 8), np.uint64)
+L.ss_debug_sub_trace2.argtypes = [ctypes.c_void_p]
+assert L.ss_debug_sub_trace2(buf2.ctypes.data) == 0
+print('tile boundary stamps (cycles): records loaded | per-lane setup | first window + stage committed | (cot, g) loops | epilogue issued | to the next tile top')
+for i in range(20):
+    b = [int(v) for v in buf2[i]]
+    nxt = int(buf2[i + 1, 0]) - b[5] if buf2[i + 1, 0] else -1
+    print(f'{i:3d} | {b[1] - b[0]:7d} | {b[2] - b[1]:7d} | {b[3] - b[2]:7d} | {b[4] - b[3]:8d} | {b[5] - b[4]:7d} | {nxt:7d}')
