@@ -45,7 +45,13 @@ __device__ __forceinline__ void bx_split3(const float (&v)[8], u16x8& h, u16x8& 
 // carrying the horizontal sum of the last output row (consecutive ranges overlap in one row): ~3 pixel reads per B element instead of 4 - 9.
 // Lanes: 4 chunks x 16 ranges per wavefront — a pixel's 4 x 32 B are one 128-B line, a chunk's 16 granules one 256-B store segment.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kBxJS = 8;
+#ifndef SS_BX_HSUM_UNROLL
+#define SS_BX_HSUM_UNROLL 0
+#endif
+#ifndef SS_BX_JS
+#define SS_BX_JS 8                             // vertical ranges a lane walks (A/B: profiles/r04/boxsum_variants.log)
+#endif
+constexpr int kBxJS = SS_BX_JS;
 
 template <int CG>                              // chunks per lane group: min(C_out / 8, 4)
 __global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __restrict__ gy, const int* __restrict__ vr, const int* __restrict__ hr,
@@ -70,11 +76,30 @@ __global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = 0.f;
         const float* p = g0 + (long long)y * W * COUT;
+#if SS_BX_HSUM_UNROLL
+        // ranges are <= 3 pixels wide (a nearest resize by ~2): the loads of a row go out together, the additions stay in x order (same bits)
+        f4 a[3], bb[3];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            if (x < nx) { a[x] = *reinterpret_cast<const f4*>(p + (long long)x * COUT); bb[x] = *reinterpret_cast<const f4*>(p + (long long)x * COUT + 4); }
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            if (x < nx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] += a[x][e]; o[4 + e] += bb[x][e]; }
+            }
+        for (int x = 3; x < nx; ++x) {
+            const f4 a2 = *reinterpret_cast<const f4*>(p + (long long)x * COUT), b2 = *reinterpret_cast<const f4*>(p + (long long)x * COUT + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] += a2[e]; o[4 + e] += b2[e]; }
+        }
+#else
         for (int x = 0; x < nx; ++x) {
             const f4 a = *reinterpret_cast<const f4*>(p + (long long)x * COUT), bb = *reinterpret_cast<const f4*>(p + (long long)x * COUT + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[e] += a[e]; o[4 + e] += bb[e]; }
         }
+#endif
     };
     const long long plane = (long long)NVR * NHR * kBxCo;
     unsigned short* const out0 = Bp + (((long long)nb * NCH + c) * 3) * plane + (long long)i * kBxCo;
