@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
 #pragma unroll
                             for (int sp = 2; sp >= 0; --sp)                     // smallest terms first
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[sp * NT + t], acc[t], 0, 0, 0);
+                                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[sp * NT + t], a, acc[t], 0, 0, 0);     // D^T: rows = output channels, columns = pixels
                         }
                         if (last) {
                             if (more) stage_commit(bst + ((sg + 1) & 1) * STG);
@@ -246,16 +246,22 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                 }
             }
         }
-        // ---- D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] -> out[nb][oy][ox0 + row][32 t + col]
+        // ---- the product is taken transposed (weights as the A operand): D[co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][pixel = lane & 31] -> a lane holds 4
+        //      consecutive output channels of ONE pixel per register quad: 4 NT 16-byte stores per tile row instead of 16 NT 4-byte ones
         if (active) {
-            const long long rowbase = ((long long)nb * ho + (oy0 + mb)) * wo;
+            const int ox = ox0 + tx;
+            if (ox < wo) {
+                float* const op = out + (((long long)nb * ho + (oy0 + mb)) * wo + ox) * COUT + 32 * NT * slice + 4 * half;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (ox < wo) store_out(out + (rowbase + ox) * COUT + 32 * (NT * slice + t) + tx, neg ? -acc[t][r] : acc[t][r]);
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        f4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = neg ? -acc[t][4 * q + e] : acc[t][4 * q + e];
+                        *reinterpret_cast<f4*>(op + 32 * t + 8 * q) = v;
+                    }
+            }
         }
     }
 }

@@ -46,10 +46,10 @@ __device__ __forceinline__ void bx_split3(const float (&v)[8], u16x8& h, u16x8& 
 // Lanes: 4 chunks x 16 ranges per wavefront — a pixel's 4 x 32 B are one 128-B line, a chunk's 16 granules one 256-B store segment.
 // ---------------------------------------------------------------------------------------------------
 #ifndef SS_BX_HSUM_UNROLL
-#define SS_BX_HSUM_UNROLL 0
+#define SS_BX_HSUM_UNROLL 1                    // the <= 3 pixel loads of a range row issued together, additions in x order (same bits): 0.65 -> 0.61 ms (boxsum_variants.log)
 #endif
 #ifndef SS_BX_JS
-#define SS_BX_JS 8                             // vertical ranges a lane walks (A/B: profiles/r04/boxsum_variants.log)
+#define SS_BX_JS 4                             // vertical ranges a lane walks (A/B: profiles/r04/boxsum_variants.log)
 #endif
 constexpr int kBxJS = SS_BX_JS;
 
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
 #pragma unroll
                         for (int u = 0; u < NT; ++u) {
                             if (SS_BX_ABLATE & 4) acc[ks][u][q] += (float)(fa[pa[q]][0] + fb[pb[q]][u][1]);
-                            else acc[ks][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa[q]], fb[pb[q]][u], acc[ks][u], 0, 0, 0);
+                            else acc[ks][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pb[q]][u], fa[pa[q]], acc[ks][u], 0, 0, 0);      // D^T: rows = input channels, columns = pixels
                         }
                 }
             }
@@ -426,18 +426,28 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
         lds_barrier();                                                          // every reader of this item's window and stages is done
         if (has_next && !(SS_BX_ABLATE & 1)) bx_win_store(wnd, wbuf, bl, nxt.nj, nxt.ni);
         if (cur.c == NCH - 1) {
-            // ---- tile epilogue: D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31]; the sum carries the sign of the last chunk
+            // ---- tile epilogue.  The product is taken TRANSPOSED (weights as the A operand): D[ci = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][pixel = lane & 31] —
+            //      a lane holds 4 consecutive input channels of ONE pixel per register quad: 4 NT 16-byte stores instead of 16 NT 4-byte ones (what the
+            //      4-byte form cost the sub-pixel forward: profiles/r04/sub_trace_v2.log).  The sum carries the sign of the last chunk.
             const float fin = ((NCH - 1) & 1) ? -1.f : 1.f;
+            const int pm = lane & 31;
+            const int py = sy0 + (pm >> 3), px = sx0 + 8 * wv + (pm & 7);
+            if ((pm >> 3) < nrow && px < w) {
+                float* const op = gx + (((long long)cur.nb * h + py) * w + px) * CIN + 32 * NT * cur.blk + 4 * (lane >> 5);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int py = sy0 + (pm >> 3), px = sx0 + 8 * wv + (pm & 7);
-                    float v = acc[0][t][r];
-                    if constexpr (KPS > 1) v += acc[1][t][r];
-                    if ((pm >> 3) < nrow && px < w) store_out(gx + (((long long)cur.nb * h + py) * w + px) * CIN + 32 * NT * cur.blk + 32 * t + (lane & 31), v * fin);
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        f4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[0][t][4 * q + e];
+                            if constexpr (KPS > 1) x += acc[1][t][4 * q + e];
+                            v[e] = x * fin;
+                        }
+                        *reinterpret_cast<f4*>(op + 32 * t + 8 * q) = v;
+                    }
+            }
         }
         cur = nxt;
     }

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                                     for (int b2 = 0; b2 < 4; ++b2)
                                         if (FULL || b2 == 0) {                  // (partial tiles: the irregular row blocks hold <= 4 rows = one M-block)
                                             if (SS_SB_ABLATE & 4) acc[b2][p] += (float)(a[b2][0] + bp[p][1]);
-                                            else acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[b2], bp[p], acc[b2], 0, 0, 0);
+                                            else acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bp[p], a[b2], acc[b2], 0, 0, 0);       // D^T: rows = channels, columns = pixels
                                         }
                             }
                         }
@@ -341,26 +341,26 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
 #endif
                 }
                 SB_STAMP2(4);
-                // ---- D[pixel = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][co = lane & 31]; the sum carries the sign of the last group
+                // ---- the product is taken TRANSPOSED (weights as the A operand): D[co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][pixel = lane & 31], so a lane holds
+                //      4 consecutive channels of ONE pixel per register quad -> 4 16-byte stores per M-block instead of 16 4-byte ones (the epilogue of the
+                //      first form took 8 - 15 k cycles per tile, a quarter of a deconv1 tile: profiles/r04/sub_trace_v2.log).  Plain stores: L2 merges the four
+                //      32-byte pieces of a pixel's 128-byte line.  The sum carries the sign of the last group.
                 if (active) {
                     const float fin = ((G - 1) & 1) ? -1.f : 1.f;
-                    float* const ob = out + (long long)nb * H * W * COUT + 32 * cot + m;
-                    // pixel pm of M-block b2: row 4 b2 + (r >> 2), column 8 wv + (r & 3) + 4 half
-                    int co4[4];
+                    const int cj = 8 * wv + (m & 7);
+                    if (cj < nh) {
+                        float* const ob = out + ((long long)nb * H * W + hrec[3 + cj]) * COUT + 32 * cot + 4 * half;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int cj = 8 * wv + q + 4 * half; co4[q] = cj < nh ? hrec[3 + cj] * COUT : -1; }
-#pragma unroll
-                    for (int b2 = 0; b2 < (FULL ? 4 : 1); ++b2)
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            const int ri = 4 * b2 + rr;
+                        for (int b2 = 0; b2 < (FULL ? 4 : 1); ++b2) {
+                            const int ri = 4 * b2 + (m >> 3);
                             if (ri < nv) {
-                                float* const orow = ob + (long long)vrec[3 + ri] * W * COUT;
+                                float* const op = ob + (long long)vrec[3 + ri] * W * COUT;
 #pragma unroll
                                 for (int q = 0; q < 4; ++q)
-                                    if (co4[q] >= 0) store_out(orow + co4[q], acc[b2][4 * rr + q] * fin);
+                                    *reinterpret_cast<f4*>(op + 8 * q) = (f4){acc[b2][4 * q] * fin, acc[b2][4 * q + 1] * fin, acc[b2][4 * q + 2] * fin, acc[b2][4 * q + 3] * fin};
                             }
                         }
+                    }
                 }
             }
         };
