@@ -248,9 +248,9 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                                     for (int t = 0; t < NT; ++t) {
                                         if (g == 0 && q == 0) {
                                             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kTa[q]], b[kTb[q]][t], zero, 0, 0, 0);
+                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kTb[q]][t], a[i][kTa[q]], zero, 0, 0, 0);      // D^T: rows = input channels, columns = pixels
                                         } else {
-                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kTa[q]], b[kTb[q]][t], tmp[i][t], 0, 0, 0);
+                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kTb[q]][t], a[i][kTa[q]], tmp[i][t], 0, 0, 0);
                                         }
                                     }
                         }
@@ -267,35 +267,29 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                 }
             }
         }
-        // ---- D[row m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31] -> g_x[nb][2 j + py][2 (i0 + cc_m) + px][32 (kind NT + t) + col]
+        // ---- the product is taken TRANSPOSED (weights as the A operand): D[ci = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][pixel m = lane & 31], so a lane holds 4
+        //      consecutive input channels of ONE pixel per register quad -> g_x[nb][2 j + py][2 (i0 + cc_m) + px][32 (kind NT + t) + ci] as 16-byte stores
+        //      (4 per class and channel tile instead of 16 4-byte ones: what the 4-byte form cost, profiles/r04/sub_trace_v2.log)
         if (active) {
+            const int qm = tx / CB, ccm = tx - qm * CB;                         // this lane's pixel: padded row qm, column ccm of the M block
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                const long long Rp = R0 + RB * (MB * mb + i) + q;               // wave-uniform
-                if (Rp >= RT) break;
+            for (int i = 0; i < MB; ++i) {
+                const long long Rp = R0 + RB * (MB * mb + i) + qm;
                 const long long nb = Rp / HP;
                 const int j = (int)(Rp - nb * HP);
-                if (j >= ho) continue;                                          // the frame's padding row
+                const bool row_ok = Rp < RT && j < ho;                          // (j == ho: the frame's padding row)
 #pragma unroll
                 for (int cls = 0; cls < 4; ++cls) {
                     const int py = cls >> 1, px = cls & 1;
-                    const int iy = 2 * j + py;
-                    if (iy >= h) continue;
-                    const long long rowbase = (nb * h + iy) * w;
+                    const int iy = 2 * j + py, ix = 2 * (i0 + ccm) + px;
+                    if (row_ok && iy < h && ix < w && (!(SS_DG_ABL & 64) || acc[i][cls][0][0] == 12345.678f)) {
+                        float* const op = gx + ((nb * h + iy) * w + ix) * CI + 32 * (kind * NT) + 4 * half;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m0 = (r & 3) + 8 * (r >> 2);                  // + 4 half
-                        if ((m0 / CB) != q && ((m0 + 4) / CB) != q) continue;   // compile-time after unrolling
-                        const int m = m0 + 4 * half;
-                        if (m / CB != q) continue;
-                        const int ix = 2 * (i0 + (m - q * CB)) + px;
-                        if (ix < w && (!(SS_DG_ABL & 64) || acc[i][cls][0][r] == 12345.678f)) {
+                        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                            for (int t = 0; t < NT; ++t)
-                                store_out(gx + (rowbase + ix) * CI + 32 * (kind * NT + t) + tx, acc[i][cls][t][r]);
-                        }
+                            for (int q4 = 0; q4 < 4; ++q4)
+                                *reinterpret_cast<f4*>(op + 32 * t + 8 * q4) =
+                                    (f4){acc[i][cls][t][4 * q4], acc[i][cls][t][4 * q4 + 1], acc[i][cls][t][4 * q4 + 2], acc[i][cls][t][4 * q4 + 3]};
                     }
                 }
             }

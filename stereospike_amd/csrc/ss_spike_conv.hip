@@ -374,6 +374,8 @@ __global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const flo
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][0], acc, 0, 0, 0);
             }
+            // (a transposed product with 16-byte plain stores — what pays in the MFMA-bound kernels — measured SLOWER here, 0.295 -> 0.32 ms: this kernel is
+            //  bound by writing its output, and 16 non-temporal 128-byte rows per wavefront store beat 4 x 32-byte pieces per line; profiles/r04/bench_f4_epilogues_v2_*.json)
             const long long rowbase = ((long long)nb * h + (oy0 + ty)) * w;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
