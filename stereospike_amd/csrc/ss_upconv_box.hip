@@ -170,15 +170,15 @@ constexpr int kWinRegs = kB2WR;
 
 struct BxLane { unsigned voff_plane; int cc; int lds0, lds1; bool act; };
 
-__device__ __forceinline__ BxLane bx_lane(long long plane_g)
+__device__ __forceinline__ BxLane bx_lane(long long plane_g, int plane_bytes = kB2Plane)
 {
     BxLane L;
     const int t = threadIdx.x, p = t / kB2WC;
     L.cc = t - p * kB2WC;
     L.act = p < 3;
     L.voff_plane = (unsigned)((L.act ? p : 0) * plane_g + L.cc * kBxCo);       // elements from the window's first granule (row 0)
-    L.lds0 = (L.act ? p : 0) * kB2Plane + L.cc * 16;                            // rows with swizzle bit 0
-    L.lds1 = (L.act ? p : 0) * kB2Plane + (L.cc ^ 1) * 16;                      // rows with swizzle bit 1 ((r >> 1) & 1)
+    L.lds0 = (L.act ? p : 0) * plane_bytes + L.cc * 16;                            // rows with swizzle bit 0
+    L.lds1 = (L.act ? p : 0) * plane_bytes + (L.cc ^ 1) * 16;                      // rows with swizzle bit 1 ((r >> 1) & 1)
     return L;
 }
 
@@ -453,6 +453,22 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
     }
 }
 
+// The weight-gradient kernel keeps its window as a RING of 16 rows (row slot = vertical range id & 15) and walks the tiles of a column strip top to bottom:
+// consecutive row tiles share 7 of their <= 15 vertical ranges, so only the new rows are fetched and stored (the kernel is bound by staging 54 KB of window
+// per 96 - 192 MFMAs of a wavefront; deconv2 0.87 -> 0.81 ms, deconv1 unchanged by this alone: profiles/r04/bench_box_bwd_v11.log .. v13.log).
+constexpr int kB3WR = 16;
+constexpr int kB3Zero = kB3WR * kB2WC * 16;
+constexpr int kB3Plane = kB3Zero + 16;
+__device__ __forceinline__ void bx3_store_rows(unsigned char* wnd, const f4 (&buf)[kWinRegs], const BxLane& L, int jf, int cnt, int ni)
+{
+    const bool on = L.act && L.cc < ni;
+#pragma unroll
+    for (int r = 0; r < kB2WR; ++r) {
+        const int sl = (jf + r) & (kB3WR - 1);
+        if (on && r < cnt) *reinterpret_cast<f4*>(wnd + (((sl >> 1) & 1) ? L.lds1 : L.lds0) + sl * (kB2WC * 16)) = buf[r];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K3: weight gradient  g_W[co][ci][tap] = sum_{nb, iy, ix} x[nb][iy][ix][ci] * B[nb][vmap[iy][ky]][hmap[ix][kx]][co]   (x spikes: EXACT products, three bf16 terms of B)
 // ---------------------------------------------------------------------------------------------------
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
                                                                          int RG, int CG)
 {
     constexpr int NQ = 2;                                                       // tap quads per wavefront: wv, wv + 4 (the 8th is a phantom: zero row)
-    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * kB2Plane];
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * kB3Plane];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NCH = COUT / kBxCo, CIB = CIN / (32 * NT);
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
     const long long n_tiles = (long long)NB * RG * CG;
     const long long t_begin = n_tiles * slice / slices, t_end = n_tiles * (slice + 1) / slices;
     const long long plane_g = (long long)NVR * NHR * kBxCo;
-    bx_zero_borders(wnd);
+    if (threadIdx.x < 3) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB3Plane + kB3Zero) = (f4){0.f, 0.f, 0.f, 0.f};        // the zero pixel of each plane
     // this lane as a SOURCE lane of the transpose reads: pixel L >> 2 of a 4-pixel sub-block, columns 4 (L & 3) .. + 3 of the 16-row half g of the M tile
     const int L = lane & 15, g = (lane >> 4) & 1, oct = lane >> 5;
     const int tq4 = 2 * g + ((L & 3) >> 1), coq = (L & 3) & 1;
@@ -523,31 +539,50 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
     __shared__ int tiles[4 * 64 + 2 * 16];                                       // the row / column tile tables (<= 64 row tiles, <= 16 column tiles: checked by the host)
     for (int i = threadIdx.x; i < 4 * RG; i += kB2Threads) tiles[i] = tr[i];
     for (int i = threadIdx.x; i < 2 * CG; i += kB2Threads) tiles[256 + i] = tc[i];
+    // the two index maps in LDS (when they fit): every tile starts by looking 16 ids per lane up, and from global memory those dependent loads sat between the
+    // tile's first barrier and its first MFMA
+    constexpr int kMapH = 160, kMapW = 192;
+    __shared__ int vm_s[5 * kMapH], hm_s[5 * kMapW];
+    const bool maps_in_lds = h <= kMapH && w <= kMapW;
+    if (maps_in_lds) {
+        for (int i = threadIdx.x; i < 5 * h; i += kB2Threads) vm_s[i] = vmap[i];
+        for (int i = threadIdx.x; i < 5 * w; i += kB2Threads) hm_s[i] = hmap[i];
+    }
     __syncthreads();
-    const BxLane bl = bx_lane(plane_g);
-    auto win_src = [&](int nb, int rg, int cg) { return Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)tiles[4 * rg + 2] * NHR + tiles[256 + 2 * cg]) * kBxCo; };
-    // tile -> (frame, row tile, column tile): one 64-bit division per workgroup, then incremental
-    int cg = (int)(t_begin % CG), rg = (int)((t_begin / CG) % RG), nb = (int)(t_begin / ((long long)CG * RG));
+    const BxLane bl = bx_lane(plane_g, kB3Plane);
+    // rows from vertical range id jf on, columns from the column tile's first horizontal id
+    auto win_src = [&](int nb, int jf, int cg) { return Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)jf * NHR + tiles[256 + 2 * cg]) * kBxCo; };
+    // tile -> (frame, column tile, row tile), ROW tile fastest (a column strip top to bottom): one 64-bit division per workgroup, then incremental
+    int rg = (int)(t_begin % RG), cg = (int)((t_begin / RG) % CG), nb = (int)(t_begin / ((long long)CG * RG));
     f4 wbuf[kWinRegs];                                                          // (a slice without tiles still writes its — zero — partials below)
+    [[maybe_unused]] int pj1 = 0;
     if constexpr (PF) {
         if (t_begin < t_end) {
-            bx_win_load(wbuf, bl, win_src(nb, rg, cg), NHR, tiles[4 * rg + 3], tiles[256 + 2 * cg + 1]);     // the first window: the only latency exposed
-            bx_win_store(wnd, wbuf, bl, tiles[4 * rg + 3], tiles[256 + 2 * cg + 1]);
+            bx_win_load(wbuf, bl, win_src(nb, tiles[4 * rg + 2], cg), NHR, tiles[4 * rg + 3], tiles[256 + 2 * cg + 1]);     // the first window: the only latency exposed
+            bx3_store_rows(wnd, wbuf, bl, tiles[4 * rg + 2], tiles[4 * rg + 3], tiles[256 + 2 * cg + 1]);
         }
     }
 #pragma unroll 1
     for (long long tl = t_begin; tl < t_end; ++tl) {
         const int sy0 = tiles[4 * rg], nrow = tiles[4 * rg + 1], j0 = tiles[4 * rg + 2], nj = tiles[4 * rg + 3];
         const int sx0 = kB2TC * cg, i0 = tiles[256 + 2 * cg], ni = tiles[256 + 2 * cg + 1];
-        int cgn = cg + 1, rgn = rg, nbn = nb;                                   // the next tile
-        if (cgn == CG) { cgn = 0; if (++rgn == RG) { rgn = 0; ++nbn; } }
-        const int njn = tiles[4 * rgn + 3], nin = tiles[256 + 2 * cgn + 1];
+        int rgn = rg + 1, cgn = cg, nbn = nb;                                   // the next tile: one row tile down, or the top of the next strip
+        if (rgn == RG) { rgn = 0; if (++cgn == CG) { cgn = 0; ++nbn; } }
+        const int j0n = tiles[4 * rgn + 2], nin = tiles[256 + 2 * cgn + 1];
+        // rows of the next window the ring does not hold yet: all of them at the top of a strip, else those below this tile's last row
+        const int jfn = rgn ? max(j0n, j0 + nj) : j0n;
+        const int njn = j0n + tiles[4 * rgn + 3] - jfn;                          // rows to fetch (<= 15)
         // PF: the next tile's window is fetched two rows per k-step, each pair issued BEHIND that k-step's spike loads (in-order vector-memory counter: see
         // bx_win_load_rows)
         const bool pf_next = PF && tl + 1 < t_end;
-        const unsigned short* const wn = win_src(nbn, rgn, cgn);
-        s16x8 xa[NT], xb[NT];
-        load_x(xa, nb, sy0, nrow, sx0, 0);                                      // in flight while the window is staged
+        const unsigned short* const wn = win_src(nbn, jfn, cgn);
+        // the spike fragments come straight from L2, TWO k-steps ahead of their MFMAs (three rotating buffers): one k-step = 12 NT MFMAs = 400 - 800 cycles
+        // is shorter than the L2 latency, at a distance of one every k-step waited for its load
+        // (NT = 4: the third buffer spills, distance 1 measured faster — 0.81 vs 1.00 ms on deconv2, profiles/r04/bench_box_bwd_v12.log)
+        constexpr int PD = NT <= 2 ? 2 : 1, XB = PD + 1;
+        s16x8 xq[XB][NT];
+        load_x(xq[0], nb, sy0, nrow, sx0, 0);                                   // in flight while the window is staged
+        if constexpr (PD > 1) load_x(xq[1], nb, sy0, nrow, sx0, 1);
         if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- this lane's read addresses in two halves: rowp[row][quad] = byte offset of the window row | swizzle bit in bit 4, colp[half * 2 + rd][quad] = byte
@@ -557,25 +592,28 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         for (int u = 0; u < NQ; ++u) {
 #pragma unroll
             for (int r = 0; r < kB2TR; ++r) {
-                const int jv = real[u] ? vmap[min(sy0 + min(r, nrow - 1), h - 1) * 5 + kyq[u]] : 0;
-                const int rw = jv - j0;
+                const int vi = min(sy0 + min(r, nrow - 1), h - 1) * 5 + kyq[u];
+                const int jv = real[u] ? (maps_in_lds ? vm_s[vi] : vmap[vi]) : 0;
+                const int rw = jv & (kB3WR - 1);                                // ring slot
                 rowp[r][u] = jv ? (rw * (kB2WC * 16) | (((rw >> 1) & 1) << 4)) : -1;
             }
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
-                const int iv = real[u] ? hmap[min(sx0 + 16 * (jx >> 1) + 8 * oct + 4 * (jx & 1) + (L >> 2), w - 1) * 5 + kxq[u]] : 0;
+                const int hi2 = min(sx0 + 16 * (jx >> 1) + 8 * oct + 4 * (jx & 1) + (L >> 2), w - 1) * 5 + kxq[u];
+                const int iv = real[u] ? (maps_in_lds ? hm_s[hi2] : hmap[hi2]) : 0;
                 colp[jx][u] = iv ? (iv - i0) * 16 : -1;
             }
         }
         auto addr_of = [&](int r, int jx, int u) {
             const int rp = rowp[r][u], cp = colp[jx][u];
             const int a = (rp & ~16) + (cp ^ (rp & 16));
-            return ((rp | cp) < 0 ? kB2Zero : a) + 8 * coq;
+            return ((rp | cp) < 0 ? kB3Zero : a) + 8 * coq;
         };
         if constexpr (!PF) {
             __syncthreads();                                                    // the previous tile's readers of the window are done
-            bx_win_load(wbuf, bl, win_src(nb, rg, cg), NHR, nj, ni);
-            bx_win_store(wnd, wbuf, bl, nj, ni);
+            const int jf = (rg && tl > t_begin) ? max(j0, pj1) : j0;             // (pj1: one past the previous tile's last row — same strip when rg > 0)
+            bx_win_load(wbuf, bl, win_src(nb, jf, cg), NHR, j0 + nj - jf, ni);
+            bx3_store_rows(wnd, wbuf, bl, jf, j0 + nj - jf, ni);
         }
         if constexpr (PF) lds_barrier(); else __syncthreads();                  // this tile's window (PF: stored at the end of the previous tile) is visible
         // k-step s = (row s >> 1, half s & 1): its A fragments (2 quads x 3 planes x 2 transpose reads) are fetched one k-step AHEAD of its MFMAs
@@ -588,8 +626,8 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
             for (int u = 0; u < NQ; ++u)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    lo[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB2Plane + a0[u]));
-                    hi[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB2Plane + a1[u]));
+                    lo[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB3Plane + a0[u]));
+                    hi[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB3Plane + a1[u]));
                 }
         };
         auto mma = [&](s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3], s16x8 (&xf)[NT]) {
@@ -604,25 +642,37 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         };
         s16x4 la[NQ][3], ha[NQ][3], lb[NQ][3], hb[NQ][3];
         read_a(0, la, ha);
+        if constexpr (PD > 1) {
 #pragma unroll
-        for (int sidx = 0; sidx < 2 * kB2TR; sidx += 2) {                       // two k-steps per trip: the buffers alternate statically
-            read_a(sidx + 1, lb, hb);
-            load_x(xb, nb, sy0, nrow, sx0, sidx + 1);
-            if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 1), 2 * (sidx + 1) + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(la, ha, xa);
-            if (sidx + 2 < 2 * kB2TR) {
-                read_a(sidx + 2, la, ha);
-                load_x(xa, nb, sy0, nrow, sx0, sidx + 2);
-                if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 2), 2 * (sidx + 2) + 2);
+            for (int sidx = 0; sidx < 2 * kB2TR; ++sidx) {                      // (the buffers rotate statically)
+                if (sidx + 1 < 2 * kB2TR) { if (sidx & 1) read_a(sidx + 1, la, ha); else read_a(sidx + 1, lb, hb); }
+                if (sidx + PD < 2 * kB2TR) load_x(xq[(sidx + PD) % XB], nb, sy0, nrow, sx0, sidx + PD);
+                if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 1), 2 * (sidx + 1) + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sidx & 1) mma(lb, hb, xq[sidx % XB]); else mma(la, ha, xq[sidx % XB]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mma(lb, hb, xb);
+        } else {
+#pragma unroll
+            for (int sidx = 0; sidx < 2 * kB2TR; sidx += 2) {                   // two k-steps per trip: the two buffers alternate statically
+                read_a(sidx + 1, lb, hb);
+                load_x(xq[1], nb, sy0, nrow, sx0, sidx + 1);
+                if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 1), 2 * (sidx + 1) + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(la, ha, xq[0]);
+                if (sidx + 2 < 2 * kB2TR) {
+                    read_a(sidx + 2, la, ha);
+                    load_x(xq[0], nb, sy0, nrow, sx0, sidx + 2);
+                    if (pf_next) bx_win_load_rows(wbuf, bl, wn, NHR, njn, nin, 2 * (sidx + 2), 2 * (sidx + 2) + 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(lb, hb, xq[1]);
+            }
         }
         if constexpr (PF) {
             lds_barrier();                                                      // every reader of this tile's window is done
-            if (tl + 1 < t_end) bx_win_store(wnd, wbuf, bl, njn, nin);
+            if (tl + 1 < t_end) bx3_store_rows(wnd, wbuf, bl, jfn, njn, nin);
         }
+        pj1 = j0 + nj;
         cg = cgn; rg = rgn; nb = nbn;
     }
     // ---- partials: D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31], m = 8 (tap - 4 quad) + channel  ->  ws[slice][co][tap][ci]
