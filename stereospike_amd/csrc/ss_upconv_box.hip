@@ -26,6 +26,15 @@ namespace {
 #ifndef SS_BX_ABLATE
 #define SS_BX_ABLATE 0                        // development aid (make variant DEFS=-DSS_BX_ABLATE=mask): data-gradient kernel without 1 window traffic,
 #endif                                       // 2 weight stream, 4 MFMAs, 8 per-stage barriers — wrong results, timing only (profiles/r04/box_dgrad_ablations.log)
+#ifndef SS_BX_TRACE
+#define SS_BX_TRACE 0                         // development aid: thread 0 of workgroup 0 stamps s_memtime over its first items of the data-gradient kernel (ss_debug_box_trace)
+#endif
+#if SS_BX_TRACE
+__device__ unsigned long long bx_trace[64][16];
+#define BX_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && titem < 64) bx_trace[titem][slot] = clock64(); } while (0)
+#else
+#define BX_STAMP(slot) do { } while (0)
+#endif
 constexpr int kBxCo = 8;                       // output channels per chunk of the plane layout (= half a k-step: a k-step is 2 taps x 8 channels)
 
 __device__ __forceinline__ void bx_split3(const float (&v)[8], u16x8& h, u16x8& m, u16x8& l)
@@ -326,8 +335,10 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
         for (int u = 0; u < kF4; ++u) *reinterpret_cast<f4*>(bst + (threadIdx.x + kB2Threads * u) * 16) = st[u];
     }
     int par = 0;                                                                // half of the stage buffer that holds stage 0 of the current item
+    [[maybe_unused]] int titem = 0;
 #pragma unroll 1
     for (long long item = it_begin; item < it_end; ++item) {
+        BX_STAMP(0);
         const bool has_next = item + 1 < it_end;
         Item nxt = cur;
         if (has_next) advance(nxt);
@@ -363,7 +374,9 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
         }
         const unsigned char* const bsrc = wsrc(cur);
         const unsigned char* const bnxt = wsrc(nxt);
+        BX_STAMP(1);
         lds_barrier();                                                          // stage 0 and this item's window (stored at the end of the previous item) are visible
+        BX_STAMP(2);
                                                                                 // (LDS-only barriers in the item loop: __syncthreads() would drain the prefetches, ss_common.hpp)
 #pragma unroll
         for (int sg = 0; sg < kNS; ++sg) {
@@ -412,6 +425,9 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                         }
                 }
             }
+#if SS_BX_TRACE
+            if (sg == 0 || sg == kNS - 1) { if (acc[0][0][0] == 12345.f && acc[KPS - 1][NT - 1][3] == 3.f) bx_trace[63][15] = 1; BX_STAMP(sg == 0 ? 3 : 5); }
+#endif
             if (more || has_next) {
                 unsigned char* const dst = bst + (((sg + 1) & 1) ^ par) * kStage;
 #pragma unroll
@@ -421,10 +437,16 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                 }
                 if (more && !(SS_BX_ABLATE & 8)) lds_barrier();
             }
+#if SS_BX_TRACE
+            if (sg == 0) BX_STAMP(4);
+#endif
         }
         par ^= 1;
+        BX_STAMP(6);
         lds_barrier();                                                          // every reader of this item's window and stages is done
+        BX_STAMP(7);
         if (has_next && !(SS_BX_ABLATE & 1)) bx_win_store(wnd, wbuf, bl, nxt.nj, nxt.ni);
+        BX_STAMP(8);
         if (cur.c == NCH - 1) {
             // ---- tile epilogue.  The product is taken TRANSPOSED (weights as the A operand): D[ci = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][pixel = lane & 31] —
             //      a lane holds 4 consecutive input channels of ONE pixel per register quad: 4 NT 16-byte stores instead of 16 NT 4-byte ones (what the
@@ -449,6 +471,10 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                     }
             }
         }
+#if SS_BX_TRACE
+        if (blockIdx.x == 0 && threadIdx.x == 0 && titem < 64) bx_trace[titem][9] = clock64(), bx_trace[titem][10] = (unsigned long long)cur.c;
+        ++titem;
+#endif
         cur = nxt;
     }
 }
@@ -707,6 +733,13 @@ __global__ __launch_bounds__(kBlock) void upconv_box_wgrad_reduce_kernel(const f
 }  // namespace
 
 extern "C" {
+
+#if SS_BX_TRACE
+int ss_debug_box_trace(unsigned long long* host_dst)
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(bx_trace), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+#endif
 
 long long ss_upconv_box_elems(long long NB, int Cout, int NVR, int NHR)
 {
