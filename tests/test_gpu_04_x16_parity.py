@@ -98,6 +98,30 @@ def test_pinned_parity_16bit_activations(dt, name, T):
     check(f'pinned_x16_{"bf16" if dt == torch.bfloat16 else "f16"}_T{T}_{name}', rep, margin=64 * u, tensor_bar=8 * U_BWD, plif_bar=U_BWD, flip_frac=u)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+def test_pinned_parity_16bit_activations_on_the_fp32_kernels(dt):
+    """EngineConfig.X16_OWN_CONVS (round 4; off by default — it costs a third of the mode's rate, profiles/r04/x16_own_convs_ab.md): the
+    encoder / bottleneck synapses of the 16-bit modes on the fp32 mode's own kernels — fp32 master weights, exact products, fp32 weight gradients; only what
+    is stored between layers is narrowed.  The oracle narrows accordingly (narrowing_points(own_convs=True)).  What is left in the backward is the 16-bit
+    storage of the activation gradients: every weight tensor within 1e-2 (2.6 u_b) relative L2 of the oracle (measured 7.9e-3 bf16 / 3.7e-3 fp16; the
+    autocast path: 1.7e-2 / 1.1e-2), and the forward disagrees on <= 4 neurons per layer (measured: 1 in the whole network; the autocast path 949 / 234)."""
+    H, W = 64, 80
+    orc, net = pair('StereoSpike', H, W)
+    x = synth_input(2, 5, 4, 81, H, W, lam=0.08)
+    gt = synth_label(2, 82, H, W)
+    with net.configured(X16_OWN_CONVS=True):
+        scale = _largest_finite_loss_scale(net, x, gt) if dt == torch.float16 else 1.0
+        rep = pinned_parity(orc, net, x, gt, amp_dtype=dt, loss_scale=scale, x16_own_convs=True)
+        plan = net.plan()
+    rep['loss_scale'] = scale
+    assert_x16_kernels(rep['launch_tags'])
+    assert plan['conv1']['synapse_fwd'].startswith('spike_conv_fwd3_mfma') and plan['conv3']['synapse_fwd'].endswith('exact_bf16x3_gemm') \
+        and plan['bottom']['synapse_fwd'] == 'dense_conv_s1_fwd6_mfma', plan
+    u = U[dt]
+    check(f'pinned_x16own_{"bf16" if dt == torch.bfloat16 else "f16"}_T5_StereoSpike', rep, margin=64 * u, tensor_bar=1e-2, plif_bar=U_BWD, flip_frac=u)
+    assert sum(v['flips'] for v in rep['layers'].values()) <= 4 * len(rep['layers']), rep['layers']
+
+
 def test_pinned_parity_config2_monocular_plif_T1_bf16():
     """BASELINE config 2's network and mode: monocular PLIF, T = 1, bf16 activations, B = 8."""
     H, W = 64, 80
