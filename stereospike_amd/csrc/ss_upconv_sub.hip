@@ -36,6 +36,9 @@ namespace {
 #ifndef SS_SB_WGS
 #define SS_SB_WGS 3                           // workgroups per CU of the packed-input kernel: 3 (168 registers, 44 B of scratch) measured 12 % faster than 2
 #endif                                       // (profiles/r04/bench_sub_fwd_v4*.log); the dense-input fallback keeps 2 (its staging needs the registers)
+#ifndef SS_SB_NT_STORE
+#define SS_SB_NT_STORE 0                      // A/B: non-temporal 16-byte stores in the epilogue (profiles/r04/bench_sub_fwd_v9.log)
+#endif
 #ifndef SS_SB_TRACE
 #define SS_SB_TRACE 0                         // development aid: wavefront 0 of workgroup 0 records s_memtime stamps of its first (cot, g) iterations (ss_debug_sub_trace)
 #endif
@@ -357,7 +360,14 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                                 float* const op = ob + (long long)vrec[3 + ri] * W * COUT;
 #pragma unroll
                                 for (int q = 0; q < 4; ++q)
-                                    *reinterpret_cast<f4*>(op + 8 * q) = (f4){acc[b2][4 * q] * fin, acc[b2][4 * q + 1] * fin, acc[b2][4 * q + 2] * fin, acc[b2][4 * q + 3] * fin};
+                                {
+                                    const f4 v = (f4){acc[b2][4 * q] * fin, acc[b2][4 * q + 1] * fin, acc[b2][4 * q + 2] * fin, acc[b2][4 * q + 3] * fin};
+#if SS_SB_NT_STORE
+                                    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(op + 8 * q));
+#else
+                                    *reinterpret_cast<f4*>(op + 8 * q) = v;
+#endif
+                                }
                             }
                         }
                     }
