@@ -616,8 +616,12 @@ int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, con
  *                                      last word of the record: the class's number of runs
  *   hblk [NHB][hrec_ints]            : the same for columns (block_cols, window_cols)
  * Every output row belongs to exactly one row block, every column to one column block; a (row block, column block) pair is one tile.
- *   order [NVB * NHB]                : the (row block * NHB + column block) pairs sorted by cost, most expensive first (the kernel's workgroups draw tiles
- *                                      (pair order[t / NB], frame t % NB) from `counter`, one device word the entry point zeroes on the launch stream)
+ *   tblk [NTB][trec_ints]            : TALL row blocks (<= 64 rows, <= 68 distinct source rows; same fields) — paired with the column blocks of <= 8 columns,
+ *                                      the four wavefronts of a tile stacked vertically (ss_upconv_sub_tall_geometry; NTB may be 0)
+ *   order [NORD]                     : the tiles of a frame, most expensive first: pair = row block * NHB + column block for a normal tile,
+ *                                      (NVB + tall row block) * NHB + column block for a tall one; every output pixel in exactly one tile.  The kernel's
+ *                                      workgroups draw tiles (pair order[t / NB], frame t % NB) from `counter`, one device word the entry point zeroes on the
+ *                                      launch stream
  *   ss_upconv_sub_geometry : block_rows 16, block_cols 32, window_rows 20, window_cols 36, record sizes 88 / 168; returns the runs per class (3).
  *   ss_upconv_sub_prep_f32 : weight [C_out][C_in][5][5] fp32 -> wm (ss_upconv_sub_wm_elems bf16 elements, 16-byte aligned): the merged taps, added in fp32
  *                            (ky outer, kx inner, from +0), exactly split into three bf16 terms, in MFMA fragment order.  Once per weight update.
@@ -627,11 +631,13 @@ int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, con
  * 9 C_in products).  Deterministic; not bit-identical to ss_upconv_fused_fwd (different association of the same sum).
  */
 int ss_upconv_sub_geometry(int* block_rows, int* block_cols, int* window_rows, int* window_cols, int* vrec_ints, int* hrec_ints);
+int ss_upconv_sub_tall_geometry(int* block_rows, int* window_rows, int* trec_ints, int* narrow_cols);   /* returns the window's capacity in pixels */
 int ss_upconv_sub_supported(int Cin, int Cout, int k);
 long long ss_upconv_sub_wm_elems(int Cin, int Cout, int NVC, int NHC);
 int ss_upconv_sub_prep_f32(const float* weight, const int* vcls, const int* hcls, void* wm, int Cin, int Cout, int NVC, int NHC, void* stream);
 int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* order, unsigned int* counter,
-                          float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, void* stream);
+                          float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC,
+                          const int* tblk, int NTB, int NORD, void* stream);
 
 #ifdef __cplusplus
 }

@@ -176,7 +176,9 @@ def lib():
     L.ss_upconv_sub_wm_elems.restype = i64
     L.ss_upconv_sub_prep_f32.argtypes = [p, p, p, p, i32, i32, i32, i32, p]
     L.ss_upconv_sub_prep_f32.restype = i32
-    L.ss_upconv_sub_fwd_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_sub_fwd_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, i32, i32, p]
+    L.ss_upconv_sub_tall_geometry.argtypes = [C.POINTER(C.c_int)] * 4
+    L.ss_upconv_sub_tall_geometry.restype = i32
     L.ss_upconv_sub_fwd_f32.restype = i32
     L.ss_upconv_box_window.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ss_upconv_box_window.restype = i32
@@ -233,7 +235,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
            'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
            'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
-           'ss_upconv_sub_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32',
+           'ss_upconv_sub_geometry', 'ss_upconv_sub_tall_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32',
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_wide_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
@@ -619,7 +621,10 @@ def upconv_sub_geometry():
     """dict(block_rows, block_cols, window_rows, window_cols, vrec_ints, hrec_ints, runs) of the sub-pixel forward kernel (ss_upconv_sub_geometry)."""
     v = [C.c_int(0) for _ in range(6)]
     runs = lib().ss_upconv_sub_geometry(*[C.byref(a) for a in v])
-    return dict(zip(('block_rows', 'block_cols', 'window_rows', 'window_cols', 'vrec_ints', 'hrec_ints'), (int(a.value) for a in v)), runs=int(runs))
+    t = [C.c_int(0) for _ in range(4)]
+    cap = lib().ss_upconv_sub_tall_geometry(*[C.byref(a) for a in t])
+    return dict(zip(('block_rows', 'block_cols', 'window_rows', 'window_cols', 'vrec_ints', 'hrec_ints'), (int(a.value) for a in v)), runs=int(runs),
+                tall_rows=int(t[0].value), tall_window_rows=int(t[1].value), trec_ints=int(t[2].value), narrow_cols=int(t[3].value), window_pixels=int(cap))
 
 
 def upconv_sub_supported(Cin, Cout, k):
@@ -650,8 +655,9 @@ def upconv_sub_fwd(x, x_packed, wm, st, out, NB, Cin, Cout, h, w):
                                          _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
                                          _x16(wm, 'wm', int(lib().ss_upconv_sub_wm_elems(int(Cin), int(Cout), int(st['NVC']), int(st['NHC']))), torch.bfloat16),
                                          _i32(st['vblk'], 'vblk', st['NVB'] * st['vrec_ints']), _i32(st['hblk'], 'hblk', st['NHB'] * st['hrec_ints']),
-                                         _i32(st['order'], 'order', st['NVB'] * st['NHB']), _i32(counter, 'counter', 1),
-                                         _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W, st['NVB'], st['NHB'], st['NHC'], _stream(out))
+                                         _i32(st['order'], 'order', st['NORD']), _i32(counter, 'counter', 1),
+                                         _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W, st['NVB'], st['NHB'], st['NHC'],
+                                         _i32(st['tblk'], 'tblk', st['NTB'] * st['trec_ints']) if st['NTB'] else None, st['NTB'], st['NORD'], _stream(out))
     _check(rc, 'ss_upconv_sub_fwd_f32')
 
 

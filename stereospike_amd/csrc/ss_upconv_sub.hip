@@ -55,6 +55,9 @@ constexpr int kSbThreads = 256;
 constexpr int kSbBR = 16, kSbBC = 32;           // output rows / columns of a tile (4 M-blocks of 4 rows per wavefront; 4 wavefronts of 8 columns)
 constexpr int kSbWR = 20, kSbWC = 36;           // distinct source rows / columns a block may read (the on-chip window)
 constexpr int kSbVRec = 88, kSbHRec = 168;      // ints per row-block / column-block record: cls, n_out, n_src, out[BR | BC], src[WR | WC], slot[BR | BC][3]
+// TALL tiles: a column block of <= 8 columns (the fragments of the irregular column classes, the last piece of a regular one) would keep ONE wavefront busy for
+// the time of a whole tile; it is paired with tall row blocks of <= 64 rows instead, the four wavefronts stacked vertically (16 rows each)
+constexpr int kSbTR = 64, kSbTWR = 68, kSbTRec = 328;                          // rows, distinct source rows, ints per tall row-block record (same fields)
 constexpr int kSbPix = 32;                      // window bytes per source pixel: 16 input channels (one k-step) as bf16
 constexpr int kSbStage = 9 * 1024;              // weight stage: the 3 merged taps of one run row x 3 split terms, 1 KB fragments (32 output channels)
 constexpr int kSbWnd = kSbWR * kSbWC * kSbPix;  // 23040 B
@@ -107,19 +110,19 @@ __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __
 // each weight fragment is read once per wavefront and feeds all 4 M-blocks: 7 KB of LDS reads per 12 MFMAs.
 template <bool PACKED>
 __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wm,
-                                                                       const int* __restrict__ vblk, const int* __restrict__ hblk,
+                                                                       const int* __restrict__ vblk, const int* __restrict__ hblk, const int* __restrict__ tblk,
                                                                        const int* __restrict__ order, unsigned* __restrict__ counter,
                                                                        float* __restrict__ out, int NB, int h, int w, int H, int W, int CIN, int COUT,
-                                                                       int NVB, int NHB, int NHC)
+                                                                       int NVB, int NHB, int NHC, int NORD)
 {
     __shared__ __attribute__((aligned(16))) unsigned char wnd[kSbWnd];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kSbStage];
-    __shared__ int vrec[kSbVRec], hrec[kSbHRec];
+    __shared__ int vrec[kSbTRec], hrec[kSbHRec];
     __shared__ long long s_next;
     const int lane = threadIdx.x & 63, m = lane & 31, half = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = CIN / 16, NCOT = COUT / 32;
-    const long long n_tiles = (long long)NB * NVB * NHB;
+    const long long n_tiles = (long long)NB * NORD;                              // NORD pairs: (row block, wide column block) and (tall row block, narrow column block)
     [[maybe_unused]] int titer = 0;
     [[maybe_unused]] int ttile = 0;
     constexpr int kWItems = PACKED ? 3 : 6;                                     // window items per thread: PACKED (pixel) = one 32-bit word of 16 codes;
@@ -138,32 +141,37 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
         if (tile >= n_tiles) break;
         SB_STAMP2(0);
         const int pair = order[tile / NB], nb = (int)(tile % NB);
-        const int vb = pair / NHB, hb = pair - vb * NHB;
+        const bool tall = pair >= NVB * NHB;                                    // pairs behind the normal ones: tall row block * NHB + column block
+        const int vb = (tall ? pair - NVB * NHB : pair) / NHB, hb = pair - (pair / NHB) * NHB;
         if (threadIdx.x == 0) drawn = (long long)atomicAdd(counter, 1u) + gridDim.x;
-        for (int i = threadIdx.x; i < kSbVRec; i += kSbThreads) vrec[i] = vblk[vb * kSbVRec + i];
+        const int* const vsrc = tall ? tblk + vb * kSbTRec : vblk + vb * kSbVRec;
+        const int vlen = tall ? kSbTRec : kSbVRec, vBR = tall ? kSbTR : kSbBR, vWR = tall ? kSbTWR : kSbWR;
+        for (int i = threadIdx.x; i < vlen; i += kSbThreads) vrec[i] = vsrc[i];
         for (int i = threadIdx.x; i < kSbHRec; i += kSbThreads) hrec[i] = hblk[hb * kSbHRec + i];
         __syncthreads();
         SB_STAMP2(1);
         const int cv = vrec[0], nv = vrec[1], nsv = vrec[2], ch = hrec[0], nh = hrec[1], nsh = hrec[2];
-        const int ngv = vrec[kSbVRec - 1], ngh = hrec[kSbHRec - 1];                   // runs per class (copied into the records' last word by the host)
+        const int ngv = vrec[vlen - 1], ngh = hrec[kSbHRec - 1];                      // runs per class (copied into the records' last word by the host)
         const int nblk = (nv + 3) >> 2;
-        const bool active = 8 * wv < nh;                                        // wave-uniform: this wavefront has columns in the tile
+        const int row0 = tall ? 16 * wv : 0, col0 = tall ? 0 : 8 * wv;           // this wavefront's first row / column slot of the tile
+        const int pitch = tall ? nsh : kSbWC;                                   // window pixels per source row
+        const bool active = tall ? row0 < nv : col0 < nh;                       // wave-uniform: this wavefront has pixels in the tile
         // this lane's pixel in M-block b: row 4 b + (m >> 3), column 8 wv + (m & 7); byte offsets of its source row / column per run
         int rs[4][3], cs[3];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int ri = min(4 * b + (m >> 3), nv - 1);
+            const int ri = min(row0 + 4 * b + (m >> 3), nv - 1);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 // the two 16-byte halves of a pixel (channels 0-7 | 8-15) swap places on odd window rows: the 16 lanes of a ds_read_b128 group are two lattice
                 // rows x 8 columns — without the swap both rows hit the even 16-byte bank groups (2-way conflict on every A read: SQ_LDS_BANK_CONFLICT
                 // 5.3e7 cycles against 4.4e7 active, profiles/r04/pmc_sub_v1.txt)
-                const int sl = vrec[3 + kSbBR + kSbWR + 3 * ri + r];
-                rs[b][r] = sl * (kSbWC * kSbPix) + 16 * ((sl & 1) ^ half);
+                const int sl = vrec[3 + vBR + vWR + 3 * ri + r];
+                rs[b][r] = sl * (pitch * kSbPix) + 16 * ((sl & 1) ^ half);
             }
         }
         {
-            const int cj = min(8 * wv + (m & 7), nh - 1);
+            const int cj = min(col0 + (m & 7), nh - 1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) cs[c] = hrec[3 + kSbBC + kSbWC + 3 * cj + c] * kSbPix;
         }
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
             xoff[u] = 0u; loff[u] = -1;
             if (pix < npix) {
                 const int wy = pix / nsh, wx = pix - wy * nsh;
-                xoff[u] = (unsigned)(((((long long)nb * h + vrec[3 + kSbBR + wy]) * w) + hrec[3 + kSbBC + wx]) * CIN + (PACKED ? 0 : 8 * (it & 1)));
-                loff[u] = (wy * kSbWC + wx) * kSbPix + (PACKED ? 16 * (wy & 1) : 16 * ((it & 1) ^ (wy & 1)));      // (PACKED: where channels 0-7 go)
+                xoff[u] = (unsigned)(((((long long)nb * h + vrec[3 + vBR + wy]) * w) + hrec[3 + kSbBC + wx]) * CIN + (PACKED ? 0 : 8 * (it & 1)));
+                loff[u] = (wy * pitch + wx) * kSbPix + (PACKED ? 16 * (wy & 1) : 16 * ((it & 1) ^ (wy & 1)));      // (PACKED: where channels 0-7 go)
             }
         }
         auto win_issue = [&](int g) {
@@ -350,12 +358,12 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                 //      32-byte pieces of a pixel's 128-byte line.  The sum carries the sign of the last group.
                 if (active) {
                     const float fin = ((G - 1) & 1) ? -1.f : 1.f;
-                    const int cj = 8 * wv + (m & 7);
+                    const int cj = col0 + (m & 7);
                     if (cj < nh) {
                         float* const ob = out + ((long long)nb * H * W + hrec[3 + cj]) * COUT + 32 * cot + 4 * half;
 #pragma unroll
                         for (int b2 = 0; b2 < (FULL ? 4 : 1); ++b2) {
-                            const int ri = 4 * b2 + (m >> 3);
+                            const int ri = row0 + 4 * b2 + (m >> 3);
                             if (ri < nv) {
                                 float* const op = ob + (long long)vrec[3 + ri] * W * COUT;
 #pragma unroll
@@ -423,6 +431,16 @@ int ss_upconv_sub_geometry(int* block_rows, int* block_cols, int* window_rows, i
     return 3;                                  /* runs per class */
 }
 
+/* the tall row blocks paired with column blocks of <= narrow_cols columns: rows, distinct source rows, ints per record; window pixels a tile may hold */
+int ss_upconv_sub_tall_geometry(int* block_rows, int* window_rows, int* trec_ints, int* narrow_cols)
+{
+    if (block_rows) *block_rows = kSbTR;
+    if (window_rows) *window_rows = kSbTWR;
+    if (trec_ints) *trec_ints = kSbTRec;
+    if (narrow_cols) *narrow_cols = 8;
+    return kSbWR * kSbWC;
+}
+
 int ss_upconv_sub_supported(int Cin, int Cout, int k)
 {
     return k == 5 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 32 == 0;
@@ -444,23 +462,24 @@ int ss_upconv_sub_prep_f32(const float* weight, const int* vcls, const int* hcls
 }
 
 int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* order, unsigned int* counter,
-                          float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, void* stream)
+                          float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, const int* tblk, int NTB, int NORD, void* stream)
 {
-    if ((!x && !x_packed) || !wm || !vblk || !hblk || !order || !counter || !out || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || NVB < 1 || NHB < 1 || NHC < 1)
+    if ((!x && !x_packed) || !wm || !vblk || !hblk || !order || !counter || !out || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || NVB < 1 || NHB < 1 || NHC < 1
+        || NORD < 1 || NTB < 0 || (NTB > 0 && !tblk) || NORD > (NVB + NTB) * NHB)
         return SS_EINVAL;
     if (!ss_upconv_sub_supported(Cin, Cout, 5) || !aligned16(out) || !aligned16(wm) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
-    if (NB * NVB * (long long)NHB > 0x7fffffffLL || NB * h * (long long)w * Cin > 0xffffffffLL) return SS_EINVAL;
+    if (NB * (long long)NORD > 0x7fffffffLL || NB * h * (long long)w * Cin > 0xffffffffLL) return SS_EINVAL;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
-    const long long n_tiles = NB * NVB * (long long)NHB;
+    const long long n_tiles = NB * (long long)NORD;
     const long long wgs = (long long)(x_packed ? SS_SB_WGS : 2) * cus;
     const unsigned grid = (unsigned)(n_tiles < wgs ? n_tiles : wgs);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess) return SS_ELAUNCH;       // the tile counter of this launch
     if (x_packed) hipLaunchKernelGGL((upconv_sub_fwd_kernel<true>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x_packed),
-                                     static_cast<const unsigned short*>(wm), vblk, hblk, order, counter, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
+                                     static_cast<const unsigned short*>(wm), vblk, hblk, tblk ? tblk : vblk, order, counter, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC, NORD);
     else hipLaunchKernelGGL((upconv_sub_fwd_kernel<false>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x),
-                            static_cast<const unsigned short*>(wm), vblk, hblk, order, counter, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC);
+                            static_cast<const unsigned short*>(wm), vblk, hblk, tblk ? tblk : vblk, order, counter, out, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC, NORD);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -758,22 +758,32 @@ def register_sub_tables(tables, host_tables, H, W):
     when the geometry has more than 3 runs per window (the stage then keeps the projected form)."""
     src_y, src_x = host_tables[0].tolist(), host_tables[3].tolist()
     dev = tables[0].device
-    geo = _lib.upconv_sub_geometry() if dev.type == 'cuda' else dict(block_rows=16, block_cols=32, window_rows=20, window_cols=36, vrec_ints=88, hrec_ints=168, runs=3)
+    geo = _lib.upconv_sub_geometry() if dev.type == 'cuda' else dict(block_rows=16, block_cols=32, window_rows=20, window_cols=36, vrec_ints=88, hrec_ints=168, runs=3,
+                                                                      tall_rows=64, tall_window_rows=68, trec_ints=328, narrow_cols=8, window_pixels=720)
     cv, ch = _axis_classes(src_y, H), _axis_classes(src_x, W)
     st = None
     if cv is not None and ch is not None:
         vblk = _axis_blocks(src_y, cv[0], cv[1], geo['block_rows'], geo['window_rows'], geo['vrec_ints'])
         hblk = _axis_blocks(src_x, ch[0], ch[1], geo['block_cols'], geo['window_cols'], geo['hrec_ints'])
+        # column blocks of <= narrow_cols columns get TALL row blocks (the four wavefronts stacked vertically) when their windows fit
+        tblk = _axis_blocks(src_y, cv[0], cv[1], geo['tall_rows'], geo['tall_window_rows'], geo['trec_ints'])
+        narrow = [i for i, hh in enumerate(hblk) if hh[1] <= geo['narrow_cols']]
+        if not narrow or max(tb[2] for tb in tblk) * max(hblk[i][2] for i in narrow) > geo['window_pixels']:
+            narrow, tblk = [], []
+        NVB, NHB = len(vblk), len(hblk)
+        pairs = [vb * NHB + hb for vb in range(NVB) for hb in range(NHB) if hb not in narrow] + [(NVB + tb) * NHB + hb for tb in range(len(tblk)) for hb in narrow]
 
         def t(a):
             return torch.tensor(a, dtype=torch.int32).reshape(-1).to(dev)
-        # tile order: (row block, column block) pairs by cost — runs x runs x (4 M-blocks | 1) MFMA rounds per wavefront — most expensive first
+
+        # tile order: by cost — runs x runs x (4 M-blocks | 1) MFMA rounds per wavefront — most expensive first
         def cost(pair):
-            v, hh = vblk[pair // len(hblk)], hblk[pair % len(hblk)]
+            v = vblk[pair // NHB] if pair < NVB * NHB else tblk[pair // NHB - NVB]
+            hh = hblk[pair % NHB]
             return v[-1] * hh[-1] * (4 if v[1] > 4 else 1)
-        order = sorted(range(len(vblk) * len(hblk)), key=lambda pr: (-cost(pr), pr))
-        st = dict(vcls=t(cv[1]), hcls=t(ch[1]), vblk=t(vblk), hblk=t(hblk), order=t(order), NVC=len(cv[1]), NHC=len(ch[1]), NVB=len(vblk), NHB=len(hblk),
-                  vrec_ints=geo['vrec_ints'], hrec_ints=geo['hrec_ints'], H=H, W=W)
+        order = sorted(pairs, key=lambda pr: (-cost(pr), pr))
+        st = dict(vcls=t(cv[1]), hcls=t(ch[1]), vblk=t(vblk), hblk=t(hblk), tblk=t(tblk) if tblk else None, order=t(order), NVC=len(cv[1]), NHC=len(ch[1]),
+                  NVB=NVB, NHB=NHB, NTB=len(tblk), NORD=len(order), vrec_ints=geo['vrec_ints'], hrec_ints=geo['hrec_ints'], trec_ints=geo['trec_ints'], H=H, W=W)
     _SUB[id(tables)] = (tables, st, H, W)
     return st
 

@@ -49,7 +49,7 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_upconv_box_dgrad_f32', 'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
                                   # ABI 8
                                   'ss_wgrad_reduce3_f32', 'ss_spike_conv_fwd_wide_supported',
-                                  'ss_upconv_sub_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32'])
+                                  'ss_upconv_sub_geometry', 'ss_upconv_sub_tall_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -97,11 +97,12 @@ def test_argument_validation_without_a_gpu():
     # ABI 8
     assert L.ss_wgrad_reduce3_f32(None, None, 4, 5, 128, 256, None) == -22
     assert L.ss_spike_conv_fwd_wide_supported(128, 256, 5, 2, 2) == 1 and L.ss_spike_conv_fwd_wide_supported(64, 128, 5, 2, 2) == 0
-    assert _lib.upconv_sub_geometry() == dict(block_rows=16, block_cols=32, window_rows=20, window_cols=36, vrec_ints=88, hrec_ints=168, runs=3)
+    assert _lib.upconv_sub_geometry() == dict(block_rows=16, block_cols=32, window_rows=20, window_cols=36, vrec_ints=88, hrec_ints=168, runs=3,
+                                              tall_rows=64, tall_window_rows=68, trec_ints=328, narrow_cols=8, window_pixels=720)
     assert L.ss_upconv_sub_supported(64, 32, 5) == 1 and L.ss_upconv_sub_supported(72, 32, 5) == 0 and L.ss_upconv_sub_supported(64, 32, 3) == 0
     assert L.ss_upconv_sub_wm_elems(64, 32, 5, 5) == 25 * 1 * 4 * 27 * 512
     assert L.ss_upconv_sub_prep_f32(None, None, None, None, 64, 32, 5, 5, None) == -22
-    assert L.ss_upconv_sub_fwd_f32(None, None, None, None, None, None, None, None, 1, 64, 32, 4, 4, 8, 8, 1, 1, 1, None) == -22
+    assert L.ss_upconv_sub_fwd_f32(None, None, None, None, None, None, None, None, 1, 64, 32, 4, 4, 8, 8, 1, 1, 1, None, 0, 1, None) == -22
 
 
 def test_product_fails_loudly_on_cpu_tensors():

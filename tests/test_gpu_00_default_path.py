@@ -77,10 +77,9 @@ def assert_default_plan(plan, full_resolution=False):
     and — deconv1 / deconv2 (EngineConfig.BOX_BWD_CIN), where the box-sum kernels' window holds the geometry — on the box-sum backward."""
     for name, (fwd, bwd) in DEFAULT_PLAN.items():
         assert plan[name]['synapse_fwd'] == fwd and plan[name]['synapse_bwd'] == bwd, (name, plan[name])
-    for lvl in (1, 2):                                                     # round 4: the sub-pixel (merged tap) implicit GEMM on the packed spikes
+    for lvl in (1, 2, 3):                                                  # round 4: the sub-pixel (merged tap) implicit GEMM on the packed spikes
         assert plan[f'deconv{lvl}']['synapse_fwd'] == 'upconv_sub_mfma(packed in)', plan[f'deconv{lvl}']
-    for lvl in (3, 4):
-        assert plan[f'deconv{lvl}']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan[f'deconv{lvl}']
+    assert plan['deconv4']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan['deconv4']
     box = [lvl for lvl in (1, 2, 3, 4) if plan[f'deconv{lvl}']['synapse_bwd'].startswith('box: boxsum+dgrad6_mfma+wgrad3_mfma')]
     # (64x80 frames: deconv1's 32 source columns reach 84 horizontal ranges, more than the on-chip window's 76 — that stage keeps the round-3 fused forms)
     assert set(box) == ({1, 2} if full_resolution else {2}), {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
@@ -98,8 +97,9 @@ def assert_default_kernels(tags, T, penalized=False):
     # packed-only outputs: the 7 encoder / bottleneck edges, the SEW block's inner layer (with its packed skip) and — its prediction head reads packed
     # spikes (fused.PACKED_HEAD) — the two largest decoder stages (deconv2's other consumer, deconv1, reads packed spikes in its fused kernels)
     assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 3, tags      # SEW inner layer, deconv2, deconv1
-    # (round 4: deconv3 writes a packed COPY beside its dense output — its head reads the dense tensor, deconv2's sub-pixel forward the packed one)
-    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 2 and fwd.get('neuron_fwd_train+skip+pkcopy', 0) == 1, tags
+    # (round 4: deconv4 and deconv3 write a packed COPY beside their dense output — the head reads the dense tensor, the next stage's sub-pixel forward
+    #  the packed one; the SEW block's last layer, the bottleneck output, stays dense only)
+    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 1 and fwd.get('neuron_fwd_train+skip+pkcopy', 0) == 2, tags
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
     assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)
@@ -252,7 +252,8 @@ def test_packed_spike_tensors_are_in_effect():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
         assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
-    assert net.deconv4[2].last_packed is None and net.bottleneck[1].sn2.last_packed is None     # dense only
+    assert net.bottleneck[1].sn2.last_packed is None                                            # dense only
+    assert net.deconv4[2].last_packed is not None and any(s[1].stride())                        # dense + packed copy (deconv3's sub-pixel forward reads it)
     # deconv3: dense (its head reads it) + a packed COPY for deconv2's sub-pixel forward / weight gradient (round 4), bit-identical contents
     pk3 = net.deconv3[2].last_packed
     assert pk3 is not None and pk3.dtype == torch.int32 and tuple(s[2].shape) == (2, 128, H // 4, W // 4) and any(s[2].stride())

@@ -382,10 +382,31 @@ def test_upconv_sub_oracle_is_the_reference_formula_and_the_product_tables(NB, C
             assert r[-1] == (kn[b['cls']] > 0).sum()                         # the record's last word: runs of its class
             seen += list(b['out'])
         assert sorted(seen) == list(range(n_out))
-    order = st['order'].numpy()
-    assert sorted(order.tolist()) == list(range(st['NVB'] * st['NHB']))                 # every (row block, column block) pair once, most expensive first
+    # the tall row blocks (<= 64 rows, paired with the column blocks of <= 8 columns) are the oracle's blocks at those limits
+    NVB, NHB, NTB = st['NVB'], st['NHB'], st['NTB']
     vb, hb = st['vblk'].view(-1, 88).numpy(), st['hblk'].view(-1, 168).numpy()
-    costs = [vb[p // st['NHB']][-1] * hb[p % st['NHB']][-1] * (4 if vb[p // st['NHB']][1] > 4 else 1) for p in order]
+    tb = st['tblk'].view(-1, 328).numpy() if NTB else np.zeros((0, 328), np.int32)
+    keys, cls, k0, kn = ns.axis_classes(sy, H)
+    tall = ns.axis_blocks(sy, H, cls, k0, kn, 64, 68)
+    assert NTB in (0, len(tall))
+    for b, r in zip(tall, tb):
+        n, m = len(b['out']), len(b['src'])
+        assert (r[0], r[1], r[2], r[-1]) == (b['cls'], n, m, (kn[b['cls']] > 0).sum()) and np.array_equal(r[3:3 + n], b['out']) and np.array_equal(r[67:67 + m], b['src'])
+        assert np.array_equal(r[135:135 + 3 * n].reshape(n, 3), b['slot'])
+    # the tiles of a frame: every output pixel in exactly one (row block, column block) pair; narrow column blocks meet tall row blocks only; cost order
+    order = st['order'].numpy()
+    assert len(order) == st['NORD'] == len(set(order.tolist()))
+    cover = np.zeros((H, W), np.int32)
+    costs = []
+    for p in order:
+        v = vb[p // NHB] if p < NVB * NHB else tb[p // NHB - NVB]
+        hh = hb[p % NHB]
+        assert (hh[1] <= 8) == (p >= NVB * NHB) or NTB == 0
+        rows, cols = v[3:3 + v[1]], hh[3:3 + hh[1]]
+        cover[np.ix_(rows, cols)] += 1
+        assert v[2] * hh[2] <= 720                                                   # the tile's window fits the 720 pixels held on chip
+        costs.append(v[-1] * hh[-1] * (4 if v[1] > 4 else 1))
+    assert (cover == 1).all()
     assert costs == sorted(costs, reverse=True)
 
 
