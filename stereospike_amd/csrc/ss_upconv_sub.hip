@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __
     }
 }
 
-// A workgroup (4 wavefronts, two workgroups per CU) takes tiles round-robin.  Per tile and per 32-channel slice of C_out the accumulators (4 M-blocks of
+// A workgroup (4 wavefronts; three workgroups per CU on packed input) draws tiles from a counter.  Per tile and per 32-channel slice of C_out the accumulators (4 M-blocks of
 // 32 pixels per wavefront) stay in registers while the kernel walks the C_in / 16 input-channel groups: the group's window — the tile's distinct source
 // rows x columns, 16 channels as bf16 — is staged HBM / L2 -> registers -> LDS (the next group's loads are issued under the current group's last weight
 // stage), the merged weights stream L2 -> registers -> LDS double-buffered in stages of one run row (<= 3 taps x 3 terms = 9 KB, 36 MFMAs per wavefront
