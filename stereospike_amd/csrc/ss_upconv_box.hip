@@ -20,6 +20,7 @@
 //
 // HBM layout of B: [nb][C_out / 8][plane 3][NVR][NHR][8] bf16 — a window row of one 8-channel chunk and plane is contiguous.
 #include "ss_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -795,7 +796,8 @@ int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vma
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* Wf = reinterpret_cast<unsigned short*>(ws);
-    const int NT = Cin % 128 == 0 ? 4 : 2;                                      // 128 input channels per workgroup where there are that many
+    static const int force_nt2 = getenv("SS_BOX_DGRAD_NT2") ? atoi(getenv("SS_BOX_DGRAD_NT2")) : 0;          // A/B only (profiles/r04/box_nt_ab.log)
+    const int NT = (Cin % 128 == 0 && !force_nt2) ? 4 : 2;                      // 128 input channels per workgroup where there are that many
     const long long frag16 = (long long)(Cin / 32) * (Cout / kBxCo) * kB2KS * 3 * 64;
     hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
@@ -814,7 +816,8 @@ static int box_wgrad_plan(int Cin, int Cout, int* NT, int* kinds, int* slices)
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
-    *NT = Cin % 128 == 0 ? 4 : (Cin % 64 == 0 ? 2 : 1);                        // input-channel tiles per kind (= per wavefront)
+    static const int force_nt2 = getenv("SS_BOX_WGRAD_NT2") ? atoi(getenv("SS_BOX_WGRAD_NT2")) : 0;          // A/B only (profiles/r04/box_nt_ab.log)
+    *NT = (Cin % 128 == 0 && !force_nt2) ? 4 : (Cin % 64 == 0 ? 2 : 1);        // input-channel tiles per kind (= per wavefront)
     *kinds = (Cout / kBxCo) * (Cin / (32 * *NT));
     int sl = (2 * cus) / *kinds;                                                // two workgroups per CU
     if (sl < 1) sl = 1;
