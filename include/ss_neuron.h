@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 8
+#define SS_ABI_VERSION 9
 int ss_abi_version(void);
 
 /* Number of floats the caller must provide as `g_k_ws` (8-byte aligned) to the ss_neuron_bwd_* entry points when g_k != NULL.
@@ -365,6 +365,9 @@ long long ss_upconv_box_elems(long long NB, int Cout, int NVR, int NHR);
 int ss_upconv_boxsum_f32(const float* g_out, const int* vr, const int* hr, void* box, long long NB, int Cout, int H, int W, int NVR, int NHR, void* stream);
 int ss_upconv_box_window(int* max_tile_rows, int* max_cols32);   /* returns the most source rows of a row tile (4); the id spans a tile may reach */
 int ss_upconv_box_dgrad_supported(int Cin, int Cout, int k, int max_tile_rows, int max_cols32);
+/* 1 when a map of n_row_tiles row tiles x w source columns x `pixels` = NB*h*w source pixels fits the kernels' on-chip tile tables (<= 64 row tiles,
+   <= 16 column tiles of 32) and 32-bit pixel indices — the launch entry points refuse anything else with SS_EINVAL (ABI 9) */
+int ss_upconv_box_tiles_supported(int n_row_tiles, int w, long long pixels);
 long long ss_upconv_box_dgrad_ws_floats(int Cin, int Cout);
 int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles, const int* tile_cols,
                             float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, void* stream);

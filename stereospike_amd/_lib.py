@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1
@@ -166,6 +166,8 @@ def lib():
     L.ss_upconv_boxsum_f32.restype = i32
     L.ss_upconv_box_dgrad_supported.argtypes = [i32, i32, i32, i32, i32]
     L.ss_upconv_box_dgrad_supported.restype = i32
+    L.ss_upconv_box_tiles_supported.argtypes = [i32, i32, i64]
+    L.ss_upconv_box_tiles_supported.restype = i32
     L.ss_upconv_box_dgrad_ws_floats.argtypes = [i32, i32]
     L.ss_upconv_box_dgrad_ws_floats.restype = i64
     L.ss_upconv_sub_geometry.argtypes = [C.POINTER(C.c_int)] * 6
@@ -241,7 +243,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_conv_s2_dgrad_supported', 'ss_conv_s2_dgrad_ws_floats', 'ss_conv_s2_dgrad_f32',
            'ss_dense_conv_s1_wgrad_supported', 'ss_dense_conv_s1_wgrad_ws_floats', 'ss_dense_conv_s1_wgrad_f32',
            'ss_head_packed_supported', 'ss_head_wgrad_packed_ws_floats', 'ss_head_proj_packed_f32', 'ss_head_wgrad_packed_f32',
-           'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_window', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_dgrad_ws_floats', 'ss_upconv_box_dgrad_f32',
+           'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_window', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_tiles_supported', 'ss_upconv_box_dgrad_ws_floats', 'ss_upconv_box_dgrad_f32',
            'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
@@ -668,12 +670,18 @@ def upconv_box_window():
     return int(n), int(r.value), int(c.value)
 
 
-def upconv_box_dgrad_supported(Cin, Cout, k, bt):
-    return bool(lib().ss_upconv_box_dgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_tile_rows']), int(bt['max_cols32'])))
+def _box_tiles_ok(bt, NB, h, w):
+    """The launch entry points' own limits (tile tables in LDS, 32-bit pixel indices): an oversized geometry is 'not supported' — the caller falls back to the
+    g_P forms — instead of raising in backward.  NB / h / w None: shape-only question."""
+    return NB is None or bool(lib().ss_upconv_box_tiles_supported(int(bt['n_row_tiles']), int(w), int(NB) * int(h) * int(w)))
 
 
-def upconv_box_wgrad_supported(Cin, Cout, k, bt):
-    return bool(lib().ss_upconv_box_wgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_tile_rows']), int(bt['max_cols32'])))
+def upconv_box_dgrad_supported(Cin, Cout, k, bt, NB=None, h=None, w=None):
+    return bool(lib().ss_upconv_box_dgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_tile_rows']), int(bt['max_cols32']))) and _box_tiles_ok(bt, NB, h, w)
+
+
+def upconv_box_wgrad_supported(Cin, Cout, k, bt, NB=None, h=None, w=None):
+    return bool(lib().ss_upconv_box_wgrad_supported(int(Cin), int(Cout), int(k), int(bt['max_tile_rows']), int(bt['max_cols32']))) and _box_tiles_ok(bt, NB, h, w)
 
 
 def upconv_box_dgrad(box, weight, bt, g_x, NB, Cin, Cout, h, w):

@@ -779,6 +779,11 @@ int ss_upconv_box_dgrad_supported(int Cin, int Cout, int k, int max_tile_rows, i
     return max_tile_rows > 0 && max_tile_rows <= kB2WR && max_cols32 > 0 && max_cols32 <= kB2WC;
 }
 
+int ss_upconv_box_tiles_supported(int n_row_tiles, int w, long long pixels)
+{
+    return n_row_tiles > 0 && n_row_tiles <= 64 && w > 0 && (w + kB2TC - 1) / kB2TC <= 16 && pixels > 0 && pixels <= 0x7fffffffLL;
+}
+
 long long ss_upconv_box_dgrad_ws_floats(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0 || Cin % 64 != 0 || Cout % kBxCo != 0) return 0;
@@ -790,8 +795,8 @@ int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vma
 {
     if (!box || !weight || !vmap || !hmap || !tile_rows || !tile_cols || !g_x || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
     if (!ss_upconv_box_dgrad_supported(Cin, Cout, 5, 1, 1)) return SS_EINVAL;                    // shape only: the caller checked the extents
-    if (n_row_tiles > 64 || (w + kB2TC - 1) / kB2TC > 16) return SS_EINVAL;                      // the tile tables live in LDS (maps up to ~250 x 512 source pixels)
-    if (!aligned16(box) || !aligned16(ws) || !aligned16(g_x) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
+    if (!ss_upconv_box_tiles_supported(n_row_tiles, w, NB * h * (long long)w)) return SS_EINVAL;    // the tile tables live in LDS (maps up to ~250 x 512 source pixels)
+    if (!aligned16(box) || !aligned16(ws) || !aligned16(g_x)) return SS_EINVAL;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -844,8 +849,8 @@ int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int*
 {
     if (x_packed && (NB * h * (long long)w * Cin) % 16 != 0) return SS_EINVAL;
     if (!box || (!x && !x_packed) || !vmap || !hmap || !tile_rows || !tile_cols || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
-    if (!ss_upconv_box_wgrad_supported(Cin, Cout, 5, 1, 1) || !aligned16(box) || !aligned16(ws) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
-    if (n_row_tiles > 64 || (w + kB2TC - 1) / kB2TC > 16) return SS_EINVAL;                      // the tile tables live in LDS
+    if (!ss_upconv_box_wgrad_supported(Cin, Cout, 5, 1, 1) || !aligned16(box) || !aligned16(ws)) return SS_EINVAL;
+    if (!ss_upconv_box_tiles_supported(n_row_tiles, w, NB * h * (long long)w)) return SS_EINVAL;    // the tile tables live in LDS
     int NT = 0, kinds = 0, slices = 0;
     if (!box_wgrad_plan(Cin, Cout, &NT, &kinds, &slices)) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);

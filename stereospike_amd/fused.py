@@ -989,7 +989,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                   and (need_x or need_w) and (x_packed is not None or x_cl.dtype == torch.float32))
         if box_ok:
             bt = box_tables(ctx.tables, H, W)
-            box_ok = (not need_x or _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt)) and (not need_w or _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt))
+            box_ok = (not need_x or _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt, NB, h, w)) and (not need_w or _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt, NB, h, w))
         if box_ok:
             e0 = TIMER.start()                                                   # the stage's whole backward ('upconv_cl_bwd', as every other form) ...
             e1 = TIMER.start()                                                   # ... and its three launches one by one ('box_*': inside the former, not additional)
@@ -1011,7 +1011,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _note('synapse_bwd', 'box: boxsum' + ('+dgrad6_mfma' if need_x else '') + ('+wgrad3_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
             if g_x is not None and g_x.dtype != ctx.x_dtype:
                 g_x = g_x.to(ctx.x_dtype)
-            return g_x, g_w, None, None, None, None, None, None, None, None, None, None, None, None
+            # a stage built with bias=True (NNConvUpsampling accepts it; the shipped decoder stages have none): its gradient as in every other form
+            g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
         g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
@@ -1031,7 +1033,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
             stage_pk = x_packed is not None and k == 5               # a stage whose input exists only as packed spikes
             if stage_pk and need_w and not (fused_bwd and c0 == 0 and c1 == NB):
                 # the fused adjoint + weight-gradient kernel reads the packed form; every other weight-gradient form reads the dense tensor
-                x_cl, x_packed, stage_pk = unpack_dense(x_packed, x_cl.shape, x_cl.dtype), None, False
+                # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one)
+                x_cl, x_packed, stage_pk = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None, False
             if dgrad_fused:
                 _lib.upconv_bwd_dgrad(g_out[c0:c1], Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous(), y_lo, y_hi, x_lo, x_hi,
                                       g_x[c0:c1], c1 - c0, Cin, Cout, h, w, H, W)

@@ -86,8 +86,8 @@ def _on_device(t):
     return t.is_cuda
 
 
-def _fusable(pred, gt):
-    return _cfg().FUSED_LOSS and _on_device(pred) and pred.dim() == 4 and pred.shape[1] == 1 and pred.shape == gt.shape \
+def _fusable(pred, gt, cfg=None):
+    return (cfg if cfg is not None else _cfg()).FUSED_LOSS and _on_device(pred) and pred.dim() == 4 and pred.shape[1] == 1 and pred.shape == gt.shape \
         and pred.dtype == torch.float32 and gt.dtype == torch.float32
 
 
@@ -108,15 +108,19 @@ def multiscale_terms(predicted, groundtruth, factors=(1., 1., 1., 1.)):
 class Total_Loss(nn.Module):
     """alpha = 0.5 for linear (metric) depth; scale_weights all 1; beta weighs the spike penalisation."""
 
-    def __init__(self, alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=False, beta=1.):
+    def __init__(self, alpha=0.5, scale_weights=(1., 1., 1., 1.), penalize_spikes=False, beta=1., config=None):
+        """config (build-side addition): the EngineConfig whose FUSED_LOSS decides the kernel form — pass `net.config` to run the loss under a network's
+        configuration.  The loss runs OUTSIDE the network's forward, so `net.configured(FUSED_LOSS=...)` alone does not reach it; None = the ambient
+        configuration at call time (`config.engine_config(...)` / the shipped default), per thread."""
         super().__init__()
+        self.config = config
         self.alpha = alpha
         self.scale_weights = scale_weights
         self.penalize_spikes = penalize_spikes
         self.beta = beta
 
     def forward(self, predicted, groundtruth, intermediary_spike_tensors=None):
-        if all(_fusable(p, _rescale(groundtruth, p)) for p in predicted):
+        if all(_fusable(p, _rescale(groundtruth, p), self.config) for p in predicted):
             si, gm, _ = multiscale_terms(predicted, groundtruth, self.scale_weights)
             loss = si + self.alpha * gm
             if self.penalize_spikes:

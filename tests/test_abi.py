@@ -49,7 +49,9 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_upconv_box_dgrad_f32', 'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
                                   # ABI 8
                                   'ss_wgrad_reduce3_f32', 'ss_spike_conv_fwd_wide_supported',
-                                  'ss_upconv_sub_geometry', 'ss_upconv_sub_tall_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32'])
+                                  'ss_upconv_sub_geometry', 'ss_upconv_sub_tall_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32',
+                                  # ABI 9
+                                  'ss_upconv_box_tiles_supported'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -60,7 +62,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == _lib.ABI_VERSION == 8
+    assert L.ss_abi_version() == _lib.ABI_VERSION == 9
     assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()

@@ -1792,3 +1792,39 @@ def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
         g_w3 = torch.empty_like(g_w)
         _lib.upconv_box_wgrad(box, None, xp, bt, g_w3, NB, Cin, Cout, h, w)
         assert torch.equal(g_w3, g_w)
+
+
+def test_upconv_box_backward_with_bias_and_oversized_geometry():
+    """(a) a k = 5 spike-input stage built with bias=True takes the exact-split forward and the box-sum backward — the bias gradient must come back
+    (it used to be dropped: bias.grad stayed None); (b) the *_supported predicates know the launch entry points' own limits (<= 64 row tiles, <= 16 column tiles,
+    32-bit pixel indices), so an oversized geometry is 'unsupported' (the caller falls back) instead of an SS_EINVAL raised inside backward."""
+    from stereospike_amd import _lib, fused, config
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    Cin, Cout, (h, w), (H, W), NB = 128, 64, (16, 20), (32, 40), 2
+    torch.manual_seed(5)
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W), bias=True).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    x = (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float().requires_grad_()
+    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen)
+    plan = {}
+    with config.recording(plan), config.layer('stage'):
+        y = up.forward_projected_cl(x, spikes_in=True)
+        y.backward(g)
+    assert plan['stage']['synapse_bwd'].startswith('box:'), plan
+    assert up.up[1].bias.grad is not None
+    want = g.double().sum((0, 1, 2))
+    assert float((up.up[1].bias.grad.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # the reference's two-op form, fp32 autograd
+    xr = x.detach().permute(0, 3, 1, 2).clone().requires_grad_()
+    wr, br = up.up[1].weight.detach().clone().requires_grad_(), up.up[1].bias.detach().clone().requires_grad_()
+    yr = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xr, size=(H + 4, W + 4), mode='nearest'), wr, br)
+    yr.backward(g.permute(0, 3, 1, 2))
+    assert float((y.detach().permute(0, 3, 1, 2) - yr.detach()).abs().max()) <= 1e-4 * float(yr.detach().abs().max())
+    assert float((up.up[1].weight.grad - wr.grad).norm() / wr.grad.norm()) <= 1e-5
+    assert float((x.grad.permute(0, 3, 1, 2) - xr.grad).norm() / xr.grad.norm()) <= 1e-5
+    # (b)
+    bt = fused.box_tables(up._tables(h, w, torch.device(DEV)), H, W)
+    assert _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt, NB, h, w) and _lib.upconv_box_wgrad_supported(Cin, Cout, 5, bt, NB, h, w)
+    big = dict(bt, n_row_tiles=65)
+    assert not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, big, NB, h, w) and not _lib.upconv_box_wgrad_supported(Cin, Cout, 5, big, NB, h, w)
+    assert not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt, NB, h, 513) and not _lib.upconv_box_wgrad_supported(Cin, Cout, 5, bt, 2 ** 31, 1, 1)
