@@ -642,6 +642,55 @@ int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const vo
                           float* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC,
                           const int* tblk, int NTB, int NORD, void* stream);
 
+/*
+ * ABI 9 — the 16-bit activation modes (BASELINE.json configs 2 / 5: bf16 / fp16 activations in HBM, fp32 membranes) on the engine's OWN synapse kernels
+ * (round 5).  The reference is fp32-only (/root/reference/train.py:194-197); the modes are a build-side addition whose semantics are:
+ *   * activations (synapse outputs = neuron inputs) and activation gradients are STORED in `dtype` (SS_DT_BF16 | SS_DT_F16) and are, as stored, the
+ *     operands of the next contraction — no conversion pass anywhere;
+ *   * spike tensors travel 2-bit packed (the packed format knows no dtype) or dense in `dtype` (small integers: exact);
+ *   * the fp32 master weight of a synapse is rounded ONCE to `dtype` (round to nearest even) inside the kernel's weight-preparation launch — what
+ *     torch.autocast does to a convolution's weight; every product of two `dtype` values is exact in fp32 (8 x 8 / 11 x 11 significand bits), the
+ *     accumulation is fp32 on v_mfma_f32_32x32x16_{bf16,f16}, the result is narrowed once on store;
+ *   * weight gradients are fp32 (fp32 accumulation of exact products, fixed-order reductions) — they are NOT rounded to 16 bits as autocast's are.
+ * One MFMA per k-step where the fp32 mode issues three (spike operand) or six (dense operands).  Every entry point below is the `_f32` entry point of
+ * the same name with the activation pointers retyped; argument meaning, validation, workspace sizes (`*_ws_floats` of the fp32 form: upper bounds),
+ * determinism and error behaviour are those of the fp32 form.  Error bounds: |result - float64(result from the SAME rounded operands)| <= 2^-21 sum |a||b|
+ * before the final narrowing (fp32 accumulation only).
+ *   ss_neuron_fwd_ex                act_dtype != 0 now also takes out_packed / skip_packed (out_seq may then be NULL): 2.25 B/update forward
+ *   ss_neuron_bwd_fork_lr_x16       ss_neuron_bwd_fork_lr_f32 with g_out_seq (nullable) / g_sum_seq / x_seq / g_x_seq in `dtype`; the rank-9 pair stays fp32
+ *   ss_dense_conv_s1_{fwd,wgrad}_x16  first encoder layer: the fp32 event-voxel input and the weight rounded once to `dtype`; out / g in `dtype`
+ *   ss_spike_conv_{fwd,wgrad}_x16   conv1 / conv2: x = dense `dtype` spikes (nullable) or x_packed; out / g in `dtype`; g_w fp32
+ *   ss_conv_s2_dgrad_x16            encoder data gradients: g, g_x in `dtype`
+ *   ss_im2col_cl_packed_x16         ss_im2col_cl_bf16_packed with the patch matrix in `dtype`;  ss_im2col_cl_x16: patch matrix of a DENSE 16-bit array
+ *   ss_upconv_sub_{prep,fwd}_x16    decoder stage forward: taps rounded once to `dtype`, their merged sums carried as TWO `dtype` terms (16 / 22 bits)
+ *   ss_upconv_box{sum,_dgrad,_wgrad}_x16  decoder stage backward on the box-sum image: ss_upconv_box_planes_x16(dtype) planes of `dtype` (bf16: hi + lo, fp16: one)
+ */
+int ss_neuron_bwd_fork_lr_x16_supported(int T, long long N, int C, int lr_rank);
+int ss_neuron_bwd_fork_lr_x16(const void* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, void* g_sum_seq,
+                              const float* g_v_last, const void* x_seq, const float* v_init, void* g_x_seq, float* g_v_init,
+                              float* g_k, float* g_k_ws, int T, long long N, float scale, int kind, float tau, const float* k,
+                              float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream);
+int ss_dense_conv_s1_fwd_x16(const float* x, const float* weight, void* out, long long NB, int Cin, int Cout, int h, int w, int dtype, void* stream);
+int ss_dense_conv_s1_wgrad_x16(const void* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate, int dtype, void* stream);
+int ss_spike_conv_fwd_x16(const void* x, const unsigned int* x_packed, const float* weight, void* out, float* ws,
+                          long long NB, int Cin, int Cout, int h, int w, int dtype, void* stream);
+int ss_spike_conv_wgrad_x16(const void* g, const void* x, const unsigned int* x_packed, float* g_w, float* ws, long long NB, int Cin, int Cout, int h,
+                            int w, int accumulate, int dtype, void* stream);
+int ss_conv_s2_dgrad_x16(const void* g, const float* weight, void* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int dtype, void* stream);
+int ss_im2col_cl_packed_x16(const unsigned int* x_packed, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, int dtype, void* stream);
+int ss_im2col_cl_x16(const void* x, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, void* stream);
+int ss_upconv_sub_prep_x16(const float* weight, const int* vcls, const int* hcls, void* wm, int Cin, int Cout, int NVC, int NHC, int dtype, void* stream);
+int ss_upconv_sub_fwd_x16(const void* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* order, unsigned int* counter,
+                          void* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, const int* tblk, int NTB, int NORD,
+                          int dtype, void* stream);
+int ss_upconv_box_planes_x16(int dtype);
+int ss_upconv_boxsum_x16(const void* g_out, const int* vr, const int* hr, void* box, long long NB, int Cout, int H, int W, int NVR, int NHR, int dtype, void* stream);
+int ss_upconv_box_dgrad_x16(const void* box, const float* weight, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles, const int* tile_cols,
+                            void* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, int dtype, void* stream);
+int ss_upconv_box_wgrad_x16(const void* box, const void* x, const unsigned int* x_packed, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles,
+                            const int* tile_cols, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, int accumulate,
+                            int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,37 @@ def lib():
     L.ss_upconv_box_dgrad_supported.argtypes = [i32, i32, i32, i32, i32]
     L.ss_upconv_box_dgrad_supported.restype = i32
     L.ss_upconv_box_tiles_supported.argtypes = [i32, i32, i64]
+    # ---- ABI 9: the 16-bit activation modes on the engine's own synapse kernels
+    L.ss_neuron_bwd_fork_lr_x16_supported.argtypes = [i32, i64, i32, i32]
+    L.ss_neuron_bwd_fork_lr_x16_supported.restype = i32
+    L.ss_neuron_bwd_fork_lr_x16.argtypes = [p, p, p, i32, i32, p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, i32, p]
+    L.ss_neuron_bwd_fork_lr_x16.restype = i32
+    L.ss_dense_conv_s1_fwd_x16.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_dense_conv_s1_fwd_x16.restype = i32
+    L.ss_dense_conv_s1_wgrad_x16.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_dense_conv_s1_wgrad_x16.restype = i32
+    L.ss_spike_conv_fwd_x16.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_spike_conv_fwd_x16.restype = i32
+    L.ss_spike_conv_wgrad_x16.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_spike_conv_wgrad_x16.restype = i32
+    L.ss_conv_s2_dgrad_x16.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.ss_conv_s2_dgrad_x16.restype = i32
+    L.ss_im2col_cl_packed_x16.argtypes = [p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_im2col_cl_packed_x16.restype = i32
+    L.ss_im2col_cl_x16.argtypes = [p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_im2col_cl_x16.restype = i32
+    L.ss_upconv_sub_prep_x16.argtypes = [p, p, p, p, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_sub_prep_x16.restype = i32
+    L.ss_upconv_sub_fwd_x16.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, i32, i32, i32, p]
+    L.ss_upconv_sub_fwd_x16.restype = i32
+    L.ss_upconv_box_planes_x16.argtypes = [i32]
+    L.ss_upconv_box_planes_x16.restype = i32
+    L.ss_upconv_boxsum_x16.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_boxsum_x16.restype = i32
+    L.ss_upconv_box_dgrad_x16.argtypes = [p, p, p, p, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_box_dgrad_x16.restype = i32
+    L.ss_upconv_box_wgrad_x16.argtypes = [p, p, p, p, p, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_box_wgrad_x16.restype = i32
     L.ss_upconv_box_tiles_supported.restype = i32
     L.ss_upconv_box_dgrad_ws_floats.argtypes = [i32, i32]
     L.ss_upconv_box_dgrad_ws_floats.restype = i64
@@ -247,7 +278,11 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
            'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
-           'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32')
+           'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32',
+           # ABI 9
+           'ss_neuron_bwd_fork_lr_x16_supported', 'ss_neuron_bwd_fork_lr_x16', 'ss_dense_conv_s1_fwd_x16', 'ss_dense_conv_s1_wgrad_x16', 'ss_spike_conv_fwd_x16',
+           'ss_spike_conv_wgrad_x16', 'ss_conv_s2_dgrad_x16', 'ss_im2col_cl_packed_x16', 'ss_im2col_cl_x16', 'ss_upconv_sub_prep_x16', 'ss_upconv_sub_fwd_x16',
+           'ss_upconv_box_planes_x16', 'ss_upconv_boxsum_x16', 'ss_upconv_box_dgrad_x16', 'ss_upconv_box_wgrad_x16')
 
 
 def _ptr(t, name, numel=None):
@@ -1028,3 +1063,186 @@ def upconv_fused_fwd(x, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H,
                 _i32(src_x, 'src_x', W + 4), _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W,
                 int(max_window), _stream(ref))
     _check(rc, 'ss_upconv_fused_fwd_f32')
+
+
+# ----------------------------------------------------------------------------------------------------------
+# ABI 9: the 16-bit activation modes on the engine's own synapse kernels (single-term operands, 16-bit I/O; include/ss_neuron.h "ABI 9")
+# ----------------------------------------------------------------------------------------------------------
+def _dt_of(t, name):
+    if t.dtype not in DT_CODE:
+        raise SSNeuronError(f'{name}: expected float16 or bfloat16, got {t.dtype}')
+    return t.dtype
+
+
+def neuron_bwd_fork_lr_x16_supported(T, N, C_, rank):
+    return bool(lib().ss_neuron_bwd_fork_lr_x16_supported(int(T), int(N), int(C_), int(rank)))
+
+
+def neuron_bwd_fork_lr_x16(g_out_seq, lr_p, lr_w, g_sum_seq, g_v_last, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind, tau, k,
+                           v_th, v_reset, surrogate, alpha, detach_reset):
+    """ss_neuron_bwd_fork_lr_f32 on 16-bit activations: g_out_seq (nullable) / g_sum_seq (nullable) / x_seq / g_x_seq 16-bit, the pair fp32."""
+    _require_hip(x_seq, 'x_seq')
+    dt = _dt_of(x_seq, 'x_seq')
+    rank, C_ = int(lr_w.shape[0]), int(lr_w.shape[1])
+    with torch.cuda.device(x_seq.device):
+        rc = lib().ss_neuron_bwd_fork_lr_x16(_x16(g_out_seq, 'g_out_seq', T * N, dt), _f32(lr_p, 'lr_p', T * (N // C_) * rank), _f32(lr_w, 'lr_w', rank * C_), rank, C_,
+                                             _x16(g_sum_seq, 'g_sum_seq', T * N, dt), _f32(g_v_last, 'g_v_last', N), _x16(x_seq, 'x_seq', T * N, dt),
+                                             _f32(v_init, 'v_init', N), _x16(g_x_seq, 'g_x_seq', T * N, dt), _f32(g_v_init, 'g_v_init', N),
+                                             _f32(g_k, 'g_k', 1), _f32(g_k_ws, 'g_k_ws'), T, N, scale, kind, tau, _f32(k, 'k', 1), v_th, v_reset, surrogate, alpha,
+                                             int(bool(detach_reset)), DT_CODE[dt], _stream(x_seq))
+    _check(rc, 'ss_neuron_bwd_fork_lr_x16')
+
+
+def dense_conv_s1_fwd_x16(x, weight, out, NB, Cin, Cout, h, w):
+    """out [NB, h, w, 32] (fp16 / bf16) = conv2d(round(x), round(weight), stride 1, pad 2), x fp32 [NB, h, w, Cin]: one MFMA term, fp32 accumulation."""
+    _require_hip(out, 'out')
+    dt = _dt_of(out, 'out')
+    with torch.cuda.device(out.device):
+        rc = lib().ss_dense_conv_s1_fwd_x16(_f32(x, 'x', NB * h * w * Cin), _f32(weight, 'weight', Cout * Cin * 25), _x16(out, 'out', NB * h * w * Cout, dt),
+                                            NB, Cin, Cout, h, w, DT_CODE[dt], _stream(out))
+    _check(rc, 'ss_dense_conv_s1_fwd_x16')
+
+
+def dense_conv_s1_wgrad_x16(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False):
+    """g_w [32, Cin, 5, 5] fp32 (+)= weight gradient of the first layer from a 16-bit output gradient g and the fp32 input x (rounded once to g's dtype)."""
+    _require_hip(g, 'g')
+    dt = _dt_of(g, 'g')
+    ws = torch.empty(int(lib().ss_dense_conv_s1_wgrad_ws_floats(int(Cin))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_dense_conv_s1_wgrad_x16(_x16(g, 'g', NB * h * w * Cout, dt), _f32(x, 'x', NB * h * w * Cin), _f32(g_w, 'g_w', Cout * Cin * 25), _f32(ws, 'ws'),
+                                              NB, Cin, Cout, h, w, int(bool(accumulate)), DT_CODE[dt], _stream(g))
+    _check(rc, 'ss_dense_conv_s1_wgrad_x16')
+
+
+def spike_conv_fwd_x16(x, x_packed, weight, out, NB, Cin, Cout, h, w):
+    """out [NB, ho, wo, Cout] (fp16 / bf16) = conv2d(x, round(weight), stride 2, pad 2) on a spike input (dense 16-bit x of out's dtype, or the packed x_packed)."""
+    _require_hip(out, 'out')
+    dt = _dt_of(out, 'out')
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ws = torch.empty(int(lib().ss_spike_conv_fwd_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=out.device)
+    with torch.cuda.device(out.device):
+        rc = lib().ss_spike_conv_fwd_x16(None if x_packed is not None else _x16(x, 'x', NB * h * w * Cin, dt),
+                                         _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                                         _f32(weight, 'weight', Cout * Cin * 25), _x16(out, 'out', NB * ho * wo * Cout, dt), _f32(ws, 'ws'),
+                                         NB, Cin, Cout, h, w, DT_CODE[dt], _stream(out))
+    _check(rc, 'ss_spike_conv_fwd_x16')
+
+
+def spike_conv_wgrad_x16(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False, x_packed=None):
+    """g_w [Cout, Cin, 5, 5] fp32 (+)= weight gradient of conv2d(x, ., stride 2, pad 2): g 16-bit NHWC, x 16-bit spikes of the same dtype or x_packed."""
+    _require_hip(g, 'g')
+    dt = _dt_of(g, 'g')
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ws = torch.empty(int(lib().ss_spike_conv_wgrad_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_spike_conv_wgrad_x16(_x16(g, 'g', NB * ho * wo * Cout, dt), None if x_packed is not None else _x16(x, 'x', NB * h * w * Cin, dt),
+                                           _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                                           _f32(g_w, 'g_w', Cout * Cin * 25), _f32(ws, 'ws'), NB, Cin, Cout, h, w, int(bool(accumulate)), DT_CODE[dt], _stream(g))
+    _check(rc, 'ss_spike_conv_wgrad_x16')
+
+
+def conv_s2_dgrad_x16(g, weight, g_x, NB, Cin, Cout, h, w):
+    """g_x [NB, h, w, Cin] (16-bit) = data gradient of conv2d(., round(weight), stride 2, pad 2) for the 16-bit output gradient g [NB, ho, wo, Cout]."""
+    _require_hip(g, 'g')
+    dt = _dt_of(g, 'g')
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ws = torch.empty(int(lib().ss_conv_s2_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = lib().ss_conv_s2_dgrad_x16(_x16(g, 'g', NB * ho * wo * Cout, dt), _f32(weight, 'weight', Cout * Cin * 25), _x16(g_x, 'g_x', NB * h * w * Cin, dt),
+                                        _f32(ws, 'ws'), NB, Cin, Cout, h, w, DT_CODE[dt], _stream(g))
+    _check(rc, 'ss_conv_s2_dgrad_x16')
+
+
+def im2col_cl_packed_x16(x_packed, A, NB, h, w, C_, k, stride, pad, ho, wo):
+    """Patch matrix A [NB*ho*wo, k*k*C] (fp16 / bf16) of a 2-bit packed spike tensor."""
+    _require_hip(x_packed, 'x_packed')
+    dt = _dt_of(A, 'A')
+    if x_packed.dtype != torch.int32:
+        raise SSNeuronError('x_packed: expected int32')
+    with torch.cuda.device(x_packed.device):
+        rc = lib().ss_im2col_cl_packed_x16(_ptr(x_packed, 'x_packed', NB * h * w * C_ // 16), _x16(A, 'A', NB * ho * wo * k * k * C_, dt),
+                                           NB, h, w, C_, k, stride, pad, ho, wo, DT_CODE[dt], _stream(x_packed))
+    _check(rc, 'ss_im2col_cl_packed_x16')
+
+
+def im2col_cl_x16(x, A, NB, h, w, C_, k, stride, pad, ho, wo):
+    """Patch matrix A [NB*ho*wo, k*k*C] of a dense 16-bit NHWC array x [NB, h, w, C] (same dtype)."""
+    _require_hip(x, 'x')
+    dt = _dt_of(x, 'x')
+    with torch.cuda.device(x.device):
+        rc = lib().ss_im2col_cl_x16(_x16(x, 'x', NB * h * w * C_, dt), _x16(A, 'A', NB * ho * wo * k * k * C_, dt), NB, h, w, C_, k, stride, pad, ho, wo, _stream(x))
+    _check(rc, 'ss_im2col_cl_x16')
+
+
+def upconv_sub_prep_x16(weight, st, Cin, Cout, dtype):
+    """The merged-tap weight fragments of the sub-pixel forward as TWO terms of `dtype` (taps rounded once to it first)."""
+    _require_hip(weight, 'weight')
+    n = int(lib().ss_upconv_sub_wm_elems(int(Cin), int(Cout), int(st['NVC']), int(st['NHC'])))
+    if n <= 0 or dtype not in DT_CODE:
+        raise SSNeuronError(f'ss_upconv_sub_prep_x16: unsupported C_in {Cin} / C_out {Cout} / dtype {dtype}')
+    wm = torch.empty(n, dtype=dtype, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib().ss_upconv_sub_prep_x16(_f32(weight, 'weight', Cout * Cin * 25), _i32(st['vcls'], 'vcls', 8 * st['NVC']), _i32(st['hcls'], 'hcls', 8 * st['NHC']),
+                                          _x16(wm, 'wm', n, dtype), Cin, Cout, st['NVC'], st['NHC'], DT_CODE[dtype], _stream(weight))
+    _check(rc, 'ss_upconv_sub_prep_x16')
+    return wm
+
+
+def upconv_sub_fwd_x16(x, x_packed, wm, st, out, NB, Cin, Cout, h, w):
+    """out [NB, H, W, Cout] (fp16 / bf16) = Conv2d(5)(UpsamplingNearest2d(x)) of a spike input (dense 16-bit x of out's dtype, or x_packed) in the sub-pixel form."""
+    _require_hip(out, 'out')
+    dt = _dt_of(out, 'out')
+    H, W = st['H'], st['W']
+    counter = torch.empty(1, dtype=torch.int32, device=out.device)
+    with torch.cuda.device(out.device):
+        rc = lib().ss_upconv_sub_fwd_x16(None if x_packed is not None else _x16(x, 'x', NB * h * w * Cin, dt),
+                                         _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
+                                         _x16(wm, 'wm', int(lib().ss_upconv_sub_wm_elems(int(Cin), int(Cout), int(st['NVC']), int(st['NHC']))), dt),
+                                         _i32(st['vblk'], 'vblk', st['NVB'] * st['vrec_ints']), _i32(st['hblk'], 'hblk', st['NHB'] * st['hrec_ints']),
+                                         _i32(st['order'], 'order', st['NORD']), _i32(counter, 'counter', 1),
+                                         _x16(out, 'out', NB * H * W * Cout, dt), NB, Cin, Cout, h, w, H, W, st['NVB'], st['NHB'], st['NHC'],
+                                         _i32(st['tblk'], 'tblk', st['NTB'] * st['trec_ints']) if st['NTB'] else None, st['NTB'], st['NORD'], DT_CODE[dt], _stream(out))
+    _check(rc, 'ss_upconv_sub_fwd_x16')
+
+
+def upconv_box_planes_x16(dtype):
+    return int(lib().ss_upconv_box_planes_x16(DT_CODE[dtype]))
+
+
+def upconv_boxsum_x16(g_out, bt, NB, Cout, H, W):
+    """g_out [NB, H, W, Cout] (fp16 / bf16) -> the box-sum image as upconv_box_planes_x16(dtype) planes of that dtype ([NB, Cout / 8, NP, NVR, NHR, 8])."""
+    _require_hip(g_out, 'g_out')
+    dt = _dt_of(g_out, 'g_out')
+    NVR, NHR, NP = bt['NVR'], bt['NHR'], upconv_box_planes_x16(g_out.dtype)
+    box = torch.empty((NB, Cout // 8, NP, NVR, NHR, 8), dtype=dt, device=g_out.device)
+    with torch.cuda.device(g_out.device):
+        rc = lib().ss_upconv_boxsum_x16(_x16(g_out, 'g_out', NB * H * W * Cout, dt), _i32(bt['vr'], 'vr', 2 * NVR), _i32(bt['hr'], 'hr', 2 * NHR),
+                                        C.c_void_p(box.data_ptr()), NB, int(Cout), H, W, NVR, NHR, DT_CODE[dt], _stream(g_out))
+    _check(rc, 'ss_upconv_boxsum_x16')
+    return box
+
+
+def upconv_box_dgrad_x16(box, weight, bt, g_x, NB, Cin, Cout, h, w):
+    """Decoder data gradient g_x [NB, h, w, Cin] (box's dtype) from the 16-bit box-sum planes and the Conv2d weight (rounded once to that dtype)."""
+    _require_hip(box, 'box')
+    dt = _dt_of(box, 'box')
+    ws = torch.empty(int(lib().ss_upconv_box_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=box.device)
+    with torch.cuda.device(box.device):
+        rc = lib().ss_upconv_box_dgrad_x16(C.c_void_p(box.data_ptr()), _f32(weight, 'weight', Cout * Cin * 25), _i32(bt['vmap'], 'vmap', 5 * h),
+                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows', 4 * bt['n_row_tiles']), bt['n_row_tiles'], _i32(bt['tile_cols'], 'tile_cols'),
+                                           _x16(g_x, 'g_x', NB * h * w * Cin, dt), _f32(ws, 'ws'), NB, int(Cin), int(Cout), h, w, bt['NVR'], bt['NHR'], DT_CODE[dt], _stream(box))
+    _check(rc, 'ss_upconv_box_dgrad_x16')
+
+
+def upconv_box_wgrad_x16(box, x, x_packed, bt, g_w, NB, Cin, Cout, h, w, accumulate=False):
+    """Decoder weight gradient g_w [Cout, Cin, 5, 5] fp32 (+)= from the 16-bit box-sum planes and the stage input (dense 16-bit spikes of box's dtype, or x_packed)."""
+    _require_hip(box, 'box')
+    dt = _dt_of(box, 'box')
+    ws = torch.empty(int(lib().ss_upconv_box_wgrad_ws_floats(int(Cin), int(Cout), NB, h, w)), dtype=torch.float32, device=box.device)
+    with torch.cuda.device(box.device):
+        rc = lib().ss_upconv_box_wgrad_x16(C.c_void_p(box.data_ptr()), _x16(x, 'x', NB * h * w * Cin, dt) if x_packed is None else None,
+                                           _i32(x_packed, 'x_packed') if x_packed is not None else None, _i32(bt['vmap'], 'vmap', 5 * h),
+                                           _i32(bt['hmap'], 'hmap', 5 * w), _i32(bt['tile_rows'], 'tile_rows', 4 * bt['n_row_tiles']), bt['n_row_tiles'], _i32(bt['tile_cols'], 'tile_cols'),
+                                           _f32(g_w, 'g_w', Cout * Cin * 25), _f32(ws, 'ws'), NB, int(Cin), int(Cout), h, w, bt['NVR'], bt['NHR'],
+                                           int(bool(accumulate)), DT_CODE[dt], _stream(box))
+    _check(rc, 'ss_upconv_box_wgrad_x16')

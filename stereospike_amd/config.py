@@ -45,8 +45,9 @@ class EngineConfig:
     PACKED_HEAD: bool = True            # prediction heads 1 / 2 read 2-bit packed spikes   [SS_PACKED_HEAD]
     PACKED_DECONV2: bool = True         # deconv2's output packed-only   [SS_PACKED_DECONV2]
     # ---- decoder backward -----------------------------------------------------------------------------------------------------------------------------
-    X16_OWN_CONVS: bool = False         # 16-bit activation modes: encoder / bottleneck synapses on the fp32 mode's own kernels (fp32 weights, fp32 weight gradients), outputs
-                                        # narrowed: 2 x more accurate, 950 -> 1 spike flips, but 653 -> 435 frames/s and +2.8 GB (profiles/r04/x16_own_convs_ab.md) [SS_X16_OWN_CONVS]
+    X16_OWN_KERNELS: bool = True        # 16-bit activation modes (torch.autocast fp16 / bf16): every synapse on the engine's own single-term 16-bit-I/O kernels (weights rounded
+                                        # once to the format, fp32 accumulation, fp32 weight gradients; include/ss_neuron.h ABI 9), packed spikes between layers.  False: the
+                                        # round-2 .. 4 path — encoder / bottleneck synapses = MIOpen convolutions under autocast (A/B: profiles/r05/)   [SS_X16_OWN_KERNELS]
     SUB_FWD: bool = True                # decoder stages, spike input: sub-pixel (merged tap) implicit GEMM forward, ss_upconv_sub.hip [SS_SUB_FWD]
     SUB_FWD_CIN: Tuple[int, ...] = (64, 128, 256)     # deconv1 .. deconv3 (deconv3 since the tall tiles: 1.01 vs 1.26 ms; deconv4's 33x44 output stays on GEMM + gather)   [SS_SUB_FWD_CIN]
     BOX_BWD: bool = True                # round 4: the stage backward on the box-sum image (ss_upconv_box.hip), no g_P anywhere   [SS_BOX_BWD]
@@ -94,7 +95,7 @@ class EngineConfig:
         return EngineConfig(
             LOWRANK_HEAD_GRAD=flag('SS_LOWRANK_HEAD_GRAD', True), PACKED_HEAD=flag('SS_PACKED_HEAD', True), PACKED_DECONV2=flag('SS_PACKED_DECONV2', True),
             BOX_BWD=flag('SS_BOX_BWD', True), BOX_BWD_CIN=ints('SS_BOX_BWD_CIN', '64,128'),
-            X16_OWN_CONVS=flag('SS_X16_OWN_CONVS', False), SUB_FWD=flag('SS_SUB_FWD', True), SUB_FWD_CIN=ints('SS_SUB_FWD_CIN', '64,128,256'),
+            X16_OWN_KERNELS=flag('SS_X16_OWN_KERNELS', True), SUB_FWD=flag('SS_SUB_FWD', True), SUB_FWD_CIN=ints('SS_SUB_FWD_CIN', '64,128,256'),
             EXACT_WGRAD_MFMA_CIN=ints('SS_WGRAD_MFMA_CIN', '64,128,256,512'), GEMM6_DGRAD=flag('SS_GEMM6_DGRAD', True),
             GEMM6_DGRAD_CIN=ints('SS_GEMM6_CIN', '128,256,512'), FUSED_UPCONV_DGRAD=flag('SS_FUSED_DGRAD', True),
             FUSED_UPCONV_DGRAD_CIN=ints('SS_FUSED_DGRAD_CIN', '64'), FUSED_UPCONV_BWD_CIN_NOGP=ints('SS_FUSED_BWD_CIN_NOGP', '64'),

@@ -230,13 +230,46 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---------------------------------------------------------------------------------------------------
+// 16-bit activation modes (round 5): the SAME kernels on 16-bit I/O with SINGLE-term operands on the native matrix-core type.
+// DT = 0: fp32 I/O, operands as exact multi-term bf16 splits (3 weight terms, 3 terms of a dense fp32 operand: six cross terms kept);
+// DT = SS_DT_BF16 / SS_DT_F16: activations / activation gradients are stored in that format — they ARE the operand (no split, no conversion); spikes are
+// exact in either format; the fp32 master weight is rounded ONCE to the format (what autocast does to a synapse); products are then exact in fp32
+// (8 x 8 / 11 x 11 significand bits), accumulation is fp32 in the MFMA, the result is narrowed once on store.  Weight gradients stay fp32.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+template <int DT> __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c)
+{
+    if constexpr (DT == SS_DT_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// code (0..3) of a 2-bit packed spike -> the 16-bit pattern of the same small integer in the operand format (DT = 0: bf16)
+template <int DT> __device__ __forceinline__ unsigned short code_to_op(unsigned c)
+{
+    if constexpr (DT == SS_DT_F16) return (unsigned short)((0x420040003C000000ull >> (16 * c)) & 0xFFFFu);    // 0x0000, 0x3C00, 0x4000, 0x4200
+    else return code_to_bf16(c);
+}
+// fp32 -> the operand format, round to nearest even (weights: once per step in the prep kernels; fp32 inputs of the first layer)
+template <int DT> __device__ __forceinline__ unsigned short round_op(float v) { return narrow<(DT == SS_DT_F16 ? SS_DT_F16 : SS_DT_BF16)>(v); }
+template <int DT> __device__ __forceinline__ float widen_op(unsigned short b) { return widen<(DT == SS_DT_F16 ? SS_DT_F16 : SS_DT_BF16)>(b); }
+// output element type of a kernel's activation result: float (DT = 0) or the 16-bit pattern
+template <int DT> struct ActT { typedef unsigned short type; };
+template <> struct ActT<0> { typedef float type; };
+// store 4 consecutive activation values (16 B as fp32, 8 B narrowed)
+template <int DT> __device__ __forceinline__ void store_act4(typename ActT<DT>::type* p, float a, float b, float c, float d)
+{
+    if constexpr (DT == 0) *reinterpret_cast<f4*>(p) = (f4){a, b, c, d};
+    else { u16x4 o; o[0] = narrow<DT>(a); o[1] = narrow<DT>(b); o[2] = narrow<DT>(c); o[3] = narrow<DT>(d); *reinterpret_cast<u16x4*>(p) = o; }
+}
+
 // x [NB * h][w][C_in] fp32 spike counts (or, PACKED, the 2-bit packed spike tensor) -> xT[(source row) * KSR + k-step][ci][16 sources] bf16,
 // KSR = ceil(w / 16), zero padded
-template <bool PACKED>
+template <bool PACKED, int DT = 0>             // DT != 0: the operand format is DT; a dense input is then the 16-bit spike tensor itself
 __global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const void* __restrict__ xv, unsigned short* __restrict__ xT, long long rows, int w,
                                                                   int CIN)
 {
     const float* x = static_cast<const float*>(xv);
+    const unsigned short* x16 = static_cast<const unsigned short*>(xv);
     const unsigned* xp = static_cast<const unsigned*>(xv);
     const int KSR = (w + 15) / 16;
     const long long total = rows * KSR * CIN;
@@ -252,7 +285,8 @@ __global__ __launch_bounds__(kBlock) void upconv_bwd_xprep_kernel(const void* __
             const long long el = (row * w + sx) * CIN + ci;
             unsigned short v = 0;
             if (sx < w) {
-                if constexpr (PACKED) v = code_to_bf16((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u);
+                if constexpr (PACKED) v = code_to_op<DT>((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u);
+                else if constexpr (DT != 0) v = x16[el];
                 else v = (unsigned short)(__float_as_uint(x[el]) >> 16);
             }
             if (rr < 8) a[rr] = v; else b[rr - 8] = v;

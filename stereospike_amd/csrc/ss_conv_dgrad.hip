@@ -43,17 +43,20 @@ __host__ __device__ constexpr int dg_cnt(int cls) { return cls == 0 ? 9 : (cls =
 
 // weight [C_out][C_in][5][5] fp32 -> Bf[chunk c of 32 co][tap][g][split][ci tile t][lane][8] bf16: element e of a lane = split term of
 // s * W[co = 32 c + 16 g + 8 (lane >> 5) + e][ci = 32 t + (lane & 31)][ky][kx], s = (-1)^n for the n-th tap of its class over all chunks
+// DT != 0 (16-bit activation modes): ONE term, the weight rounded once to the operand format (sign alternation kept: exact)
+template <int DT = 0>
 __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, unsigned* __restrict__ counters,
                                                                     int Cin, int Cout)
 {
+    constexpr int NSP = DT ? 1 : 3;
     if (blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0u;         // the per-XCD item counters of the main kernel
     const int NTALL = Cin / 32;
-    const long long total = (long long)(Cout / 32) * 25 * 2 * 3 * NTALL * 64;
+    const long long total = (long long)(Cout / 32) * 25 * 2 * NSP * NTALL * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
         long long r = i >> 6;
         const int t = (int)(r % NTALL); r /= NTALL;
-        const int sp = (int)(r % 3); r /= 3;
+        const int sp = (int)(r % NSP); r /= NSP;
         const int g = (int)(r & 1); r >>= 1;
         const int tap = (int)(r % 25); const int c = (int)(r / 25);
         const int ky = tap / 5, kx = tap - 5 * ky;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float*
             const int co = 32 * c + 16 * g + 8 * (lane >> 5) + e;
             float v = W[(((long long)co * Cin + ci) * 5 + ky) * 5 + kx];
             if (n & 1) v = -v;
+            if constexpr (DT != 0) { o[e] = round_op<DT>(v); continue; }
             const unsigned short h1 = narrow<SS_DT_BF16>(v);
             const float r1 = v - widen<SS_DT_BF16>(h1);
             const unsigned short h2 = narrow<SS_DT_BF16>(r1);
@@ -76,17 +80,20 @@ __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float*
     }
 }
 
-template <int CO, int NTALL, int NT, int CB, int MB = 1>
-__global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const float* __restrict__ G, const unsigned short* __restrict__ Bf,
-                                                                      float* __restrict__ gx, unsigned* __restrict__ counters, int NB, int h, int w, int ho, int wo)
+// DT != 0 (16-bit activation modes, round 5): g IS the operand (one 16-byte copy per granule into ONE plane), one weight term, one MFMA per (k-step, M block,
+// N tile) on the native matrix-core type, g_x narrowed once on store
+template <int CO, int NTALL, int NT, int CB, int MB = 1, int DT = 0>
+__global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const typename ActT<DT>::type* __restrict__ G, const unsigned short* __restrict__ Bf,
+                                                                      typename ActT<DT>::type* __restrict__ gx, unsigned* __restrict__ counters, int NB, int h, int w, int ho, int wo)
 {
+    constexpr int NSP = DT ? 1 : 3;
     constexpr int CI = 32 * NTALL, KINDS = NTALL / NT, NCH = CO / 32;
     constexpr int RB = 32 / CB, TJR = 4 * RB * MB, WR = TJR + 2, WC = CB + 2, ROWB = WC * 64, PLANE = WR * ROWB;      // MB: M blocks (RB rows each) per wavefront
     static_assert(MB == 1 || (2 * RB) % 4 == 0, "the granule swizzle of a wavefront's M blocks must agree");
-    constexpr int STG = 6 * NT * 1024;                                          // bytes of one weight stage: one tap = 2 k-steps x 3 splits x NT tiles
+    constexpr int STG = 2 * NSP * NT * 1024;                                    // bytes of one weight stage: one tap = 2 k-steps x 3 splits x NT tiles
     constexpr int LPT = STG / 16 / kDgThreads, REM = STG / 16 - LPT * kDgThreads;
     constexpr int kItems = WR * WC * 4, kIter = (kItems + kDgThreads - 1) / kDgThreads;     // (window pixel, 8-channel granule)
-    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[NSP * PLANE];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * STG];
     const int lane = threadIdx.x & 63;
     const int mb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);            // wavefront = RB padded rows of the tile
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
             if (u == LPT && (REM == 0 || (int)threadIdx.x >= REM)) break;
             const int pidx = threadIdx.x + kDgThreads * u;                      // 16-B piece of the stage: [g][split][tile of this kind][lane]
             const int ln = pidx & 63, tt = (pidx >> 6) % NT, gs = (pidx >> 6) / NT;
-            st[u] = *reinterpret_cast<const f4*>(Bf + (((stage * 6 + gs) * NTALL + kind * NT + tt) * 64 + ln) * 8);
+            st[u] = *reinterpret_cast<const f4*>(Bf + (((stage * (2 * NSP) + gs) * NTALL + kind * NT + tt) * 64 + ln) * 8);
         }
     };
     auto stage_commit = [&](unsigned char* dst) {
@@ -169,7 +176,21 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
             // ---- window of g (32 channels of this chunk) -> three bf16 planes in LDS (g = gh + gm + gl exactly), zero outside
-            if (!(SS_DG_ABL & 32)) {
+            if constexpr (DT != 0) {
+                u16x8 vv[kIter];
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    vv[u] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (goff[u] >= 0) vv[u] = *reinterpret_cast<const u16x8*>(G + goff[u] + 32 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < kIter; ++u) {
+                    const int i = threadIdx.x + kDgThreads * u;
+                    const int pix = i >> 2, q = i & 3;
+                    const int wy = pix / WC, wc = pix - wy * WC;
+                    if (i < kItems) *reinterpret_cast<u16x8*>(wnd + wy * ROWB + wc * 64 + ((q ^ (((wc >> 2) + 2 * wy) & 3)) << 4)) = vv[u];
+                }
+            } else if (!(SS_DG_ABL & 32)) {
                 f4 va[kIter], vb[kIter];
 #pragma unroll
                 for (int u = 0; u < kIter; ++u) {
@@ -227,30 +248,31 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                         for (int g = 0; g < 2; ++g) {
                             // the granule swizzle depends on the window row: one row up / down moves the slot by 2 (^ 32 bytes), like the second k-step
                             const unsigned char* const ap = wnd + dy * ROWB + (abase[dx + 1] ^ ((g ^ (dy & 1)) << 5));
-                            s16x8 a[MB][3], b[3][NT];
+                            s16x8 a[MB][NSP], b[NSP][NT];
 #pragma unroll
                             for (int i = 0; i < MB; ++i)
 #pragma unroll
-                                for (int sp = 0; sp < 3; ++sp)
+                                for (int sp = 0; sp < NSP; ++sp)
                                     a[i][sp] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 8) ? wnd + lane * 16 + sp * 1024 : ap + i * RB * ROWB + sp * PLANE);
 #pragma unroll
-                            for (int sp = 0; sp < 3; ++sp)
+                            for (int sp = 0; sp < NSP; ++sp)
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 4) ? bst + lane * 16 + (sp * NT + t) * 1024 : bk + ((g * 3 + sp) * NT + t) * 1024);
+                                for (int t = 0; t < NT; ++t) b[sp][t] = *reinterpret_cast<const s16x8*>((SS_DG_ABL & 4) ? bst + lane * 16 + (sp * NT + t) * 1024 : bk + ((g * NSP + sp) * NT + t) * 1024);
                             // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh — term-major over the wavefront's M blocks and N tiles
                             // (consecutive MFMAs run on different accumulators)
-                            constexpr int kTa[6] = {2, 1, 0, 1, 0, 0}, kTb[6] = {0, 1, 2, 0, 1, 0};
+                            constexpr int kNQ = DT ? 1 : 6;
+                            constexpr int kTa[6] = {DT ? 0 : 2, 1, 0, 1, 0, 0}, kTb[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                            for (int q = 0; q < 6; ++q)
+                            for (int q = 0; q < kNQ; ++q)
 #pragma unroll
                                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                                     for (int t = 0; t < NT; ++t) {
                                         if (g == 0 && q == 0) {
                                             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kTb[q]][t], a[i][kTa[q]], zero, 0, 0, 0);      // D^T: rows = input channels, columns = pixels
+                                            tmp[i][t] = mfma32<DT>(b[kTb[q]][t], a[i][kTa[q]], zero);      // D^T: rows = input channels, columns = pixels
                                         } else {
-                                            tmp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[kTb[q]][t], a[i][kTa[q]], tmp[i][t], 0, 0, 0);
+                                            tmp[i][t] = mfma32<DT>(b[kTb[q]][t], a[i][kTa[q]], tmp[i][t]);
                                         }
                                     }
                         }
@@ -283,13 +305,12 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const floa
                     const int py = cls >> 1, px = cls & 1;
                     const int iy = 2 * j + py, ix = 2 * (i0 + ccm) + px;
                     if (row_ok && iy < h && ix < w && (!(SS_DG_ABL & 64) || acc[i][cls][0][0] == 12345.678f)) {
-                        float* const op = gx + ((nb * h + iy) * w + ix) * CI + 32 * (kind * NT) + 4 * half;
+                        typename ActT<DT>::type* const op = gx + ((nb * h + iy) * w + ix) * CI + 32 * (kind * NT) + 4 * half;
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4)
-                                *reinterpret_cast<f4*>(op + 32 * t + 8 * q4) =
-                                    (f4){acc[i][cls][t][4 * q4], acc[i][cls][t][4 * q4 + 1], acc[i][cls][t][4 * q4 + 2], acc[i][cls][t][4 * q4 + 3]};
+                                store_act4<DT>(op + 32 * t + 8 * q4, acc[i][cls][t][4 * q4], acc[i][cls][t][4 * q4 + 1], acc[i][cls][t][4 * q4 + 2], acc[i][cls][t][4 * q4 + 3]);
                     }
                 }
             }
@@ -323,7 +344,7 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
     unsigned* counters = reinterpret_cast<unsigned*>(ws + (long long)25 * Cin * Cout * 3 / 2);
-    hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, counters, Cin, Cout);
+    hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel<0>, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, counters, Cin, Cout);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     // column blocking of the (j, i) grid: 8 columns x 4 rows per wavefront wastes <= 1 / 8 of a block on any width; 32 x 1 only when it fits as well
     bool wide = ((wo + 31) / 32) * 32 <= ((wo + 7) / 8) * 8;
@@ -344,6 +365,39 @@ int ss_conv_s2_dgrad_f32(const float* g, const float* weight, float* g_x, float*
     else if (Cin == 128) SS_DG(256, 4, 2);
     else SS_DG(512, 8, 2);
 #undef SS_DG
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ss_conv_s2_dgrad_f32 on 16-bit activation gradients (ABI 9): g and g_x in `dtype`, weight fp32 (rounded once to `dtype`), fp32 accumulation; ws as for
+   the fp32 form. */
+int ss_conv_s2_dgrad_x16(const void* g, const float* weight, void* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int dtype, void* stream)
+{
+    if (!g || !weight || !g_x || !ws || NB <= 0 || h <= 0 || w <= 0 || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (!ss_conv_s2_dgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(g) || !aligned16(ws) || !aligned16(g_x)) return SS_EINVAL;
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    if (NB * h * (long long)w * Cin > 0x7fffffffffLL || NB * ho * (long long)wo * Cout > 0x7fffffffLL) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
+    unsigned* counters = reinterpret_cast<unsigned*>(ws + (long long)25 * Cin * Cout * 3 / 2);
+    const int pg = grid_for((long long)25 * Cin * Cout / 8, 4096);
+    if (dtype == SS_DT_F16) hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel<SS_DT_F16>, dim3(pg), dim3(kBlock), 0, s, weight, Bf, counters, Cin, Cout);
+    else hipLaunchKernelGGL(conv_s2_dgrad_prep_kernel<SS_DT_BF16>, dim3(pg), dim3(kBlock), 0, s, weight, Bf, counters, Cin, Cout);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    const bool wide = ((wo + 31) / 32) * 32 <= ((wo + 7) / 8) * 8;
+    const unsigned grid = (unsigned)(2 * cus < 8 ? 8 : 2 * cus);
+    const unsigned short* g16 = static_cast<const unsigned short*>(g);
+    unsigned short* gx16 = static_cast<unsigned short*>(g_x);
+#define SS_DG16D(CO_, NTALL_, NT_, DTT) do { \
+        if (wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 32, 1, DTT>), dim3(grid), dim3(kDgThreads), 0, s, g16, Bf, gx16, counters, (int)NB, h, w, ho, wo); \
+        else hipLaunchKernelGGL((conv_s2_dgrad_kernel<CO_, NTALL_, NT_, 8, 1, DTT>), dim3(grid), dim3(kDgThreads), 0, s, g16, Bf, gx16, counters, (int)NB, h, w, ho, wo); } while (0)
+#define SS_DG16(DTT) do { \
+        if (Cin == 32 && !wide) hipLaunchKernelGGL((conv_s2_dgrad_kernel<64, 1, 1, 8, 2, DTT>), dim3(grid), dim3(kDgThreads), 0, s, g16, Bf, gx16, counters, (int)NB, h, w, ho, wo); \
+        else if (Cin == 32) SS_DG16D(64, 1, 1, DTT); else if (Cin == 64) SS_DG16D(128, 2, 2, DTT); else if (Cin == 128) SS_DG16D(256, 4, 2, DTT); else SS_DG16D(512, 8, 2, DTT); } while (0)
+    if (dtype == SS_DT_F16) SS_DG16(SS_DT_F16); else SS_DG16(SS_DT_BF16);
+#undef SS_DG16
+#undef SS_DG16D
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -373,16 +427,19 @@ constexpr int kW1WR = kW1TR + 4, kW1WC = 40;           // window rows; window co
 constexpr int kW1GS = kW1TR * kW1TC + 4;               // pixel stride (floats) of a channel's row in gT: 16-B aligned, banks spread
 constexpr int kW1Groups = 512;                         // workgroups (two per CU) = partial blocks of the second pass
 
-template <int CI>
-__global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(const float* __restrict__ G, const float* __restrict__ X, float* __restrict__ part,
+// DT != 0 (16-bit activation modes): g arrives in the 16-bit format (widened exactly while it is staged — it IS the operand), the fp32 input is rounded once
+// to the format as in the forward; one MFMA per (k-step, N tile); the weight gradient stays fp32
+template <int CI, int DT = 0>
+__global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(const typename ActT<DT>::type* __restrict__ G, const float* __restrict__ X, float* __restrict__ part,
                                                                             int NB, int h, int w)
 {
+    constexpr int NSP = DT ? 1 : 3;
     constexpr int NV = 25 * CI, NT = (NV + 31) / 32;                            // valid (tap, ci) columns; N tiles
     constexpr int CS = kW1WR * kW1WC + 2;                                       // elements per input channel of a plane: + one dword, so that the CI lanes of a tap
                                                                                 // (same window position, consecutive channels) read CI different banks
     constexpr int PL = CI * CS;                                                 // elements of one bf16 plane of the window
     __shared__ __attribute__((aligned(16))) float gT[32 * kW1GS];
-    __shared__ __attribute__((aligned(16))) unsigned short xT[3 * PL + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short xT[NSP * PL + 8];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mn = lane & 31, kq = lane >> 5;                                   // A: m = co; B: n = column of the N tile; k group of 8 pixels
@@ -417,7 +474,13 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
             const int i = threadIdx.x + kW1Threads * u;
             const int pix = i >> 3, q = i & 7, py = pix / kW1TC, px = pix - py * kW1TC;
             gv[u] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (y0 + py < h && x0 + px < w) gv[u] = load_stream(reinterpret_cast<const f4*>(G + (((long long)nb * h + y0 + py) * w + x0 + px) * 32) + q);
+            if (y0 + py < h && x0 + px < w) {
+                if constexpr (DT == 0) gv[u] = load_stream(reinterpret_cast<const f4*>(G + (((long long)nb * h + y0 + py) * w + x0 + px) * 32) + q);
+                else {
+                    const u16x4 g4 = load_stream(reinterpret_cast<const u16x4*>(G + (((long long)nb * h + y0 + py) * w + x0 + px) * 32) + q);
+                    gv[u] = (f4){widen<DT>(g4[0]), widen<DT>(g4[1]), widen<DT>(g4[2]), widen<DT>(g4[3])};
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
@@ -449,14 +512,17 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
 #pragma unroll
                 for (int c = 0; c < CI; ++c) {
                     const float v = xv[u][c];
+                    unsigned short* const q = xT + c * CS + wy * kW1WC + wx;
+                    if constexpr (DT != 0) { q[0] = round_op<DT>(v); continue; }
                     const __bf16 h1 = (__bf16)v;
                     const float r1 = v - (float)h1;
                     const __bf16 h2 = (__bf16)r1;
                     const __bf16 h3 = (__bf16)(r1 - (float)h2);
-                    unsigned short* const q = xT + c * CS + wy * kW1WC + wx;
-                    q[0] = __builtin_bit_cast(unsigned short, h1);
-                    q[PL] = __builtin_bit_cast(unsigned short, h2);
-                    q[2 * PL] = __builtin_bit_cast(unsigned short, h3);
+                    if constexpr (DT == 0) {
+                        q[0] = __builtin_bit_cast(unsigned short, h1);
+                        q[PL] = __builtin_bit_cast(unsigned short, h2);
+                        q[2 * PL] = __builtin_bit_cast(unsigned short, h3);
+                    }
                 }
             }
         }
@@ -479,6 +545,7 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = (e < 4 ? ga[e] : gb[e - 4]) * sgn;
+                if constexpr (DT != 0) { ah[e] = (short)round_op<DT>(v); continue; }     // (exact: v is a value of the format)
                 const __bf16 h1 = (__bf16)v;
                 const float r1 = v - (float)h1;
                 const __bf16 h2 = (__bf16)r1;
@@ -490,9 +557,9 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
                 // 8 consecutive window columns starting at element `el` of a plane: five aligned dwords, shifted by the start's parity
                 const int el = boff[t] + py * kW1WC + pxb;
                 const unsigned sh = (el & 1) * 2;
-                s16x8 b[3];
+                s16x8 b[NSP];
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) {
+                for (int sp = 0; sp < NSP; ++sp) {
                     const unsigned* const d = reinterpret_cast<const unsigned*>(xT + sp * PL + (el & ~1));
                     unsigned dw[5];
 #pragma unroll
@@ -503,6 +570,10 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
                     for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_alignbyte(dw[q + 1], dw[q], sh);
                     b[sp] = __builtin_bit_cast(s16x8, o);
                 }
+                if constexpr (DT != 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    tmp[t] = mfma32<DT>(ah, b[0], j == 0 ? zero : tmp[t]);
+                } else {
                 // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
                 if (j == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -510,11 +581,12 @@ __global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_kernel(cons
                 } else {
                     tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0], tmp[t], 0, 0, 0);
                 }
-                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1], tmp[t], 0, 0, 0);
-                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[NSP > 1 ? 1 : 0], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[NSP - 1], tmp[t], 0, 0, 0);
                 tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0], tmp[t], 0, 0, 0);
-                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1], tmp[t], 0, 0, 0);
+                tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[NSP > 1 ? 1 : 0], tmp[t], 0, 0, 0);
                 tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0], tmp[t], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -596,6 +668,28 @@ int ss_dense_conv_s1_wgrad_f32(const float* g, const float* x, float* g_w, float
     const int NTW = ((25 * Cin + 31) / 32) * 32;
     if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<4>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
     else hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<2>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    const int len = 32 * NTW, per_range = ((int)grid + kW1Ranges - 1) / kW1Ranges;
+    double* mid = reinterpret_cast<double*>(ws + (long long)kW1Groups * len);
+    hipLaunchKernelGGL(dense_conv_s1_wgrad_reduce_kernel, dim3((len + kBlock - 1) / kBlock, kW1Ranges), dim3(kBlock), 0, s, ws, mid, (int)grid, per_range, len);
+    hipLaunchKernelGGL(dense_conv_s1_wgrad_finish_kernel, dim3((32 * Cin * 25 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, mid, g_w, kW1Ranges, Cin, NTW, accumulate);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ss_dense_conv_s1_wgrad_f32 on a 16-bit output gradient (ABI 9): g in `dtype`, x fp32 (rounded once to `dtype`: the forward's operand), g_w fp32 */
+int ss_dense_conv_s1_wgrad_x16(const void* g, const float* x, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int accumulate, int dtype, void* stream)
+{
+    if (!g || !x || !g_w || !ws || NB <= 0 || NB > 0x7fffffff || h <= 0 || w <= 0 || !ss_dense_conv_s1_wgrad_supported(Cin, Cout, 5, 1, 2)) return SS_EINVAL;
+    if (!aligned16(g) || !aligned16(ws) || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n_tiles = NB * ((h + kW1TR - 1) / kW1TR) * ((w + kW1TC - 1) / kW1TC);
+    const unsigned grid = (unsigned)(n_tiles < kW1Groups ? n_tiles : kW1Groups);
+    const int NTW = ((25 * Cin + 31) / 32) * 32;
+    const unsigned short* g16 = static_cast<const unsigned short*>(g);
+#define SS_W116(CI_) do { if (dtype == SS_DT_F16) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<CI_, SS_DT_F16>), dim3(grid), dim3(kW1Threads), 0, s, g16, x, ws, (int)NB, h, w); \
+                          else hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<CI_, SS_DT_BF16>), dim3(grid), dim3(kW1Threads), 0, s, g16, x, ws, (int)NB, h, w); } while (0)
+    if (Cin == 4) SS_W116(4); else SS_W116(2);
+#undef SS_W116
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const int len = 32 * NTW, per_range = ((int)grid + kW1Ranges - 1) / kW1Ranges;
     double* mid = reinterpret_cast<double*>(ws + (long long)kW1Groups * len);

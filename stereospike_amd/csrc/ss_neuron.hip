@@ -216,12 +216,17 @@ struct Fwd16Args {
     int T; long long N;
     float scale, tau, v_th, v_reset; const float* k;
     unsigned* cnt_ws;              // nullable (with nnz): per-workgroup counter partials (ss_neuron_fwd_ex)
+    // ss_neuron_fwd_ex only (PK instantiations, round 5): 2-bit packed spike I/O exactly as in the fp32 kernel — the packed format knows no activation dtype
+    const unsigned* skip_packed;   // nullable: the skip operand read from a packed spike tensor instead of skip_seq
+    unsigned* out_packed;          // nullable: out (z + skip, values 0..3) written packed; out_seq may then be NULL (2.25 B/update forward)
 };
 
 // TS > 0: compile-time T, all T (independent) loads of a lane issued before the recurrence starts, like the fp32 kernel; TS = 0: run-time T.
-template <int KIND, int DT, int TS, bool SKIP, bool SAVE_H, int VEC>
+// PK: the ss_neuron_fwd_ex form with 2-bit packed spike output and / or packed skip input (VEC = 8 | 4, compile-time T only, no saved h)
+template <int KIND, int DT, int TS, bool SKIP, bool SAVE_H, int VEC, bool PK = false>
 __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
 {
+    static_assert(!PK || (TS > 0 && (VEC == 8 || VEC == 4) && !SAVE_H), "packed I/O: compile-time T, 16 / 8-byte lanes, no saved h");
     typedef typename U16Vec<VEC>::type uvec_t;
     const int T = (TS > 0) ? TS : a.T;
     const long long NV = a.N / VEC;
@@ -261,7 +266,46 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
             }
         };
 
-        if constexpr (TS > 0) {
+        if constexpr (PK) {
+            const long long NW = a.N / 16;                 // packed words per time step
+            const bool skip_pk = SKIP && a.skip_packed != nullptr;
+            uvec_t xs[TS];
+            unsigned sb[TS];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.x_seq + ((long long)t * NV + i) * VEC));
+            if (SKIP) {
+                if (skip_pk) {
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) sb[t] = load_packed<VEC>(a.skip_packed + (long long)t * NW, i);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {           // dense 16-bit skip: small integers 0..3, exact in the 2-bit code
+                        const uvec_t sv = *reinterpret_cast<const uvec_t*>(a.skip_seq + ((long long)t * NV + i) * VEC);
+                        sb[t] = 0u;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) sb[t] |= ((unsigned)widen<DT>(sv[e]) & 3u) << (2 * e);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                uvec_t ov;
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float hh = charge<KIND>(v[e], widen<DT>(xs[t][e]) * scale, tau, k, v_reset);
+                    const float z = heaviside(hh - v_th);
+                    v[e] = (1.f - z) * hh + z * v_reset;
+                    unsigned code = (unsigned)(z != 0.f) + (SKIP ? ((sb[t] >> (2 * e)) & 3u) : 0u);
+                    code = code > 3u ? 3u : code;       // contract (ss_neuron.h): z + skip <= 3
+                    c_spk += (z != 0.f); c_out += (code != 0u);
+                    bits |= code << (2 * e);
+                    ov[e] = code_to_op<DT>(code);
+                }
+                if (a.out_seq) store_out(reinterpret_cast<uvec_t*>(a.out_seq + ((long long)t * NV + i) * VEC), ov);
+                if (a.out_packed) store_packed<VEC>(a.out_packed + (long long)t * NW, i, bits);
+            }
+        } else if constexpr (TS > 0) {
             uvec_t xs[TS], ss[SKIP ? TS : 1];
 #pragma unroll
             for (int t = 0; t < TS; ++t) {
@@ -393,11 +437,21 @@ int launch_fwd16(const Fwd16Args& a, hipStream_t s)
 {
     // lane width: 8 neurons (one 16-B load per step) while all T loads fit comfortably in registers, 4 for the longer sequences
     constexpr int V = (TS == 0 || TS <= 5) ? SS_F16_V5 : SS_F16_V10;
-    const bool skip = a.skip_seq != nullptr, save_h = a.h_seq != nullptr;
+    const bool skip = a.skip_seq != nullptr || a.skip_packed != nullptr, save_h = a.h_seq != nullptr;
     const bool vec = (a.N % V == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
-                     (!a.v_init || aligned16(a.v_init)) && (!skip || aligned16(a.skip_seq)) && (!save_h || aligned16(a.h_seq));
+                     (!a.v_init || aligned16(a.v_init)) && (!a.skip_seq || aligned16(a.skip_seq)) && (!save_h || aligned16(a.h_seq));
     const int cap = (a.nnz && !a.cnt_ws) ? kMaxGridGk : kMaxGrid;
     const int grid = vec ? grid_for(a.N / V, cap) : grid_for(a.N, cap);
+    if (a.out_packed || a.skip_packed) {                  // packed spike I/O: 16-B lanes, compile-time T, no saved h
+        if constexpr (TS == 0) return SS_EINVAL;
+        else {
+            if (!vec || a.N % 16 != 0 || save_h) return SS_EINVAL;
+            if (skip) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, true, false, V, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            else hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, false, false, V, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+            return finish_counts(a.nnz, a.cnt_ws, grid, s);
+        }
+    }
 #define SS_L16(SK, SH) do { if (vec) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, SK, SH, V>), dim3(grid), dim3(kBlock), 0, s, a); \
                             else hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, SK, SH, 1>), dim3(grid), dim3(kBlock), 0, s, a); } while (0)
     if (skip) { if (save_h) SS_L16(true, true); else SS_L16(true, false); }
@@ -459,7 +513,7 @@ int ss_neuron_fwd_x16(const void* x_seq, const float* v_init, const void* skip_s
     if (out_seq == x_seq) return SS_EINVAL;
     if (N == 0) return SS_OK;
     Fwd16Args a{static_cast<const unsigned short*>(x_seq), v_init, static_cast<const unsigned short*>(skip_seq),
-                static_cast<unsigned short*>(out_seq), h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k, nullptr};
+                static_cast<unsigned short*>(out_seq), h_seq, v_last, nnz, T, N, scale, tau, v_th, v_reset, k, nullptr, nullptr, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define SS_D16(KK) (dtype == SS_DT_F16 ? dispatch_fwd16<KK, SS_DT_F16>(a, s) : dispatch_fwd16<KK, SS_DT_BF16>(a, s))
     switch (kind) {
@@ -495,10 +549,12 @@ int ss_neuron_fwd_ex(const ss_neuron_fwd_desc* d, void* stream)
         }
     }
     if (d->act_dtype != SS_DT_F16 && d->act_dtype != SS_DT_BF16) return SS_EINVAL;
-    if (d->out_packed || d->skip_packed || !d->out_seq) return SS_EINVAL;          // packed I/O: fp32 activations only
+    // packed I/O on 16-bit activations (ABI 9): the same contract as the fp32 form — whole words, compile-time T, no saved h
+    if ((d->out_packed || d->skip_packed) && (d->h_seq || d->N % 16 != 0 || !ss_neuron_bwd_rc_supported(d->T))) return SS_EINVAL;
     if (d->N == 0) return SS_OK;
     Fwd16Args a{static_cast<const unsigned short*>(d->x_seq), d->v_init, static_cast<const unsigned short*>(d->skip_seq),
-                static_cast<unsigned short*>(d->out_seq), d->h_seq, d->v_last, d->nnz, d->T, d->N, d->scale, d->tau, d->v_th, d->v_reset, d->k, d->cnt_ws};
+                static_cast<unsigned short*>(d->out_seq), d->h_seq, d->v_last, d->nnz, d->T, d->N, d->scale, d->tau, d->v_th, d->v_reset, d->k, d->cnt_ws,
+                d->skip_packed, d->out_packed};
 #define SS_D16(KK) (d->act_dtype == SS_DT_F16 ? dispatch_fwd16<KK, SS_DT_F16>(a, s) : dispatch_fwd16<KK, SS_DT_BF16>(a, s))
     switch (d->kind) {
         case SS_KIND_IF: return SS_D16(SS_KIND_IF);

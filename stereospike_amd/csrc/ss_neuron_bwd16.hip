@@ -88,11 +88,24 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_kernel(Bwd16Args a)
 
 // G2: a second consumer's 16-bit gradient is added on load (fp32 sum of the two widened values — not rounded to 16 bits in between,
 // unlike autograd's accumulation); g_sum_seq (nullable) receives that sum narrowed once: dL/dskip of a stage that has both.
-template <int KIND, int SG, int DT, int TS, int VEC, bool G2 = false>
+// LR (round 5; with G2): the second gradient arrives as the prediction head's rank-9 pair, exactly as in ss_neuron_bwd_fork_lr_f32 — g2[t][n] =
+// sum_j lr_p[(t * N / C + n / C) * 9 + j] * lr_w[j * C + n % C], both fp32 (taps ascending, multiply and add rounded separately) — and is added to the
+// widened first gradient in fp32; the first gradient may be absent (a.g_out_seq == NULL: the full-resolution stage has no other consumer).
+constexpr int kLr16MaxC = 512, kLr16Rank = 9;
+template <int KIND, int SG, int DT, int TS, int VEC, bool G2 = false, bool LR = false>
 __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, const unsigned short* __restrict__ x_seq,
-                                                                 const unsigned short* __restrict__ g_out2_seq, unsigned short* __restrict__ g_sum_seq)
+                                                                 const unsigned short* __restrict__ g_out2_seq, unsigned short* __restrict__ g_sum_seq,
+                                                                 const float* __restrict__ lr_p = nullptr, const float* __restrict__ lr_w = nullptr, int lr_C = 0)
 {
+    static_assert(!LR || (G2 && VEC > 1), "low-rank second gradient: vector lanes of the forked form");
     typedef typename U16Vec<VEC>::type uvec_t;
+    __shared__ __attribute__((aligned(16))) float lr_ws[LR ? kLr16Rank * kLr16MaxC : 4];
+    int lr_c0 = 0;
+    if constexpr (LR) {
+        for (int q = threadIdx.x; q < kLr16Rank * lr_C; q += kBlock) lr_ws[q] = lr_w[q];
+        lr_c0 = (int)((threadIdx.x * (unsigned)VEC) % (unsigned)lr_C);        // the lane's channels are the same in every trip (kBlock * VEC is a multiple of C: host)
+        __syncthreads();
+    }
     const long long NV = a.N / VEC;
     const float k = (KIND == SS_KIND_PLIF) ? *a.k : 0.f;
     const float scale = a.scale, tau = a.tau, v_th = a.v_th, v_reset = a.v_reset, alpha = a.alpha;
@@ -105,12 +118,37 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
         uvec_t xs[TS], gs[TS];
 #pragma unroll
         for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const uvec_t*>(x_seq + ((long long)t * NV + i) * VEC));
+        const bool has_g1 = !LR || a.g_out_seq != nullptr;    // wave-uniform
+        if (has_g1) {
 #pragma unroll
-        for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.g_out_seq + ((long long)t * NV + i) * VEC));
-        uvec_t g2[G2 ? TS : 1];
-        if constexpr (G2) {
+            for (int t = TS - 1; t >= 0; --t) gs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.g_out_seq + ((long long)t * NV + i) * VEC));
+        }
+        uvec_t g2[(G2 && !LR) ? TS : 1];
+        if constexpr (G2 && !LR) {
 #pragma unroll
             for (int t = TS - 1; t >= 0; --t) g2[t] = load_stream(reinterpret_cast<const uvec_t*>(g_out2_seq + ((long long)t * NV + i) * VEC));
+        }
+        float lracc[LR ? TS : 1][LR ? VEC : 1];
+        if constexpr (LR) {
+            const long long rows = a.N / lr_C;
+            const float* pp = lr_p + ((i * VEC) / lr_C) * kLr16Rank;
+            float pj[TS][kLr16Rank];
+#pragma unroll
+            for (int t = TS - 1; t >= 0; --t)
+#pragma unroll
+                for (int j = 0; j < kLr16Rank; ++j) pj[t][j] = pp[(long long)t * rows * kLr16Rank + j];
+            int c0v = lr_c0;
+            asm volatile("" : "+v"(c0v));                  // keep the nine LDS reads inside the loop
+#pragma unroll
+            for (int j = 0; j < kLr16Rank; ++j) {
+                float wj[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) wj[e] = lr_ws[j * lr_C + c0v + e];
+#pragma unroll
+                for (int t = TS - 1; t >= 0; --t)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) lracc[t][e] = (j == 0) ? pj[t][0] * wj[e] : lracc[t][e] + pj[t][j] * wj[e];
+            }
         }
         float v0[VEC], gv[VEC], h[TS][VEC];
 #pragma unroll
@@ -139,13 +177,16 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
             uvec_t xv, sumv;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                unsigned short gb;
-                if constexpr (VEC == 1) gb = gs[t]; else gb = gs[t][e];
+                unsigned short gb = 0;
+                if (has_g1) { if constexpr (VEC == 1) gb = gs[t]; else gb = gs[t][e]; }
                 const float he = h[t][e];
                 const float xh = he - v_th;
                 const float z = heaviside(xh);
-                float g_s = widen<DT>(gb);
-                if constexpr (G2) {
+                float g_s = has_g1 ? widen<DT>(gb) : 0.f;
+                if constexpr (LR) {
+                    g_s = has_g1 ? g_s + lracc[t][e] : lracc[t][e];
+                    sumv[e] = narrow<DT>(g_s);
+                } else if constexpr (G2) {
                     unsigned short gb2;
                     if constexpr (VEC == 1) gb2 = g2[t]; else gb2 = g2[t][e];
                     g_s = g_s + widen<DT>(gb2);
@@ -195,9 +236,20 @@ int dispatch_bwd16(const Bwd16Args& a, hipStream_t s, int* grid_out)
 }
 
 template <int KIND, int SG, int DT, int TS>
-int launch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsigned short* g2, unsigned short* g_sum, hipStream_t s, int* grid_out)
+int launch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsigned short* g2, unsigned short* g_sum, hipStream_t s, int* grid_out,
+                    const float* lr_p = nullptr, const float* lr_w = nullptr, int lr_C = 0)
 {
     constexpr int V = (TS <= 5) ? SS_RC16_V5 : SS_RC16_V10;    // measured on the MI355X: tools/bench_rc16.py
+    if (lr_p) {                                               // low-rank second gradient: vector lanes only
+        const bool ok = (a.N % V == 0) && aligned16(a.g_out_seq) && aligned16(x_seq) && aligned16(a.g_x_seq) && aligned16(g_sum) && aligned16(lr_w) &&
+                        (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) && (!a.v_init || aligned16(a.v_init));
+        if (!ok || (kBlock * V) % lr_C != 0 || lr_C % V != 0) return SS_EINVAL;
+        int grid = grid_for(a.N / V, kMaxGridBwd);
+        if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
+        *grid_out = grid;
+        hipLaunchKernelGGL((neuron_bwd16_rc_kernel<KIND, SG, DT, TS, V, true, true>), dim3(grid), dim3(kBlock), 0, s, a, x_seq, g2, g_sum, lr_p, lr_w, lr_C);
+        return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+    }
     const bool vec = (a.N % V == 0) && aligned16(a.g_out_seq) && aligned16(x_seq) && aligned16(a.g_x_seq) && aligned16(g2) && aligned16(g_sum) &&
                      (!a.g_v_last || aligned16(a.g_v_last)) && (!a.g_v_init || aligned16(a.g_v_init)) &&
                      (!a.v_init || aligned16(a.v_init));
@@ -215,15 +267,16 @@ int launch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsig
 }
 
 template <int KIND, int SG, int DT>
-int dispatch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsigned short* g2, unsigned short* g_sum, hipStream_t s, int* grid_out)
+int dispatch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const unsigned short* g2, unsigned short* g_sum, hipStream_t s, int* grid_out,
+                      const float* lr_p = nullptr, const float* lr_w = nullptr, int lr_C = 0)
 {
     switch (a.T) {
-        case 1: return launch_bwd16_rc<KIND, SG, DT, 1>(a, x_seq, g2, g_sum, s, grid_out);
-        case 2: return launch_bwd16_rc<KIND, SG, DT, 2>(a, x_seq, g2, g_sum, s, grid_out);
-        case 4: return launch_bwd16_rc<KIND, SG, DT, 4>(a, x_seq, g2, g_sum, s, grid_out);
-        case 5: return launch_bwd16_rc<KIND, SG, DT, 5>(a, x_seq, g2, g_sum, s, grid_out);
-        case 8: return launch_bwd16_rc<KIND, SG, DT, 8>(a, x_seq, g2, g_sum, s, grid_out);
-        case 10: return launch_bwd16_rc<KIND, SG, DT, 10>(a, x_seq, g2, g_sum, s, grid_out);
+        case 1: return launch_bwd16_rc<KIND, SG, DT, 1>(a, x_seq, g2, g_sum, s, grid_out, lr_p, lr_w, lr_C);
+        case 2: return launch_bwd16_rc<KIND, SG, DT, 2>(a, x_seq, g2, g_sum, s, grid_out, lr_p, lr_w, lr_C);
+        case 4: return launch_bwd16_rc<KIND, SG, DT, 4>(a, x_seq, g2, g_sum, s, grid_out, lr_p, lr_w, lr_C);
+        case 5: return launch_bwd16_rc<KIND, SG, DT, 5>(a, x_seq, g2, g_sum, s, grid_out, lr_p, lr_w, lr_C);
+        case 8: return launch_bwd16_rc<KIND, SG, DT, 8>(a, x_seq, g2, g_sum, s, grid_out, lr_p, lr_w, lr_C);
+        case 10: return launch_bwd16_rc<KIND, SG, DT, 10>(a, x_seq, g2, g_sum, s, grid_out, lr_p, lr_w, lr_C);
         default: return SS_EINVAL;
     }
 }
@@ -235,9 +288,10 @@ extern "C" {
 static int neuron_bwd_x16_impl(const void* g_out_seq, const void* g_out2_seq, void* g_sum_seq, const float* g_v_last, const float* h_seq, const void* x_seq, const float* v_init,
                                void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
                                int T, long long N, float scale, int kind, float tau, const float* k,
-                               float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+                               float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream,
+                               const float* lr_p = nullptr, const float* lr_w = nullptr, int lr_C = 0)
 {
-    if (!g_out_seq || (!h_seq && !x_seq) || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
+    if ((!g_out_seq && !lr_p) || (!h_seq && !x_seq) || !g_x_seq || T <= 0 || N < 0) return SS_EINVAL;
     if (kind < SS_KIND_IF || kind > SS_KIND_PLIF || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
     if (surrogate != SS_SG_ATAN && surrogate != SS_SG_SIGMOID) return SS_EINVAL;
     if (kind == SS_KIND_PLIF && !k) return SS_EINVAL;
@@ -254,8 +308,8 @@ static int neuron_bwd_x16_impl(const void* g_out_seq, const void* g_out2_seq, vo
     const unsigned short* xq = static_cast<const unsigned short*>(x_seq);
     int grid = 0, rc;
     const unsigned short* g2q = static_cast<const unsigned short*>(g_out2_seq);
-    unsigned short* gsq = g2q ? static_cast<unsigned short*>(g_sum_seq) : nullptr;
-#define SS_B16D(KK, SGG, DTT) (xq ? dispatch_bwd16_rc<KK, SGG, DTT>(a, xq, g2q, gsq, s, &grid) : dispatch_bwd16<KK, SGG, DTT>(a, s, &grid))
+    unsigned short* gsq = (g2q || lr_p) ? static_cast<unsigned short*>(g_sum_seq) : nullptr;
+#define SS_B16D(KK, SGG, DTT) (xq ? dispatch_bwd16_rc<KK, SGG, DTT>(a, xq, g2q, gsq, s, &grid, lr_p, lr_w, lr_C) : dispatch_bwd16<KK, SGG, DTT>(a, s, &grid))
 #define SS_B16(KK, SGG) (dtype == SS_DT_F16 ? SS_B16D(KK, SGG, SS_DT_F16) : SS_B16D(KK, SGG, SS_DT_BF16))
 #define SS_B16S(KK) (surrogate == SS_SG_ATAN ? SS_B16(KK, SS_SG_ATAN) : SS_B16(KK, SS_SG_SIGMOID))
     switch (kind) {
@@ -303,6 +357,25 @@ int ss_neuron_bwd_fork_x16(const void* g_out_seq, const void* g_out2_seq, void* 
     if (g_out2_seq == g_x_seq || (g_sum_seq && g_sum_seq == g_x_seq)) return SS_EINVAL;
     return neuron_bwd_x16_impl(g_out_seq, g_out2_seq, g_sum_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind,
                                tau, k, v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream);
+}
+
+/* ss_neuron_bwd_fork_lr_f32 on 16-bit activations (ABI 9): g_out_seq (nullable) / g_sum_seq (nullable) / x_seq / g_x_seq in `dtype`, the rank-9 pair fp32 */
+int ss_neuron_bwd_fork_lr_x16_supported(int T, long long N, int C, int lr_rank)
+{
+    const int V = T <= 5 ? SS_RC16_V5 : SS_RC16_V10;
+    return ss_neuron_bwd_rc_supported(T) && lr_rank == kLr16Rank && C >= 4 && C <= kLr16MaxC && C % V == 0 && C % 4 == 0 && (kBlock * V) % C == 0 && N > 0 && N % C == 0;
+}
+
+int ss_neuron_bwd_fork_lr_x16(const void* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, void* g_sum_seq,
+                              const float* g_v_last, const void* x_seq, const float* v_init, void* g_x_seq, float* g_v_init,
+                              float* g_k, float* g_k_ws, int T, long long N, float scale, int kind, float tau, const float* k,
+                              float v_th, float v_reset, int surrogate, float alpha, int detach_reset, int dtype, void* stream)
+{
+    if (!lr_p || !lr_w || !x_seq) return SS_EINVAL;
+    if (!ss_neuron_bwd_fork_lr_x16_supported(T, N, C, lr_rank)) return SS_EINVAL;
+    if (g_sum_seq && (!g_out_seq || g_sum_seq == g_x_seq)) return SS_EINVAL;   // without a dense first gradient the "sum" IS the low-rank pair
+    return neuron_bwd_x16_impl(g_out_seq, nullptr, g_sum_seq, g_v_last, nullptr, x_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws, T, N, scale, kind,
+                               tau, k, v_th, v_reset, surrogate, alpha, detach_reset, dtype, stream, lr_p, lr_w, C);
 }
 
 }  // extern "C"

@@ -33,15 +33,18 @@ constexpr int kScRowB = kScWC * kScPix;
 
 // weight [C_out][C_in][5][5] fp32 -> Bf[chunk of 32 ci][s = tap * 2 + ci16 group][split][co tile][lane][8] bf16: element e of a lane = split term
 // of W[co = 32 tile + (lane & 31)][ci = 32 chunk + 16 group + 8 (lane >> 5) + e][ky][kx]   (exact 3-way split, round to nearest)
+// DT != 0 (16-bit activation modes): ONE term, the weight rounded once to the operand format
+template <int DT = 0>
 __global__ __launch_bounds__(kBlock) void spike_conv_fwd_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, int Cin, int Cout)
 {
+    constexpr int NSP = DT ? 1 : 3;
     const int NT = Cout / 32;
-    const long long total = (long long)(Cin / 32) * 50 * 3 * NT * 64;
+    const long long total = (long long)(Cin / 32) * 50 * NSP * NT * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
         long long r = i >> 6;
         const int t = (int)(r % NT); r /= NT;
-        const int sp = (int)(r % 3); r /= 3;
+        const int sp = (int)(r % NSP); r /= NSP;
         const int s = (int)(r % 50); const int c = (int)(r / 50);
         const int tap = s >> 1, g = s & 1, ky = tap / 5, kx = tap - 5 * ky;
         const int co = 32 * t + (lane & 31);
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(kBlock) void spike_conv_fwd_prep_kernel(const float
         for (int e = 0; e < 8; ++e) {
             const int ci = 32 * c + 16 * g + 8 * (lane >> 5) + e;
             const float v = W[(((long long)co * Cin + ci) * 5 + ky) * 5 + kx];
+            if constexpr (DT != 0) { o[e] = round_op<DT>(v); continue; }
             const unsigned short h1 = narrow<SS_DT_BF16>(v);
             const float r1 = v - widen<SS_DT_BF16>(h1);
             const unsigned short h2 = narrow<SS_DT_BF16>(r1);
@@ -63,21 +67,23 @@ __global__ __launch_bounds__(kBlock) void spike_conv_fwd_prep_kernel(const float
 // NTW: 32-channel output tiles per workgroup.  NTW == C_out / 32 for the shipped shapes (conv1, conv2); the wide shapes of conv3 / conv4 (C_out 256 / 512)
 // run C_out / (32 NTW) workgroup SLICES per tile (slice = blockIdx.x % slices), each re-staging the window — built for the A/B against the library path
 // (profiles/r04/conv34_ab.log), not dispatched by the network
-template <int CIN, int COUT, bool PACKED, int NTW = COUT / 32>
+// DT != 0 (16-bit activation modes, round 5): ONE weight term on the native matrix-core type, the dense input (if any) is the 16-bit spike tensor itself,
+// the output is narrowed once on store
+template <int CIN, int COUT, bool PACKED, int NTW = COUT / 32, int DT = 0>
 __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Bf,
-                                                                       float* __restrict__ out, int NB, int h, int w, int ho, int wo)
+                                                                       typename ActT<DT>::type* __restrict__ out, int NB, int h, int w, int ho, int wo)
 {
-    constexpr int NTG = COUT / 32, NT = NTW, NCH = CIN / 32, NSL = NTG / NTW;
+    constexpr int NTG = COUT / 32, NT = NTW, NCH = CIN / 32, NSL = NTG / NTW, NSP = DT ? 1 : 3;
     static_assert(NTG % NTW == 0, "slices");
 #ifdef SS_SC_KPS1
     constexpr int KPS = 1;                                                      // A/B build (tools/): one k-step per stage everywhere
 #else
-    constexpr int KPS = NT <= 2 ? 2 : 1;
+    constexpr int KPS = NSP * NT <= 6 ? 2 : 1;
 #endif
                                         // k-steps per weight stage and barrier: a whole tap where it fits beside the window
                                                                                 // at two workgroups per CU (C_out 64: 24 KB of stages; C_out 128 would need 48)
-    constexpr int KST = 3 * NT * 1024;                                          // bytes of one k-step's weight fragments (of this slice: the LDS stage)
-    constexpr int KSTG = 3 * NTG * 1024;                                        // ... of all of C_out: the stride in Bf
+    constexpr int KST = NSP * NT * 1024;                                        // bytes of one k-step's weight fragments (of this slice: the LDS stage)
+    constexpr int KSTG = NSP * NTG * 1024;                                      // ... of all of C_out: the stride in Bf
     constexpr int STG = KPS * KST;                                              // bytes of one weight stage
     constexpr int LPT = STG / 16 / kScThreads;                                  // whole 16-B pieces per thread and stage (+ a partial round)
     constexpr int REM = STG / 16 - LPT * kScThreads;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
     auto piece = [&](int p) -> long long {
         if constexpr (NSL == 1) return (long long)p * 16;
         else {
-            const int ks = p / (3 * NT * 64), rem = p - ks * (3 * NT * 64), sp = rem / (NT * 64), q = rem - sp * (NT * 64);
+            const int ks = p / (NSP * NT * 64), rem = p - ks * (NSP * NT * 64), sp = rem / (NT * 64), q = rem - sp * (NT * 64);
             return (long long)ks * KSTG + (sp * NTG + NT * slice) * 1024 + q * 16;
         }
     };
@@ -156,9 +162,33 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                         for (int q = 0; q < 2; ++q) {                             // granule 2 j + q = channels 16 j + 8 q .. + 7
                             u16x8 o;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = code_to_bf16((wv[u] >> (2 * (8 * q + e))) & 3u);
+                            for (int e = 0; e < 8; ++e) o[e] = code_to_op<DT>((wv[u] >> (2 * (8 * q + e))) & 3u);
                             *reinterpret_cast<u16x8*>(pp + (((2 * j + q) ^ swz) << 4)) = o;
                         }
+                    }
+                }
+            } else if constexpr (DT != 0) {
+                const unsigned short* x = static_cast<const unsigned short*>(xin);       // the 16-bit spike tensor: already the operand
+                constexpr int kItems = kScWR * kScWC * 4, kIter = (kItems + kScThreads - 1) / kScThreads;   // (pixel, 8-channel granule)
+#pragma unroll 1
+                for (int u0 = 0; u0 < kIter; u0 += 4) {
+                    u16x8 vv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = threadIdx.x + kScThreads * (u0 + v);
+                        const int pix = i >> 2, q = i & 3;
+                        const int wy = pix / kScWC, col = pix - wy * kScWC;
+                        const int iy = iy0 + wy, ix = ix0 + col;
+                        vv[v] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        if (i < kItems && iy >= 0 && iy < h && ix >= 0 && ix < w)
+                            vv[v] = *reinterpret_cast<const u16x8*>(x + (((long long)nb * h + iy) * w + ix) * CIN + 32 * c + 8 * q);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = threadIdx.x + kScThreads * (u0 + v);
+                        const int pix = i >> 2, q = i & 3;
+                        const int wy = pix / kScWC, col = pix - wy * kScWC;
+                        if (i < kItems) *reinterpret_cast<u16x8*>(wnd + wy * kScRowB + col * kScPix + ((q ^ ((col >> 2) & 3)) << 4)) = vv[v];
                     }
                 }
             } else {
@@ -230,13 +260,13 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
 #pragma unroll
                             for (int e = 0; e < 8; ++e) a[e] = (short)(a[e] ^ sgn);          // -0 for a zero spike count: harmless
                             const unsigned char* const bk = bst + (sg & 1) * STG + (s % KPS) * KST + lane * 16;
-                            s16x8 b[3 * NT];                                    // [split][tile]
+                            s16x8 b[NSP * NT];                                  // [split][tile]
 #pragma unroll
-                            for (int u = 0; u < 3 * NT; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
+                            for (int u = 0; u < NSP * NT; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);
 #pragma unroll
-                            for (int sp = 2; sp >= 0; --sp)                     // smallest terms first
+                            for (int sp = NSP - 1; sp >= 0; --sp)               // smallest terms first
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[sp * NT + t], a, acc[t], 0, 0, 0);     // D^T: rows = output channels, columns = pixels
+                                for (int t = 0; t < NT; ++t) acc[t] = mfma32<DT>(b[sp * NT + t], a, acc[t]);     // D^T: rows = output channels, columns = pixels
                         }
                         if (last) {
                             if (more) stage_commit(bst + ((sg + 1) & 1) * STG);
@@ -251,7 +281,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
         if (active) {
             const int ox = ox0 + tx;
             if (ox < wo) {
-                float* const op = out + (((long long)nb * ho + (oy0 + mb)) * wo + ox) * COUT + 32 * NT * slice + 4 * half;
+                typename ActT<DT>::type* const op = out + (((long long)nb * ho + (oy0 + mb)) * wo + ox) * COUT + 32 * NT * slice + 4 * half;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                         f4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = neg ? -acc[t][4 * q + e] : acc[t][4 * q + e];
-                        *reinterpret_cast<f4*>(op + 32 * t + 8 * q) = v;
+                        store_act4<DT>(op + 32 * t + 8 * q, v[0], v[1], v[2], v[3]);
                     }
             }
         }
@@ -279,29 +309,33 @@ constexpr int kS1Threads = 256;
 constexpr int kS1TR = 16, kS1TC = 32;                  // output rows (4 per wavefront) x output columns of a tile
 constexpr int kS1WR = kS1TR + 4, kS1WC = kS1TC + 4;
 
-template <int CI>
-__global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ out,
+// DT != 0 (16-bit activation modes): the fp32 input and the weight are rounded ONCE to the operand format (what autocast does to both operands of the
+// first layer; event counts are exact), one MFMA per k-step, the output narrowed on store
+template <int CI, int DT = 0>
+__global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, typename ActT<DT>::type* __restrict__ out,
                                                                         int NB, int h, int w)
 {
     constexpr int COUT = 32, KS = (25 * CI + 15) / 16, TPL = 8 / CI;           // k-steps; taps per lane and k-step
     constexpr int PIXB = CI * 2, PLANE = kS1WR * kS1WC * PIXB;                 // bytes per window pixel and per split plane
-    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * PLANE + 16];
+    constexpr int NSP = DT ? 1 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[NSP * PLANE + 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tx = lane & 31, half = lane >> 5;
     // ---- the weight as B fragments in registers: b[ks][split], element e = split of W[co = tx][ci][ky][kx], k = 16 ks + 8 half + e = tap * CI + ci
-    s16x8 b[KS][3];
+    s16x8 b[KS][NSP];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int kk = 16 * ks + 8 * half + e, tap = kk / CI, ci = kk - tap * CI;
             const float v = tap < 25 ? W[((long long)tx * CI + ci) * 25 + tap] : 0.f;
+            if constexpr (DT != 0) { b[ks][0][e] = (short)round_op<DT>(v); continue; }
             const __bf16 h1 = (__bf16)v;
             const float r1 = v - (float)h1;
             const __bf16 h2 = (__bf16)r1;
             const __bf16 h3 = (__bf16)(r1 - (float)h2);
-            b[ks][0][e] = __builtin_bit_cast(short, h1); b[ks][1][e] = __builtin_bit_cast(short, h2); b[ks][2][e] = __builtin_bit_cast(short, h3);
+            if constexpr (DT == 0) { b[ks][0][e] = __builtin_bit_cast(short, h1); b[ks][1][e] = __builtin_bit_cast(short, h2); b[ks][2][e] = __builtin_bit_cast(short, h3); }
         }
     // window byte offsets of this lane's taps (relative to its output pixel), per k-step: tap -> (ky, kx); padding taps read tap 24 (B is zero there)
     int toff[KS][TPL];
@@ -336,14 +370,17 @@ __global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const flo
             }
 #pragma unroll
             for (int c = 0; c < CI; ++c) {
+                unsigned short* const q = reinterpret_cast<unsigned short*>(wnd + i * PIXB) + c;
+                if constexpr (DT != 0) { q[0] = round_op<DT>(v[c]); continue; }
                 const __bf16 h1 = (__bf16)v[c];
                 const float r1 = v[c] - (float)h1;
                 const __bf16 h2 = (__bf16)r1;
                 const __bf16 h3 = (__bf16)(r1 - (float)h2);
-                unsigned short* const q = reinterpret_cast<unsigned short*>(wnd + i * PIXB) + c;
-                q[0] = __builtin_bit_cast(unsigned short, h1);
-                q[PLANE / 2] = __builtin_bit_cast(unsigned short, h2);
-                q[PLANE] = __builtin_bit_cast(unsigned short, h3);
+                if constexpr (DT == 0) {
+                    q[0] = __builtin_bit_cast(unsigned short, h1);
+                    q[PLANE / 2] = __builtin_bit_cast(unsigned short, h2);
+                    q[PLANE] = __builtin_bit_cast(unsigned short, h3);
+                }
             }
         }
         __syncthreads();
@@ -357,22 +394,26 @@ __global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const flo
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s16x8 a[3];
+                s16x8 a[NSP];
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < NSP; ++sp)
 #pragma unroll
                     for (int q = 0; q < TPL; ++q) {
                         const unsigned short* const src = reinterpret_cast<const unsigned short*>(pix + sp * PLANE + toff[ks][q]);
 #pragma unroll
                         for (int c = 0; c < CI; ++c) a[sp][q * CI + c] = (short)src[c];
                     }
+                if constexpr (DT != 0) {
+                    acc = mfma32<DT>(a[0], b[ks][0], acc);
+                } else {
                 // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[ks][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ks][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[ks][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NSP - 1], b[ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NSP > 1 ? 1 : 0], b[ks][NSP > 1 ? 1 : 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][NSP - 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NSP > 1 ? 1 : 0], b[ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][NSP > 1 ? 1 : 0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[ks][0], acc, 0, 0, 0);
+                }
             }
             // (a transposed product with 16-byte plain stores — what pays in the MFMA-bound kernels — measured SLOWER here, 0.295 -> 0.32 ms: this kernel is
             //  bound by writing its output, and 16 non-temporal 128-byte rows per wavefront store beat 4 x 32-byte pieces per line; profiles/r04/bench_f4_epilogues_v2_*.json)
@@ -380,7 +421,10 @@ __global__ __launch_bounds__(kS1Threads) void dense_conv_s1_fwd_kernel(const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (ox < w) store_out(out + (rowbase + ox) * COUT + tx, acc[r]);
+                if (ox < w) {
+                    if constexpr (DT == 0) store_out(out + (rowbase + ox) * COUT + tx, acc[r]);
+                    else store_out(out + (rowbase + ox) * COUT + tx, narrow<DT>(acc[r]));
+                }
             }
         }
     }
@@ -402,6 +446,36 @@ int ss_spike_conv_fwd_wide_supported(int Cin, int Cout, int k, int stride, int p
     return k == 5 && stride == 2 && pad == 2 && ((Cin == 128 && Cout == 256) || (Cin == 256 && Cout == 512));
 }
 
+/* ss_spike_conv_fwd_f32 on 16-bit activations (ABI 9): x (nullable) = the dense 16-bit spike tensor, x_packed (nullable) the 2-bit packed one, weight fp32
+   (rounded once to `dtype` in the prep kernel), out in `dtype`; ws as for the fp32 form (a third of it is used). */
+int ss_spike_conv_fwd_x16(const void* x, const unsigned int* x_packed, const float* weight, void* out, float* ws,
+                          long long NB, int Cin, int Cout, int h, int w, int dtype, void* stream)
+{
+    if ((!x && !x_packed) || !weight || !out || !ws || NB <= 0 || h <= 0 || w <= 0 || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (!ss_spike_conv_fwd_supported(Cin, Cout, 5, 2, 2) || !aligned16(out) || !aligned16(ws) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
+    const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
+    if (NB * h * (long long)w * Cin > 0x7fffffffffLL || (x_packed && (NB * h * (long long)w * Cin) % 16 != 0)) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* o16 = static_cast<unsigned short*>(out);
+    const int pg = grid_for((long long)25 * Cin * Cout / 8, 4096);
+    if (dtype == SS_DT_F16) hipLaunchKernelGGL(spike_conv_fwd_prep_kernel<SS_DT_F16>, dim3(pg), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
+    else hipLaunchKernelGGL(spike_conv_fwd_prep_kernel<SS_DT_BF16>, dim3(pg), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    const long long n_tiles = NB * ((ho + kScTR - 1) / kScTR) * ((wo + kScTC - 1) / kScTC);
+    const unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);
+#define SS_SC16(CI, CO, DTT) do { if (x_packed) hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, true, CO / 32, DTT>), dim3(grid), dim3(kScThreads), 0, s, \
+                                      static_cast<const void*>(x_packed), Bf, o16, (int)NB, h, w, ho, wo); \
+                                  else hipLaunchKernelGGL((spike_conv_fwd_kernel<CI, CO, false, CO / 32, DTT>), dim3(grid), dim3(kScThreads), 0, s, \
+                                      x, Bf, o16, (int)NB, h, w, ho, wo); } while (0)
+    if (dtype == SS_DT_F16) { if (Cin == 32) SS_SC16(32, 64, SS_DT_F16); else SS_SC16(64, 128, SS_DT_F16); }
+    else { if (Cin == 32) SS_SC16(32, 64, SS_DT_BF16); else SS_SC16(64, 128, SS_DT_BF16); }
+#undef SS_SC16
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
 long long ss_spike_conv_fwd_ws_floats(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return 0;
@@ -420,7 +494,7 @@ int ss_spike_conv_fwd_f32(const float* x, const unsigned int* x_packed, const fl
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* Bf = reinterpret_cast<unsigned short*>(ws);
-    hipLaunchKernelGGL(spike_conv_fwd_prep_kernel, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
+    hipLaunchKernelGGL(spike_conv_fwd_prep_kernel<0>, dim3(grid_for((long long)25 * Cin * Cout * 3 / 8, 4096)), dim3(kBlock), 0, s, weight, Bf, Cin, Cout);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const long long n_tiles = NB * ((ho + kScTR - 1) / kScTR) * ((wo + kScTC - 1) / kScTC);
     unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);           // two workgroups per CU, persistent over their tile ranges
@@ -453,6 +527,22 @@ int ss_dense_conv_s1_fwd_f32(const float* x, const float* weight, float* out, lo
     const unsigned grid = (unsigned)(n_tiles < 4096 ? n_tiles : 4096);
     if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_fwd_kernel<4>), dim3(grid), dim3(kS1Threads), 0, s, x, weight, out, (int)NB, h, w);
     else hipLaunchKernelGGL((dense_conv_s1_fwd_kernel<2>), dim3(grid), dim3(kS1Threads), 0, s, x, weight, out, (int)NB, h, w);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ss_dense_conv_s1_fwd_f32 with a 16-bit output (ABI 9): x fp32 (the event-voxel input), x and weight rounded once to `dtype`, out in `dtype` */
+int ss_dense_conv_s1_fwd_x16(const float* x, const float* weight, void* out, long long NB, int Cin, int Cout, int h, int w, int dtype, void* stream)
+{
+    if (!x || !weight || !out || NB <= 0 || h <= 0 || w <= 0 || !ss_dense_conv_s1_fwd_supported(Cin, Cout, 5, 1, 2) || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long n_tiles = NB * ((h + kS1TR - 1) / kS1TR) * ((w + kS1TC - 1) / kS1TC);
+    const unsigned grid = (unsigned)(n_tiles < 4096 ? n_tiles : 4096);
+    unsigned short* o16 = static_cast<unsigned short*>(out);
+#define SS_S116(CI_) do { if (dtype == SS_DT_F16) hipLaunchKernelGGL((dense_conv_s1_fwd_kernel<CI_, SS_DT_F16>), dim3(grid), dim3(kS1Threads), 0, s, x, weight, o16, (int)NB, h, w); \
+                          else hipLaunchKernelGGL((dense_conv_s1_fwd_kernel<CI_, SS_DT_BF16>), dim3(grid), dim3(kS1Threads), 0, s, x, weight, o16, (int)NB, h, w); } while (0)
+    if (Cin == 4) SS_S116(4); else SS_S116(2);
+#undef SS_S116
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

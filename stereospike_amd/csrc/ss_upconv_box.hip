@@ -38,6 +38,27 @@ __device__ unsigned long long bx_trace[64][16];
 #endif
 constexpr int kBxCo = 8;                       // output channels per chunk of the plane layout (= half a k-step: a k-step is 2 taps x 8 channels)
 
+// 16-bit activation modes (DT != 0, round 5): g_y arrives in the 16-bit format; a box sum of <= 9 such values needs more bits than one 16-bit value holds:
+// bf16 mode TWO planes (hi + lo, 16 significand bits: the weight gradients of that mode sit at 0.8 of their parity bar from activation-gradient storage
+// alone, no further rounding point is added), fp16 mode ONE plane (11 bits: one more rounding of the class the mode already has per layer crossing).
+// The weight is ONE term (rounded once to the format), so a k-step costs NP MFMAs instead of six (data gradient) / three (weight gradient).
+template <int DT> struct BxT { static constexpr int NP = DT == 0 ? 3 : (DT == SS_DT_BF16 ? 2 : 1), NW = DT == 0 ? 3 : 1; };
+
+template <int DT> __device__ __forceinline__ void bx_split(const float (&v)[8], u16x8 (&pl)[BxT<DT>::NP])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned short h1 = round_op<DT>(v[e]);
+        pl[0][e] = h1;
+        if constexpr (BxT<DT>::NP > 1) {
+            const float r1 = v[e] - widen_op<DT>(h1);
+            const unsigned short h2 = round_op<DT>(r1);
+            pl[1][e] = h2;
+            if constexpr (BxT<DT>::NP > 2) pl[2][e] = round_op<DT>(r1 - widen_op<DT>(h2));
+        }
+    }
+}
+
 __device__ __forceinline__ void bx_split3(const float (&v)[8], u16x8& h, u16x8& m, u16x8& l)
 {
 #pragma unroll
@@ -63,10 +84,11 @@ __device__ __forceinline__ void bx_split3(const float (&v)[8], u16x8& h, u16x8& 
 #endif
 constexpr int kBxJS = SS_BX_JS;
 
-template <int CG>                              // chunks per lane group: min(C_out / 8, 4)
-__global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __restrict__ gy, const int* __restrict__ vr, const int* __restrict__ hr,
+template <int CG, int DT = 0>                  // chunks per lane group: min(C_out / 8, 4)
+__global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const typename ActT<DT>::type* __restrict__ gy, const int* __restrict__ vr, const int* __restrict__ hr,
                                                                unsigned short* __restrict__ Bp, int NB, int H, int W, int COUT, int NVR, int NHR)
 {
+    constexpr int NP = BxT<DT>::NP;
     const int NCH = COUT / kBxCo, NCG = NCH / CG;
     const int IPB = kBlock / CG;                                              // horizontal ranges per workgroup
     const int ib = (NHR + IPB - 1) / IPB, jb = (NVR + kBxJS - 1) / kBxJS;
@@ -79,13 +101,30 @@ __global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __re
     const int i = bi * IPB + (int)(threadIdx.x / CG);
     if (i >= NHR) return;
     const int x0 = hr[2 * i], nx = hr[2 * i + 1];
-    const float* const g0 = gy + ((long long)nb * H * W + x0) * COUT + kBxCo * c;
+    const typename ActT<DT>::type* const g0 = gy + ((long long)nb * H * W + x0) * COUT + kBxCo * c;
     int cy = -1;                                                               // output row whose horizontal sum is cached
     float cv[8];
     auto hsum = [&](int y, float (&o)[8]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        const float* p = g0 + (long long)y * W * COUT;
+        const typename ActT<DT>::type* p = g0 + (long long)y * W * COUT;
+        if constexpr (DT != 0) {                                                // 8 channels = ONE 16-byte load per pixel, widened exactly; same order of additions
+            u16x8 a16[3];
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+                if (x < nx) a16[x] = *reinterpret_cast<const u16x8*>(p + (long long)x * COUT);
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+                if (x < nx) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += widen<DT>(a16[x][e]);
+                }
+            for (int x = 3; x < nx; ++x) {
+                const u16x8 a2 = *reinterpret_cast<const u16x8*>(p + (long long)x * COUT);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += widen<DT>(a2[e]);
+            }
+        } else {
 #if SS_BX_HSUM_UNROLL
         // ranges are <= 3 pixels wide (a nearest resize by ~2): the loads of a row go out together, the additions stay in x order (same bits)
         f4 a[3], bb[3];
@@ -110,9 +149,10 @@ __global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __re
             for (int e = 0; e < 4; ++e) { o[e] += a[e]; o[4 + e] += bb[e]; }
         }
 #endif
+        }
     };
     const long long plane = (long long)NVR * NHR * kBxCo;
-    unsigned short* const out0 = Bp + (((long long)nb * NCH + c) * 3) * plane + (long long)i * kBxCo;
+    unsigned short* const out0 = Bp + (((long long)nb * NCH + c) * NP) * plane + (long long)i * kBxCo;
     for (int jj = 0; jj < kBxJS; ++jj) {
         const int j = bj * kBxJS + jj;
         if (j >= NVR) break;
@@ -138,12 +178,19 @@ __global__ __launch_bounds__(kBlock) void upconv_boxsum_kernel(const float* __re
                 for (int e = 0; e < 8; ++e) acc[e] += hs[e];
             }
         }
-        u16x8 ph, pm, pl;
-        bx_split3(acc, ph, pm, pl);
         unsigned short* const o = out0 + (long long)j * NHR * kBxCo;
-        *reinterpret_cast<u16x8*>(o) = ph;
-        *reinterpret_cast<u16x8*>(o + plane) = pm;
-        *reinterpret_cast<u16x8*>(o + 2 * plane) = pl;
+        if constexpr (DT == 0) {
+            u16x8 ph, pm, pl;
+            bx_split3(acc, ph, pm, pl);
+            *reinterpret_cast<u16x8*>(o) = ph;
+            *reinterpret_cast<u16x8*>(o + plane) = pm;
+            *reinterpret_cast<u16x8*>(o + 2 * plane) = pl;
+        } else {
+            u16x8 pq[NP];
+            bx_split<DT>(acc, pq);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u16x8*>(o + q * plane) = pq[q];
+        }
     }
 }
 
@@ -166,9 +213,9 @@ __device__ __forceinline__ int bx_slot(int rw, int cw) { return (rw * kB2WC + (c
 // byte offset (inside a plane) of the pixel of range ids (jv, iv); either id 0 = the empty range -> the zero pixel
 __device__ __forceinline__ int bx_addr(int jv, int iv, int j0, int i0) { return (jv && iv) ? bx_slot(jv - j0, iv - i0) : kB2Zero; }
 
-__device__ __forceinline__ void bx_zero_borders(unsigned char* wnd)
+__device__ __forceinline__ void bx_zero_borders(unsigned char* wnd, int np = 3)
 {
-    if (threadIdx.x < 3) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB2Plane + kB2Zero) = (f4){0.f, 0.f, 0.f, 0.f};
+    if ((int)threadIdx.x < np) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB2Plane + kB2Zero) = (f4){0.f, 0.f, 0.f, 0.f};
 }
 
 // The window of (frame nb, chunk c) — 3 planes x nj rows x ni granules, HBM rows contiguous — travels HBM -> registers -> LDS in two halves so that the
@@ -180,12 +227,12 @@ constexpr int kWinRegs = kB2WR;
 
 struct BxLane { unsigned voff_plane; int cc; int lds0, lds1; bool act; };
 
-__device__ __forceinline__ BxLane bx_lane(long long plane_g, int plane_bytes = kB2Plane)
+__device__ __forceinline__ BxLane bx_lane(long long plane_g, int plane_bytes = kB2Plane, int np = 3)
 {
     BxLane L;
     const int t = threadIdx.x, p = t / kB2WC;
     L.cc = t - p * kB2WC;
-    L.act = p < 3;
+    L.act = p < np;
     L.voff_plane = (unsigned)((L.act ? p : 0) * plane_g + L.cc * kBxCo);       // elements from the window's first granule (row 0)
     L.lds0 = (L.act ? p : 0) * plane_bytes + L.cc * 16;                            // rows with swizzle bit 0
     L.lds1 = (L.act ? p : 0) * plane_bytes + (L.cc ^ 1) * 16;                      // rows with swizzle bit 1 ((r >> 1) & 1)
@@ -238,15 +285,17 @@ __device__ __forceinline__ void bx_win_store(unsigned char* wnd, const f4 (&buf)
 // ss_gemm6_f32's order; the running sum's sign alternates per chunk (the bf16 MFMA's fp32 accumulation drifts down by ~2^-28 of the magnitude sum).
 // weight [C_out][C_in][5][5] fp32 -> Wf[ci block of 32 NT][chunk][k-step 13][plane 3][tile NT][lane 64][8] bf16: element e of a lane = split term of
 // (+ / -) W[co = 8 chunk + e][ci = 32 NT blk + 32 tile + (lane & 31)][tap = 2 s + (lane >> 5)]  (tap 25: zero; odd chunks negated)
+template <int DT = 0>
 __global__ __launch_bounds__(kBlock) void upconv_box_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, int Cin, int Cout, int NT)
 {
+    constexpr int NW = BxT<DT>::NW;
     const int NCH = Cout / kBxCo;
-    const long long total = (long long)(Cin / (32 * NT)) * NCH * kB2KS * 3 * NT * 64;
+    const long long total = (long long)(Cin / (32 * NT)) * NCH * kB2KS * NW * NT * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
         long long r = i >> 6;
         const int t = (int)(r % NT); r /= NT;
-        const int sp = (int)(r % 3); r /= 3;
+        const int sp = (int)(r % NW); r /= NW;
         const int s = (int)(r % kB2KS); r /= kB2KS;
         const int c = (int)(r % NCH); const int blk = (int)(r / NCH);
         const int tap = 2 * s + (lane >> 5);
@@ -257,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void upconv_box_dgrad_prep_kernel(const flo
             const int co = kBxCo * c + e;
             float v = tap < 25 ? W[((long long)co * Cin + ci) * 25 + tap] : 0.f;
             if (c & 1) v = -v;
+            if constexpr (DT != 0) { o[e] = round_op<DT>(v); continue; }
             const unsigned short h1 = narrow<SS_DT_BF16>(v);
             const float r1 = v - widen<SS_DT_BF16>(h1);
             const unsigned short h2 = narrow<SS_DT_BF16>(r1);
@@ -267,25 +317,26 @@ __global__ __launch_bounds__(kBlock) void upconv_box_dgrad_prep_kernel(const flo
     }
 }
 
-template <int NT, int KPS>
+template <int NT, int KPS, int DT = 0>
 __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const unsigned short* __restrict__ Bp, const unsigned short* __restrict__ Wf,
                                                                          const int* __restrict__ vmap, const int* __restrict__ hmap,
                                                                          const int* __restrict__ tr, const int* __restrict__ tc,
-                                                                         float* __restrict__ gx, int NB, int h, int w, int NVR, int NHR, int CIN, int NCH, int RG, int CG)
+                                                                         typename ActT<DT>::type* __restrict__ gx, int NB, int h, int w, int NVR, int NHR, int CIN, int NCH, int RG, int CG)
 {
-    constexpr int kKB = 3 * NT * 1024;                                          // bytes of one k-step of weights
+    constexpr int NP = BxT<DT>::NP, NW = BxT<DT>::NW;
+    constexpr int kKB = NW * NT * 1024;                                         // bytes of one k-step of weights
     constexpr int kStage = KPS * kKB;                                           // 12 KB
     constexpr int kNS = (kB2KS + KPS - 1) / KPS;                                // stages per chunk (7 | 13)
     constexpr int kF4 = kStage / (16 * kB2Threads);                             // 16-byte pieces per thread and stage (3)
     static_assert(kStage % (16 * kB2Threads) == 0, "stage size");
-    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * kB2Plane];
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[NP * kB2Plane];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kStage];
     __shared__ int tiles[4 * 64 + 2 * 16];                                       // the row / column tile tables (<= 64 row tiles, <= 16 column tiles: checked by the host)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NBLK = CIN / (32 * NT);
     const long long n_tiles = (long long)NB * RG * CG * NBLK;
-    bx_zero_borders(wnd);
+    bx_zero_borders(wnd, NP);
     for (int i = threadIdx.x; i < 4 * RG; i += kB2Threads) tiles[i] = tr[i];
     for (int i = threadIdx.x; i < 2 * CG; i += kB2Threads) tiles[256 + i] = tc[i];
     __syncthreads();
@@ -313,8 +364,8 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
         if (++d.c == NCH) { d.c = 0; if (++d.blk == NBLK) { d.blk = 0; if (++d.cg == CG) { d.cg = 0; if (++d.rg == RG) { d.rg = 0; ++d.nb; } } } }
         extents(d);
     };
-    const BxLane bl = bx_lane(plane_g);
-    auto win_src = [&](const Item& d) { return Bp + (((long long)d.nb * NCH + d.c) * 3) * plane_g + ((long long)d.j0 * NHR + d.i0) * kBxCo; };
+    const BxLane bl = bx_lane(plane_g, kB2Plane, NP);
+    auto win_src = [&](const Item& d) { return Bp + (((long long)d.nb * NCH + d.c) * NP) * plane_g + ((long long)d.j0 * NHR + d.i0) * kBxCo; };
     const long long it_begin = t_begin * NCH, it_end = t_end * NCH;
     if (it_begin >= it_end) return;
     f4 wbuf[kWinRegs];
@@ -408,21 +459,22 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                 if (s2 < kB2KS) {
                     const unsigned char* const ap = wnd + addr[s2];
                     const unsigned char* const bk = bst + ((sg & 1) ^ par) * kStage + ks * kKB + lane * 16;
-                    s16x8 fa[3], fb[3][NT];
+                    s16x8 fa[NP], fb[NW][NT];
 #pragma unroll
-                    for (int p2 = 0; p2 < 3; ++p2) {
-                        fa[p2] = *reinterpret_cast<const s16x8*>(ap + p2 * kB2Plane);
+                    for (int p2 = 0; p2 < NP; ++p2) fa[p2] = *reinterpret_cast<const s16x8*>(ap + p2 * kB2Plane);
+#pragma unroll
+                    for (int p2 = 0; p2 < NW; ++p2)
 #pragma unroll
                         for (int u = 0; u < NT; ++u) fb[p2][u] = *reinterpret_cast<const s16x8*>(bk + (p2 * NT + u) * 1024);
-                    }
-                    // the six cross terms, smallest first: (h, l) (m, m) (l, h) (h, m) (m, h) (h, h)
-                    constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {2, 1, 0, 1, 0, 0};
+                    // fp32 mode: the six cross terms, smallest first: (h, l) (m, m) (l, h) (h, m) (m, h) (h, h); 16-bit modes: the planes of B against the ONE weight term, lo first
+                    constexpr int kNQ = DT ? NP : 6;
+                    constexpr int pa[6] = {DT ? NP - 1 : 0, DT ? 0 : 1, 2, 0, 1, 0}, pb[6] = {DT ? 0 : 2, DT ? 0 : 1, 0, 1, 0, 0};
 #pragma unroll
-                    for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < kNQ; ++q)
 #pragma unroll
                         for (int u = 0; u < NT; ++u) {
                             if (SS_BX_ABLATE & 4) acc[ks][u][q] += (float)(fa[pa[q]][0] + fb[pb[q]][u][1]);
-                            else acc[ks][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pb[q]][u], fa[pa[q]], acc[ks][u], 0, 0, 0);      // D^T: rows = input channels, columns = pixels
+                            else acc[ks][u] = mfma32<DT>(fb[pb[q]][u], fa[pa[q]], acc[ks][u]);      // D^T: rows = input channels, columns = pixels
                         }
                 }
             }
@@ -456,7 +508,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
             const int pm = lane & 31;
             const int py = sy0 + (pm >> 3), px = sx0 + 8 * wv + (pm & 7);
             if ((pm >> 3) < nrow && px < w) {
-                float* const op = gx + (((long long)cur.nb * h + py) * w + px) * CIN + 32 * NT * cur.blk + 4 * (lane >> 5);
+                typename ActT<DT>::type* const op = gx + (((long long)cur.nb * h + py) * w + px) * CIN + 32 * NT * cur.blk + 4 * (lane >> 5);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -468,7 +520,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                             if constexpr (KPS > 1) x += acc[1][t][4 * q + e];
                             v[e] = x * fin;
                         }
-                        *reinterpret_cast<f4*>(op + 32 * t + 8 * q) = v;
+                        store_act4<DT>(op + 32 * t + 8 * q, v[0], v[1], v[2], v[3]);
                     }
             }
         }
@@ -508,7 +560,7 @@ __device__ __forceinline__ void bx3_store_rows(unsigned char* wnd, const f4 (&bu
 // the group's lanes address INDIVIDUALLY (measured: out[i][r] = in[lane 4 r + i / 4][element i % 4], profiles/r04/tr16.log), so each source lane points at
 // "its" pixel through the two index maps and the gather along k costs nothing.  The main loop is branch-free: rows / columns beyond the tile meet a zeroed
 // spike fragment, phantom taps and quads read the window's zero row.  Partials -> ws[slice][co][tap][ci] -> upconv_box_wgrad_reduce_kernel (fixed order).
-template <int NT, bool PF>                     // NT: input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of
+template <int NT, bool PF, int DT = 0>         // NT: input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of
                                                // them, so every transposed A fragment feeds NT MFMAs.  PF: the next tile's window is fetched into registers while this
                                                // tile multiplies (14 x 16 B per thread: NT <= 2 only — NT = 4 holds 128 accumulator registers)
 __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const unsigned short* __restrict__ Bp, const unsigned short* __restrict__ xT,
@@ -518,7 +570,8 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
                                                                          int RG, int CG)
 {
     constexpr int NQ = 2;                                                       // tap quads per wavefront: wv, wv + 4 (the 8th is a phantom: zero row)
-    __shared__ __attribute__((aligned(16))) unsigned char wnd[3 * kB3Plane];
+    constexpr int NP = BxT<DT>::NP;
+    __shared__ __attribute__((aligned(16))) unsigned char wnd[NP * kB3Plane];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NCH = COUT / kBxCo, CIB = CIN / (32 * NT);
@@ -528,7 +581,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
     const long long n_tiles = (long long)NB * RG * CG;
     const long long t_begin = n_tiles * slice / slices, t_end = n_tiles * (slice + 1) / slices;
     const long long plane_g = (long long)NVR * NHR * kBxCo;
-    if (threadIdx.x < 3) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB3Plane + kB3Zero) = (f4){0.f, 0.f, 0.f, 0.f};        // the zero pixel of each plane
+    if ((int)threadIdx.x < NP) *reinterpret_cast<f4*>(wnd + threadIdx.x * kB3Plane + kB3Zero) = (f4){0.f, 0.f, 0.f, 0.f};        // the zero pixel of each plane
     // this lane as a SOURCE lane of the transpose reads: pixel L >> 2 of a 4-pixel sub-block, columns 4 (L & 3) .. + 3 of the 16-row half g of the M tile
     const int L = lane & 15, g = (lane >> 4) & 1, oct = lane >> 5;
     const int tq4 = 2 * g + ((L & 3) >> 1), coq = (L & 3) & 1;
@@ -576,9 +629,9 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         for (int i = threadIdx.x; i < 5 * w; i += kB2Threads) hm_s[i] = hmap[i];
     }
     __syncthreads();
-    const BxLane bl = bx_lane(plane_g, kB3Plane);
+    const BxLane bl = bx_lane(plane_g, kB3Plane, NP);
     // rows from vertical range id jf on, columns from the column tile's first horizontal id
-    auto win_src = [&](int nb, int jf, int cg) { return Bp + (((long long)nb * NCH + c) * 3) * plane_g + ((long long)jf * NHR + tiles[256 + 2 * cg]) * kBxCo; };
+    auto win_src = [&](int nb, int jf, int cg) { return Bp + (((long long)nb * NCH + c) * NP) * plane_g + ((long long)jf * NHR + tiles[256 + 2 * cg]) * kBxCo; };
     // tile -> (frame, column tile, row tile), ROW tile fastest (a column strip top to bottom): one 64-bit division per workgroup, then incremental
     int rg = (int)(t_begin % RG), cg = (int)((t_begin / RG) % CG), nb = (int)(t_begin / ((long long)CG * RG));
     f4 wbuf[kWinRegs];                                                          // (a slice without tiles still writes its — zero — partials below)
@@ -644,7 +697,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         }
         if constexpr (PF) lds_barrier(); else __syncthreads();                  // this tile's window (PF: stored at the end of the previous tile) is visible
         // k-step s = (row s >> 1, half s & 1): its A fragments (2 quads x 3 planes x 2 transpose reads) are fetched one k-step AHEAD of its MFMAs
-        auto read_a = [&](int sidx, s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3]) {
+        auto read_a = [&](int sidx, s16x4 (&lo)[NQ][NP], s16x4 (&hi)[NQ][NP]) {
             const int r = sidx >> 1, half = sidx & 1;
             int a0[NQ], a1[NQ];
 #pragma unroll
@@ -652,22 +705,22 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
 #pragma unroll
             for (int u = 0; u < NQ; ++u)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     lo[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB3Plane + a0[u]));
                     hi[u][p] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(wnd + p * kB3Plane + a1[u]));
                 }
         };
-        auto mma = [&](s16x4 (&lo)[NQ][3], s16x4 (&hi)[NQ][3], s16x8 (&xf)[NT]) {
+        auto mma = [&](s16x4 (&lo)[NQ][NP], s16x4 (&hi)[NQ][NP], s16x8 (&xf)[NT]) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int u = 0; u < NQ; ++u) {
                     const s16x8 af = {lo[u][p][0], lo[u][p][1], lo[u][p][2], lo[u][p][3], hi[u][p][0], hi[u][p][1], hi[u][p][2], hi[u][p][3]};
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, xf[t], acc[u][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) acc[u][t] = mfma32<DT>(af, xf[t], acc[u][t]);
                 }
         };
-        s16x4 la[NQ][3], ha[NQ][3], lb[NQ][3], hb[NQ][3];
+        s16x4 la[NQ][NP], ha[NQ][NP], lb[NQ][NP], hb[NQ][NP];
         read_a(0, la, ha);
         if constexpr (PD > 1) {
 #pragma unroll
@@ -804,7 +857,7 @@ int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vma
     static const int force_nt2 = getenv("SS_BOX_DGRAD_NT2") ? atoi(getenv("SS_BOX_DGRAD_NT2")) : 0;          // A/B only (profiles/r04/box_nt_ab.log)
     const int NT = (Cin % 128 == 0 && !force_nt2) ? 4 : 2;                      // 128 input channels per workgroup where there are that many
     const long long frag16 = (long long)(Cin / 32) * (Cout / kBxCo) * kB2KS * 3 * 64;
-    hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
+    hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel<0>, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
     const long long n_tiles = NB * RG * CG * (Cin / (32 * NT));
@@ -869,6 +922,93 @@ int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int*
                                       (int)NB, h, w, NVR, NHR, Cin, Cout, kinds, RG, CG)
     if (NT == 4) SS_BW(4, false); else if (NT == 2) SS_BW(2, true); else SS_BW(1, true);
 #undef SS_BW
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    hipLaunchKernelGGL(upconv_box_wgrad_reduce_kernel, dim3(grid_for((long long)Cout * 25 * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cout, Cin, accumulate);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ---- the three kernels on 16-bit activation gradients (ABI 9).  g_out / g_x in `dtype`; the box image holds ss_upconv_box_planes_x16(dtype) planes of that
+   format (bf16: 2, fp16: 1); the weight is rounded once to `dtype`; x: the dense 16-bit spike tensor of the same dtype, or the 2-bit packed one; g_w fp32. */
+int ss_upconv_box_planes_x16(int dtype) { return dtype == SS_DT_BF16 ? BxT<SS_DT_BF16>::NP : (dtype == SS_DT_F16 ? BxT<SS_DT_F16>::NP : 0); }
+
+int ss_upconv_boxsum_x16(const void* g_out, const int* vr, const int* hr, void* box, long long NB, int Cout, int H, int W, int NVR, int NHR, int dtype, void* stream)
+{
+    if (!g_out || !vr || !hr || !box || NB <= 0 || H <= 0 || W <= 0 || NVR <= 0 || NHR <= 0 || Cout <= 0 || Cout % kBxCo != 0) return SS_EINVAL;
+    if (!aligned16(g_out) || !aligned16(box) || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    const int NCH = Cout / kBxCo;
+    const int CG = NCH % 4 == 0 ? 4 : (NCH % 2 == 0 ? 2 : 1);
+    const long long ib = (NHR + kBlock / CG - 1) / (kBlock / CG), jb = (NVR + kBxJS - 1) / kBxJS;
+    const long long grid = NB * (NCH / CG) * jb * ib;
+    if (grid > 0x7fffffffLL) return SS_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Bp = static_cast<unsigned short*>(box);
+    const unsigned short* g16 = static_cast<const unsigned short*>(g_out);
+#define SS_BS16(CG_, DTT) hipLaunchKernelGGL((upconv_boxsum_kernel<CG_, DTT>), dim3((unsigned)grid), dim3(kBlock), 0, s, g16, vr, hr, Bp, (int)NB, H, W, Cout, NVR, NHR)
+#define SS_BS16D(DTT) do { if (CG == 4) SS_BS16(4, DTT); else if (CG == 2) SS_BS16(2, DTT); else SS_BS16(1, DTT); } while (0)
+    if (dtype == SS_DT_F16) SS_BS16D(SS_DT_F16); else SS_BS16D(SS_DT_BF16);
+#undef SS_BS16D
+#undef SS_BS16
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_box_dgrad_x16(const void* box, const float* weight, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles, const int* tile_cols,
+                            void* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, int dtype, void* stream)
+{
+    if (!box || !weight || !vmap || !hmap || !tile_rows || !tile_cols || !g_x || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
+    if (!ss_upconv_box_dgrad_supported(Cin, Cout, 5, 1, 1) || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (!ss_upconv_box_tiles_supported(n_row_tiles, w, NB * h * (long long)w)) return SS_EINVAL;
+    if (!aligned16(box) || !aligned16(ws) || !aligned16(g_x)) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* Wf = reinterpret_cast<unsigned short*>(ws);
+    const int NT = Cin % 128 == 0 ? 4 : 2;
+    const long long frag16 = (long long)(Cin / 32) * (Cout / kBxCo) * kB2KS * 64;
+    if (dtype == SS_DT_F16) hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel<SS_DT_F16>, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
+    else hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel<SS_DT_BF16>, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
+    const long long n_tiles = NB * RG * CG * (Cin / (32 * NT));
+    const unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);
+    const unsigned short* Bp = static_cast<const unsigned short*>(box);
+    unsigned short* gx16 = static_cast<unsigned short*>(g_x);
+#define SS_BD16(DTT) do { \
+        if (NT == 4) hipLaunchKernelGGL((upconv_box_dgrad_kernel<4, 1, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
+                                        (int)NB, h, w, NVR, NHR, Cin, Cout / kBxCo, RG, CG); \
+        else hipLaunchKernelGGL((upconv_box_dgrad_kernel<2, 2, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
+                                (int)NB, h, w, NVR, NHR, Cin, Cout / kBxCo, RG, CG); } while (0)
+    if (dtype == SS_DT_F16) SS_BD16(SS_DT_F16); else SS_BD16(SS_DT_BF16);
+#undef SS_BD16
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+int ss_upconv_box_wgrad_x16(const void* box, const void* x, const unsigned int* x_packed, const int* vmap, const int* hmap, const int* tile_rows, int n_row_tiles,
+                            const int* tile_cols, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int NVR, int NHR, int accumulate,
+                            int dtype, void* stream)
+{
+    if (x_packed && (NB * h * (long long)w * Cin) % 16 != 0) return SS_EINVAL;
+    if (!box || (!x && !x_packed) || !vmap || !hmap || !tile_rows || !tile_cols || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
+    if (!ss_upconv_box_wgrad_supported(Cin, Cout, 5, 1, 1) || !aligned16(box) || !aligned16(ws) || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (!ss_upconv_box_tiles_supported(n_row_tiles, w, NB * h * (long long)w)) return SS_EINVAL;
+    int NT = 0, kinds = 0, slices = 0;
+    if (!box_wgrad_plan(Cin, Cout, &NT, &kinds, &slices)) return SS_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    long long part = (long long)slices * Cout * 25 * Cin;
+    part = (part + 3) / 4 * 4;
+    unsigned short* xT = reinterpret_cast<unsigned short*>(ws + part);
+    const int xg = grid_for(NB * h * ((w + 15) / 16) * Cin, kMaxGridBwd);
+    const unsigned grid = (unsigned)(kinds * slices);
+    const unsigned short* Bp = static_cast<const unsigned short*>(box);
+    const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
+#define SS_BW16K(NT_, PF_, DTT) hipLaunchKernelGGL((upconv_box_wgrad_kernel<NT_, PF_, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, xT, vmap, hmap, tile_rows, tile_cols, ws, \
+                                                  (int)NB, h, w, NVR, NHR, Cin, Cout, kinds, RG, CG)
+#define SS_BW16(DTT) do { \
+        if (x_packed) hipLaunchKernelGGL((upconv_bwd_xprep_kernel<true, DTT>), dim3(xg), dim3(kBlock), 0, s, static_cast<const void*>(x_packed), xT, NB * h, w, Cin); \
+        else hipLaunchKernelGGL((upconv_bwd_xprep_kernel<false, DTT>), dim3(xg), dim3(kBlock), 0, s, x, xT, NB * h, w, Cin); \
+        if (NT == 4) SS_BW16K(4, false, DTT); else if (NT == 2) SS_BW16K(2, true, DTT); else SS_BW16K(1, true, DTT); } while (0)
+    if (dtype == SS_DT_F16) SS_BW16(SS_DT_F16); else SS_BW16(SS_DT_BF16);
+#undef SS_BW16
+#undef SS_BW16K
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(upconv_box_wgrad_reduce_kernel, dim3(grid_for((long long)Cout * 25 * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cout, Cin, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;

@@ -59,14 +59,19 @@ constexpr int kSbVRec = 88, kSbHRec = 168;      // ints per row-block / column-b
 // the time of a whole tile; it is paired with tall row blocks of <= 64 rows instead, the four wavefronts stacked vertically (16 rows each)
 constexpr int kSbTR = 64, kSbTWR = 68, kSbTRec = 328;                          // rows, distinct source rows, ints per tall row-block record (same fields)
 constexpr int kSbPix = 32;                      // window bytes per source pixel: 16 input channels (one k-step) as bf16
-constexpr int kSbStage = 9 * 1024;              // weight stage: the 3 merged taps of one run row x 3 split terms, 1 KB fragments (32 output channels)
+// weight stage: the <= 3 merged taps of one run row x NTERM split terms, 1 KB fragments (32 output channels): 9 KB in the fp32 mode
+// 16-bit activation modes (DT != 0, round 5): the taps are rounded ONCE to the operand format (the mode's weight), their merged sums — which need more bits than
+// one 16-bit value holds — travel as TWO terms of the format (hi + lo: 16 / 22 significand bits); 2 MFMAs per merged tap instead of 3, the output narrowed on store
+template <int DT> struct SbT { static constexpr int NTERM = DT ? 2 : 3, STAGE = 3 * NTERM * 1024; };
 constexpr int kSbWnd = kSbWR * kSbWC * kSbPix;  // 23040 B
 
 // W [C_out][C_in][5][5] fp32 -> Wm fragments [pair = cv * NHC + ch][C_out / 32][g = C_in / 16][r 3][c 3][term 3][lane 64][8] bf16: element e of a lane =
 // split term of (-1)^g * sum of W[co = 32 cot + (lane & 31)][ci = 16 g + 8 (lane >> 5) + e] over the taps of run (r, c); zero where the class has no such run
+template <int DT = 0>
 __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __restrict__ W, const int* __restrict__ vcls, const int* __restrict__ hcls,
                                                                  unsigned short* __restrict__ Wm, int Cin, int Cout, int NVC, int NHC)
 {
+    constexpr int NTERM = SbT<DT>::NTERM;
     const int NCOT = Cout / 32, G = Cin / 16;
     const long long total = (long long)NVC * NHC * NCOT * G * 9 * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
@@ -86,8 +91,13 @@ __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __
             const float* wp = W + ((long long)co * Cin + ci) * 25;
             float a = 0.f;
             for (int ky = ky0; ky < ky0 + kyn; ++ky)
-                for (int kx = kx0; kx < kx0 + kxn; ++kx) a += wp[ky * 5 + kx];
+                for (int kx = kx0; kx < kx0 + kxn; ++kx) a += DT ? widen_op<DT>(round_op<DT>(wp[ky * 5 + kx])) : wp[ky * 5 + kx];
             if (g & 1) a = -a;
+            if constexpr (DT != 0) {
+                const unsigned short t1 = round_op<DT>(a);
+                ph[e] = t1; pm[e] = round_op<DT>(a - widen_op<DT>(t1));
+                continue;
+            }
             const unsigned short h1 = narrow<SS_DT_BF16>(a);
             const float r1 = a - widen<SS_DT_BF16>(h1);
             const unsigned short h2 = narrow<SS_DT_BF16>(r1);
@@ -95,10 +105,10 @@ __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __
             ph[e] = h1; pm[e] = h2; pl[e] = narrow<SS_DT_BF16>(r2);
         }
         // [.. r][c][term][lane][8]: this thread's three fragments sit 1 KB apart
-        unsigned short* o = Wm + ((i >> 6) * 3 * 64 + lane) * 8;
+        unsigned short* o = Wm + ((i >> 6) * NTERM * 64 + lane) * 8;
         *reinterpret_cast<u16x8*>(o) = ph;
         *reinterpret_cast<u16x8*>(o + 64 * 8) = pm;
-        *reinterpret_cast<u16x8*>(o + 2 * 64 * 8) = pl;
+        if constexpr (NTERM == 3) *reinterpret_cast<u16x8*>(o + 2 * 64 * 8) = pl;
     }
 }
 
@@ -108,13 +118,14 @@ __global__ __launch_bounds__(kBlock) void upconv_sub_prep_kernel(const float* __
 // stage), the merged weights stream L2 -> registers -> LDS double-buffered in stages of one run row (<= 3 taps x 3 terms = 9 KB, 36 MFMAs per wavefront
 // between two barriers).  A k-step is one merged tap x 16 channels: the lane's A fragment is ONE 16-byte LDS read at (row slot, column slot) of its pixel,
 // each weight fragment is read once per wavefront and feeds all 4 M-blocks: 7 KB of LDS reads per 12 MFMAs.
-template <bool PACKED>
+template <bool PACKED, int DT = 0>
 __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub_fwd_kernel(const void* __restrict__ xin, const unsigned short* __restrict__ Wm,
                                                                        const int* __restrict__ vblk, const int* __restrict__ hblk, const int* __restrict__ tblk,
                                                                        const int* __restrict__ order, unsigned* __restrict__ counter,
-                                                                       float* __restrict__ out, int NB, int h, int w, int H, int W, int CIN, int COUT,
+                                                                       typename ActT<DT>::type* __restrict__ out, int NB, int h, int w, int H, int W, int CIN, int COUT,
                                                                        int NVB, int NHB, int NHC, int NORD)
 {
+    constexpr int NTERM = SbT<DT>::NTERM, kSbStage = SbT<DT>::STAGE;         // (shadows the fp32 form's stage size)
     __shared__ __attribute__((aligned(16))) unsigned char wnd[kSbWnd];
     __shared__ __attribute__((aligned(16))) unsigned char bst[2 * kSbStage];
     __shared__ int vrec[kSbTRec], hrec[kSbHRec];
@@ -212,10 +223,21 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                         for (int q = 0; q < 2; ++q) {
                             u16x8 o;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = code_to_bf16((wreg_p[u] >> (2 * (8 * q + e))) & 3u);
+                            for (int e = 0; e < 8; ++e) o[e] = code_to_op<DT>((wreg_p[u] >> (2 * (8 * q + e))) & 3u);
                             *reinterpret_cast<u16x8*>(q == 0 ? pp : wnd + (loff[u] ^ 16)) = o;
                         }
                     }
+                }
+            } else if constexpr (DT != 0) {                                  // dense 16-bit spike tensor: already the operand
+#pragma unroll
+                for (int u0 = 0; u0 < kWItems; u0 += 3) {
+                    u16x8 d[3];
+#pragma unroll
+                    for (int v = 0; v < 3; ++v)
+                        if (loff[u0 + v] >= 0) d[v] = *reinterpret_cast<const u16x8*>(static_cast<const unsigned short*>(xin) + xoff[u0 + v] + 16 * g);
+#pragma unroll
+                    for (int v = 0; v < 3; ++v)
+                        if (loff[u0 + v] >= 0) *reinterpret_cast<u16x8*>(wnd + loff[u0 + v]) = d[v];
                 }
             } else {
 #pragma unroll
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
         };
         // ---- weight stages: stage r of (cot, g) = ngh taps x 3 terms, contiguous in Wm
         f4 st[kSt];
-        const int stage_bytes = ngh * 3 * 1024;
+        const int stage_bytes = ngh * NTERM * 1024;
         auto stage_issue = [&](const unsigned char* src) {
 #pragma unroll
             for (int u = 0; u < kSt; ++u) {
@@ -313,19 +335,19 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                             const unsigned char* const bk = bst + par * kSbStage + lane * 16;
 #pragma unroll
                             for (int c = 0; c < NGH; ++c) {
-                                s16x8 bp[3];
+                                s16x8 bp[NTERM];
 #pragma unroll
-                                for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const s16x8*>(bk + (c * 3 + p) * 1024);
+                                for (int p = 0; p < NTERM; ++p) bp[p] = *reinterpret_cast<const s16x8*>(bk + (c * NTERM + p) * 1024);
                                 s16x8 a[4];
 #pragma unroll
                                 for (int b2 = 0; b2 < 4; ++b2) a[b2] = *reinterpret_cast<const s16x8*>(wnd + rs[b2][r] + cs[c]);
 #pragma unroll
-                                for (int p = 2; p >= 0; --p)                    // smallest terms first
+                                for (int p = NTERM - 1; p >= 0; --p)            // smallest terms first
 #pragma unroll
                                     for (int b2 = 0; b2 < 4; ++b2)
                                         if (FULL || b2 == 0) {                  // (partial tiles: the irregular row blocks hold <= 4 rows = one M-block)
                                             if (SS_SB_ABLATE & 4) acc[b2][p] += (float)(a[b2][0] + bp[p][1]);
-                                            else acc[b2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bp[p], a[b2], acc[b2], 0, 0, 0);       // D^T: rows = channels, columns = pixels
+                                            else acc[b2] = mfma32<DT>(bp[p], a[b2], acc[b2]);       // D^T: rows = channels, columns = pixels
                                         }
                             }
                         }
@@ -360,21 +382,24 @@ __global__ __launch_bounds__(kSbThreads, PACKED ? SS_SB_WGS : 2) void upconv_sub
                     const float fin = ((G - 1) & 1) ? -1.f : 1.f;
                     const int cj = col0 + (m & 7);
                     if (cj < nh) {
-                        float* const ob = out + ((long long)nb * H * W + hrec[3 + cj]) * COUT + 32 * cot + 4 * half;
+                        typename ActT<DT>::type* const ob = out + ((long long)nb * H * W + hrec[3 + cj]) * COUT + 32 * cot + 4 * half;
 #pragma unroll
                         for (int b2 = 0; b2 < (FULL ? 4 : 1); ++b2) {
                             const int ri = row0 + 4 * b2 + (m >> 3);
                             if (ri < nv) {
-                                float* const op = ob + (long long)vrec[3 + ri] * W * COUT;
+                                typename ActT<DT>::type* const op = ob + (long long)vrec[3 + ri] * W * COUT;
 #pragma unroll
                                 for (int q = 0; q < 4; ++q)
                                 {
                                     const f4 v = (f4){acc[b2][4 * q] * fin, acc[b2][4 * q + 1] * fin, acc[b2][4 * q + 2] * fin, acc[b2][4 * q + 3] * fin};
+                                    if constexpr (DT != 0) store_act4<DT>(op + 8 * q, v[0], v[1], v[2], v[3]);
+                                    else {
 #if SS_SB_NT_STORE
                                     __builtin_nontemporal_store(v, reinterpret_cast<f4*>(op + 8 * q));
 #else
                                     *reinterpret_cast<f4*>(op + 8 * q) = v;
 #endif
+                                    }
                                 }
                             }
                         }
@@ -456,8 +481,50 @@ int ss_upconv_sub_prep_f32(const float* weight, const int* vcls, const int* hcls
 {
     if (!weight || !vcls || !hcls || !wm || !ss_upconv_sub_supported(Cin, Cout, 5) || NVC < 1 || NHC < 1 || !aligned16(wm)) return SS_EINVAL;
     const long long total = (long long)NVC * NHC * (Cout / 32) * (Cin / 16) * 9 * 64;
-    hipLaunchKernelGGL(upconv_sub_prep_kernel, dim3(grid_for(total, 4096)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(upconv_sub_prep_kernel<0>, dim3(grid_for(total, 4096)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        weight, vcls, hcls, static_cast<unsigned short*>(wm), Cin, Cout, NVC, NHC);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* 16-bit activation modes (ABI 9): the merged-tap weights as TWO terms of `dtype` (taps rounded once to it first); wm: ss_upconv_sub_wm_elems(...) elements
+   (two thirds used) */
+int ss_upconv_sub_prep_x16(const float* weight, const int* vcls, const int* hcls, void* wm, int Cin, int Cout, int NVC, int NHC, int dtype, void* stream)
+{
+    if (!weight || !vcls || !hcls || !wm || !ss_upconv_sub_supported(Cin, Cout, 5) || NVC < 1 || NHC < 1 || !aligned16(wm)) return SS_EINVAL;
+    if (dtype != SS_DT_F16 && dtype != SS_DT_BF16) return SS_EINVAL;
+    const long long total = (long long)NVC * NHC * (Cout / 32) * (Cin / 16) * 9 * 64;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SS_DT_F16) hipLaunchKernelGGL(upconv_sub_prep_kernel<SS_DT_F16>, dim3(grid_for(total, 4096)), dim3(kBlock), 0, s, weight, vcls, hcls, static_cast<unsigned short*>(wm), Cin, Cout, NVC, NHC);
+    else hipLaunchKernelGGL(upconv_sub_prep_kernel<SS_DT_BF16>, dim3(grid_for(total, 4096)), dim3(kBlock), 0, s, weight, vcls, hcls, static_cast<unsigned short*>(wm), Cin, Cout, NVC, NHC);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ss_upconv_sub_fwd_f32 on 16-bit activations: x (nullable) the dense 16-bit spike tensor, x_packed (nullable) the 2-bit packed one, out in `dtype` */
+int ss_upconv_sub_fwd_x16(const void* x, const unsigned int* x_packed, const void* wm, const int* vblk, const int* hblk, const int* order, unsigned int* counter,
+                          void* out, long long NB, int Cin, int Cout, int h, int w, int H, int W, int NVB, int NHB, int NHC, const int* tblk, int NTB, int NORD,
+                          int dtype, void* stream)
+{
+    if ((!x && !x_packed) || !wm || !vblk || !hblk || !order || !counter || !out || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || NVB < 1 || NHB < 1 || NHC < 1
+        || NORD < 1 || NTB < 0 || (NTB > 0 && !tblk) || NORD > (NVB + NTB) * NHB || (dtype != SS_DT_F16 && dtype != SS_DT_BF16))
+        return SS_EINVAL;
+    if (!ss_upconv_sub_supported(Cin, Cout, 5) || !aligned16(out) || !aligned16(wm) || (x && !x_packed && !aligned16(x))) return SS_EINVAL;
+    if (NB * (long long)NORD > 0x7fffffffLL || NB * h * (long long)w * Cin > 0xffffffffLL) return SS_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return SS_ELAUNCH;
+    const long long n_tiles = NB * (long long)NORD;
+    const long long wgs = (long long)(x_packed ? SS_SB_WGS : 2) * cus;
+    const unsigned grid = (unsigned)(n_tiles < wgs ? n_tiles : wgs);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(counter, 0, sizeof(unsigned), s) != hipSuccess) return SS_ELAUNCH;
+    unsigned short* o16 = static_cast<unsigned short*>(out);
+    const unsigned short* wmp = static_cast<const unsigned short*>(wm);
+#define SS_SUB16(DTT) do { \
+        if (x_packed) hipLaunchKernelGGL((upconv_sub_fwd_kernel<true, DTT>), dim3(grid), dim3(kSbThreads), 0, s, static_cast<const void*>(x_packed), wmp, vblk, hblk, \
+                                         tblk ? tblk : vblk, order, counter, o16, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC, NORD); \
+        else hipLaunchKernelGGL((upconv_sub_fwd_kernel<false, DTT>), dim3(grid), dim3(kSbThreads), 0, s, x, wmp, vblk, hblk, \
+                                tblk ? tblk : vblk, order, counter, o16, (int)NB, h, w, H, W, Cin, Cout, NVB, NHB, NHC, NORD); } while (0)
+    if (dtype == SS_DT_F16) SS_SUB16(SS_DT_F16); else SS_SUB16(SS_DT_BF16);
+#undef SS_SUB16
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

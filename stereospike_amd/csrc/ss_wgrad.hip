@@ -119,6 +119,8 @@ __global__ __launch_bounds__(kBlock) void unpack_spikes_kernel(const unsigned* _
 }
 
 // im2col_cl_bf16_kernel reading its NHWC input from a packed spike tensor: 8 channels = 16 bits of one word (C % 8 == 0)
+// DT: the operand format of the patch matrix (0 / SS_DT_BF16: bf16; SS_DT_F16: fp16 — the 16-bit activation modes' single-term GEMMs)
+template <int DT = 0>
 __global__ __launch_bounds__(kBlock) void im2col_cl_bf16_packed_kernel(const unsigned* __restrict__ xp, unsigned short* __restrict__ A,
                                                                        int h, int w, int C, int k, int stride, int pad, int ho, int wo)
 {
@@ -136,8 +138,28 @@ __global__ __launch_bounds__(kBlock) void im2col_cl_bf16_packed_kernel(const uns
         const long long e = (((long long)nb * h + iy) * w + ix) * C + c8 * 8;
         const unsigned bits = (xp[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = code_to_bf16((bits >> (2 * q)) & 3u);
+        for (int q = 0; q < 8; ++q) o[q] = code_to_op<DT>((bits >> (2 * q)) & 3u);
     }
+    *reinterpret_cast<u16x8*>(A + ((long long)row * (k * k) + tap) * C + c8 * 8) = o;
+}
+
+// im2col of a DENSE 16-bit NHWC array (any values: an activation gradient) into a patch matrix of the same format: a plain gather of 16-byte granules.
+// (The data gradient of a 3 x 3 / stride 1 / padding 1 convolution is the same convolution of g with the flipped, channel-transposed kernel: the caller
+// flips the weight matrix, the patch matrix is the plain one.)
+__global__ __launch_bounds__(kBlock) void im2col_cl_x16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ A,
+                                                               int h, int w, int C, int k, int stride, int pad, int ho, int wo)
+{
+    const unsigned row = blockIdx.x;
+    const unsigned C8 = (unsigned)C / 8;
+    const unsigned r = blockIdx.y * kBlock + threadIdx.x;
+    if (r >= (unsigned)(k * k) * C8) return;
+    const unsigned ox = row % (unsigned)wo, t = row / (unsigned)wo;
+    const unsigned oy = t % (unsigned)ho, nb = t / (unsigned)ho;
+    const unsigned tap = r / C8, c8 = r - tap * C8;
+    const unsigned ky = tap / (unsigned)k, kx = tap - ky * (unsigned)k;
+    const int iy = (int)(oy * stride + ky) - pad, ix = (int)(ox * stride + kx) - pad;
+    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w) o = *reinterpret_cast<const u16x8*>(x + (((long long)nb * h + iy) * w + ix) * C + c8 * 8);
     *reinterpret_cast<u16x8*>(A + ((long long)row * (k * k) + tap) * C + c8 * 8) = o;
 }
 
@@ -302,10 +324,12 @@ __global__ __launch_bounds__(kBlock) void spike_wgrad_reduce_kernel(const float*
 // of tap (ky, kx) read from five column-decimated bf16 copies of x (one per kx: xK[kx][nb][iy + 2][ox / 8][ci][ox % 8] =
 // x[nb][iy][2 ox + kx - 2][ci], zero padded), so that the fragment of 8 consecutive ox is ONE aligned 16-B load, coalesced over ci.  The 25 C_in / 32 "virtual
 // channel" tiles (tap, ci tile) are dealt to workgroup kinds x wavefronts; every wavefront keeps NVC x (C_out / 32) accumulator tiles.
-template <int CIT, int COT, int NVC>
+// DT != 0 (16-bit activation modes): g is ONE term (it is stored in the operand format), one MFMA per (k-step, virtual-channel tile)
+template <int CIT, int COT, int NVC, int DT = 0>
 __global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const unsigned short* __restrict__ gT, const unsigned short* __restrict__ xK,
                                                                      float* __restrict__ ws, int NB, int h, int ho, int wo, int Q)
 {
+    constexpr int NSP = DT ? 1 : 3;
     // wavefront = (C_out tile, group of virtual-channel tiles): a wavefront loads the three pre-split g fragments of ITS C_out tile (the first
     // version split g in every wavefront: 56x redundant VALU work) and NVC spike fragments per k-step, and issues 3 NVC MFMAs
     constexpr int CIN = 32 * CIT, COUT = 32 * COT, NV = 25 * CIT, NG = 8 / COT;
@@ -335,14 +359,14 @@ __global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const unsi
     const long long per = (KS + slices - 1) / slices;
     const long long ks0 = slice * per, ks1 = min(ks0 + per, KS);
     constexpr int PF = 2;
-    s16x8 gs[PF][3], xn[PF][NVC];
-    auto load_step = [&](s16x8 (&gd)[3], s16x8 (&xd)[NVC], long long ks) {
+    s16x8 gs[PF][NSP], xn[PF][NVC];
+    auto load_step = [&](s16x8 (&gd)[NSP], s16x8 (&xd)[NVC], long long ks) {
         const int c = (int)(ks % KSR);
         const long long ro = ks / KSR;                                     // nb * ho + oy
         const int oy = (int)(ro % ho);
         const long long nb = ro / ho;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) gd[sp] = *reinterpret_cast<const s16x8*>(gT + (((ks * 3 + sp) * COT + cot) * 64 + lane) * 8);
+        for (int sp = 0; sp < NSP; ++sp) gd[sp] = *reinterpret_cast<const s16x8*>(gT + (((ks * NSP + sp) * COT + cot) * 64 + lane) * 8);
 #pragma unroll
         for (int j = 0; j < NVC; ++j)
             xd[j] = *reinterpret_cast<const s16x8*>(xK + xbase[j] + (((nb * HP + 2 * oy) * OX8 + 2 * c) * CIN) * 8LL);
@@ -355,10 +379,10 @@ __global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const unsi
             if (ks + u < ks1) {
                 if (ks + u + 1 < ks1) load_step(gs[(u + 1) % PF], xn[(u + 1) % PF], ks + u + 1);
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
+                for (int sp = 0; sp < NSP; ++sp)
 #pragma unroll
                     for (int j = 0; j < NVC; ++j)
-                        if (own[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs[u][sp], xn[u][j], acc[j], 0, 0, 0);
+                        if (own[j]) acc[j] = mfma32<DT>(gs[u][sp], xn[u][j], acc[j]);
             }
         }
     }
@@ -378,7 +402,9 @@ __global__ __launch_bounds__(kSwThreads) void spike_conv_wgrad_kernel(const unsi
 
 // g [NB * ho][wo][C_out] fp32 -> gT[k-step][split][C_out tile][lane][8] bf16: the exact three-term split of g in MFMA fragment order (lane ->
 // co = 32 tile + (lane & 31), the 8 consecutive ox of its half of the k-step; zero beyond wo)
-__global__ __launch_bounds__(kBlock) void spike_conv_gprep_kernel(const float* __restrict__ g, unsigned short* __restrict__ gT, long long rows, int wo,
+// DT != 0: g is a 16-bit tensor already in the operand format — ONE term, a plain re-layout
+template <int DT = 0>
+__global__ __launch_bounds__(kBlock) void spike_conv_gprep_kernel(const typename ActT<DT>::type* __restrict__ g, unsigned short* __restrict__ gT, long long rows, int wo,
                                                                   int COUT)
 {
     const int KSR = (wo + 15) / 16, COT = COUT / 32;
@@ -389,11 +415,21 @@ __global__ __launch_bounds__(kBlock) void spike_conv_gprep_kernel(const float* _
         const int t = (int)(r % COT); r /= COT;
         const int c = (int)(r % KSR); const long long ro = r / KSR;
         const long long ks = ro * KSR + c;
+        if constexpr (DT != 0) {
+            u16x8 o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ox = 16 * c + 8 * (lane >> 5) + e;
+                o1[e] = ox < wo ? g[(ro * wo + ox) * COUT + 32 * t + (lane & 31)] : (unsigned short)0;
+            }
+            *reinterpret_cast<u16x8*>(gT + ((ks * COT + t) * 64 + lane) * 8) = o1;
+            continue;
+        }
         u16x8 o[3];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ox = 16 * c + 8 * (lane >> 5) + e;
-            const float v = ox < wo ? g[(ro * wo + ox) * COUT + 32 * t + (lane & 31)] : 0.f;
+            const float v = ox < wo ? (float)g[(ro * wo + ox) * COUT + 32 * t + (lane & 31)] : 0.f;
             const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
             const float r1 = v - __uint_as_float(uh);
             const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
@@ -425,11 +461,12 @@ __global__ __launch_bounds__(kBlock) void spike_conv_wgrad_reduce_kernel(const f
 
 // x [NB][h][w][C] fp32 spike counts -> xK[kx][nb][iy + 2][ox / 8][ci][ox % 8] bf16 = x[nb][iy][2 ox + kx - 2][ci] (zero outside), ox < 16 ceil(wo / 16).
 // A lane owns (nb, padded row, 8-ox chunk, ci): 19 input columns -> the five kx fragments; reads and 16-B writes coalesced over ci.
-template <bool PACKED>
+template <bool PACKED, int DT = 0>             // DT != 0: the operand format is DT; a dense input is then the 16-bit spike tensor itself
 __global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const void* __restrict__ xv, unsigned short* __restrict__ xK, int NB, int h, int w, int C,
                                                                   int wo)
 {
     const float* x = static_cast<const float*>(xv);
+    const unsigned short* x16 = static_cast<const unsigned short*>(xv);
     const unsigned* xp = static_cast<const unsigned*>(xv);                  // PACKED: the 2-bit packed spike tensor (16 neurons per word)
     const int OX8 = 2 * ((wo + 15) / 16), HP = h + 4;
     const long long total = (long long)NB * HP * OX8 * C;
@@ -445,7 +482,8 @@ __global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const void* __
             const int ix = 16 * o8 - 2 + t;
             const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
             const long long el = (((long long)nb * h + iy) * w + ix) * C + ci;
-            if constexpr (PACKED) v[t] = ok ? code_to_bf16((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u) : (unsigned short)0;
+            if constexpr (PACKED) v[t] = ok ? code_to_op<DT>((xp[el >> 4] >> (2 * (int)(el & 15))) & 3u) : (unsigned short)0;
+            else if constexpr (DT != 0) v[t] = ok ? x16[el] : (unsigned short)0;
             else v[t] = ok ? (unsigned short)(__float_as_uint(x[el]) >> 16) : (unsigned short)0;
         }
 #pragma unroll
@@ -842,8 +880,38 @@ int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB
     const long long rows = NB * ho * wo;
     const long long per_row = (long long)k * k * (C / 8);
     if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
-    hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel<0>, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), x_packed, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ss_im2col_cl_bf16_packed with the patch matrix in `dtype` (ABI 9: SS_DT_F16 for the fp16 activation mode's single-term GEMMs; SS_DT_BF16 == the bf16 form) */
+int ss_im2col_cl_packed_x16(const unsigned int* x_packed, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, int dtype, void* stream)
+{
+    if (dtype == SS_DT_BF16) return ss_im2col_cl_bf16_packed(x_packed, A, NB, h, w, C, k, stride, pad, ho, wo, stream);
+    if (dtype != SS_DT_F16) return SS_EINVAL;
+    if (!x_packed || !A || NB <= 0 || h <= 0 || w <= 0 || C <= 0 || C % 8 != 0 || k <= 0 || stride <= 0 || pad < 0 || ho <= 0 || wo <= 0) return SS_EINVAL;
+    if ((ho - 1) * stride - pad + k - 1 >= h + pad || (wo - 1) * stride - pad + k - 1 >= w + pad) return SS_EINVAL;
+    if (!aligned16(A) || (NB * h * w * C) % 16 != 0) return SS_EINVAL;
+    const long long rows = NB * ho * wo;
+    const long long per_row = (long long)k * k * (C / 8);
+    if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
+    hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel<SS_DT_F16>, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), x_packed, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* im2col of a dense 16-bit NHWC array (fp16 or bf16: the element type is not interpreted) into a patch matrix A[(nb, oy, ox)][(ky, kx, c)] of the same type (ABI 9) */
+int ss_im2col_cl_x16(const void* x, void* A, long long NB, int h, int w, int C, int k, int stride, int pad, int ho, int wo, void* stream)
+{
+    if (!x || !A || NB <= 0 || h <= 0 || w <= 0 || C <= 0 || C % 8 != 0 || k <= 0 || stride <= 0 || pad < 0 || ho <= 0 || wo <= 0) return SS_EINVAL;
+    if ((ho - 1) * stride - pad + k - 1 >= h + pad || (wo - 1) * stride - pad + k - 1 >= w + pad) return SS_EINVAL;
+    if (!aligned16(x) || !aligned16(A)) return SS_EINVAL;
+    const long long rows = NB * ho * wo;
+    const long long per_row = (long long)k * k * (C / 8);
+    if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
+    hipLaunchKernelGGL(im2col_cl_x16_kernel, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(x), static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -1058,10 +1126,43 @@ int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* 
                                      static_cast<const void*>(x_packed), xK, (int)NB, h, w, Cin, wo);
     else hipLaunchKernelGGL(spike_conv_xprep_kernel<false>, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
                             static_cast<const void*>(x), xK, (int)NB, h, w, Cin, wo);
-    hipLaunchKernelGGL(spike_conv_gprep_kernel, dim3(grid_for(NB * ho * ksr * (Cout / 32) * 64, kMaxGridBwd)), dim3(kBlock), 0, s, g, gT, NB * ho, wo, Cout);
+    hipLaunchKernelGGL(spike_conv_gprep_kernel<0>, dim3(grid_for(NB * ho * ksr * (Cout / 32) * 64, kMaxGridBwd)), dim3(kBlock), 0, s, g, gT, NB * ho, wo, Cout);
     const unsigned grid = (unsigned)(Q * slices);
     if (Cin == 32) hipLaunchKernelGGL((spike_conv_wgrad_kernel<1, 2, 7>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q);
     else hipLaunchKernelGGL((spike_conv_wgrad_kernel<2, 4, 7>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q);
+    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+    hipLaunchKernelGGL(spike_conv_wgrad_reduce_kernel, dim3(grid_for(25LL * Cin * Cout, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cin, Cout, accumulate);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
+/* ss_spike_conv_wgrad_f32 on a 16-bit output gradient (ABI 9): g in `dtype` (the operand itself: one term), x the dense 16-bit spike tensor of the same
+   dtype or the 2-bit packed one, g_w fp32 (exact products, fp32 accumulation, fixed-order reduction); ws as for the fp32 form */
+int ss_spike_conv_wgrad_x16(const void* g, const void* x, const unsigned int* x_packed, float* g_w, float* ws, long long NB, int Cin, int Cout, int h,
+                            int w, int accumulate, int dtype, void* stream)
+{
+    if (x_packed && (NB * h * w * Cin) % 16 != 0) return SS_EINVAL;
+    if (!g || (!x && !x_packed) || !g_w || !ws || NB <= 0 || NB > 0x7fffffff || h <= 0 || w <= 0 || !ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || !aligned16(ws))
+        return SS_EINVAL;
+    if (dtype != SS_DT_F16 && dtype != SS_DT_BF16) return SS_EINVAL;
+    int Q = 0, slices = 0;
+    if (!spike_conv_wgrad_plan(Cin, &Q, &slices)) return SS_ELAUNCH;
+    const int ho = (h + 4 - 5) / 2 + 1, wo = (w + 4 - 5) / 2 + 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long ksr = (wo + 15) / 16, oxp = ksr * 16;
+    const long long part = (long long)slices * 25 * Cin * Cout, xk = ((5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + 3) & ~3LL;
+    unsigned short* xK = reinterpret_cast<unsigned short*>(ws + part);
+    unsigned short* gT = reinterpret_cast<unsigned short*>(ws + part + xk);
+    const int xg = grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd), gg = grid_for(NB * ho * ksr * (Cout / 32) * 64, kMaxGridBwd);
+    const unsigned grid = (unsigned)(Q * slices);
+    const unsigned short* g16 = static_cast<const unsigned short*>(g);
+#define SS_SCW16(DTT) do { \
+        if (x_packed) hipLaunchKernelGGL((spike_conv_xprep_kernel<true, DTT>), dim3(xg), dim3(kBlock), 0, s, static_cast<const void*>(x_packed), xK, (int)NB, h, w, Cin, wo); \
+        else hipLaunchKernelGGL((spike_conv_xprep_kernel<false, DTT>), dim3(xg), dim3(kBlock), 0, s, x, xK, (int)NB, h, w, Cin, wo); \
+        hipLaunchKernelGGL(spike_conv_gprep_kernel<DTT>, dim3(gg), dim3(kBlock), 0, s, g16, gT, NB * ho, wo, Cout); \
+        if (Cin == 32) hipLaunchKernelGGL((spike_conv_wgrad_kernel<1, 2, 7, DTT>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q); \
+        else hipLaunchKernelGGL((spike_conv_wgrad_kernel<2, 4, 7, DTT>), dim3(grid), dim3(kSwThreads), 0, s, gT, xK, ws, (int)NB, h, ho, wo, Q); } while (0)
+    if (dtype == SS_DT_F16) SS_SCW16(SS_DT_F16); else SS_SCW16(SS_DT_BF16);
+#undef SS_SCW16
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(spike_conv_wgrad_reduce_kernel, dim3(grid_for(25LL * Cin * Cout, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, Cin, Cout, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;

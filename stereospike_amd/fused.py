@@ -88,6 +88,18 @@ def spike_anchor(shape, dtype, device):
     return torch.zeros(1, dtype=dtype, device=device).as_strided(tuple(shape), (0,) * len(shape))
 
 
+def x16_mode(device=None):
+    """The activation dtype (torch.float16 | torch.bfloat16) when the caller runs under 16-bit torch.autocast AND the 16-bit activation modes are routed
+    to the engine's own single-term kernels (EngineConfig.X16_OWN_KERNELS, round 5: include/ss_neuron.h "ABI 9"); None otherwise — fp32 mode, or the
+    modes' round-2 .. 4 path (synapses = MIOpen convolutions under autocast)."""
+    if device is not None and torch.device(device).type != 'cuda':
+        return None
+    if not (torch.is_autocast_enabled('cuda') and _cfg().X16_OWN_KERNELS):
+        return None
+    adt = torch.get_autocast_dtype('cuda')
+    return adt if adt in (torch.float16, torch.bfloat16) else None
+
+
 def unpack_dense(packed, shape, dtype=torch.float32):
     """Packed int32 [T, N/16] -> dense tensor of `shape` (for a consumer that cannot read the packed form)."""
     out = torch.empty(tuple(shape), dtype=dtype, device=packed.device)
@@ -117,22 +129,29 @@ def _lr_layout(rows, C, rank=_LR_RANK):
     return _LR_HDR, o_w, o_w + rank * C
 
 
-def lowrank_buffer(shape, device, rank=_LR_RANK):
+def lowrank_buffer(shape, device, rank=_LR_RANK, dtype=torch.float32):
     """shape [..., C] of the dense gradient the pair stands for -> (anchor, g_P [rows, rank], W2 [rank, C]): the zero-stride gradient to
-    return to autograd and the two views the producer fills (g_P by the adjoint kernel, W2 by a copy of the head's weight)."""
+    return to autograd and the two views the producer fills (g_P by the adjoint kernel, W2 by a copy of the head's weight).
+    dtype: the dtype of the gradient the anchor stands in for (autograd casts a gradient whose dtype differs from its output's — which would materialise
+    the anchor — so in the 16-bit activation modes the anchor is a fp16 / bf16 VIEW of element 0 of the same fp32 buffer; the pair itself stays fp32).
+    The header words are 0x7FC07FC0: a NaN as fp32 and, read as two 16-bit halves, as fp16 / bf16."""
     C = int(shape[-1])
     rows = 1
     for d in shape[:-1]:
         rows *= int(d)
     o_p, o_w, n = _lr_layout(rows, C, rank)
     buf = torch.empty(n, dtype=torch.float32, device=device)
-    buf[:_LR_HDR].fill_(float('nan'))
-    return buf.as_strided(tuple(shape), (0,) * len(shape)), buf[o_p:o_p + rows * rank].view(rows, rank), buf[o_w:o_w + rank * C].view(rank, C)
+    buf[:_LR_HDR].view(torch.int32).fill_(0x7FC07FC0)
+    if dtype == torch.float32:
+        anchor = buf.as_strided(tuple(shape), (0,) * len(shape))
+    else:
+        anchor = torch.empty(0, dtype=dtype, device=device).set_(buf.untyped_storage(), 0, tuple(shape), (0,) * len(shape))
+    return anchor, buf[o_p:o_p + rows * rank].view(rows, rank), buf[o_w:o_w + rank * C].view(rank, C)
 
 
-def lowrank_anchor(shape, lr_p, lr_w):
+def lowrank_anchor(shape, lr_p, lr_w, dtype=torch.float32):
     """The anchor of an existing pair (copies both into a fresh buffer; the product path fills a lowrank_buffer in place instead)."""
-    a, p, w = lowrank_buffer(shape, lr_p.device, lr_w.shape[0])
+    a, p, w = lowrank_buffer(shape, lr_p.device, lr_w.shape[0], dtype)
     p.copy_(lr_p)
     w.copy_(lr_w)
     return a
@@ -145,7 +164,7 @@ def lowrank_of(g, rank=_LR_RANK):
     gradient of `(torch.stack(terms) * w).sum()` is an expanded view of element 0 of a len(terms)-float storage) and is handled as the dense
     gradient it is — unless its first element carries the pair buffer's NaN header, i.e. a real pair reached a layer it was not made for: that
     RAISES (one host read, on this rare path only and never inside a stream capture; without it the NaN header still surfaces as NaN gradients)."""
-    if g is None or g.dtype != torch.float32 or g.dim() == 0 or any(g.stride()) or g.storage_offset() != 0:
+    if g is None or g.dtype not in (torch.float32, torch.float16, torch.bfloat16) or g.dim() == 0 or any(g.stride()) or g.storage_offset() != 0:
         return None
     st = g.untyped_storage()
     n = st.nbytes() // 4
@@ -164,9 +183,10 @@ def lowrank_of(g, rank=_LR_RANK):
     return flat[o_p:o_p + rows * rank].view(rows, rank), flat[o_w:o_w + rank * C].view(rank, C)
 
 
-def lowrank_dense(lr, shape):
+def lowrank_dense(lr, shape, dtype=torch.float32):
     """The dense gradient a low-rank pair stands for (consumers without the fused form)."""
-    return torch.mm(lr[0], lr[1]).view(tuple(shape))
+    g = torch.mm(lr[0], lr[1]).view(tuple(shape))
+    return g if dtype == torch.float32 else g.to(dtype)
 
 
 class _FusedNeuron(torch.autograd.Function):
@@ -183,8 +203,8 @@ class _FusedNeuron(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:4])
         half = x_seq.dtype in (torch.float16, torch.bfloat16)       # 16-bit activations, fp32 membrane (configs 2 / 5)
         recompute = need_grad and _cfg().RECOMPUTE_H and _lib.neuron_bwd_rc_supported(T)
-        # the packed kernel form: fp32 activations, compile-time T, whole words, no saved h
-        can_pk = (not half) and N % 16 == 0 and _lib.neuron_bwd_rc_supported(T) and (recompute or not need_grad)
+        # the packed kernel form: compile-time T, whole words, no saved h (fp32 activations; 16-bit ones since ABI 9)
+        can_pk = N % 16 == 0 and _lib.neuron_bwd_rc_supported(T) and (recompute or not need_grad)
         if skip_packed is not None and not can_pk:
             skip_seq, skip_packed = unpack_dense(skip_packed, x_seq.shape, x_seq.dtype), None
         if not can_pk:
@@ -247,15 +267,16 @@ class _FusedNeuron(torch.autograd.Function):
         l1, l2 = lowrank_of(g_out_seq), lowrank_of(g_out2_seq)    # a prediction head's gradient as a low-rank pair (see lowrank_buffer)
         if l1 is not None or l2 is not None:
             if l1 is not None and l2 is not None:      # two pairs: one stays low-rank
-                g_out_seq, l1 = lowrank_dense(l1, h_seq.shape), None
+                g_out_seq, l1 = lowrank_dense(l1, h_seq.shape, ctx.io_dtype), None
             if l1 is not None:
                 g_out_seq, g_out2_seq, l2 = g_out2_seq, g_out_seq, l1
             if l2 is not None:
                 C = int(l2[1].shape[1])
-                if ctx.recompute and not half and h_seq.shape[-1] == C and _lib.neuron_bwd_fork_lr_supported(T, N, C, l2[1].shape[0]):
+                lr_ok = (_lib.neuron_bwd_fork_lr_x16_supported if half else _lib.neuron_bwd_fork_lr_supported)(T, N, C, l2[1].shape[0])
+                if ctx.recompute and h_seq.shape[-1] == C and lr_ok:
                     lr, lr_anchor, g_out2_seq = l2, g_out2_seq, None
                 else:
-                    g_out2_seq = lowrank_dense(l2, h_seq.shape)
+                    g_out2_seq = lowrank_dense(l2, h_seq.shape, ctx.io_dtype)
         if g_out_seq is None and lr is None:
             g_out_seq, g_out2_seq = g_out2_seq, None
         if g_out_seq is None and lr is None:
@@ -281,12 +302,13 @@ class _FusedNeuron(torch.autograd.Function):
         want_gskip = ctx.has_skip and ctx.needs_input_grad[2]
         g_sum = torch.empty_like(g_out_seq) if ((fuse2 or lr is not None) and want_gskip and g_out_seq is not None) else None
         if lr is not None:
-            _lib.neuron_bwd_fork_lr(g_out_seq, lr[0], lr[1], g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
+            (_lib.neuron_bwd_fork_lr_x16 if half else _lib.neuron_bwd_fork_lr)(g_out_seq, lr[0], lr[1], g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                                     T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
-            per = 8 + 4 * lr[1].shape[0] / lr[1].shape[1] + (4 if g_out_seq is not None else 0) + (4 if g_sum is not None else 0)
+            es = 2 if half else 4
+            per = 2 * es + 4 * lr[1].shape[0] / lr[1].shape[1] + (es if g_out_seq is not None else 0) + (es if g_sum is not None else 0)
             tag = 'neuron_bwd+lr' + ('+sum' if g_sum is not None else '') if g_out_seq is not None else 'neuron_bwd+lronly'
             TIMER.stop(e0, tag, int(per * T * N), T * N)
-            _note('neuron_bwd', tag, ctx.site)
+            _note('neuron_bwd', tag + ('+x16' if half else ''), ctx.site)
             # dL/dskip: the dense sum when there was a dense first gradient, else the low-rank pair itself travels on (identity)
             g_skip = (g_sum if g_out_seq is not None else lr_anchor.view(h_seq.shape)) if want_gskip else None
             return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
@@ -811,8 +833,14 @@ class _UpConvProjectedCL(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
     def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0,
-                lowrank_grad=False, x_packed=None):
+                lowrank_grad=False, x_packed=None, own16=None):
         ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
+        # own16 (round 5): the 16-bit activation mode's dtype when the mode runs on the engine's own single-term kernels (x16_mode()) — decoder stages then take
+        # the sub-pixel forward / box-sum backward on 16-bit I/O, and a packed head keeps its exact fp32 weights
+        ctx.own16 = own16
+        sub16_ok = bool(own16 is not None and _cfg().SUB_FWD and k == 5 and spikes_in and bias is None and act_dtype == own16 and x_cl.shape[-1] in _cfg().SUB_FWD_CIN
+                        and x_cl.is_cuda and _lib.upconv_sub_supported(x_cl.shape[-1], weight.shape[0], k) and x_cl.numel() < 2 ** 32
+                        and (x_packed is not None or x_cl.dtype == own16) and sub_tables(tables, H, W) is not None)
         # x_packed (one-channel 3 x 3 head on a packed-only neuron output, fp32 mode): the input as a 2-bit packed spike tensor; x_cl is then a
         # data-less anchor that carries shape and autograd edge.  Projection and weight gradient read the packed form (ss_head_*_packed_f32)
         if x_packed is not None and k != 3:
@@ -820,7 +848,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             # of this stage gets the dense tensor back first
             sub_ok = (_cfg().SUB_FWD and k == 5 and x_cl.shape[-1] in _cfg().SUB_FWD_CIN and _lib.upconv_sub_supported(x_cl.shape[-1], weight.shape[0], k)
                       and sub_tables(tables, H, W) is not None)
-            if not (spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
+            if not sub16_ok and not (spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
                     and (sub_ok or (_cfg().FUSED_UPCONV_MFMA and _lib.upconv_fused_form(x_cl.shape[-1], weight.shape[0], k, max_window) != 0))):
                 x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None     # (a dense copy came along: use it)
         if x_packed is not None and k == 3:
@@ -882,6 +910,20 @@ class _UpConvProjectedCL(torch.autograd.Function):
         x16_fused = (_cfg().FUSED_UPCONV_MFMA and _cfg().FUSED_UPCONV_X16 and spikes_in and act_dtype is not None and bias is None and half_in
                      and x_cl.dtype == act_dtype and lowp == (act_dtype == torch.bfloat16) and (lowp or _cfg().EXACT_SPLIT_GEMM)
                      and _lib.upconv_fused_form(Cin, Cout, k, max_window) == 2)
+        if sub16_ok:                                  # decoder stage, 16-bit mode on own kernels: merged-tap implicit GEMM, two terms of the mode's format
+            st16 = sub_tables(tables, H, W)
+            e0 = TIMER.start()
+            wm = _lib.upconv_sub_prep_x16(weight.contiguous(), st16, Cin, Cout, own16)
+            _lib.upconv_sub_fwd_x16(None if x_packed is not None else x_cl, x_packed, wm, st16, out, NB, Cin, Cout, h, w)
+            TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()) + 2 * out.numel(), out.numel())
+            _note('synapse_fwd', 'upconv_sub_mfma_x16' + ('(packed in)' if x_packed is not None else ''))
+            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
+            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+            ctx.exact = False
+            ctx.tables, ctx.k, ctx.n = tables, k, n
+            ctx.wshape = weight.shape
+            ctx.has_bias = False
+            return out
         if x16_fused:
             e0 = TIMER.start()
             _lib.upconv_fused2_x16(x_cl, weight.contiguous(), src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
@@ -982,7 +1024,37 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # one-channel 3 x 3 head on a forked neuron output: g_x = g_P [rows, 9] @ W2 [9, C_in] is left to the consumer's backward kernel
         # (anomaly detection scans every backward output for NaNs and would trip over the anchor: it gets the dense form)
         lowrank = (need_x and ctx.lowrank_grad and ctx.ecfg.LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
-                   and ctx.x_dtype == torch.float32 and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
+                   and (ctx.x_dtype == torch.float32 or ctx.own16 is not None) and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
+        # ---- round 5: the 16-bit activation modes on own kernels — the same box-sum backward on 16-bit I/O (box planes in the mode's format, ONE weight term)
+        own16 = ctx.own16
+        box16_ok = (own16 is not None and ctx.ecfg.BOX_BWD and k == 5 and g16 and g_out.dtype == own16 and n >= NB and Cin in ctx.ecfg.BOX_BWD_CIN and (need_x or need_w)
+                    and (x_packed is not None or x_cl.dtype == own16))
+        if box16_ok:
+            bt = box_tables(ctx.tables, H, W)
+            box16_ok = (not need_x or _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt, NB, h, w)) and (not need_w or _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt, NB, h, w))
+        if box16_ok:
+            e0 = TIMER.start()
+            e1 = TIMER.start()
+            box = _lib.upconv_boxsum_x16(g_out, bt, NB, Cout, H, W)
+            TIMER.stop(e1, 'box_boxsum', 2 * g_out.numel() + 2 * box.numel(), g_out.numel())
+            g_x = g_w = None
+            wc = weight.detach().contiguous()
+            if need_x:
+                g_x = torch.empty(x_cl.shape, dtype=own16, device=g_out.device)
+                e1 = TIMER.start()
+                _lib.upconv_box_dgrad_x16(box, wc, bt, g_x, NB, Cin, Cout, h, w)
+                TIMER.stop(e1, 'box_dgrad', 2 * box.numel() + 2 * g_x.numel(), g_x.numel())
+            if need_w:
+                g_w = torch.empty(wc.shape, dtype=torch.float32, device=g_out.device)
+                e1 = TIMER.start()
+                _lib.upconv_box_wgrad_x16(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
+                TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()), g_out.numel())
+            TIMER.stop(e0, 'upconv_cl_bwd', 2 * (x_cl.numel() + g_out.numel()), g_out.numel())
+            _note('synapse_bwd', 'box_x16: boxsum' + ('+dgrad1_mfma' if need_x else '') + ('+wgrad1_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
+            if g_x is not None and g_x.dtype != ctx.x_dtype:
+                g_x = g_x.to(ctx.x_dtype)
+            g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None, None
         # ---- round 4: the whole stage backward on the box-sum image (ss_upconv_box.hip): one HBM-bound box-sum launch, then both contractions as implicit
         #      GEMMs over its three bf16 planes — no per-tap tensor g_P in HBM or on chip, no per-fragment operand arithmetic
         box_ok = (ctx.ecfg.BOX_BWD and k == 5 and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and n >= NB and not lowrank and Cin in ctx.ecfg.BOX_BWD_CIN
@@ -1013,7 +1085,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 g_x = g_x.to(ctx.x_dtype)
             # a stage built with bias=True (NNConvUpsampling accepts it; the shipped decoder stages have none): its gradient as in every other form
             g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
+            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None, None
         g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
@@ -1053,7 +1125,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
             else:
                 if lowrank:      # the adjoint writes g_P straight into the pair buffer the consumer's neuron backward will read
-                    lr_anchor, g_P, lr_w = lowrank_buffer(x_cl.shape, x_cl.device, kk * Cout)
+                    lr_anchor, g_P, lr_w = lowrank_buffer(x_cl.shape, x_cl.device, kk * Cout, ctx.x_dtype)
                     lr_w.copy_(W2)
                 else:
                     g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
@@ -1113,7 +1185,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
         g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if g_x is not None and g_x.dtype != ctx.x_dtype:
             g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -1302,6 +1374,8 @@ class _SpikeConvWgradCL(torch.autograd.Function):
 def spike_conv_fwd_applies(conv, device, dtype=torch.float32) -> bool:
     """True when `conv` on a spike NHWC array runs its FORWARD through ss_spike_conv_fwd_f32 (and can therefore take a packed-only input)."""
     import torch.nn as nn
+    if x16_mode(device) is not None:
+        return conv16_kind(conv, True) == 's2'
     return bool(_cfg().SPIKE_CONV_FWD_MFMA and _cfg().SPIKE_CONV_WGRAD_MFMA and isinstance(conv, nn.Conv2d) and device.type == 'cuda' and dtype == torch.float32
                 and not torch.is_autocast_enabled('cuda') and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
                 and conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2)
@@ -1384,11 +1458,193 @@ def dense_conv_s1_cl(x_cl: torch.Tensor, conv) -> Optional[torch.Tensor]:
 
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 16-bit activation modes on the engine's own kernels (round 5; EngineConfig.X16_OWN_KERNELS, include/ss_neuron.h ABI 9): the encoder / bottleneck synapses.
+# Called with autocast DISABLED (conv_cl16): every dtype below is explicit.  adt = torch.float16 | torch.bfloat16.
+# ----------------------------------------------------------------------------------------------------------
+class _DenseConvS1CL16(torch.autograd.Function):
+    """The first encoder layer (/root/reference/network/SNN_models.py:75-79) in a 16-bit activation mode: x_cl fp32 NHWC (the event-voxel input) ->
+    y in adt; input and weight rounded once to adt inside the kernels (autocast's semantics for this convolution), fp32 accumulation, fp32 weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, adt):
+        ctx.ecfg, ctx.site = _cfg(), _site()
+        x_cl = x_cl.float().contiguous()
+        NB, h, w, Cin = x_cl.shape
+        Cout = weight.shape[0]
+        y = torch.empty((NB, h, w, Cout), dtype=adt, device=x_cl.device)
+        e0 = TIMER.start()
+        _lib.dense_conv_s1_fwd_x16(x_cl, weight.detach().float().contiguous(), y, NB, Cin, Cout, h, w)
+        TIMER.stop(e0, 'dense_conv_s1_fwd', 2 * y.numel() + 4 * x_cl.numel(), y.numel())
+        _note('synapse_fwd', 'dense_conv_s1_fwd1_mfma_x16')
+        ctx.save_for_backward(x_cl, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_cl, weight = ctx.saved_tensors
+        NB, h, w, Cin = x_cl.shape
+        g = g.contiguous()
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            e0 = TIMER.start()
+            _lib.dense_conv_s1_wgrad_x16(g, x_cl, gw, NB, Cin, weight.shape[0], h, w)
+            TIMER.stop(e0, 'dense_conv_s1_wgrad', 2 * g.numel() + 4 * x_cl.numel(), g.numel())
+        gx = None
+        if ctx.needs_input_grad[0]:          # (never in the shipped models: the network input needs no gradient)
+            gx = torch.ops.aten.convolution_backward(g.float().permute(0, 3, 1, 2), x_cl.permute(0, 3, 1, 2), weight.float().contiguous(memory_format=torch.channels_last),
+                                                     None, [1, 1], [2, 2], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).contiguous()
+        _note('synapse_bwd', 'g_x: ' + ('miopen' if gx is not None else 'none') + '; g_w: ' + ('dense_conv_s1_wgrad1_mfma_x16' if gw is not None else 'none'), ctx.site)
+        return gx, gw, None
+
+
+class _SpikeConvS2CL16(torch.autograd.Function):
+    """conv1 / conv2 (/root/reference/network/SNN_models.py:80-90) in a 16-bit activation mode: forward, weight gradient and data gradient as single-term MFMA
+    implicit GEMMs on 16-bit I/O; the spike input is read 2-bit packed when the producer wrote it (x_cl may then be a data-less anchor)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, x_packed, adt):
+        ctx.ecfg, ctx.site = _cfg(), _site()
+        NB, h, w, Cin = x_cl.shape
+        Cout = weight.shape[0]
+        if x_packed is None:
+            x_cl = x_cl.to(adt).contiguous()                      # spike counts: exact in either format
+        y = torch.empty((NB, (h - 1) // 2 + 1, (w - 1) // 2 + 1, Cout), dtype=adt, device=x_cl.device)
+        e0 = TIMER.start()
+        _lib.spike_conv_fwd_x16(None if x_packed is not None else x_cl, None if x_packed is None else x_packed.contiguous(),
+                                weight.detach().float().contiguous(), y, NB, Cin, Cout, h, w)
+        TIMER.stop(e0, 'spike_conv_fwd', 2 * y.numel() + (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()), y.numel())
+        _note('synapse_fwd', 'spike_conv_fwd1_mfma_x16' + ('(packed in)' if x_packed is not None else ''))
+        ctx.save_for_backward(x_cl, weight, x_packed)
+        ctx.adt = adt
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_cl, weight, x_packed = ctx.saved_tensors
+        NB, h, w, Cin = x_cl.shape
+        Cout = weight.shape[0]
+        g = g.to(ctx.adt).contiguous()
+        g_x = g_w = None
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            _lib.spike_conv_wgrad_x16(g, None if x_packed is not None else x_cl, g_w, NB, Cin, Cout, h, w, x_packed=None if x_packed is None else x_packed.contiguous())
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty((NB, h, w, Cin), dtype=ctx.adt, device=g.device)
+            e0 = TIMER.start()
+            _lib.conv_s2_dgrad_x16(g, weight.detach().float().contiguous(), g_x, NB, Cin, Cout, h, w)
+            TIMER.stop(e0, 'conv_s2_dgrad', 2 * (g.numel() + g_x.numel()), g_x.numel())
+        _note('synapse_bwd', 'g_x: ' + ('conv_s2_dgrad1_mfma_x16' if g_x is not None else 'none') + '; g_w: ' + ('spike_conv_wgrad1_mfma_x16' if g_w is not None else 'none'), ctx.site)
+        return g_x, g_w, None, None
+
+
+class _SpikeConvGemmCL16(torch.autograd.Function):
+    """conv3 / conv4 and the SEW bottleneck convs (/root/reference/network/SNN_models.py:91-107, blocks.py:145-154) in a 16-bit activation mode:
+    forward : A = im2col(x) in adt (from the packed spikes when the producer wrote them; kept for backward), y = A @ W_adt — ONE single-term library GEMM with the
+              adt output written by its epilogue (the fp32 mode: three terms + a summing pass);
+    wgrad   : g_W = A^T @ g, both adt, fp32 accumulation AND fp32 output (split-K slices summed in fp32);
+    dgrad   : stride-2 5 x 5: ss_conv_s2_dgrad_x16; 3 x 3 stride 1: the same convolution of g with the flipped, transposed kernel — im2col of the dense adt
+              gradient (ss_im2col_cl_x16) + one single-term GEMM (the fp32 mode's Winograd transform would round its 16-bit intermediates)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, stride, pad, x_packed, adt):
+        ctx.ecfg, ctx.site = _cfg(), _site()
+        NB, h, w, Cin = x_cl.shape
+        Cout, _, k, _ = weight.shape
+        ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+        M, K = NB * ho * wo, k * k * Cin
+        A = torch.empty((M, K), dtype=adt, device=x_cl.device)
+        if x_packed is not None:
+            _lib.im2col_cl_packed_x16(x_packed.contiguous(), A, NB, h, w, Cin, k, stride, pad, ho, wo)
+        else:
+            _lib.im2col_cl_x16(x_cl.to(adt).contiguous(), A, NB, h, w, Cin, k, stride, pad, ho, wo)
+        Wt = weight.detach().permute(2, 3, 1, 0).reshape(K, Cout).to(adt)            # rows (ky, kx, c): the im2col column order; rounded once
+        y = torch.mm(A, Wt).view(NB, ho, wo, Cout)
+        _note('synapse_fwd', 'im2col' + ('(packed in)' if x_packed is not None else '') + '+gemm1_x16')
+        ctx.save_for_backward(A, weight)
+        ctx.geom = (NB, h, w, Cin, Cout, k, stride, pad, ho, wo)
+        ctx.adt = adt
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        A, weight = ctx.saved_tensors
+        NB, h, w, Cin, Cout, k, stride, pad, ho, wo = ctx.geom
+        adt = ctx.adt
+        M, K = NB * ho * wo, k * k * Cin
+        g = g.to(adt).contiguous()
+        g_x = g_w = None
+        if ctx.needs_input_grad[1]:
+            S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)
+            g2 = g.view(M, Cout)
+            if S > 1:
+                gw = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g2.view(S, M // S, Cout), out_dtype=torch.float32).sum(0)
+            else:
+                gw = torch.mm(A.t(), g2, out_dtype=torch.float32)
+            g_w = gw.view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
+        how_x = 'none'
+        if ctx.needs_input_grad[0] and k == 5 and _lib.conv_s2_dgrad_supported(Cin, Cout, k, stride, pad):
+            g_x = torch.empty((NB, h, w, Cin), dtype=adt, device=g.device)
+            e0 = TIMER.start()
+            _lib.conv_s2_dgrad_x16(g, weight.detach().float().contiguous(), g_x, NB, Cin, Cout, h, w)
+            TIMER.stop(e0, 'conv_s2_dgrad', 2 * (g.numel() + g_x.numel()), g_x.numel())
+            how_x = 'conv_s2_dgrad1_mfma_x16'
+        elif ctx.needs_input_grad[0] and stride == 1 and 2 * pad == k - 1 and Cout % 8 == 0:
+            Ag = torch.empty((NB * h * w, k * k * Cout), dtype=adt, device=g.device)
+            _lib.im2col_cl_x16(g, Ag, NB, ho, wo, Cout, k, 1, pad, h, w)
+            Wd = weight.detach().flip(2, 3).permute(2, 3, 0, 1).reshape(k * k * Cout, Cin).to(adt)     # [(jy, jx, co)][ci] = W[co][ci][k-1-jy][k-1-jx]
+            g_x = torch.mm(Ag, Wd).view(NB, h, w, Cin)
+            how_x = 'im2col+gemm1_x16'
+        elif ctx.needs_input_grad[0]:
+            how_x = 'miopen'
+            x_meta = torch.empty((NB, Cin, h, w), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+            g_x = torch.ops.aten.convolution_backward(g.float().permute(0, 3, 1, 2), x_meta, weight.float().contiguous(memory_format=torch.channels_last), None,
+                                                      [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).contiguous().to(adt)
+        _note('synapse_bwd', f'g_x: {how_x}; g_w: ' + ('gemm1_x16(fp32 out)' if g_w is not None else 'none'), ctx.site)
+        return g_x, g_w, None, None, None, None
+
+
+def conv16_kind(conv, spikes_in: bool):
+    """Which own 16-bit kernel family runs `conv` (an nn.Conv2d of the encoder / bottleneck) in the 16-bit activation modes: 's1' (first layer), 's2'
+    (conv1 / conv2 implicit GEMMs), 'gemm' (im2col + single-term GEMM: conv3, conv4, the bottleneck), or None (the caller keeps MIOpen under autocast)."""
+    import torch.nn as nn
+    if not (isinstance(conv, nn.Conv2d) and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and not isinstance(conv.padding, str)):
+        return None
+    ks, st, pd = conv.kernel_size, conv.stride, conv.padding
+    if ks[0] != ks[1] or st[0] != st[1] or pd[0] != pd[1]:
+        return None
+    k, s_, p_ = ks[0], st[0], pd[0]
+    if not spikes_in:
+        return 's1' if _lib.dense_conv_s1_fwd_supported(conv.in_channels, conv.out_channels, k, s_, p_) and _lib.dense_conv_s1_wgrad_supported(conv.in_channels, conv.out_channels, k, s_, p_) else None
+    if (k, s_, p_) == (5, 2, 2) and _lib.spike_conv_fwd_supported(conv.in_channels, conv.out_channels, 5, 2, 2) and _lib.spike_conv_wgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2) \
+            and _lib.conv_s2_dgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2):
+        return 's2'
+    if conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.in_channels >= _cfg().SPIKE_CONV_MIN_CIN:
+        return 'gemm'
+    return None
+
+
+def conv_cl16(conv, x_cl: torch.Tensor, spikes_in: bool, x_packed: Optional[torch.Tensor], adt) -> Optional[torch.Tensor]:
+    """conv on an NHWC array in the 16-bit activation mode `adt` through the engine's own kernels, or None when no family applies."""
+    kind = conv16_kind(conv, spikes_in)
+    if kind is None:
+        return None
+    with torch.autocast('cuda', enabled=False):
+        if kind == 's1':
+            return _DenseConvS1CL16.apply(x_cl, conv.weight, adt)
+        if kind == 's2':
+            return _SpikeConvS2CL16.apply(x_cl, conv.weight, x_packed, adt)
+        return _SpikeConvGemmCL16.apply(x_cl, conv.weight, conv.stride[0], conv.padding[0], x_packed, adt)
+
+
 def spike_conv_applies(conv, device, dtype=torch.float32) -> bool:
     """True when `conv` (nn.Conv2d) on a spike NHWC array of `dtype` on `device` runs through _SpikeConvCL (exact bf16x3 GEMM form)."""
     import torch.nn as nn
     if not isinstance(conv, nn.Conv2d):
         return False
+    if x16_mode(device) is not None:                       # 16-bit activation modes on own kernels: the im2col + single-term GEMM family reads packed spikes
+        return conv16_kind(conv, True) == 'gemm'
     k = conv.kernel_size[0]
     return bool(_cfg().EXACT_SPLIT_GEMM and device.type == 'cuda' and dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
                 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size == (k, k)
@@ -1457,8 +1713,12 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
     lowp_bwd = amp and adt in (torch.bfloat16, torch.float16)
     # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
     act_dtype = adt if (lowp_bwd and k == 5 and _cfg().ACT16_GATHER) else None
+    own16 = x16_mode(x_cl.device)
+    if own16 is not None and k == 3 and x_packed is not None:
+        # a prediction head on packed spikes in a 16-bit mode: the packed kernels with the exact fp32 weight, fp32 P and output (the head feeds the fp32 I-pool)
+        lowp = lowp_bwd = False
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
-        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad, x_packed)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad, x_packed, own16)
 
 
 _guard_module(__name__, 'fused')

@@ -172,7 +172,8 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
             # the decoder are read packed; a layer whose next synapse is an exact-split conv (reads packed through its im2col) writes
             # no dense output at all.  dense=1, packed-only=2, off=0.
             from .. import fused as _fused
-            pk_on = _cfg().PACK_SPIKES and x_seq.dtype == torch.float32 and not torch.is_autocast_enabled('cuda') and x_seq.is_cuda
+            own16 = _fused.x16_mode(x_seq.device)          # 16-bit activation mode on the engine's own kernels (round 5): packed spikes there as well
+            pk_on = _cfg().PACK_SPIKES and x_seq.is_cuda and ((x_seq.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')) or own16 is not None)
 
             def mode(next_conv):
                 if not pk_on:
@@ -184,6 +185,8 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                     return None
                 if _fused.spike_conv_applies(conv, x_seq.device):
                     return packed
+                if own16 is not None:
+                    return packed if _fused.spike_conv_fwd_applies(conv, x_seq.device) else None
                 wg = (_cfg().SPIKE_CONV_WGRAD_MFMA and getattr(conv, 'kernel_size', None) == (5, 5) and conv.stride == (2, 2)
                       and conv.in_channels in (32, 64))
                 return packed if wg else None
@@ -227,6 +230,9 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 cur = cur.permute(0, 1, 3, 4, 2).contiguous()          # decoder runs on NHWC arrays [T, B, h, w, C]
         last_dense = {}                                                # index into `spikes` -> the last step of a packed-only stage output, unpacked
         prev_pk = None
+        from .. import fused as _fused
+        own16 = _fused.x16_mode(x_seq.device) if enc_cl else None
+        plain32 = lambda t: t.dtype == torch.float32 and not torch.is_autocast_enabled('cuda')       # noqa: E731  (the fp32 mode)
         for lvl in (4, 3, 2, 1):
             stage, head = getattr(self, f'deconv{lvl}'), getattr(self, f'predict_depth{lvl}')
             if cl:
@@ -236,15 +242,18 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 # writes no dense output at all
                 # (round 3, last: deconv2 as well — its other consumer, deconv1, reads packed spikes in its fused forward and weight-gradient kernels)
                 C_out = stage[0].up[1].out_channels
-                head_pk = bool(lvl in (1, 2) and enc_cl and _cfg().PACK_SPIKES and _cfg().PACKED_HEAD and _cfg().FORK_OUTPUTS and cur.dtype == torch.float32
-                               and not torch.is_autocast_enabled('cuda') and _fused._lib.head_packed_supported(C_out, 1, 3))
+                head_pk = bool(lvl in (1, 2) and enc_cl and _cfg().PACK_SPIKES and _cfg().PACKED_HEAD and _cfg().FORK_OUTPUTS and (plain32(cur) or own16 is not None)
+                               and _fused._lib.head_packed_supported(C_out, 1, 3))
                 if head_pk and lvl == 2:
                     nxt = self.deconv1[0]
                     hh, ww = stage[0].up[0].size[0] - 4, stage[0].up[0].size[1] - 4          # this stage's output = the next stage's input geometry
-                    head_pk = _cfg().PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
+                    if own16 is not None:       # (a stage whose run-time form cannot read packed spikes unpacks them: correct, just not free)
+                        head_pk = _cfg().PACKED_DECONV2 and _fused.stage_takes_packed_copy(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0])
+                    else:
+                        head_pk = _cfg().PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
                 # (round 4) a stage whose head needs the dense tensor still hands the next stage a packed COPY when that stage's sub-pixel forward reads one
                 copy_pk = False
-                if not head_pk and lvl > 1 and enc_cl and cur.dtype == torch.float32 and not torch.is_autocast_enabled('cuda'):
+                if not head_pk and lvl > 1 and enc_cl and (plain32(cur) or own16 is not None):
                     nxt = getattr(self, f'deconv{lvl - 1}')[0]
                     copy_pk = _fused.stage_takes_packed_copy(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0])
                 with _config.layer(f'deconv{lvl}'):

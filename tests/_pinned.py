@@ -135,13 +135,13 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-300))
 
 
-def _oracle_chunk_worker(conn, orc, x, z_by_node, float64, amp_dtype, returns_spikes, threads, own_convs=False):
+def _oracle_chunk_worker(conn, orc, x, z_by_node, float64, amp_dtype, returns_spikes, threads, own=True):
     """One chunk of samples of a large batch in its own process (oracle on CPU only; the parent holds the GPU): forward WITH the graph kept,
     depths to the parent, depth gradients back, backward, parameter gradients + flip statistics + PLIF sums to the parent."""
     torch.set_num_threads(max(1, int(threads)))
     stats, plif = {}, {}
     orc.zero_grad()
-    narrow = narrowing_points(amp_dtype, own_convs) if amp_dtype is not None else None
+    narrow = narrowing_points(amp_dtype, own) if amp_dtype is not None else None
     out, _ = run_oracle_pinned(orc, x, z_by_node, float64=float64, stats=stats, plif=plif, narrow=narrow)
     d, s = out if returns_spikes else (out, [])
     # payloads travel as numpy arrays (pickled by value): torch's shared-memory tensor passing needs the sender to outlive the receive
@@ -215,25 +215,28 @@ def launch_tags():
     return {k: v['launches'] for k, v in fused.TIMER.summary().items()}
 
 
-def narrowing_points(amp_dtype, own_convs=False):
-    """Where the product's 16-bit activation modes store 16-bit values / use 16-bit weights (module name -> (weight dtype, output dtype)):
-      encoder + bottleneck convs: output in the autocast dtype; weight = rounded to the autocast dtype on the default MIOpen-under-autocast path, the fp32 master copy on
-        the engine's own kernels (own_convs=True: EngineConfig.X16_OWN_CONVS, round 4);
-      decoder stages (NNConvUpsampling k = 5, stereospike_amd/fused.py::_UpConvProjectedCL): output in the autocast dtype; weight rounded to
-        bf16 in the bf16 mode (autocast's own semantics), the EXACT fp32 weight in the fp16 mode (exact bf16x3 split);
-      prediction heads (k = 3): fp32 output (they feed the fp32 I-pool); weight as the decoder stages."""
+def narrowing_points(amp_dtype, own=True):
+    """Where the product's 16-bit activation modes store 16-bit values / use 16-bit weights (module name -> (weight dtype, output dtype)).
+    own=True — the shipped path since round 5 (EngineConfig.X16_OWN_KERNELS: every synapse on the engine's own single-term kernels, ABI 9):
+      encoder + bottleneck convs, decoder stages deconv1 .. deconv3 (sub-pixel forward): weight rounded ONCE to the mode's dtype inside the kernel's weight
+        preparation, output stored in the mode's dtype;
+      deconv4 (projection GEMM + gather, stereospike_amd/fused.py::_UpConvProjectedCL): output in the mode's dtype; weight rounded to bf16 in the bf16 mode,
+        the EXACT fp32 weight in the fp16 mode (exact bf16x3 split);
+      prediction heads (k = 3, fp32 output — they feed the fp32 I-pool): heads 1 / 2 read packed spikes with the exact fp32 weight; heads 3 / 4 as deconv4.
+    own=False — the round-2 .. 4 path (X16_OWN_KERNELS off: encoder / bottleneck synapses = MIOpen convolutions under autocast): encoder + bottleneck
+      weight and output in the autocast dtype; every decoder stage and head as deconv4 / heads 3, 4 above."""
     def policy(name):
         dec_w = torch.bfloat16 if amp_dtype == torch.bfloat16 else None
         if name.startswith('predict_depth'):
-            return dec_w, None
+            return (None if (own and name[13] in '12') else dec_w), None
         if name.startswith('deconv'):
-            return dec_w, amp_dtype
-        return (None if own_convs else amp_dtype), amp_dtype       # (round 4: the fp32 mode's kernels — exact fp32 weights — with a narrowed output)
+            return (amp_dtype if (own and name[6] in '123') else dec_w), amp_dtype
+        return amp_dtype, amp_dtype
     return policy
 
 
 def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=None, float64=True, oracle_chunk=None, loss_scale=1.0,
-                  oracle_procs=False, penalize_spikes=False, beta=1.0, x16_own_convs=False):
+                  oracle_procs=False, penalize_spikes=False, beta=1.0, x16_own=True):
     """Free product run (forward + Total_Loss + backward) vs the trajectory-pinned oracle.  Returns a report dict.
     amp_dtype: the product runs under torch.autocast with 16-bit activations (fp32 membranes); the oracle narrows at the same points
     (narrowing_points).  loss_scale: the product's loss is multiplied by it before backward and its gradients divided afterwards (fp16
@@ -279,7 +282,7 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
     orc.zero_grad()
     plif, stats = {}, {}
     B = x.shape[0]
-    narrow = narrowing_points(amp_dtype, x16_own_convs) if amp_dtype is not None else None
+    narrow = narrowing_points(amp_dtype, x16_own) if amp_dtype is not None else None
     if oracle_chunk is None or oracle_chunk >= B:
         res_o, _ = run_oracle_pinned(orc, x, z_by_node, float64=float64, stats=stats, plif=plif, narrow=narrow)
         d_o, s_o = res_o if returns_spikes else (res_o, [])

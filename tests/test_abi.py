@@ -51,7 +51,10 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_wgrad_reduce3_f32', 'ss_spike_conv_fwd_wide_supported',
                                   'ss_upconv_sub_geometry', 'ss_upconv_sub_tall_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32',
                                   # ABI 9
-                                  'ss_upconv_box_tiles_supported'])
+                                  'ss_upconv_box_tiles_supported', 'ss_neuron_bwd_fork_lr_x16_supported', 'ss_neuron_bwd_fork_lr_x16', 'ss_dense_conv_s1_fwd_x16',
+                                  'ss_dense_conv_s1_wgrad_x16', 'ss_spike_conv_fwd_x16', 'ss_spike_conv_wgrad_x16', 'ss_conv_s2_dgrad_x16', 'ss_im2col_cl_packed_x16',
+                                  'ss_im2col_cl_x16', 'ss_upconv_sub_prep_x16', 'ss_upconv_sub_fwd_x16', 'ss_upconv_box_planes_x16', 'ss_upconv_boxsum_x16',
+                                  'ss_upconv_box_dgrad_x16', 'ss_upconv_box_wgrad_x16'])
 
 
 def test_library_loads_and_exports_every_declared_symbol():
