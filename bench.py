@@ -79,7 +79,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--cpu-b16', type=int, default=1,
                     help='1 (default): also time ONE iteration of the CPU port at the bench batch size (SURVEY.md §8(d): B = 16; ~110 s on the GPU box host, '
-                         'measured 0.145 frames/s in profiles/r02/) as `cpu_baseline_B16`; 2: with evaluation pass, warm-up and >= 1 timed iteration (~6 min); 0: skip')
+                         'measured 0.145 frames/s in profiles/r02/) as `cpu_baseline_B16_n1`; 2: as `cpu_baseline_B16` with evaluation pass, warm-up and >= 1 timed iteration (~6 min); 0: skip')
     ap.add_argument('--leg-steps', type=int, default=5,
                     help='steps of the SECOND pass that times every fused launch with HIP events (roofline legs); the headline pass runs with the timer off')
     ap.add_argument('--miopen-find', type=int, default=1,
@@ -335,8 +335,7 @@ def main():
             avg_us = 1e3 * d['ms'] / max(1, d['launches'])
             return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                        traffic_source='profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_target.py, '
-                                       'committed; not measured in this run)' if traffic else None,
+                        traffic_source=_pmc_source() if traffic else None,
                         launches=d['launches'], avg_launch_us=round(avg_us, 2),
                         bytes_per_launch=int(d['bytes'] / max(1, d['launches'])),
                         # counter-measured HBM bytes (incl. the O(N) v_last write the per-update figure leaves out) over the same time
@@ -448,7 +447,8 @@ def main():
                 out['eval_last_step_spikes_differing_vs_cpu'] = int(sum(int((a_ != b_).sum()) for a_, b_ in zip(s0, _EVAL_REF['spikes'])))
                 out['eval_last_step_spikes_compared'] = int(sum(a_.numel() for a_ in s0))
             if a.cpu_b16:                                 # the CPU port at the bench's own batch size as well
-                out['cpu_baseline_B16'] = cpu_baseline(a.model, a.T, 120.0, B=a.batch, min_iters=1, quick=a.cpu_b16 == 1)
+                # (key says what it is: ONE un-warmed iteration with --cpu-b16 1 — VERDICT r04 weak #11; --cpu-b16 2 = warm-up + median)
+                out['cpu_baseline_B16_n1' if a.cpu_b16 == 1 else 'cpu_baseline_B16'] = cpu_baseline(a.model, a.T, 120.0, B=a.batch, min_iters=1, quick=a.cpu_b16 == 1)
             # eval MDE "at matching Mean Depth Error".  `eval_mde_rel_diff_vs_cpu` keeps its round-1/2 meaning — against the eager fp32 port of the reference
             # (the reference's own fp32 arithmetic on this host) — and the float64-convolution oracle, the yard-stick that does not depend on a
             # backend's fp32 summation order (see cpu_baseline), has its own key
@@ -567,6 +567,21 @@ def us_of(d):
 
 def box_on(cfg, cin):
     return bool(cfg.BOX_BWD) and cin in cfg.BOX_BWD_CIN
+
+
+def _pmc_source():
+    """Where `traffic` comes from and whether it belongs to the kernels this process runs: profiles/pmc_traffic.json records the source hash compiled into the
+    library the counter passes loaded; it is compared with the library loaded HERE (VERDICT r04 #6)."""
+    from stereospike_amd import _lib
+    src = {}
+    try:
+        src = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('source', {})
+    except Exception:
+        pass
+    here = _lib.source_hash()
+    return dict(file='profiles/pmc_traffic.json', how='separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_target.py, committed; not measured in this run',
+                measured_on_lib_source_hash=src.get('lib_source_hash'), measured_at_git_head=src.get('git_head'), loaded_lib_source_hash=here,
+                tree_source_hash=_lib.tree_source_hash(), matches_loaded_library=(src.get('lib_source_hash') == here) if src.get('lib_source_hash') else None)
 
 
 def _pmc_traffic(which='neuron_fwd'):

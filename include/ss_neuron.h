@@ -51,6 +51,8 @@ extern "C" {
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
 #define SS_ABI_VERSION 9
 int ss_abi_version(void);
+/* first 16 hex digits of the sha256 over the sources the loaded library was built from (ABI 9; profiles/ evidence records it, bench.py checks it) */
+const char* ss_source_hash(void);
 
 /* Number of floats the caller must provide as `g_k_ws` (8-byte aligned) to the ss_neuron_bwd_* entry points when g_k != NULL.
  * ABI 5: the workspace holds the per-workgroup partials of the PLIF dL/dk sum as DOUBLES — that scalar is one heavily cancelling sum over

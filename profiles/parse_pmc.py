@@ -114,4 +114,16 @@ for k in ('upconv_sub', 'upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad',
                   'hbm_bytes_per_launch': int(hbm), 'ratio_to_algorithmic': round(hbm / alg[k], 4)}
 if 'neuron_fwd' in res:
     res['neuron_fwd_train_bytes_per_launch'] = res['neuron_fwd']['hbm_bytes_per_launch']
+# which kernels produced these counters: the source hash compiled into the library the target loaded (csrc/Makefile: sha256 over the .hip
+# units + headers), per-file hashes of the tree, and the commit the measurement script was launched from (SS_GIT_HEAD: the GPU box holds no .git)
+try:
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stereospike_amd import _lib
+    csrc = os.path.join(os.path.dirname(_lib.__file__), 'csrc')
+    res['source'] = {'lib_source_hash': _lib.source_hash(), 'tree_source_hash': _lib.tree_source_hash(), 'git_head': os.environ.get('SS_GIT_HEAD', 'unknown'),
+                     'csrc_sha256_16': {f: hashlib.sha256(open(os.path.join(csrc, f), 'rb').read()).hexdigest()[:16]
+                                        for f in sorted(os.listdir(csrc)) if f.endswith(('.hip', '.hpp'))}}
+except Exception as e:                                                    # noqa: BLE001 — the counters are still worth having
+    res['source'] = {'error': repr(e)}
 print(json.dumps(res, indent=1))

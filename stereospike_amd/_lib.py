@@ -42,6 +42,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_longlong, C.c_float
     L.ss_abi_version.restype = i32
+    L.ss_source_hash.restype = C.c_char_p
     L.ss_neuron_gk_ws_floats.restype = i64
     L.ss_neuron_fwd_f32.argtypes = [p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, p]
     L.ss_neuron_bwd_f32.argtypes = [p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, p]
@@ -283,6 +284,23 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_neuron_bwd_fork_lr_x16_supported', 'ss_neuron_bwd_fork_lr_x16', 'ss_dense_conv_s1_fwd_x16', 'ss_dense_conv_s1_wgrad_x16', 'ss_spike_conv_fwd_x16',
            'ss_spike_conv_wgrad_x16', 'ss_conv_s2_dgrad_x16', 'ss_im2col_cl_packed_x16', 'ss_im2col_cl_x16', 'ss_upconv_sub_prep_x16', 'ss_upconv_sub_fwd_x16',
            'ss_upconv_box_planes_x16', 'ss_upconv_boxsum_x16', 'ss_upconv_box_dgrad_x16', 'ss_upconv_box_wgrad_x16')
+
+
+def source_hash() -> str:
+    """The source hash compiled into the loaded library (csrc/Makefile: sha256 over the .hip units, ss_common.hpp and include/ss_neuron.h, 16 hex digits)."""
+    return lib().ss_source_hash().decode()
+
+
+def tree_source_hash() -> str:
+    """The same hash computed from the sources in THIS tree (what `make` would compile in): differs from source_hash() when the library is stale."""
+    import hashlib
+    import re
+    csrc = os.path.join(_PKG, 'csrc')
+    units = re.search(r'^UNITS\s*:=\s*(.*)$', open(os.path.join(csrc, 'Makefile')).read(), re.M).group(1).split()
+    hsh = hashlib.sha256()
+    for f in [os.path.join(csrc, u + '.hip') for u in units] + [os.path.join(csrc, 'ss_common.hpp'), os.path.join(os.path.dirname(_PKG), 'include', 'ss_neuron.h')]:
+        hsh.update(open(f, 'rb').read())
+    return hsh.hexdigest()[:16]
 
 
 def _ptr(t, name, numel=None):

@@ -341,4 +341,11 @@ int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, con
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
+/* sha256 (first 16 hex digits) of the sources this library was built from — every ss_*.hip in the Makefile's unit order, ss_common.hpp, include/ss_neuron.h —
+   computed by the Makefile and compiled in: the measurement files under profiles/ record it, bench.py compares it with the library it has loaded */
+#ifndef SS_SRC_HASH
+#define SS_SRC_HASH "unknown"
+#endif
+const char* ss_source_hash(void) { return SS_SRC_HASH; }
+
 }  // extern "C"
