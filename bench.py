@@ -93,12 +93,8 @@ def parse():
     ap.add_argument('--encoder-nhwc', type=int, default=1, help='1: encoder/bottleneck activations in NHWC as well')
     ap.add_argument('--recompute-h', type=int, default=1,
                     help='1 (default): neuron backward recomputes h from the layer input (forward writes 8 B/update); 0: forward saves h_seq')
-    ap.add_argument('--wgrad-split-rows', type=int, default=None, help='decoder weight-gradient split-K rows per slice (default fused.WGRAD_SPLIT_ROWS)')
     ap.add_argument('--exact-split', type=int, default=1,
                     help='1 (default): decoder forward projections of spike inputs as exact bf16x3 GEMMs on the bf16 MFMA path; 0: plain fp32 GEMM')
-    ap.add_argument('--split-wgrad-min-k', type=int, default=None, help='fused.EXACT_SPLIT_WGRAD_MIN_K override (experiments)')
-    ap.add_argument('--spike-wgrad-split', type=int, default=None, help='fused.SPIKE_CONV_WGRAD_SPLIT override (experiments)')
-    ap.add_argument('--spike-conv-min-cin', type=int, default=None, help='fused.SPIKE_CONV_MIN_CIN override (experiments)')
     ap.add_argument('--gemm-tuning', type=int, default=1,
                     help='1 (default): load the tracked TunableOp record (GEMM algorithm per shape) read-only; 2: tune unseen shapes and '
                          'write gpurun_out/tunableop_results.csv; 0: library defaults')
@@ -108,8 +104,9 @@ def parse():
     ap.add_argument('--fork-outputs', type=int, default=1, help='1 (default): two-consumer spike tensors as forked handles, gradients summed in the neuron backward kernel')
     ap.add_argument('--count-rates', type=int, default=0,
                     help='1: firing-rate counters of all 14 layers inside the training step (BASELINE.json config 5), from the fused kernels')
-    ap.add_argument('--fused-form', type=int, default=2, choices=[1, 2], help='kernel form of the fused up-conv: 2 (default) wavefront-specialised persistent workgroups, 1 the first form (A/B)')
-    ap.add_argument('--fused-mfma', type=int, default=1, help='1 (default): deconv1 / deconv2 forward as ONE hand-written MFMA kernel (projection + gather, P only in LDS); 0: GEMM + gather kernel')
+    ap.add_argument('--sub-fwd', type=int, default=1, help='1 (default): decoder stages forward as the sub-pixel (merged tap) implicit GEMM (ss_upconv_sub.hip); 0: projection GEMM + gather kernel (A/B)')
+    ap.add_argument('--x16-own', type=int, default=1, help='1 (default): the 16-bit activation modes (--dtype bf16 / f16) on the engine\'s own single-term kernels; 0: the round-2 .. 4 path '
+                                                            '(encoder / bottleneck synapses = MIOpen convolutions under autocast) (A/B)')
     ap.add_argument('--pack-spikes', type=int, default=1, help='1 (default): 2-bit packed spike tensors on the edges whose consumers read them')
     ap.add_argument('--box-bwd', type=int, default=1, help='1 (default): decoder backward on the box-sum image (ss_upconv_box.hip); 0: the g_P forms of rounds 2 - 3 (A/B)')
     ap.add_argument('--fuse-upconv', type=int, default=1,
@@ -231,16 +228,8 @@ def main():
     # switches applied — handed to the network, which owns it; nothing global is mutated
     from stereospike_amd.config import EngineConfig
     ov = dict(FUSE_UPCONV=bool(a.fuse_upconv), FORK_OUTPUTS=bool(a.fork_outputs), RECOMPUTE_H=bool(a.recompute_h), EXACT_SPLIT_GEMM=bool(a.exact_split),
-              FUSED_UPCONV_MFMA=bool(a.fused_mfma), FUSED_UPCONV_FORM=int(a.fused_form), PACK_SPIKES=bool(a.pack_spikes),
+              SUB_FWD=bool(a.sub_fwd), PACK_SPIKES=bool(a.pack_spikes), X16_OWN_KERNELS=bool(a.x16_own),
               DECODER_CHANNELS_LAST=bool(a.decoder_nhwc), ENCODER_CHANNELS_LAST=bool(a.encoder_nhwc), BOX_BWD=bool(a.box_bwd))
-    if a.split_wgrad_min_k is not None:
-        ov['EXACT_SPLIT_WGRAD_MIN_K'] = a.split_wgrad_min_k
-    if a.spike_wgrad_split is not None:
-        ov['SPIKE_CONV_WGRAD_SPLIT'] = a.spike_wgrad_split
-    if a.spike_conv_min_cin is not None:
-        ov['SPIKE_CONV_MIN_CIN'] = a.spike_conv_min_cin
-    if a.wgrad_split_rows:
-        ov['WGRAD_SPLIT_ROWS'] = a.wgrad_split_rows
     engine_cfg = EngineConfig.default().replace(**ov)
     net = build_net(a.model, dev, engine_cfg)
     if a.channels_last:
@@ -474,7 +463,7 @@ def main():
 
 
 def _roof_upconv(shapes, a, cfg):
-    """The hand-written MFMA kernel of the decoder (ss_upconv_fused_fwd_f32: projection + gather of deconv1, the largest stage) on the
+    """The hand-written MFMA kernel of the decoder forward (ss_upconv_sub_fwd_f32 at deconv1, the largest stage) on the
     HBM roofline by its algorithmic bytes (input spikes + output + weights; P never leaves LDS) and on the bf16 MFMA roofline by the
     useful FLOPs of the minimal projection (3 exact bf16 terms); HIP-event time of its launches in the timed region (incl. the tiny
     weight-preparation launch)."""
@@ -493,7 +482,7 @@ def _roof_upconv(shapes, a, cfg):
     nbytes = 4 * (src_px * cin + out_elems) + 2 * 3 * 25 * cin * cout
     flops = 2.0 * src_px * cin * 25 * cout * 3
     us = 1e3 * d['ms'] / d['launches']
-    if cfg.SUB_FWD and cin in cfg.SUB_FWD_CIN:
+    if cfg.SUB_FWD and a.dtype == 'f32':
         # round 4: the sub-pixel (merged tap) implicit GEMM on the packed input — 9 instead of 6.25 multiply-adds per output element and input channel
         # (1.44 x the projection's minimum), no P, no gather, no halo
         nbytes = src_px * cin // 4 + 4 * out_elems + 2 * 25 * 27 * 512 * (cin // 16) * (cout // 32)
@@ -507,18 +496,7 @@ def _roof_upconv(shapes, a, cfg):
                               note='frac: useful FLOPs of the minimal projection x 3 exact bf16 terms; issued_frac: what the kernel issues (9 merged taps per output pixel)'),
                     note='latency / issue bound at 3 workgroups per CU (profiles/r04/sub_fwd_ablations.log); replaces upconv_fused2_fwd_kernel (1.9 x halo MFMAs, gather wavefronts)',
                     fused=True)
-    form2 = cfg.FUSED_UPCONV_FORM == 2
-    return dict(kernel=('upconv_fused2_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only; wavefront-specialised '
-                        'persistent form)') if form2 else
-                       'upconv_fused_fwd_kernel<64, 32> (deconv1 forward: projection + gather in one MFMA kernel, P in LDS only)',
-                bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-                avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=_pmc_traffic('upconv_fused2' if form2 else 'upconv_fused'),
-                mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
-                          note='useful FLOPs of the minimal projection x 3 exact bf16 terms; the kernel issues ~1.9x that (source-window halo)'),
-                note=('issue bound: the MFMAs of the 4 producer wavefronts and the LDS / VALU instructions of the 4 gathering wavefronts share each '
-                      "SIMD's issue slots (per-step trace in DESIGN.md 3.5); replaces GEMM + P round trip (11.5 GB) + gather") if form2 else
-                     'LDS / latency bound at one 4-wave workgroup per CU (100 KiB P tile); replaces GEMM + P round trip (11.5 GB) + gather',
-                fused=bool(a.fused_mfma))
+    return None            # projection GEMM + gather (--sub-fwd 0): a library GEMM and an HBM-bound gather, no single kernel to price
 
 
 def _roof_upconv_bwd(shapes, a, cfg):
@@ -540,17 +518,15 @@ def _roof_upconv_bwd(shapes, a, cfg):
     macs = src_px * cin * 25 * cout
     flops = 2.0 * macs * (6 + 3)
     us = 1e3 * d['ms'] / d['launches']
-    box = bool(cfg.BOX_BWD) and cin in cfg.BOX_BWD_CIN
-    on_chip = bool(cfg.FUSED_UPCONV_DGRAD) and cin in cfg.FUSED_UPCONV_DGRAD_CIN
+    if a.dtype != 'f32':
+        return None                                    # (the byte / term counts below are the fp32 mode's)
+    box = bool(cfg.BOX_BWD)
     # counter-measured HBM bytes of the group (profiles/pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes on tools/pmc_target.py)
-    parts = [_pmc_traffic(kk) for kk in (('upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad') if box_on(cfg, cin) else
-                                         ('upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp') if on_chip else ())]
+    parts = [_pmc_traffic(kk) for kk in (('upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad') if box else ())]
     traffic = int(sum(parts)) if parts and all(p is not None for p in parts) else None
     return dict(kernel=('upconv_boxsum_kernel + upconv_box_dgrad_kernel<32> + upconv_box_wgrad_kernel<2> (deconv1 backward on the box-sum image: one HBM-bound '
                         'box-sum launch, then both contractions as implicit GEMMs over its three bf16 planes; no g_P)') if box else
-                       ('upconv_bwd_dgrad_kernel<32> + upconv_bwd_fused_kernel<64, 32> (deconv1 backward: adjoint gather + data gradient, adjoint gather + '
-                        'weight gradient; g_P on chip only)') if on_chip else
-                       'upconv_bwd_fused_kernel<64, 32> + fp32 GEMM (deconv1 backward: adjoint + weight gradient fused, g_P written once, read by the data-gradient GEMM)',
+                       'upconv_cl_bwd_kernel + fp32 GEMM + spike_wgrad_kernel (deconv1 backward on the per-tap tensor g_P in HBM: --box-bwd 0)',
                 bound='hbm', achieved=round(nbytes / us / 1e3, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
                 avg_launch_us=round(us, 1), bytes_per_launch=int(nbytes), traffic=traffic,
                 traffic_note=('sum of the three launches; the three bf16 planes of the box-sum image (1.55 GB at deconv1) are written once and read by both '
@@ -558,15 +534,11 @@ def _roof_upconv_bwd(shapes, a, cfg):
                               'neither is HBM-bound, the contractions sit on the LDS / MFMA issue limits (profiles/r04/box_dgrad_ablations.log)') if box else None,
                 mfma=dict(achieved_TFLOPs=round(flops / us / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us / 1e6 / 2500.0, 4),
                           note='6 bf16 cross terms per MAC (dense x dense data gradient) + 3 exact terms per MAC (spike x dense weight gradient)'),
-                g_P_in_hbm=not (on_chip or box))
+                g_P_in_hbm=not box)
 
 
 def us_of(d):
     return 1e3 * d['ms'] / d['launches']
-
-
-def box_on(cfg, cin):
-    return bool(cfg.BOX_BWD) and cin in cfg.BOX_BWD_CIN
 
 
 def _pmc_source():

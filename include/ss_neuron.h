@@ -249,47 +249,9 @@ int ss_unpack_spikes(const unsigned int* packed, void* out, long long n, int out
 int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB, int h, int w, int C, int k, int stride, int pad,
                              int ho, int wo, void* stream);
 
-/*
- * FUSED projection + gather of NNConvUpsampling (forward) on the bf16 matrix cores — the hand-written MFMA kernel of the decoder
- * stages (/root/reference/network/blocks.py:110-132; SNN_models.py:110-129).  Same map as a projection GEMM followed by
- * ss_upconv_cl_fwd_f32, but the per-tap projection tensor P (25 * C_out floats per SOURCE pixel) lives only in LDS: a workgroup owns a
- * 16 x 16 tile of output pixels, builds P for the tile's source window (<= 128 low-resolution pixels) with v_mfma_f32_32x32x16_bf16 —
- * x is a spike tensor (values 0..3, exact in bf16; fp32 NHWC array `x` or the 2-bit packed form `x_packed`), the fp32 weight is split
- * exactly into three bf16 terms, fp32 accumulation — and gathers the 25 taps from LDS.  Value: fp32-GEMM accuracy (exact products,
- * fp32 accumulation order: channels within a split, splits hi/mid/lo, then taps in (ky, kx) order).
- *   ss_upconv_fused_supported(C_in, C_out, k): the compiled stage shapes ((64, 32) and (128, 64), k = 5 — deconv1 / deconv2).
- *   ss_upconv_fused_prep_w: W [C_out][C_in][5][5] fp32 -> Wf, the 3-way-split weights in MFMA B-fragment order
- *                           (ss_upconv_fused_wf_elems(C_in, C_out) bf16 elements; redo after every weight update).
- *   ss_upconv_fused_fwd_f32: out [NB][H][W][C_out] fp32.  max_window = the largest (source rows x source columns) window any 16 x 16 tile
- *                           needs, computed by the caller from the tables; SS_EINVAL if it exceeds 128 (use the unfused form then).
- */
-int ss_upconv_fused_supported(int Cin, int Cout, int k);
-long long ss_upconv_fused_wf_elems(int Cin, int Cout);
-int ss_upconv_fused_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream);
-int ss_upconv_fused_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
-                            long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
-
-/*
- * The same map (blocks.py:110-132) and the SAME VALUE bit for bit, second kernel form (ABI 3): persistent workgroups of 8 wavefronts,
- * four of which run the MFMAs while the other four gather the previous pass of P from a double-buffered LDS pass buffer; the source
- * window goes once, coalesced, from HBM to LDS as bf16; P is produced in passes of four 32-column tiles (column = tap * C_out + co:
- * no padding columns); the output pixel's 25-tap sum stays in registers and is written once; workgroups walk XCD-contiguous bands of
- * tiles.  Own weight layout: ss_upconv_fused2_prep_w -> ss_upconv_fused2_wf_elems(C_in, C_out) = 75 * C_in * C_out bf16 elements.
- * ss_upconv_fused2_supported(C_in, C_out, k, max_window): the compiled stage shapes with max_window <= 122 source pixels per tile
- * (the first form covers 123..128).
- */
-int ss_upconv_fused2_supported(int Cin, int Cout, int k, int max_window);
-long long ss_upconv_fused2_wf_elems(int Cin, int Cout);
-int ss_upconv_fused2_prep_w(const float* W, void* Wf, int Cin, int Cout, void* stream);
-int ss_upconv_fused2_fwd_f32(const float* x, const unsigned int* x_packed, const void* Wf, const int* src_y, const int* src_x, float* out,
-                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
-/* The same kernel for 16-bit activation modes (BASELINE.json configs 2 / 5; decoder stages under torch.autocast): x and out are fp16 / bf16
- * arrays (dtype = SS_DT_F16 / SS_DT_BF16; spikes are exact in both), the sums are fp32 and narrowed (nearest even) on store.
- * nsplit = 3: exact fp32 weights (compiled for fp16: the forward of the fp16 mode stays exact); nsplit = 1: weights rounded once to bf16, what
- * bf16 autocast does to every synapse (compiled for bf16).  ss_upconv_fused2_prep_w_x16 writes nsplit terms (same buffer size as _prep_w). */
-int ss_upconv_fused2_prep_w_x16(const float* W, void* Wf, int Cin, int Cout, int nsplit, void* stream);
-int ss_upconv_fused2_fwd_x16(const void* x, int dtype, const void* Wf, int nsplit, const int* src_y, const int* src_x, void* out,
-                             long long NB, int Cin, int Cout, int h, int w, int H, int W, int max_window, void* stream);
+/* (ABI 9: the fused projection + gather kernels of rounds 2 - 3 — ss_upconv_fused_*, ss_upconv_fused2_* — and the fused adjoint kernels ss_upconv_bwd_fused_f32 /
+ * ss_upconv_bwd_dgrad_f32 are GONE: the sub-pixel forward (ss_upconv_sub_*) and the box-sum backward (ss_upconv_box_*) replaced them on every stage they ran on;
+ * geometries those do not take run the projection GEMM + ss_upconv_cl_* gather forms.) */
 
 /*
  * Weight gradient of a synapse on spike inputs as an exact bf16x3 MFMA contraction over the rows (ABI 3) — the decoder's
@@ -305,45 +267,9 @@ long long ss_spike_wgrad_ws_floats(int Cin, int N, long long R);
 int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, long long R, int Cin, int N, int accumulate, void* stream);
 
 /*
- * Decoder backward, fused (ABI 3): the adjoint gather of ss_upconv_cl_bwd_f32 (same g_P, same summation order) AND the exact bf16x3 MFMA
- * weight gradient of ss_spike_wgrad_f32 in one pass — a lane computes g_P for 8 consecutive source pixels of one column, which IS the MFMA
- * fragment of the contraction over sources; g_P is written once (for the data-gradient GEMM) and never read back for g_w.
- *   g_out [NB][H][W][C_out] fp32 (gradient of the stage output), x [NB][h][w][C_in] fp32 spike counts, tables as for ss_upconv_cl_bwd_f32,
- *   g_P [NB*h*w][25*C_out] (tap-major columns; NULLABLE since ABI 5: not written), g_w [C_in][25*C_out] (+= when accumulate), ws: ss_upconv_bwd_fused_ws_floats floats.
- * ss_upconv_bwd_fused_supported: compiled stage shapes ((64,32), (128,64), k = 5) whose tables fit the on-chip window: max_rows4 / max_rows2 =
- * largest output-row span incl. the 4 extra tap rows of 4 / 2 consecutive source rows, max_cols16 = the same for 16 consecutive source columns,
- * max_span = most rows / columns a source pixel collects per tap (<= 3) — the caller derives them from the tables.
- */
-int ss_upconv_bwd_fused_supported(int Cin, int Cout, int k, int max_rows4, int max_rows2, int max_cols16, int max_span);
-long long ss_upconv_bwd_fused_ws_floats(int Cin, int Cout, long long NB, int h, int w);
-int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const unsigned int* x_packed /* ABI 6: the stage input as 2-bit packed spikes (x may then be NULL) */,
-                            const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
-                            float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
-                            int accumulate, void* stream);
-
-/*
- * ABI 5 — decoder DATA gradient with g_P on chip only (ss_upconv_bwd.hip).  Replaces, for one decoder stage, the pair
- * ss_upconv_cl_bwd_f32 (g_P -> HBM) + fp32 GEMM / ss_gemm6_f32 (g_P <- HBM) of the autograd backward of NNConvUpsampling w.r.t. its input
- * (/root/reference/network/blocks.py:110-132; call sites SNN_models.py:110-129):
- *   g_x[nb][sy][sx][ci] = sum_{ky,kx,co} ( sum over the output pixels (y, x) with src_y[y+ky] == sy, src_x[x+kx] == sx of g_out[nb][y][x][co] )
- *                                        * weight[co][ci][ky][kx]
- * g_out [NB][H][W][C_out], g_x [NB][h][w][C_in] NHWC fp32; weight [C_out][C_in][5][5] (the Conv2d parameter as it is); ws:
- * ss_upconv_bwd_dgrad_ws_floats(C_in, C_out) floats.  The inner sums are formed in LDS / registers in ss_upconv_cl_bwd_f32's order (bit-identical
- * g_P), the contraction runs on the bf16 matrix cores with the six cross terms of ss_gemm6_f32: |g_x - float64| <= 2^-21 sum |g_P| |W|.
- * With g_P == NULL in ss_upconv_bwd_fused_f32 (weight gradient) the per-tap gradient tensor of a stage reaches HBM nowhere.
- * ss_upconv_bwd_dgrad_supported: k = 5, C_in % 64 == 0, C_out in {32, 64, 128, 256}, tables that fit the on-chip window: max_rows4 <= 13,
- * max_cols32 <= 72 (largest output-row / -column span incl. the 4 tap rows / columns of 4 consecutive source rows / 32 consecutive source
- * columns), 1 <= max_span <= 3.
- */
-int ss_upconv_bwd_dgrad_supported(int Cin, int Cout, int k, int max_rows4, int max_cols32, int max_span);
-long long ss_upconv_bwd_dgrad_ws_floats(int Cin, int Cout);
-int ss_upconv_bwd_dgrad_f32(const float* g_out, const float* weight, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
-                            float* g_x, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W, void* stream);
-
-/*
  * ABI 7 — the decoder's backward on the BOX-SUM image (ss_upconv_box.hip; round 4).  Replaces, for one decoder stage, the whole autograd backward of
  * NNConvUpsampling (/root/reference/network/blocks.py:110-132; call sites SNN_models.py:110-129) — the adjoint gather ss_upconv_cl_bwd_f32 and both
- * contractions on its per-tap tensor g_P (ss_gemm6_f32 / ss_spike_wgrad_f32, or the fused round-3 forms ss_upconv_bwd_dgrad_f32 / ss_upconv_bwd_fused_f32):
+ * contractions on its per-tap tensor g_P (ss_gemm6_f32 / ss_spike_wgrad_f32):
  *
  *   ss_upconv_boxsum_f32    B[nb][j][i][co] = sum_{Y in VR[j]} ( sum_{X in HR[i]} g_out[nb][Y][X][co] ), rows top to bottom, columns left to right, every
  *                           sum started from +0 (ss_upconv_cl_bwd_f32's order: g_P[nb][iy][ix][ky,kx][co] == B[nb][vmap[iy][ky]][hmap[ix][kx]][co] bit for bit),
@@ -633,7 +559,7 @@ int ss_loss_grad_f32(const float* pred, const float* gt, const double* sums, con
  *   ss_upconv_sub_fwd_f32  : x fp32 NHWC [NB][h][w][C_in] spike counts exact in bf16 (or x_packed: the 2-bit packed tensor; x may then be NULL) ->
  *                            out fp32 NHWC [NB][H][W][C_out], every element written.  C_in % 16 == 0, C_out % 32 == 0, NB h w C_in < 2^32.
  * Accuracy: exact products; |out - float64| <= 2^-21 sum |x||W| element-wise (fp32 rounding of the <= 9-term weight sums + fp32 accumulation over
- * 9 C_in products).  Deterministic; not bit-identical to ss_upconv_fused_fwd (different association of the same sum).
+ * 9 C_in products).  Deterministic; not bit-identical to the projected form (different association of the same sum).
  */
 int ss_upconv_sub_geometry(int* block_rows, int* block_cols, int* window_rows, int* window_cols, int* vrec_ints, int* hrec_ints);
 int ss_upconv_sub_tall_geometry(int* block_rows, int* window_rows, int* trec_ints, int* narrow_cols);   /* returns the window's capacity in pixels */
@@ -665,7 +591,7 @@ int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const vo
  *   ss_conv_s2_dgrad_x16            encoder data gradients: g, g_x in `dtype`
  *   ss_im2col_cl_packed_x16         ss_im2col_cl_bf16_packed with the patch matrix in `dtype`;  ss_im2col_cl_x16: patch matrix of a DENSE 16-bit array
  *   ss_upconv_sub_{prep,fwd}_x16    decoder stage forward: taps rounded once to `dtype`, their merged sums carried as TWO `dtype` terms (16 / 22 bits)
- *   ss_upconv_box{sum,_dgrad,_wgrad}_x16  decoder stage backward on the box-sum image: ss_upconv_box_planes_x16(dtype) planes of `dtype` (bf16: hi + lo, fp16: one)
+ *   ss_upconv_box{sum,_dgrad,_wgrad}_x16  decoder stage backward on the box-sum image: ss_upconv_box_planes_x16(dtype) planes of `dtype` (one: the box sum rounded once, as the g_P path rounds g_P)
  */
 int ss_neuron_bwd_fork_lr_x16_supported(int T, long long N, int C, int lr_rank);
 int ss_neuron_bwd_fork_lr_x16(const void* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, void* g_sum_seq,

@@ -97,32 +97,6 @@ def lib():
     L.ss_unpack_spikes.restype = i32
     L.ss_im2col_cl_bf16_packed.argtypes = [p, p, i64, i32, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_im2col_cl_bf16_packed.restype = i32
-    L.ss_upconv_fused_supported.argtypes = [i32, i32, i32]
-    L.ss_upconv_fused_supported.restype = i32
-    L.ss_upconv_fused_wf_elems.argtypes = [i32, i32]
-    L.ss_upconv_fused_wf_elems.restype = i64
-    L.ss_upconv_fused_prep_w.argtypes = [p, p, i32, i32, p]
-    L.ss_upconv_fused_prep_w.restype = i32
-    L.ss_upconv_fused_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
-    L.ss_upconv_fused_fwd_f32.restype = i32
-    L.ss_upconv_fused2_supported.argtypes = [i32, i32, i32, i32]
-    L.ss_upconv_fused2_supported.restype = i32
-    L.ss_upconv_fused2_wf_elems.argtypes = [i32, i32]
-    L.ss_upconv_fused2_wf_elems.restype = i64
-    L.ss_upconv_fused2_prep_w.argtypes = [p, p, i32, i32, p]
-    L.ss_upconv_fused2_prep_w.restype = i32
-    L.ss_upconv_fused2_fwd_f32.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
-    L.ss_upconv_fused2_fwd_f32.restype = i32
-    L.ss_upconv_fused2_prep_w_x16.argtypes = [p, p, i32, i32, i32, p]
-    L.ss_upconv_fused2_prep_w_x16.restype = i32
-    L.ss_upconv_fused2_fwd_x16.argtypes = [p, i32, p, i32, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
-    L.ss_upconv_fused2_fwd_x16.restype = i32
-    L.ss_upconv_bwd_fused_supported.argtypes = [i32, i32, i32, i32, i32, i32, i32]
-    L.ss_upconv_bwd_fused_supported.restype = i32
-    L.ss_upconv_bwd_fused_ws_floats.argtypes = [i32, i32, i64, i32, i32]
-    L.ss_upconv_bwd_fused_ws_floats.restype = i64
-    L.ss_upconv_bwd_fused_f32.argtypes = [p, p, p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
-    L.ss_upconv_bwd_fused_f32.restype = i32
     L.ss_spike_conv_fwd_supported.argtypes = [i32, i32, i32, i32, i32]
     L.ss_spike_conv_fwd_supported.restype = i32
     L.ss_spike_conv_fwd_wide_supported.argtypes = [i32, i32, i32, i32, i32]
@@ -155,12 +129,6 @@ def lib():
     L.ss_head_proj_packed_f32.restype = i32
     L.ss_head_wgrad_packed_f32.argtypes = [p, p, p, p, i64, i32, i32, p]
     L.ss_head_wgrad_packed_f32.restype = i32
-    L.ss_upconv_bwd_dgrad_supported.argtypes = [i32, i32, i32, i32, i32, i32]
-    L.ss_upconv_bwd_dgrad_supported.restype = i32
-    L.ss_upconv_bwd_dgrad_ws_floats.argtypes = [i32, i32]
-    L.ss_upconv_bwd_dgrad_ws_floats.restype = i64
-    L.ss_upconv_bwd_dgrad_f32.argtypes = [p, p, p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
-    L.ss_upconv_bwd_dgrad_f32.restype = i32
     L.ss_upconv_box_elems.argtypes = [i64, i32, i32, i32]
     L.ss_upconv_box_elems.restype = i64
     L.ss_upconv_boxsum_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i32, i32, p]
@@ -262,13 +230,13 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
            'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_wgrad_reduce3_f32', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
            'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed',
-           'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
-           'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w', 'ss_upconv_fused2_fwd_f32',
+           
+           
            'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32', 'ss_wino_dgrad_output_f32',
            'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
-           'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16',
-           'ss_upconv_bwd_fused_supported', 'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32',
-           'ss_upconv_bwd_dgrad_supported', 'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32',
+           
+           
+           
            'ss_upconv_sub_geometry', 'ss_upconv_sub_tall_geometry', 'ss_upconv_sub_supported', 'ss_upconv_sub_wm_elems', 'ss_upconv_sub_prep_f32', 'ss_upconv_sub_fwd_f32',
            'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_wide_supported', 'ss_spike_conv_fwd_ws_floats', 'ss_spike_conv_fwd_f32',
            'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32',
@@ -603,60 +571,6 @@ def split3_bf16(g, g3, M, N):
     with torch.cuda.device(g.device):
         rc = lib().ss_split3_bf16(_f32(g, 'g', M * N), _x16(g3, 'g3', 3 * M * N, torch.bfloat16), M, N, _stream(g))
     _check(rc, 'ss_split3_bf16')
-
-
-def upconv_fused2_x16(x, weight, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window):
-    """Fused projection + gather (form 2) on 16-bit activations: x [NB, h, w, Cin] and out [NB, H, W, Cout] fp16 or bf16 (same dtype), weight
-    [Cout, Cin, 5, 5] fp32.  fp16: exact fp32 weights (3 bf16 terms); bf16: weights rounded once to bf16 (autocast semantics)."""
-    _require_hip(x, 'x')
-    if x.dtype not in (torch.float16, torch.bfloat16) or out.dtype != x.dtype:
-        raise SSNeuronError('upconv_fused2_x16: x and out must both be fp16 or both bf16')
-    nsplit = 3 if x.dtype == torch.float16 else 1
-    Wf = torch.empty(upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = lib().ss_upconv_fused2_prep_w_x16(_f32(weight, 'weight', Cout * Cin * 25), _x16(Wf, 'Wf', Wf.numel(), torch.bfloat16), Cin, Cout, nsplit,
-                                               _stream(x))
-        _check(rc, 'ss_upconv_fused2_prep_w_x16')
-        rc = lib().ss_upconv_fused2_fwd_x16(_x16(x, 'x', NB * h * w * Cin, x.dtype), DT_CODE[x.dtype], _x16(Wf, 'Wf', Wf.numel(), torch.bfloat16), nsplit,
-                                            _i32(src_y, 'src_y', H + 4), _i32(src_x, 'src_x', W + 4), _x16(out, 'out', NB * H * W * Cout, out.dtype),
-                                            NB, Cin, Cout, h, w, H, W, int(max_window), _stream(x))
-    _check(rc, 'ss_upconv_fused2_fwd_x16')
-
-
-def upconv_bwd_fused_supported(Cin, Cout, k, extents):
-    """extents = (max_rows4, max_rows2, max_cols16, max_span[, max_cols32]) from fused.adjoint_extents(tables)."""
-    return bool(lib().ss_upconv_bwd_fused_supported(int(Cin), int(Cout), int(k), *[int(v) for v in extents[:4]]))
-
-
-def upconv_bwd_fused(g_out, x, y_lo, y_hi, x_lo, x_hi, g_P, g_w, NB, Cin, Cout, h, w, H, W, accumulate=False, x_packed=None):
-    """Adjoint gather (g_P written unless None) + exact bf16x3 MFMA weight gradient (g_w [Cin, 25 * Cout]) in one pass.  x_packed: the stage input as a
-    2-bit packed spike tensor (x is then not read)."""
-    _require_hip(g_out, 'g_out')
-    ws = torch.empty(int(lib().ss_upconv_bwd_fused_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g_out.device)
-    with torch.cuda.device(g_out.device):
-        rc = lib().ss_upconv_bwd_fused_f32(_f32(g_out, 'g_out', NB * H * W * Cout), None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
-                                           _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16), _i32(y_lo, 'y_lo', h),
-                                           _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
-                                           None if g_P is None else _f32(g_P, 'g_P', NB * h * w * 25 * Cout), _f32(g_w, 'g_w', Cin * 25 * Cout), _f32(ws, 'ws'),
-                                           NB, Cin, Cout, h, w, H, W, int(bool(accumulate)), _stream(g_out))
-    _check(rc, 'ss_upconv_bwd_fused_f32')
-
-
-def upconv_bwd_dgrad_supported(Cin, Cout, k, extents):
-    """extents = (max_rows4, max_rows2, max_cols16, max_span, max_cols32) from fused.adjoint_extents(tables)."""
-    return bool(lib().ss_upconv_bwd_dgrad_supported(int(Cin), int(Cout), int(k), int(extents[0]), int(extents[4]), int(extents[3])))
-
-
-def upconv_bwd_dgrad(g_out, weight, y_lo, y_hi, x_lo, x_hi, g_x, NB, Cin, Cout, h, w, H, W):
-    """Decoder data gradient g_x [NB, h, w, Cin] from g_out [NB, H, W, Cout] and the Conv2d weight [Cout, Cin, 5, 5]: adjoint gather + six-term
-    bf16 MFMA contraction in one kernel, the per-tap gradient tensor g_P only on chip."""
-    _require_hip(g_out, 'g_out')
-    ws = torch.empty(int(lib().ss_upconv_bwd_dgrad_ws_floats(int(Cin), int(Cout))), dtype=torch.float32, device=g_out.device)
-    with torch.cuda.device(g_out.device):
-        rc = lib().ss_upconv_bwd_dgrad_f32(_f32(g_out, 'g_out', NB * H * W * Cout), _f32(weight, 'weight', Cout * Cin * 25), _i32(y_lo, 'y_lo', h),
-                                           _i32(y_hi, 'y_hi', h), _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w), _f32(g_x, 'g_x', NB * h * w * Cin),
-                                           _f32(ws, 'ws'), NB, Cin, Cout, h, w, H, W, _stream(g_out))
-    _check(rc, 'ss_upconv_bwd_dgrad_f32')
 
 
 def upconv_boxsum(g_out, bt, NB, Cout, H, W):
@@ -1038,54 +952,6 @@ def im2col_cl_bf16_packed(x_packed, A, NB, h, w, C_, k, stride, pad, ho, wo):
     _check(rc, 'ss_im2col_cl_bf16_packed')
 
 
-def upconv_fused_supported(Cin, Cout, k):
-    return bool(lib().ss_upconv_fused_supported(int(Cin), int(Cout), int(k)))
-
-
-def upconv_fused_form(Cin, Cout, k, max_window):
-    """Which fused MFMA kernel serves this stage: 2 = wavefront-specialised persistent form (max_window <= 122), 1 = first form
-    (max_window <= 128), 0 = none (caller uses GEMM + gather)."""
-    if max_window <= 0:
-        return 0
-    if lib().ss_upconv_fused2_supported(int(Cin), int(Cout), int(k), int(max_window)):
-        return 2
-    return 1 if (max_window <= 128 and upconv_fused_supported(Cin, Cout, k)) else 0
-
-
-def upconv_fused_wf_elems(Cin, Cout, form=1):
-    L = lib()
-    return int((L.ss_upconv_fused2_wf_elems if form == 2 else L.ss_upconv_fused_wf_elems)(int(Cin), int(Cout)))
-
-
-def upconv_fused_prep_w(weight, Wf, Cin, Cout, form=1):
-    """weight [Cout, Cin, 5, 5] fp32 -> Wf (bf16, upconv_fused_wf_elems(form) elements): 3-way split, MFMA fragment order of `form`."""
-    _require_hip(weight, 'weight')
-    n = upconv_fused_wf_elems(Cin, Cout, form)
-    fn = lib().ss_upconv_fused2_prep_w if form == 2 else lib().ss_upconv_fused_prep_w
-    with torch.cuda.device(weight.device):
-        rc = fn(_f32(weight, 'weight', Cout * Cin * 25), _x16(Wf, 'Wf', n, torch.bfloat16), Cin, Cout, _stream(weight))
-    _check(rc, 'ss_upconv_fused_prep_w')
-
-
-def upconv_fused_fwd(x, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form=1):
-    """Fused projection + gather (bf16 MFMA, P in LDS only).  x: fp32 NHWC spikes or None; x_packed: int32 packed form or None.
-    form: kernel form the weights were prepared for (upconv_fused_form)."""
-    ref = x if x is not None else x_packed
-    _require_hip(ref, 'x')
-    if x_packed is not None and x_packed.dtype != torch.int32:
-        raise SSNeuronError('x_packed: expected int32')
-    fn = lib().ss_upconv_fused2_fwd_f32 if form == 2 else lib().ss_upconv_fused_fwd_f32
-    with torch.cuda.device(ref.device):
-        rc = fn(_f32(x, 'x', NB * h * w * Cin), _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
-                _x16(Wf, 'Wf', upconv_fused_wf_elems(Cin, Cout, form), torch.bfloat16), _i32(src_y, 'src_y', H + 4),
-                _i32(src_x, 'src_x', W + 4), _f32(out, 'out', NB * H * W * Cout), NB, Cin, Cout, h, w, H, W,
-                int(max_window), _stream(ref))
-    _check(rc, 'ss_upconv_fused_fwd_f32')
-
-
-# ----------------------------------------------------------------------------------------------------------
-# ABI 9: the 16-bit activation modes on the engine's own synapse kernels (single-term operands, 16-bit I/O; include/ss_neuron.h "ABI 9")
-# ----------------------------------------------------------------------------------------------------------
 def _dt_of(t, name):
     if t.dtype not in DT_CODE:
         raise SSNeuronError(f'{name}: expected float16 or bfloat16, got {t.dtype}')

@@ -1,4 +1,4 @@
-"""Engine configuration: ONE frozen object instead of ~40 process-global module attributes.
+"""Engine configuration: ONE frozen object (23 switches since the round-5 pruning; per-stage kernel choices are made from the geometry, fused.stage_plan).
 
     cfg = EngineConfig.default()                       # the shipped configuration; SS_* environment variables only seed THIS object
     net = StereoSpike(..., config=cfg.replace(PACK_SPIKES=False))     # a network owns its configuration: two networks with different settings coexist
@@ -31,50 +31,25 @@ class EngineConfig:
     DECODER_CHANNELS_LAST: bool = True  # decoder in NHWC memory
     ENCODER_CHANNELS_LAST: bool = True  # encoder / bottleneck in NHWC memory as well
     FUSED_LOSS: bool = True             # per-scale loss terms from one statistics kernel + one stencil kernel
-    # ---- decoder forward ------------------------------------------------------------------------------------------------------------------------------
-    PROJECTION_IMPL: str = 'auto'       # NCHW projected form: 'chunked' | 'conv' | 'matmul' | 'auto'
-    P_CHUNK_BYTES: int = 96 << 20
-    P_MAX_BYTES_CL: int = 16 << 30
-    EXACT_SPLIT_GEMM: bool = True       # synapses on spike inputs as exact bf16x3 GEMMs / MFMA kernels
-    EXACT_SPLIT_MIN_K: int = 128
-    FUSED_UPCONV_MFMA: bool = True      # deconv1 / deconv2 forward: projection + gather in ONE MFMA kernel
-    FUSED_UPCONV_X16: bool = True
-    FUSED_UPCONV_FORM: int = 2
-    ACT16_GATHER: bool = True
-    ASSERT_EXACT_SPLIT: bool = False    # tests: verify (with a host sync) that a "spike" input really is bf16-exact
-    PACKED_HEAD: bool = True            # prediction heads 1 / 2 read 2-bit packed spikes   [SS_PACKED_HEAD]
-    PACKED_DECONV2: bool = True         # deconv2's output packed-only   [SS_PACKED_DECONV2]
-    # ---- decoder backward -----------------------------------------------------------------------------------------------------------------------------
     X16_OWN_KERNELS: bool = True        # 16-bit activation modes (torch.autocast fp16 / bf16): every synapse on the engine's own single-term 16-bit-I/O kernels (weights rounded
                                         # once to the format, fp32 accumulation, fp32 weight gradients; include/ss_neuron.h ABI 9), packed spikes between layers.  False: the
                                         # round-2 .. 4 path — encoder / bottleneck synapses = MIOpen convolutions under autocast (A/B: profiles/r05/)   [SS_X16_OWN_KERNELS]
+    # ---- decoder (which STAGE takes which form is decided from its geometry: fused.stage_plan) ------------------------------------------------------------
+    EXACT_SPLIT_GEMM: bool = True       # synapses on spike inputs as exact bf16x3 GEMMs / MFMA kernels
+    ASSERT_EXACT_SPLIT: bool = False    # tests: verify (with a host sync) that a "spike" input really is bf16-exact
+    PACKED_HEAD: bool = True            # prediction heads 1 / 2 read 2-bit packed spikes   [SS_PACKED_HEAD]
+    PACKED_DECONV2: bool = True         # deconv2's output packed-only   [SS_PACKED_DECONV2]
     SUB_FWD: bool = True                # decoder stages, spike input: sub-pixel (merged tap) implicit GEMM forward, ss_upconv_sub.hip [SS_SUB_FWD]
-    SUB_FWD_CIN: Tuple[int, ...] = (64, 128, 256)     # deconv1 .. deconv3 (deconv3 since the tall tiles: 1.01 vs 1.26 ms; deconv4's 33x44 output stays on GEMM + gather)   [SS_SUB_FWD_CIN]
-    BOX_BWD: bool = True                # round 4: the stage backward on the box-sum image (ss_upconv_box.hip), no g_P anywhere   [SS_BOX_BWD]
-    BOX_BWD_CIN: Tuple[int, ...] = (64, 128)     # deconv1 / deconv2; the wide stages' 33x44 / 17x22 maps fill 4 x 32-pixel tiles to 57 / 47 % and stay on
-                                                 # adjoint -> g_P -> ss_gemm6_f32 + ss_spike_wgrad_f32 (profiles/r04/bench_box_bwd_v5.log)   [SS_BOX_BWD_CIN]
-    WGRAD_SPLIT_ROWS: int = 8192
-    EXACT_WGRAD_MFMA: bool = True
-    EXACT_WGRAD_MFMA_CIN: Tuple[int, ...] = (64, 128, 256, 512)                  # [SS_WGRAD_MFMA_CIN]
-    EXACT_SPLIT_WGRAD_MIN_K: int = 256
-    GEMM6_DGRAD: bool = True            # [SS_GEMM6_DGRAD]
-    GEMM6_DGRAD_CIN: Tuple[int, ...] = (128, 256, 512)                           # [SS_GEMM6_CIN]
-    FUSED_UPCONV_BWD: bool = True
-    FUSED_UPCONV_DGRAD: bool = True     # [SS_FUSED_DGRAD]
-    FUSED_UPCONV_DGRAD_CIN: Tuple[int, ...] = (64,)                              # [SS_FUSED_DGRAD_CIN]
-    FUSED_UPCONV_BWD_CIN_NOGP: Tuple[int, ...] = (64,)                           # [SS_FUSED_BWD_CIN_NOGP]
-    FUSED_UPCONV_BWD_CIN: Tuple[int, ...] = (64,)                                # [SS_FUSED_BWD_CIN]
+    BOX_BWD: bool = True                # decoder stages: the backward on the box-sum image (ss_upconv_box.hip), no g_P anywhere   [SS_BOX_BWD]
+    EXACT_WGRAD_MFMA: bool = True       # g_P forms: weight gradient on spike inputs as the exact bf16x3 MFMA contraction (ss_spike_wgrad_f32)
+    GEMM6_DGRAD: bool = True            # g_P forms: data gradient of the wide stages on ss_gemm6_f32   [SS_GEMM6_DGRAD]
     # ---- encoder / bottleneck convolutions ----------------------------------------------------------------------------------------------------------------
     WINOGRAD_DGRAD: bool = True
-    WINOGRAD_GEMM6: bool = False        # [SS_WINOGRAD_GEMM6]
-    WGRAD_REDUCE3: bool = True          # encoder / bottleneck weight-gradient GEMM: slices + terms summed and laid out by ss_wgrad_reduce3_f32
     CONV_DGRAD_MFMA: bool = True        # [SS_CONV_DGRAD_MFMA]
     SPIKE_CONV_FWD_MFMA: bool = True    # [SS_CONV_FWD_MFMA]
     SPIKE_CONV_WGRAD_MFMA: bool = True  # [SS_CONV_WGRAD_MFMA]
     DENSE_CONV_S1_MFMA: bool = True     # [SS_CONV_S1_MFMA]
     DENSE_CONV_S1_WGRAD_MFMA: bool = True   # [SS_CONV_S1_WGRAD_MFMA]
-    SPIKE_CONV_WGRAD_SPLIT: int = 8
-    SPIKE_CONV_MIN_CIN: int = 128
 
     def replace(self, **kw) -> 'EngineConfig':
         unknown = set(kw) - {f.name for f in dataclasses.fields(self)}
@@ -90,16 +65,9 @@ class EngineConfig:
         def flag(name, default):
             return e.get(name, '1' if default else '0') == '1'
 
-        def ints(name, default):
-            return tuple(int(c) for c in e.get(name, default).split(',') if c)
         return EngineConfig(
             LOWRANK_HEAD_GRAD=flag('SS_LOWRANK_HEAD_GRAD', True), PACKED_HEAD=flag('SS_PACKED_HEAD', True), PACKED_DECONV2=flag('SS_PACKED_DECONV2', True),
-            BOX_BWD=flag('SS_BOX_BWD', True), BOX_BWD_CIN=ints('SS_BOX_BWD_CIN', '64,128'),
-            X16_OWN_KERNELS=flag('SS_X16_OWN_KERNELS', True), SUB_FWD=flag('SS_SUB_FWD', True), SUB_FWD_CIN=ints('SS_SUB_FWD_CIN', '64,128,256'),
-            EXACT_WGRAD_MFMA_CIN=ints('SS_WGRAD_MFMA_CIN', '64,128,256,512'), GEMM6_DGRAD=flag('SS_GEMM6_DGRAD', True),
-            GEMM6_DGRAD_CIN=ints('SS_GEMM6_CIN', '128,256,512'), FUSED_UPCONV_DGRAD=flag('SS_FUSED_DGRAD', True),
-            FUSED_UPCONV_DGRAD_CIN=ints('SS_FUSED_DGRAD_CIN', '64'), FUSED_UPCONV_BWD_CIN_NOGP=ints('SS_FUSED_BWD_CIN_NOGP', '64'),
-            FUSED_UPCONV_BWD_CIN=ints('SS_FUSED_BWD_CIN', '64'), WINOGRAD_GEMM6=flag('SS_WINOGRAD_GEMM6', False),
+            BOX_BWD=flag('SS_BOX_BWD', True), X16_OWN_KERNELS=flag('SS_X16_OWN_KERNELS', True), SUB_FWD=flag('SS_SUB_FWD', True), GEMM6_DGRAD=flag('SS_GEMM6_DGRAD', True),
             CONV_DGRAD_MFMA=flag('SS_CONV_DGRAD_MFMA', True), SPIKE_CONV_FWD_MFMA=flag('SS_CONV_FWD_MFMA', True),
             SPIKE_CONV_WGRAD_MFMA=flag('SS_CONV_WGRAD_MFMA', True), DENSE_CONV_S1_MFMA=flag('SS_CONV_S1_MFMA', True),
             DENSE_CONV_S1_WGRAD_MFMA=flag('SS_CONV_S1_WGRAD_MFMA', True))

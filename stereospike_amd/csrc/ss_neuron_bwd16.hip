@@ -132,22 +132,40 @@ __global__ __launch_bounds__(kBlock) void neuron_bwd16_rc_kernel(Bwd16Args a, co
         if constexpr (LR) {
             const long long rows = a.N / lr_C;
             const float* pp = lr_p + ((i * VEC) / lr_C) * kLr16Rank;
-            float pj[TS][kLr16Rank];
-#pragma unroll
-            for (int t = TS - 1; t >= 0; --t)
-#pragma unroll
-                for (int j = 0; j < kLr16Rank; ++j) pj[t][j] = pp[(long long)t * rows * kLr16Rank + j];
             int c0v = lr_c0;
-            asm volatile("" : "+v"(c0v));                  // keep the nine LDS reads inside the loop
-#pragma unroll
-            for (int j = 0; j < kLr16Rank; ++j) {
-                float wj[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) wj[e] = lr_ws[j * lr_C + c0v + e];
+            asm volatile("" : "+v"(c0v));                  // keep the LDS reads inside the loop
+            if constexpr (TS <= 5) {                       // all T x 9 pair values up front (45 registers), the nine weight slices read once
+                float pj[TS][kLr16Rank];
 #pragma unroll
                 for (int t = TS - 1; t >= 0; --t)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) lracc[t][e] = (j == 0) ? pj[t][0] * wj[e] : lracc[t][e] + pj[t][j] * wj[e];
+                    for (int j = 0; j < kLr16Rank; ++j) pj[t][j] = pp[(long long)t * rows * kLr16Rank + j];
+#pragma unroll
+                for (int j = 0; j < kLr16Rank; ++j) {
+                    float wj[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) wj[e] = lr_ws[j * lr_C + c0v + e];
+#pragma unroll
+                    for (int t = TS - 1; t >= 0; --t)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) lracc[t][e] = (j == 0) ? pj[t][0] * wj[e] : lracc[t][e] + pj[t][j] * wj[e];
+                }
+            } else {                                       // longer sequences: the lane's 9 x VEC weights in registers, the pair walked step by step (same op order)
+                float wj[kLr16Rank][VEC];
+#pragma unroll
+                for (int j = 0; j < kLr16Rank; ++j)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) wj[j][e] = lr_ws[j * lr_C + c0v + e];
+#pragma unroll
+                for (int t = TS - 1; t >= 0; --t) {
+                    float pt[kLr16Rank];
+#pragma unroll
+                    for (int j = 0; j < kLr16Rank; ++j) pt[j] = pp[(long long)t * rows * kLr16Rank + j];
+#pragma unroll
+                    for (int j = 0; j < kLr16Rank; ++j)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) lracc[t][e] = (j == 0) ? pt[0] * wj[0][e] : lracc[t][e] + pt[j] * wj[j][e];
+                }
             }
         }
         float v0[VEC], gv[VEC], h[TS][VEC];

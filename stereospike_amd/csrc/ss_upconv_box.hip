@@ -38,11 +38,13 @@ __device__ unsigned long long bx_trace[64][16];
 #endif
 constexpr int kBxCo = 8;                       // output channels per chunk of the plane layout (= half a k-step: a k-step is 2 taps x 8 channels)
 
-// 16-bit activation modes (DT != 0, round 5): g_y arrives in the 16-bit format; a box sum of <= 9 such values needs more bits than one 16-bit value holds:
-// bf16 mode TWO planes (hi + lo, 16 significand bits: the weight gradients of that mode sit at 0.8 of their parity bar from activation-gradient storage
-// alone, no further rounding point is added), fp16 mode ONE plane (11 bits: one more rounding of the class the mode already has per layer crossing).
+// 16-bit activation modes (DT != 0, round 5): g_y arrives in the 16-bit format and the box sum — fp32 additions of <= 9 widened values, the fp32 kernel's order —
+// is stored as ONE plane of the format: one more rounding of the class the mode already has at every layer crossing, and exactly what the modes' g_P path does
+// (ss_upconv_cl_bwd_lowp writes every g_P element — the same rectangle sum — as bf16).  Measured end to end (tests/test_gpu_04_x16_parity.py): weight tensors
+// 7.4e-3 -> see profiles/r05 of their 1e-2 bar in bf16.  (The plane count stays a compile-time trait: two planes — hi + lo, 16 significand bits in bf16 — were the
+// first build; 2 MFMAs per k-step and twice the plane traffic for a rounding the g_P path does not spare either.)
 // The weight is ONE term (rounded once to the format), so a k-step costs NP MFMAs instead of six (data gradient) / three (weight gradient).
-template <int DT> struct BxT { static constexpr int NP = DT == 0 ? 3 : (DT == SS_DT_BF16 ? 2 : 1), NW = DT == 0 ? 3 : 1; };
+template <int DT> struct BxT { static constexpr int NP = DT == 0 ? 3 : 1, NW = DT == 0 ? 3 : 1; };
 
 template <int DT> __device__ __forceinline__ void bx_split(const float (&v)[8], u16x8 (&pl)[BxT<DT>::NP])
 {
@@ -928,7 +930,7 @@ int ss_upconv_box_wgrad_f32(const void* box, const float* x, const unsigned int*
 }
 
 /* ---- the three kernels on 16-bit activation gradients (ABI 9).  g_out / g_x in `dtype`; the box image holds ss_upconv_box_planes_x16(dtype) planes of that
-   format (bf16: 2, fp16: 1); the weight is rounded once to `dtype`; x: the dense 16-bit spike tensor of the same dtype, or the 2-bit packed one; g_w fp32. */
+   format (one); the weight is rounded once to `dtype`; x: the dense 16-bit spike tensor of the same dtype, or the 2-bit packed one; g_w fp32. */
 int ss_upconv_box_planes_x16(int dtype) { return dtype == SS_DT_BF16 ? BxT<SS_DT_BF16>::NP : (dtype == SS_DT_F16 ? BxT<SS_DT_F16>::NP : 0); }
 
 int ss_upconv_boxsum_x16(const void* g_out, const int* vr, const int* hr, void* box, long long NB, int Cout, int H, int W, int NVR, int NHR, int dtype, void* stream)

@@ -497,190 +497,6 @@ __global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Decoder backward, fused: adjoint gather (g_P) + exact bf16x3 MFMA weight gradient in ONE pass — g_P is written once for the data-gradient
-// GEMM and never read back for the weight gradient
-// ---------------------------------------------------------------------------------------------------
-// Reference: autograd through NNConvUpsampling (/root/reference/network/blocks.py:110-132; decoder stages SNN_models.py:110-129).
-//   g_P[src][tap][co] = sum over the output pixels whose tap lands on src of g_y[pix][co]        (ss_upconv_cl_bwd_f32: same value, same
-//                                                                                                 summation order — rows top to bottom, columns
-//                                                                                                 left to right inside a row)
-//   g_W[ci][tap, co]  = sum_src x[src][ci] * g_P[src][tap][co]                                   (ss_spike_wgrad_f32: x spikes, exact products)
-// A lane computes g_P for 8 CONSECUTIVE SOURCE PIXELS of one column n = (tap, co) — exactly the MFMA fragment of the contraction over
-// sources (k = 8 (lane >> 5) + e, row n = lane & 31) — from the g_y window of the tile held in LDS ([row][col][co] fp32, lanes = consecutive
-// co: conflict-free), stores the 8 values to g_P (128-B segments), splits them exactly into three bf16 terms and multiplies them with the
-// spike fragments (pre-transposed, one source row = ceil(w / 16) k-steps, zero padded).  Work split as in spike_wgrad_kernel: Q workgroup
-// kinds own contiguous ranges of the 25 C_out / 32 column tiles, a wavefront keeps its <= NTW tiles' accumulators for the whole launch,
-// slices of the (frame, TR source rows, 16 source columns) tiles are walked persistently; partials -> ws -> spike_wgrad_reduce_kernel.
-template <int CIN, int COUT, int TR, int NTW, int WRM, int WCM>
-__global__ __launch_bounds__(kSwThreads, CIN == 64 ? 4 : 2) void upconv_bwd_fused_kernel(const float* __restrict__ gy, const unsigned short* __restrict__ xT,
-                                                                     const int* __restrict__ y_lo, const int* __restrict__ y_hi,
-                                                                     const int* __restrict__ x_lo, const int* __restrict__ x_hi,
-                                                                     float* __restrict__ gP, float* __restrict__ ws,
-                                                                     int NB, int h, int w, int H, int W, int Q)
-{
-    constexpr int CIT = CIN / 32, N = 25 * COUT, NT = N / 32, NPT = COUT / 32, CB = COUT * 4, ROWB = WCM * CB, C4 = COUT / 4;
-    __shared__ __attribute__((aligned(16))) unsigned char wnd[WRM * ROWB + 2 * CB];     // + slack: the unconditional third column read
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = (int)(blockIdx.x % Q), slice = (int)(blockIdx.x / Q), slices = (int)(gridDim.x / Q);
-    const int tpk = (NT + Q - 1) / Q, kt = min(tpk, NT - q * tpk);
-    const int tile0 = q * tpk + wave;
-    bool own[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) own[j] = wave + 8 * j < kt;
-    f32x16 acc[NTW][CIT];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int t = 0; t < CIT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
-    const int KSR = (w + 15) / 16, RG = (h + TR - 1) / TR;
-    const int n_tiles = NB * RG * KSR;
-    const unsigned xoffT = (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * 8u;
-#pragma unroll 1
-    for (int t = slice; t < n_tiles; t += slices) {
-        const int c = t % KSR, rg = (t / KSR) % RG, nb = t / (KSR * RG);
-        const int sy0 = rg * TR, sx0 = 16 * c, nrow = min(TR, h - sy0);
-        const int wy0 = y_lo[sy0] - 4, WRt = y_hi[sy0 + nrow - 1] - wy0;
-        const int wx0 = x_lo[sx0] - 4, WCt = x_hi[min(sx0 + 15, w - 1)] - wx0;
-        __syncthreads();                                                  // the previous tile's reads of the window are done
-        // ---- g_y window -> LDS (zero outside the image)
-        if constexpr (CIN == 64) {
-            // C_in 64 (4 workgroups' worth of wavefronts per SIMD): the rolled loop is FASTER — other wavefronts cover its latency, and the batched
-            // form below costs registers / issue slots here (2.54 -> 3.14 ms at deconv1, profiles/r03/upconv_bwd_variants.log)
-            const int rowf4 = min(WCt + 2, WCM) * C4;                      // + 2: the multiplied-by-zero third column must be finite
-            for (int i = threadIdx.x; i < WRt * rowf4; i += kSwThreads) {
-                const int wy = i / rowf4, rem = i - wy * rowf4;
-                const int y = wy0 + wy, x = wx0 + rem / C4;
-                f4 v = {0.f, 0.f, 0.f, 0.f};
-                if (y >= 0 && y < H && x >= 0 && x < W)
-                    v = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT) + (rem % C4));
-                *reinterpret_cast<f4*>(wnd + wy * ROWB + rem * 16) = v;
-            }
-        } else
-        {   // C_in 128 (2 wavefronts per SIMD): loads of a thread issued in batches before its stores (a rolled loop serialised one L2 / HBM
-            // round trip per iteration: 2.81 -> 2.08 ms at deconv2)
-            constexpr int kPerRow = WCM * C4, kIter = (WRM * kPerRow + kSwThreads - 1) / kSwThreads;
-            const int cols = min(WCt + 2, WCM);                              // + 2: the multiplied-by-zero third column must be finite
-            constexpr int kBatch = CIN == 64 ? 9 : 7;                        // loads in flight per thread (the C_in 128 form has 128 accumulator registers)
-#pragma unroll 1
-            for (int u0 = 0; u0 < kIter; u0 += kBatch) {
-                f4 buf[kBatch];
-#pragma unroll
-                for (int v = 0; v < kBatch; ++v) {
-                    const int i = threadIdx.x + kSwThreads * (u0 + v);
-                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
-                    const int y = wy0 + wy, x = wx0 + rem / C4;
-                    buf[v] = (f4){0.f, 0.f, 0.f, 0.f};
-                    if (u0 + v < kIter && wy < WRt && rem / C4 < cols && y >= 0 && y < H && x >= 0 && x < W)
-                        buf[v] = load_stream(reinterpret_cast<const f4*>(gy + (((long long)nb * H + y) * W + x) * COUT) + (rem % C4));
-                }
-#pragma unroll
-                for (int v = 0; v < kBatch; ++v) {
-                    const int i = threadIdx.x + kSwThreads * (u0 + v);
-                    const int wy = i / kPerRow, rem = i - wy * kPerRow;
-                    if (u0 + v < kIter && wy < WRt && rem / C4 < cols) *reinterpret_cast<f4*>(wnd + wy * ROWB + rem * 16) = buf[v];
-                }
-            }
-        }
-        // ---- this lane's 8 source columns: window byte offset of their first contributing column at kx = 0, and 0 / 1 multipliers of the
-        //      second / third column (fma(r, 1, cs) == cs + r and fma(r, 0, cs) == cs exactly: the adjoint kernel's sums, no selects)
-        int xo[8];
-        float m1[8], m2[8];
-        unsigned valid = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int sx = sx0 + 8 * (lane >> 5) + e;
-            const int sxc = min(sx, w - 1);
-            const int lo = x_lo[sxc], hi = x_hi[sxc];
-            xo[e] = (lo - wx0) * CB;
-            m1[e] = hi - lo > 1 ? 1.f : 0.f;
-            m2[e] = hi - lo > 2 ? 1.f : 0.f;
-            if (sx < w) valid |= 1u << e;
-        }
-        __syncthreads();
-        if (own[0]) {
-#pragma unroll 1
-            for (int tr = 0; tr < nrow; ++tr) {
-                const int sy = sy0 + tr;
-                const int ys = y_lo[sy] - wy0, ry = y_hi[sy] - y_lo[sy];
-                const long long srow = (long long)nb * h + sy;                // source row index
-                s16x8 xn[CIT];
-                {
-                    const unsigned short* xb = xT + (srow * KSR + c) * (CIN * 16);
-#pragma unroll
-                    for (int tt = 0; tt < CIT; ++tt) xn[tt] = *reinterpret_cast<const s16x8*>(xb + 32 * 16 * tt + xoffT);
-                }
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    if (own[j]) {
-                        const int tile = tile0 + 8 * j;
-                        const int tap = tile / NPT, half = tile - tap * NPT;
-                        const int ky = tap / 5, kx = tap - 5 * ky;
-                        const unsigned char* const base = wnd + (ys - ky) * ROWB - kx * CB + (half * 32 + (lane & 31)) * 4;
-                        float gv[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const unsigned char* const p = base + xo[e];      // rows / columns at immediate offsets
-                            float a = 0.f;
-#pragma unroll
-                            for (int rr = 0; rr < 3; ++rr) {
-                                if (rr < ry) {                                // wave-uniform
-                                    float cs = *reinterpret_cast<const float*>(p + rr * ROWB);
-                                    cs = __builtin_fmaf(*reinterpret_cast<const float*>(p + rr * ROWB + CB), m1[e], cs);
-                                    cs = __builtin_fmaf(*reinterpret_cast<const float*>(p + rr * ROWB + 2 * CB), m2[e], cs);
-                                    a += cs;
-                                }
-                            }
-                            gv[e] = a;
-                        }
-                        // g_P[(srow * w + sx)][n], n = 32 tile + (lane & 31)
-                        if (gP) {                                                 // nullable (ABI 5): the data gradient comes from ss_upconv_bwd_dgrad_f32
-                            float* const gp = gP + (srow * w + sx0 + 8 * (lane >> 5)) * N + 32 * tile + (lane & 31);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (valid & (1u << e)) store_out(gp + (long long)e * N, gv[e]);
-                        }
-                        s16x8 gs[3];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float v = gv[e];
-                            const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
-                            const float r1 = v - __uint_as_float(uh);
-                            const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
-                            const float r2 = r1 - __uint_as_float(um);
-                            gs[0][e] = (short)(uh >> 16); gs[1][e] = (short)(um >> 16); gs[2][e] = (short)(__float_as_uint(r2) >> 16);
-                        }
-#pragma unroll
-                        for (int sp = 0; sp < 3; ++sp)
-#pragma unroll
-                            for (int tt = 0; tt < CIT; ++tt)
-                                acc[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs[sp], xn[tt], acc[j][tt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-    if (!own[0]) return;
-    float* const wsl = ws + (long long)slice * N * CIN;
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        if (own[j]) {
-#pragma unroll
-            for (int tt = 0; tt < CIT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = 32 * (tile0 + 8 * j) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    wsl[(long long)n * CIN + 32 * tt + (lane & 31)] = acc[j][tt][r];
-                }
-        }
-    }
-}
-
-// (upconv_bwd_xprep_kernel — the spike operand in fragment order — lives in ss_common.hpp: ss_upconv_box.hip uses it as well)
-
-// ---------------------------------------------------------------------------------------------------
 // Dense x dense fp32 GEMM on the bf16 matrix cores with SIX cross terms:  C[R][N] = A[R][K] @ B[K][N]   (decoder data gradient g_x = g_P @ W2)
 // ---------------------------------------------------------------------------------------------------
 // Both operands are dense fp32 (no spike operand), so the exact 3-term split of ONE operand is not enough.  a = ah + am + al and
@@ -984,68 +800,6 @@ int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, lo
     if (Cin == 64) hipLaunchKernelGGL((spike_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
     else if (Cin == 128) hipLaunchKernelGGL((spike_wgrad_kernel<4, 1, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
     else hipLaunchKernelGGL((spike_wgrad_kernel<8, 1, 2>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
-    if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
-    hipLaunchKernelGGL(spike_wgrad_reduce_kernel, dim3(grid_for((long long)N * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, N, Cin, accumulate);
-    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
-}
-
-// TR source rows per tile, window capacity (rows x columns of output pixels) per compiled shape
-static void upconv_bwd_fused_shape(int Cin, int* TR, int* WRM, int* WCM, int* ntw)
-{
-    if (Cin == 64) { *TR = 4; *WRM = 14; *WCM = 40; *ntw = 2; } else { *TR = 2; *WRM = 10; *WCM = 40; *ntw = 2; }
-}
-
-int ss_upconv_bwd_fused_supported(int Cin, int Cout, int k, int max_rows4, int max_rows2, int max_cols16, int max_span)
-{
-    // max_rows4 / max_rows2: largest output-row span (incl. the k - 1 taps) of 4 / 2 consecutive source rows; max_cols16: the same for 16
-    // consecutive source columns; max_span: most output rows / columns one source pixel collects per tap — computed by the caller from the tables
-    if (!ss_upconv_fused_supported(Cin, Cout, k) || max_span < 1 || max_span > 3) return 0;
-    int TR, WRM, WCM, ntw;
-    upconv_bwd_fused_shape(Cin, &TR, &WRM, &WCM, &ntw);
-    return (TR == 4 ? max_rows4 : max_rows2) <= WRM && max_cols16 <= WCM && max_rows2 > 0 && max_rows4 > 0 && max_cols16 > 0;
-}
-
-static int upconv_bwd_fused_plan(int Cin, int Cout, int* Q, int* slices)
-{
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
-    int TR, WRM, WCM, ntw;
-    upconv_bwd_fused_shape(Cin, &TR, &WRM, &WCM, &ntw);
-    const int nt = 25 * Cout / 32;
-    *Q = (nt + 8 * ntw - 1) / (8 * ntw);
-    const int wgs = Cin == 64 ? 2 * cus : cus;            // C_in 64: 118 registers, 67 KiB LDS -> two workgroups per CU (window loads overlap compute)
-    *slices = wgs / *Q > 0 ? wgs / *Q : 1;
-    return 1;
-}
-
-long long ss_upconv_bwd_fused_ws_floats(int Cin, int Cout, long long NB, int h, int w)
-{
-    int Q = 0, slices = 0;
-    if (!ss_upconv_fused_supported(Cin, Cout, 5) || NB <= 0 || h <= 0 || w <= 0 || !upconv_bwd_fused_plan(Cin, Cout, &Q, &slices)) return 0;
-    return (long long)slices * 25 * Cout * Cin + NB * h * ((w + 15) / 16) * Cin * 8;
-}
-
-int ss_upconv_bwd_fused_f32(const float* g_out, const float* x, const unsigned int* x_packed, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
-                            float* g_P, float* g_w, float* ws, long long NB, int Cin, int Cout, int h, int w, int H, int W,
-                            int accumulate, void* stream)
-{
-    if (x_packed && (NB * h * (long long)w * Cin) % 16 != 0) return SS_EINVAL;
-    if (!g_out || (!x && !x_packed) || !y_lo || !y_hi || !x_lo || !x_hi || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
-    if (!ss_upconv_fused_supported(Cin, Cout, 5) || !aligned16(g_out) || !aligned16(ws) || NB * h * (long long)w > 0x7fffffffLL) return SS_EINVAL;
-    int Q = 0, slices = 0;
-    if (!upconv_bwd_fused_plan(Cin, Cout, &Q, &slices)) return SS_ELAUNCH;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int N = 25 * Cout;
-    unsigned short* xT = reinterpret_cast<unsigned short*>(ws + (long long)slices * N * Cin);
-    if (x_packed) hipLaunchKernelGGL(upconv_bwd_xprep_kernel<true>, dim3(grid_for(NB * h * ((w + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
-                                     static_cast<const void*>(x_packed), xT, NB * h, w, Cin);
-    else hipLaunchKernelGGL(upconv_bwd_xprep_kernel<false>, dim3(grid_for(NB * h * ((w + 15) / 16) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
-                            static_cast<const void*>(x), xT, NB * h, w, Cin);
-    const unsigned grid = (unsigned)(Q * slices);
-    if (Cin == 64) hipLaunchKernelGGL((upconv_bwd_fused_kernel<64, 32, 4, 2, 14, 40>), dim3(grid), dim3(kSwThreads), 0, s, g_out, xT, y_lo, y_hi, x_lo, x_hi,
-                                      g_P, ws, (int)NB, h, w, H, W, Q);
-    else hipLaunchKernelGGL((upconv_bwd_fused_kernel<128, 64, 2, 2, 10, 40>), dim3(grid), dim3(kSwThreads), 0, s, g_out, xT, y_lo, y_hi, x_lo, x_hi,
-                            g_P, ws, (int)NB, h, w, H, W, Q);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(spike_wgrad_reduce_kernel, dim3(grid_for((long long)N * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, N, Cin, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;

@@ -71,6 +71,14 @@ class KernelTimer:
 
 TIMER = KernelTimer()
 
+# fixed tuning constants (EngineConfig fields until round 5; none of the shipped configurations changed them)
+_P_CHUNK_BYTES = 96 << 20             # NCHW projected form: P produced and consumed in chunks of frames that stay in the 256 MiB Infinity Cache
+_P_MAX_BYTES_CL = 16 << 30            # NHWC projected form: frames are chunked only when P would exceed this
+_EXACT_SPLIT_MIN_K = 128              # exact bf16x3 projection GEMM from this C_in on (below it the fp32 GEMM is as fast)
+_WGRAD_SPLIT_ROWS = 8192              # library weight-gradient GEMM: split-K slice length
+_SPIKE_CONV_WGRAD_SPLIT = 8           # encoder / bottleneck weight-gradient GEMM: split-K slices
+_SPIKE_CONV_MIN_CIN = 128             # im2col + GEMM form of a conv on spikes from this C_in on
+
 
 # Training keeps the layer INPUT (the conv output, which autograd would otherwise free) instead of a separately written h_seq and
 # recomputes h inside the backward kernel: the forward launch writes 8 instead of 12 B/update, the backward reads the same 12.
@@ -500,7 +508,7 @@ class _UpConvProjected(torch.autograd.Function):
         W2 = weight.permute(0, 2, 3, 1).reshape(Cout * kk, Cin).contiguous()        # rows ordered (co, ky, kx)
         src_y, _, _, src_x, _, _ = tables
         out = torch.empty((NB, Cout, H, W), dtype=x.dtype, device=x.device)
-        n = max(1, min(NB, _cfg().P_CHUNK_BYTES // (Cout * kk * hw * 4)))
+        n = max(1, min(NB, _P_CHUNK_BYTES // (Cout * kk * hw * 4)))
         one_bias = bias if (bias is not None and Cout == 1) else None
         e0 = TIMER.start()
         for c0 in range(0, NB, n):
@@ -560,9 +568,9 @@ def upconv_projected(x: torch.Tensor, weight: torch.Tensor, bias, tables, k: int
     Conv2d weight [C_out, C_in, k, k]."""
     NB, Cin, h, w = x.shape
     Cout = weight.shape[0]
-    impl = _cfg().PROJECTION_IMPL
+    impl = 'auto'
     if impl == 'auto':
-        impl = 'chunked' if _cfg().P_CHUNK_BYTES // (Cout * k * k * h * w * 4) >= 4 else 'conv'
+        impl = 'chunked' if _P_CHUNK_BYTES // (Cout * k * k * h * w * 4) >= 4 else 'conv'
     if impl == 'chunked':
         return _UpConvProjected.apply(x, weight, bias, tables, k, H, W)
     w_taps = weight.permute(0, 2, 3, 1).reshape(Cout * k * k, Cin)              # rows ordered (co, ky, kx)
@@ -610,38 +618,6 @@ def _split3_bf16(Wt):
 
 
 
-
-
-def _extents_of(y_lo, y_hi, x_lo, x_hi):
-    def span(lo, hi, n):
-        return max(hi[min(i + n - 1, len(lo) - 1)] - lo[i] for i in range(0, len(lo), n)) + 4
-    return (span(y_lo, y_hi, 4), span(y_lo, y_hi, 2), span(x_lo, x_hi, 16),
-            max(max(b - a for a, b in zip(y_lo, y_hi)), max(b - a for a, b in zip(x_lo, x_hi))), span(x_lo, x_hi, 32))
-
-
-def register_extents(tables, host_tables):
-    """Called where the resize tables are BUILT (NNConvUpsampling._tables, from the host copies): the extents are then known without ever
-    reading a device tensor back — no host synchronisation in backward, nothing that could land inside a stream capture."""
-    _EXTENTS[id(tables)] = (tables, _extents_of(*(host_tables[i].tolist() for i in (1, 2, 4, 5))))
-
-
-def adjoint_extents(tables):
-    """(max_rows4, max_rows2, max_cols16, max_span, max_cols32) of the inverse resize tables (y_lo, y_hi, x_lo, x_hi at indices 1, 2, 4, 5): the output
-    window that 4 / 2 consecutive source rows and 16 consecutive source columns need (incl. the 4 extra tap rows / columns), and the widest
-    per-source range — what ss_upconv_bwd_fused_supported checks against its on-chip window.  Host-side, cached on the tables tuple
-    (register_extents); tables built elsewhere are read back once, and never during a stream capture."""
-    hit = _EXTENTS.get(id(tables))
-    if hit is not None and hit[0] is tables:
-        return hit[1]
-    if tables[1].is_cuda and torch.cuda.is_current_stream_capturing():
-        raise _lib.SSNeuronError('adjoint_extents: resize tables without registered extents inside a stream capture (build them through '
-                                 'NNConvUpsampling._tables, or run one eager backward first)')
-    ext = _extents_of(*(tables[i].cpu().tolist() for i in (1, 2, 4, 5)))
-    _EXTENTS[id(tables)] = (tables, ext)
-    return ext
-
-
-_EXTENTS = {}
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -822,6 +798,36 @@ def sub_tables(tables, H, W):
 _SUB = {}
 
 
+# ---- which kernel forms a decoder stage takes: decided ONCE per (resize tables = module and input geometry), from the geometry (no
+#      channel-count tuples standing in for "deconv1 .. 3").  Measured table behind the two thresholds (MI355X, BASELINE config 3, 80 frames):
+#        sub-pixel forward vs exact GEMM + gather   deconv1 130x173 src  0.63 vs 1.34 ms | deconv2 65x87  0.69 vs 1.25 | deconv3 33x44  1.01 vs 1.26 | deconv4 17x22  slower
+#                                                   (profiles/r04/bench_sub_fwd_v10.log)
+#        box-sum backward vs adjoint -> g_P -> GEMMs deconv1 2.78 vs 3.72 ms | deconv2 2.15 vs 2.87 | deconv3 33x44 and deconv4 17x22: slower (tile fill 57 / 47 %;
+#                                                   profiles/r04/bench_box_bwd_v5.log, bench_box_bwd_v14.log)
+#      i.e. the per-frame tile kernels lose on source maps of few pixels with many channels (few, mostly empty tiles per frame, long per-tile weight streams).
+_SUB_MIN_SRC_PIXELS = 1024          # wide stages (C_in > 128): source pixels per frame from which the sub-pixel forward wins
+_BOX_MIN_SRC_PIXELS = 2048          # ... and the box-sum backward
+_STAGE = {}
+
+
+def stage_plan(tables, Cin: int, Cout: int, k: int, h: int, w: int, H: int, W: int) -> dict:
+    """{'sub_fwd': bool, 'box_bwd': bool} of the decoder stage whose resize tables these are (spike input, k = 5): what the GEOMETRY admits and where it was
+    measured to win.  The run-time switches (EngineConfig.SUB_FWD / BOX_BWD), dtypes and operand forms are checked at the dispatch site."""
+    key = (id(tables), Cin, Cout, k, h, w, H, W)
+    hit = _STAGE.get(key)
+    if hit is not None and hit[0] is tables:
+        return hit[1]
+    plan = dict(sub_fwd=False, box_bwd=False)
+    if k == 5 and tables[0].is_cuda:
+        narrow_or_large = lambda floor: Cin <= 128 or h * w >= floor      # noqa: E731
+        plan['sub_fwd'] = bool(_lib.upconv_sub_supported(Cin, Cout, k) and narrow_or_large(_SUB_MIN_SRC_PIXELS) and sub_tables(tables, H, W) is not None)
+        if narrow_or_large(_BOX_MIN_SRC_PIXELS):
+            bt = box_tables(tables, H, W)
+            plan['box_bwd'] = bool(_lib.upconv_box_dgrad_supported(Cin, Cout, k, bt) and _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt))
+    _STAGE[key] = (tables, plan)
+    return plan
+
+
 class _UpConvProjectedCL(torch.autograd.Function):
     """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
     forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
@@ -832,24 +838,22 @@ class _UpConvProjectedCL(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None, max_window=0,
+    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None,
                 lowrank_grad=False, x_packed=None, own16=None):
         ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         # own16 (round 5): the 16-bit activation mode's dtype when the mode runs on the engine's own single-term kernels (x16_mode()) — decoder stages then take
         # the sub-pixel forward / box-sum backward on 16-bit I/O, and a packed head keeps its exact fp32 weights
         ctx.own16 = own16
-        sub16_ok = bool(own16 is not None and _cfg().SUB_FWD and k == 5 and spikes_in and bias is None and act_dtype == own16 and x_cl.shape[-1] in _cfg().SUB_FWD_CIN
-                        and x_cl.is_cuda and _lib.upconv_sub_supported(x_cl.shape[-1], weight.shape[0], k) and x_cl.numel() < 2 ** 32
-                        and (x_packed is not None or x_cl.dtype == own16) and sub_tables(tables, H, W) is not None)
+        plan = stage_plan(tables, x_cl.shape[-1], weight.shape[0], k, x_cl.shape[1], x_cl.shape[2], H, W) if (k == 5 and spikes_in and x_cl.is_cuda) else dict(sub_fwd=False, box_bwd=False)
+        ctx.stage_plan = plan
+        sub_geo = bool(_cfg().SUB_FWD and plan['sub_fwd'] and bias is None and x_cl.numel() < 2 ** 32)       # the sub-pixel forward applies to this geometry
+        sub16_ok = bool(own16 is not None and sub_geo and act_dtype == own16 and (x_packed is not None or x_cl.dtype == own16))
+        sub32_ok = bool(sub_geo and not lowp and act_dtype is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32)
         # x_packed (one-channel 3 x 3 head on a packed-only neuron output, fp32 mode): the input as a 2-bit packed spike tensor; x_cl is then a
         # data-less anchor that carries shape and autograd edge.  Projection and weight gradient read the packed form (ss_head_*_packed_f32)
         if x_packed is not None and k != 3:
-            # a decoder stage on a packed-only input (deconv1 reading deconv2's output): the fused MFMA forward reads the packed form; any other form
-            # of this stage gets the dense tensor back first
-            sub_ok = (_cfg().SUB_FWD and k == 5 and x_cl.shape[-1] in _cfg().SUB_FWD_CIN and _lib.upconv_sub_supported(x_cl.shape[-1], weight.shape[0], k)
-                      and sub_tables(tables, H, W) is not None)
-            if not sub16_ok and not (spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and x_cl.dtype == torch.float32
-                    and (sub_ok or (_cfg().FUSED_UPCONV_MFMA and _lib.upconv_fused_form(x_cl.shape[-1], weight.shape[0], k, max_window) != 0))):
+            # a decoder stage on a packed(-only) input: the sub-pixel forward reads the packed form; any other form of this stage gets the dense tensor back first
+            if not (sub16_ok or sub32_ok):
                 x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None     # (a dense copy came along: use it)
         if x_packed is not None and k == 3:
             NB, h, w, Cin = x_cl.shape
@@ -897,19 +901,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
         out = torch.empty((NB, H, W, Cout), dtype=act_dtype or torch.float32, device=x_cl.device)
         # one pass: measured on the MI355X (profiles/r01/chunk_sweep*.log) cache-sized chunks lose more in GEMM efficiency (M = n*h*w
         # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
-        n = max(1, min(NB, _cfg().P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
-        exact = spikes_in and not lowp and _cfg().EXACT_SPLIT_GEMM and Cin >= _cfg().EXACT_SPLIT_MIN_K
-        # fused projection + gather on the bf16 matrix cores (P only in LDS): spike inputs, fp32 activations, the compiled stage shapes
-        form = 0
-        if (_cfg().FUSED_UPCONV_MFMA and spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and not half_in):
-            form = _lib.upconv_fused_form(Cin, Cout, k, max_window)           # 2: wavefront-specialised persistent kernel; 1: first form
-            if form == 2 and _cfg().FUSED_UPCONV_FORM == 1 and max_window <= 128:
-                form = 1
-        # 16-bit autocast, decoder stage with 16-bit spike input and 16-bit activation output: the same kernel (form 2) on 16-bit I/O —
-        # fp16: exact fp32 weights like the fp32 mode; bf16: weights rounded once to bf16, autocast's own semantics for every synapse
-        x16_fused = (_cfg().FUSED_UPCONV_MFMA and _cfg().FUSED_UPCONV_X16 and spikes_in and act_dtype is not None and bias is None and half_in
-                     and x_cl.dtype == act_dtype and lowp == (act_dtype == torch.bfloat16) and (lowp or _cfg().EXACT_SPLIT_GEMM)
-                     and _lib.upconv_fused_form(Cin, Cout, k, max_window) == 2)
+        n = max(1, min(NB, _P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
+        exact = spikes_in and not lowp and _cfg().EXACT_SPLIT_GEMM and Cin >= _EXACT_SPLIT_MIN_K
         if sub16_ok:                                  # decoder stage, 16-bit mode on own kernels: merged-tap implicit GEMM, two terms of the mode's format
             st16 = sub_tables(tables, H, W)
             e0 = TIMER.start()
@@ -924,24 +917,8 @@ class _UpConvProjectedCL(torch.autograd.Function):
             ctx.wshape = weight.shape
             ctx.has_bias = False
             return out
-        if x16_fused:
-            e0 = TIMER.start()
-            _lib.upconv_fused2_x16(x_cl, weight.contiguous(), src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window)
-            TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-            _note('synapse_fwd', 'upconv_fused2_mfma_x16')
-            ctx.save_for_backward(x_cl, Wt, None, weight)
-            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
-            ctx.exact = not lowp
-            ctx.tables, ctx.k, ctx.n = tables, k, n
-            ctx.wshape = weight.shape
-            ctx.has_bias = False
-            return out
         # round 4: the sub-pixel (merged tap) implicit GEMM — 9 instead of 25 multiply-adds per output element and channel, no P, no gather, no halo
-        st = None
-        if (_cfg().SUB_FWD and k == 5 and spikes_in and not lowp and act_dtype is None and bias is None and _cfg().EXACT_SPLIT_GEMM and not half_in
-                and x_cl.dtype == torch.float32 and Cin in _cfg().SUB_FWD_CIN and x_cl.is_cuda and _lib.upconv_sub_supported(Cin, Cout, k)
-                and NB * h * w * Cin < 2 ** 32):
-            st = sub_tables(tables, H, W)
+        st = sub_tables(tables, H, W) if sub32_ok else None
         if st is not None:
             if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
                 assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
@@ -950,22 +927,6 @@ class _UpConvProjectedCL(torch.autograd.Function):
             _lib.upconv_sub_fwd(None if x_packed is not None else x_cl, x_packed, wm, st, out, NB, Cin, Cout, h, w)
             TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
             _note('synapse_fwd', 'upconv_sub_mfma' + ('(packed in)' if x_packed is not None else ''))
-            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
-            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
-            ctx.exact = True
-            ctx.tables, ctx.k, ctx.n = tables, k, n
-            ctx.wshape = weight.shape
-            ctx.has_bias = False
-            return out
-        if form:
-            if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
-                assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
-            Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, form), dtype=torch.bfloat16, device=x_cl.device)
-            e0 = TIMER.start()
-            _lib.upconv_fused_prep_w(weight.contiguous(), Wf, Cin, Cout, form)
-            _lib.upconv_fused_fwd(None if x_packed is not None else x_cl, x_packed, Wf, src_y, src_x, out, NB, Cin, Cout, h, w, H, W, max_window, form)
-            TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
-            _note('synapse_fwd', f'upconv_fused{form}_mfma' + ('(packed in)' if x_packed is not None else ''))
             ctx.save_for_backward(x_cl, Wt, x_packed, weight)
             ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
             ctx.exact = True
@@ -1027,11 +988,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
                    and (ctx.x_dtype == torch.float32 or ctx.own16 is not None) and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
         # ---- round 5: the 16-bit activation modes on own kernels — the same box-sum backward on 16-bit I/O (box planes in the mode's format, ONE weight term)
         own16 = ctx.own16
-        box16_ok = (own16 is not None and ctx.ecfg.BOX_BWD and k == 5 and g16 and g_out.dtype == own16 and n >= NB and Cin in ctx.ecfg.BOX_BWD_CIN and (need_x or need_w)
-                    and (x_packed is not None or x_cl.dtype == own16))
-        if box16_ok:
+        box_geo = ctx.ecfg.BOX_BWD and k == 5 and ctx.stage_plan['box_bwd'] and (need_x or need_w)
+        if box_geo:
             bt = box_tables(ctx.tables, H, W)
-            box16_ok = (not need_x or _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt, NB, h, w)) and (not need_w or _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt, NB, h, w))
+            box_geo = _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt, NB, h, w) and _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt, NB, h, w)     # (+ the launch limits at this NB)
+        box16_ok = bool(box_geo and own16 is not None and g16 and g_out.dtype == own16 and (x_packed is not None or x_cl.dtype == own16))
         if box16_ok:
             e0 = TIMER.start()
             e1 = TIMER.start()
@@ -1054,14 +1015,10 @@ class _UpConvProjectedCL(torch.autograd.Function):
             if g_x is not None and g_x.dtype != ctx.x_dtype:
                 g_x = g_x.to(ctx.x_dtype)
             g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None, None
+            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
         # ---- round 4: the whole stage backward on the box-sum image (ss_upconv_box.hip): one HBM-bound box-sum launch, then both contractions as implicit
         #      GEMMs over its three bf16 planes — no per-tap tensor g_P in HBM or on chip, no per-fragment operand arithmetic
-        box_ok = (ctx.ecfg.BOX_BWD and k == 5 and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and n >= NB and not lowrank and Cin in ctx.ecfg.BOX_BWD_CIN
-                  and (need_x or need_w) and (x_packed is not None or x_cl.dtype == torch.float32))
-        if box_ok:
-            bt = box_tables(ctx.tables, H, W)
-            box_ok = (not need_x or _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt, NB, h, w)) and (not need_w or _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt, NB, h, w))
+        box_ok = bool(box_geo and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and not lowrank and (x_packed is not None or x_cl.dtype == torch.float32))
         if box_ok:
             e0 = TIMER.start()                                                   # the stage's whole backward ('upconv_cl_bwd', as every other form) ...
             e1 = TIMER.start()                                                   # ... and its three launches one by one ('box_*': inside the former, not additional)
@@ -1085,7 +1042,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 g_x = g_x.to(ctx.x_dtype)
             # a stage built with bias=True (NNConvUpsampling accepts it; the shipped decoder stages have none): its gradient as in every other form
             g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None, None
+            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
         g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
@@ -1096,30 +1053,11 @@ class _UpConvProjectedCL(torch.autograd.Function):
         for c0 in range(0, NB, n):
             c1 = min(NB, c0 + n)
             rows = (c1 - c0) * h * w
-            # data gradient with g_P on chip only: adjoint gather + six-term MFMA contraction in one kernel (ss_upconv_bwd_dgrad_f32)
-            dgrad_fused = (ctx.ecfg.FUSED_UPCONV_DGRAD and need_x and not lowrank and not lowp and not g16 and k == 5 and g_out.dtype == torch.float32
-                           and Cin in ctx.ecfg.FUSED_UPCONV_DGRAD_CIN and _lib.upconv_bwd_dgrad_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
-            fused_bwd = (ctx.ecfg.FUSED_UPCONV_BWD and need_w and ctx.exact and not lowp and not g16 and k == 5 and x_cl.dtype == torch.float32
-                         and Cin in (ctx.ecfg.FUSED_UPCONV_BWD_CIN_NOGP if dgrad_fused else ctx.ecfg.FUSED_UPCONV_BWD_CIN)
-                         and _lib.upconv_bwd_fused_supported(Cin, Cout, k, adjoint_extents(ctx.tables)))
-            stage_pk = x_packed is not None and k == 5               # a stage whose input exists only as packed spikes
-            if stage_pk and need_w and not (fused_bwd and c0 == 0 and c1 == NB):
-                # the fused adjoint + weight-gradient kernel reads the packed form; every other weight-gradient form reads the dense tensor
+            if x_packed is not None and k == 5 and need_w:
+                # a stage whose input arrived as packed spikes and whose geometry the box-sum kernels do not take: the g_P forms read the dense tensor
                 # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one)
-                x_cl, x_packed, stage_pk = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None, False
-            if dgrad_fused:
-                _lib.upconv_bwd_dgrad(g_out[c0:c1], Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous(), y_lo, y_hi, x_lo, x_hi,
-                                      g_x[c0:c1], c1 - c0, Cin, Cout, h, w, H, W)
-            if dgrad_fused and (fused_bwd or not need_w):
-                g_P = None                                                        # the per-tap gradient tensor never reaches HBM
-                if fused_bwd:
-                    _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, None, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True,
-                                          x_packed=x_packed if stage_pk else None)
-            elif fused_bwd:
-                g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
-                _lib.upconv_bwd_fused(g_out[c0:c1], x_cl[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, g_Wt, c1 - c0, Cin, Cout, h, w, H, W, accumulate=True,
-                                      x_packed=x_packed if stage_pk else None)
-            elif lowp and k == 5:
+                x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None
+            if lowp and k == 5:
                 # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
                 _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
@@ -1132,42 +1070,29 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
                 if lowp:
                     g_P = g_P.to(torch.bfloat16)
+            # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy) where the fp32 library GEMM is compute-bound: wide stages
+            # (measured: C_in 64 — deconv1 — is faster on the library's fp32 GEMM, 1.63 vs 2.48 ms, profiles/r04/bench_box_bwd_v5.log)
+            gemm6 = bool(need_x and not lowrank and not lowp and ctx.ecfg.GEMM6_DGRAD and Cin >= 128 and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin))
             if lowrank:
                 g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
-            elif dgrad_fused:
-                pass                                                              # g_x written by the fused kernel above
-            elif need_x and not lowp and ctx.ecfg.GEMM6_DGRAD and Cin in ctx.ecfg.GEMM6_DGRAD_CIN and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin):
-                # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy): the fp32 GEMM is compute-bound here
+            elif gemm6:
                 _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
             elif need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
-            if fused_bwd:
-                pass                                                              # g_Wt accumulated by the fused kernel above
-            elif need_w and x_packed is not None and k == 3:
+            spike_wgrad = bool(need_w and ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32 and _lib.spike_wgrad_supported(Cin, kk * Cout))
+            if need_w and x_packed is not None and k == 3:
                 _lib.head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=True)     # reads the 2-bit packed spikes (1/16 of the dense tensor)
-            elif (need_w and ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32
-                    and Cin in ctx.ecfg.EXACT_WGRAD_MFMA_CIN and _lib.spike_wgrad_supported(Cin, kk * Cout)):
+            elif spike_wgrad:
                 # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
                 _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)
-            elif need_w and ctx.exact and not lowp and Cin >= ctx.ecfg.EXACT_SPLIT_WGRAD_MIN_K:
-                # x is a spike tensor: g_Wt = x^T @ (gh + gm + gl) with exact products on the bf16 MFMA path (one extra 10 B/element pass
-                # over g_P for the split — pays only where the GEMM is compute-bound, i.e. the widest stage)
-                g3 = torch.empty((rows, 3 * kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
-                _lib.split3_bf16(g_P, g3, rows, kk * Cout)
-                xb = x_cl[c0:c1].view(rows, Cin).to(torch.bfloat16)
-                S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if rows % d == 0)
-                gw3 = torch.bmm(xb.view(S, rows // S, Cin).transpose(1, 2), g3.view(S, rows // S, 3 * kk * Cout),
-                                out_dtype=torch.float32).sum(0) if S > 1 else torch.mm(xb.t(), g3, out_dtype=torch.float32)
-                g_Wt += gw3.view(Cin, 3, kk * Cout).sum(1)
-                del g3, gw3
             elif need_w:
                 xs = x_cl[c0:c1].view(rows, Cin)
                 if lowp and xs.dtype != torch.bfloat16:
                     xs = xs.to(torch.bfloat16)                                    # spikes: exact
                 elif not lowp and xs.dtype != torch.float32:
                     xs = xs.float()
-                S = max(1, rows // ctx.ecfg.WGRAD_SPLIT_ROWS)
+                S = max(1, rows // _WGRAD_SPLIT_ROWS)
                 L = rows // S
                 if S > 1:
                     g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout), **f32).sum(0)
@@ -1176,16 +1101,14 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 else:
                     g_Wt += torch.mm(xs.t(), g_P, **f32)
         TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
-        how_x = 'none' if not need_x else ('lowrank_pair' if lowrank else ('fused_adjoint+dgrad6_mfma' if dgrad_fused else ('adjoint+gemm6' if (
-            not lowp and ctx.ecfg.GEMM6_DGRAD and Cin in ctx.ecfg.GEMM6_DGRAD_CIN and _lib.gemm6_supported(kk * Cout, Cin)) else 'adjoint+library_gemm')))
-        how_w = 'none' if not need_w else ('fused_adjoint+wgrad3_mfma' if fused_bwd else ('head_wgrad_packed_mfma' if (x_packed is not None and k == 3) else (
-            'spike_wgrad_mfma' if (ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and Cin in ctx.ecfg.EXACT_WGRAD_MFMA_CIN) else 'library_gemm')))
+        how_x = 'none' if not need_x else ('lowrank_pair' if lowrank else ('adjoint+gemm6' if gemm6 else 'adjoint+library_gemm'))
+        how_w = 'none' if not need_w else ('head_wgrad_packed_mfma' if (x_packed is not None and k == 3) else ('spike_wgrad_mfma' if spike_wgrad else 'library_gemm'))
         _note('synapse_bwd', f'g_x: {how_x}; g_w: {how_w}' + ('; 16-bit' if (lowp or g16) else ''), ctx.site)
         g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
         g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if g_x is not None and g_x.dtype != ctx.x_dtype:
             g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None, None
+        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -1233,12 +1156,12 @@ class _SpikeConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             g3 = torch.empty((M, 3 * Cout), dtype=torch.bfloat16, device=g.device)
             _lib.split3_bf16(g, g3, M, Cout)
-            S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)   # split-K: the output is only K x 3*Cout
+            S = next(d for d in (_SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)   # split-K: the output is only K x 3*Cout
             if S > 1:
                 gw3 = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g3.view(S, M // S, 3 * Cout), out_dtype=torch.float32)      # [S, K, 3*Cout]
             else:
                 gw3 = torch.mm(A.t(), g3, out_dtype=torch.float32)                # [K, 3*Cout]
-            if ctx.ecfg.WGRAD_REDUCE3 and Cin % 8 == 0 and Cout % 32 == 0 and k <= 7:
+            if Cin % 8 == 0 and Cout % 32 == 0 and k <= 7:
                 # slices and terms summed and the Conv2d layout written by one kernel (instead of two torch reductions and a permuting copy)
                 g_w = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=g.device)
                 _lib.wgrad_reduce3(gw3, g_w, S, k, Cin, Cout)
@@ -1248,7 +1171,7 @@ class _SpikeConvCL(torch.autograd.Function):
                 g_w = gw3.view(K, 3, Cout).sum(1).view(k, k, Cin, Cout).permute(3, 2, 0, 1).contiguous()
         how_x = 'none'
         if ctx.needs_input_grad[0] and ctx.ecfg.WINOGRAD_DGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 4 == 0 and Cout % 4 == 0:
-            g_x = winograd_dgrad_cl(g, weight, ctx.ecfg.WINOGRAD_GEMM6)
+            g_x = winograd_dgrad_cl(g, weight)
             how_x = 'winograd_f2x2_3x3+batched_gemm'
         elif ctx.needs_input_grad[0] and ctx.ecfg.CONV_DGRAD_MFMA and _lib.conv_s2_dgrad_supported(Cin, Cout, k, stride, pad):
             g_x = conv_s2_dgrad_cl(g, weight, h, w)
@@ -1295,7 +1218,7 @@ def winograd_dgrad_cl(g: torch.Tensor, weight: torch.Tensor, gemm6: Optional[boo
     V = torch.empty((16, T, Cout), dtype=torch.float32, device=g.device)
     _lib.wino_dgrad_weights(weight.detach().float().contiguous(), U, Cout, Cin)
     _lib.wino_dgrad_input(g, V, NB, H, W, Cout)
-    if (_cfg().WINOGRAD_GEMM6 if gemm6 is None else gemm6) and _lib.gemm6_supported(Cout, Cin) and (T * Cout) % 4 == 0:
+    if gemm6 and _lib.gemm6_supported(Cout, Cin) and (T * Cout) % 4 == 0:      # (A/B only: the library's batched fp32 GEMM is faster, profiles/r04/bench_wino_gemm6_*.json)
         M = torch.empty((16, T, Cin), dtype=torch.float32, device=g.device)          # the 16 products on the bf16 matrix cores, six cross terms
         _lib.gemm6_batched(V, U, M, 16, T, Cout, Cin)
     else:
@@ -1559,7 +1482,7 @@ class _SpikeConvGemmCL16(torch.autograd.Function):
             _lib.im2col_cl_packed_x16(x_packed.contiguous(), A, NB, h, w, Cin, k, stride, pad, ho, wo)
         else:
             _lib.im2col_cl_x16(x_cl.to(adt).contiguous(), A, NB, h, w, Cin, k, stride, pad, ho, wo)
-        Wt = weight.detach().permute(2, 3, 1, 0).reshape(K, Cout).to(adt)            # rows (ky, kx, c): the im2col column order; rounded once
+        Wt = weight.detach().to(adt).permute(2, 3, 1, 0).reshape(K, Cout)            # rows (ky, kx, c): the im2col column order; rounded once
         y = torch.mm(A, Wt).view(NB, ho, wo, Cout)
         _note('synapse_fwd', 'im2col' + ('(packed in)' if x_packed is not None else '') + '+gemm1_x16')
         ctx.save_for_backward(A, weight)
@@ -1576,7 +1499,7 @@ class _SpikeConvGemmCL16(torch.autograd.Function):
         g = g.to(adt).contiguous()
         g_x = g_w = None
         if ctx.needs_input_grad[1]:
-            S = next(d for d in (ctx.ecfg.SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)
+            S = next(d for d in (_SPIKE_CONV_WGRAD_SPLIT, 4, 2, 1) if M % d == 0)
             g2 = g.view(M, Cout)
             if S > 1:
                 gw = torch.bmm(A.view(S, M // S, K).transpose(1, 2), g2.view(S, M // S, Cout), out_dtype=torch.float32).sum(0)
@@ -1593,7 +1516,7 @@ class _SpikeConvGemmCL16(torch.autograd.Function):
         elif ctx.needs_input_grad[0] and stride == 1 and 2 * pad == k - 1 and Cout % 8 == 0:
             Ag = torch.empty((NB * h * w, k * k * Cout), dtype=adt, device=g.device)
             _lib.im2col_cl_x16(g, Ag, NB, ho, wo, Cout, k, 1, pad, h, w)
-            Wd = weight.detach().flip(2, 3).permute(2, 3, 0, 1).reshape(k * k * Cout, Cin).to(adt)     # [(jy, jx, co)][ci] = W[co][ci][k-1-jy][k-1-jx]
+            Wd = weight.detach().to(adt).flip(2, 3).permute(2, 3, 0, 1).reshape(k * k * Cout, Cin)     # [(jy, jx, co)][ci] = W[co][ci][k-1-jy][k-1-jx]
             g_x = torch.mm(Ag, Wd).view(NB, h, w, Cin)
             how_x = 'im2col+gemm1_x16'
         elif ctx.needs_input_grad[0]:
@@ -1620,7 +1543,7 @@ def conv16_kind(conv, spikes_in: bool):
     if (k, s_, p_) == (5, 2, 2) and _lib.spike_conv_fwd_supported(conv.in_channels, conv.out_channels, 5, 2, 2) and _lib.spike_conv_wgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2) \
             and _lib.conv_s2_dgrad_supported(conv.in_channels, conv.out_channels, 5, 2, 2):
         return 's2'
-    if conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.in_channels >= _cfg().SPIKE_CONV_MIN_CIN:
+    if conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.in_channels >= _SPIKE_CONV_MIN_CIN:
         return 'gemm'
     return None
 
@@ -1649,7 +1572,7 @@ def spike_conv_applies(conv, device, dtype=torch.float32) -> bool:
     return bool(_cfg().EXACT_SPLIT_GEMM and device.type == 'cuda' and dtype == torch.float32 and not torch.is_autocast_enabled('cuda')
                 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and conv.kernel_size == (k, k)
                 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and not isinstance(conv.padding, str)
-                and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= _cfg().SPIKE_CONV_MIN_CIN)
+                and conv.in_channels % 8 == 0 and conv.out_channels % 4 == 0 and conv.in_channels >= _SPIKE_CONV_MIN_CIN)
 
 
 def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
@@ -1662,21 +1585,17 @@ def spike_conv_cl(x_cl: torch.Tensor, conv, x_packed: Optional[torch.Tensor] = N
 
 
 
-def stage_reads_packed(Cin: int, Cout: int, k: int, max_window: int) -> bool:
-    """True when a decoder stage (NNConvUpsampling, fp32 mode) reads its input as 2-bit packed spikes in forward (fused MFMA kernel) AND in its weight
-    gradient (fused adjoint + MFMA kernel), its data gradient needing no input at all — the producer may then write packed-only.  (Should a run-time
-    condition still send the stage down another form, _UpConvProjectedCL unpacks: correct, just not free.)"""
-    return bool(_cfg().PACK_SPIKES and _cfg().FUSED_UPCONV_MFMA and _cfg().EXACT_SPLIT_GEMM and k == 5 and _lib.upconv_fused_form(Cin, Cout, k, max_window) != 0
-                and _cfg().FUSED_UPCONV_BWD and _cfg().FUSED_UPCONV_DGRAD and Cin in _cfg().FUSED_UPCONV_DGRAD_CIN and Cin in _cfg().FUSED_UPCONV_BWD_CIN_NOGP)
-
-
-
-
-def stage_takes_packed_copy(Cin: int, Cout: int, k: int) -> bool:
-    """True when a decoder stage's sub-pixel forward (ss_upconv_sub_fwd_f32) and box-sum weight gradient read their input as 2-bit packed spikes when they
-    are given them: the producer then writes the packed form BESIDE its dense output (pack = 1: 0.25 B per element more) and the stage never touches the
-    dense tensor (32 x fewer input bytes, no fp32 -> bf16 conversion while staging)."""
-    return bool(_cfg().PACK_SPIKES and _cfg().SUB_FWD and _cfg().EXACT_SPLIT_GEMM and k == 5 and Cin in _cfg().SUB_FWD_CIN and _lib.upconv_sub_supported(Cin, Cout, k))
+def stage_takes_packed_copy(stage, h: int, w: int, device) -> bool:
+    """True when the decoder stage `stage` (an NNConvUpsampling with k = 5) reads its input as 2-bit packed spikes on an h x w source map: its sub-pixel forward
+    (ss_upconv_sub_fwd_*) and box-sum weight gradient read them when they are given them — the producer then writes the packed form (beside its dense output, or
+    instead of it when its other consumer reads packed spikes too) and the stage never touches a dense tensor (32 x fewer input bytes, no conversion while
+    staging).  Should the backward's geometry check still send the stage down the g_P forms, _UpConvProjectedCL unpacks: correct, just not free."""
+    conv = stage.up[1]
+    k = conv.kernel_size[0]
+    if not (_cfg().PACK_SPIKES and _cfg().SUB_FWD and _cfg().EXACT_SPLIT_GEMM and k == 5 and torch.device(device).type == 'cuda'):
+        return False
+    Hu, Wu = stage.up[0].size
+    return bool(stage_plan(stage._tables(h, w, device), conv.in_channels, conv.out_channels, k, h, w, Hu - k + 1, Wu - k + 1)['sub_fwd'])
 
 
 class _UnpackLastStep(torch.autograd.Function):
@@ -1702,23 +1621,21 @@ def unpack_last_step(anchor: torch.Tensor, packed: torch.Tensor) -> torch.Tensor
 
 
 def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, k: int, H: int, W: int, spikes_in: bool = False,
-                        max_window: int = 0, lowrank_grad: bool = False, x_packed: Optional[torch.Tensor] = None):
+                        lowrank_grad: bool = False, x_packed: Optional[torch.Tensor] = None):
     """Channels-last NNConvUpsampling: x_cl [NB, h, w, C_in] (plain contiguous NHWC array) -> [NB, H, W, C_out].
-    spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection.
-    max_window: largest source window (rows x columns) of any 16 x 16 output tile (NNConvUpsampling.max_tile_window); > 0 enables the
-    fused MFMA kernel for the stage shapes it is compiled for."""
+    spikes_in: the caller guarantees x_cl holds spike counts (small integers, exact in bf16) — enables the exact bf16x3 projection."""
     amp = x_cl.is_cuda and torch.is_autocast_enabled('cuda')
     adt = torch.get_autocast_dtype('cuda') if amp else None
     lowp = amp and adt == torch.bfloat16
     lowp_bwd = amp and adt in (torch.bfloat16, torch.float16)
     # decoder stages (k = 5) hand 16-bit activations to their neuron layer under 16-bit autocast; the heads (k = 3) feed the fp32 I-pool
-    act_dtype = adt if (lowp_bwd and k == 5 and _cfg().ACT16_GATHER) else None
+    act_dtype = adt if (lowp_bwd and k == 5) else None
     own16 = x16_mode(x_cl.device)
     if own16 is not None and k == 3 and x_packed is not None:
         # a prediction head on packed spikes in a 16-bit mode: the packed kernels with the exact fp32 weight, fp32 P and output (the head feeds the fp32 I-pool)
         lowp = lowp_bwd = False
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
-        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, max_window, lowrank_grad, x_packed, own16)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, lowrank_grad, x_packed, own16)
 
 
 _guard_module(__name__, 'fused')

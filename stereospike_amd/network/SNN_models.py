@@ -244,18 +244,13 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
                 C_out = stage[0].up[1].out_channels
                 head_pk = bool(lvl in (1, 2) and enc_cl and _cfg().PACK_SPIKES and _cfg().PACKED_HEAD and _cfg().FORK_OUTPUTS and (plain32(cur) or own16 is not None)
                                and _fused._lib.head_packed_supported(C_out, 1, 3))
-                if head_pk and lvl == 2:
-                    nxt = self.deconv1[0]
-                    hh, ww = stage[0].up[0].size[0] - 4, stage[0].up[0].size[1] - 4          # this stage's output = the next stage's input geometry
-                    if own16 is not None:       # (a stage whose run-time form cannot read packed spikes unpacks them: correct, just not free)
-                        head_pk = _cfg().PACKED_DECONV2 and _fused.stage_takes_packed_copy(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0])
-                    else:
-                        head_pk = _cfg().PACKED_DECONV2 and _fused.stage_reads_packed(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0], nxt.max_tile_window(hh, ww))
+                hh, ww = stage[0].up[0].size[0] - 4, stage[0].up[0].size[1] - 4              # this stage's output = the next stage's input geometry
+                if head_pk and lvl == 2:        # packed-only: its other consumer, deconv1, must read packed spikes too (a run-time form that cannot, unpacks)
+                    head_pk = _cfg().PACKED_DECONV2 and _fused.stage_takes_packed_copy(self.deconv1[0], hh, ww, cur.device)
                 # (round 4) a stage whose head needs the dense tensor still hands the next stage a packed COPY when that stage's sub-pixel forward reads one
                 copy_pk = False
                 if not head_pk and lvl > 1 and enc_cl and (plain32(cur) or own16 is not None):
-                    nxt = getattr(self, f'deconv{lvl - 1}')[0]
-                    copy_pk = _fused.stage_takes_packed_copy(C_out, nxt.up[1].out_channels, nxt.up[1].kernel_size[0])
+                    copy_pk = _fused.stage_takes_packed_copy(getattr(self, f'deconv{lvl - 1}')[0], hh, ww, cur.device)
                 with _config.layer(f'deconv{lvl}'):
                     r = stage.forward_sequence_cl(cur, skip, nnz(f'deconv{lvl}'), spikes_in=True, fork=_cfg().FORK_OUTPUTS,
                                                   skip_packed=enc_pk[lvl - 1] if enc_cl else None, pack=2 if head_pk else (1 if copy_pk else 0), x_packed=prev_pk)

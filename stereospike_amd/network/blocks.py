@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import config as _config
 from ..clock_driven import neuron, surrogate
 from ..config import current as _cfg
-from ..fused import nearest_tables, register_box_tables, register_extents, register_sub_tables, upconv_projected, upconv_projected_cl
+from ..fused import nearest_tables, register_box_tables, register_sub_tables, upconv_projected, upconv_projected_cl
 
 
 # Execution layout (fields of config.EngineConfig; reads of `blocks.<NAME>` answer with the configuration in effect, assignments are refused):
@@ -82,9 +82,8 @@ class NNConvUpsampling(_UpConv):
             Hu, Wu = self.up[0].size
             ty, tx = nearest_tables(h, Hu), nearest_tables(w, Wu)
             cache[key] = tuple(t.to(device) for t in (ty + tx))
-            register_extents(cache[key], ty + tx)              # host-side, from the CPU copies: backward never reads a table back
             k = self.up[1].kernel_size[0]
-            if k == 5:                                         # decoder stages: the index tables of the box-sum backward (ss_upconv_box.hip)
+            if k == 5:                                         # decoder stages (host-side, from the CPU copies: backward never reads a table back): the index tables of the box-sum backward (ss_upconv_box.hip)
                 register_box_tables(cache[key], ty + tx, Hu - k + 1, Wu - k + 1)
                 register_sub_tables(cache[key], ty + tx, Hu - k + 1, Wu - k + 1)      # ... and of the sub-pixel forward (ss_upconv_sub.hip)
         return cache[key]
@@ -97,21 +96,6 @@ class NNConvUpsampling(_UpConv):
                                 Hu - k + 1, Wu - k + 1)
 
 
-    def max_tile_window(self, h, w, tile=16):
-        """Largest low-resolution window (rows x columns) a tile x tile block of output pixels reads through the k x k taps — decides
-        whether the fused MFMA kernel (<= 128 source pixels per workgroup) applies to this geometry.  Host-side, cached."""
-        cache = self.__dict__.setdefault('_win_cache', {})
-        if (h, w, tile) not in cache:
-            k = self.up[1].kernel_size[0]
-            Hu, Wu = self.up[0].size
-
-            def extent(n_in, n_up):
-                src = nearest_tables(n_in, n_up)[0]
-                n_out = n_up - k + 1
-                return max(int(src[min(o + tile - 1, n_out - 1) + k - 1]) - int(src[o]) + 1 for o in range(0, n_out, tile))
-            cache[(h, w, tile)] = extent(h, Hu) * extent(w, Wu)
-        return cache[(h, w, tile)]
-
     def forward_projected_cl(self, x_cl: torch.Tensor, spikes_in: bool = False, lowrank_grad: bool = False,
                              x_packed: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_cl [NB, h, w, C_in] (contiguous NHWC array) -> [NB, H, W, C_out] (NHWC array).  spikes_in: x_cl is a spike tensor.
@@ -121,9 +105,8 @@ class NNConvUpsampling(_UpConv):
         conv = self.up[1]
         k = conv.kernel_size[0]
         Hu, Wu = self.up[0].size
-        win = self.max_tile_window(x_cl.shape[1], x_cl.shape[2]) if (spikes_in and k == 5) else 0
         return upconv_projected_cl(x_cl, conv.weight, conv.bias, self._tables(x_cl.shape[1], x_cl.shape[2], x_cl.device),
-                                   k, Hu - k + 1, Wu - k + 1, spikes_in, win, lowrank_grad, x_packed)
+                                   k, Hu - k + 1, Wu - k + 1, spikes_in, lowrank_grad, x_packed)
 
 
 class BilinConvUpsampling(_UpConv):

@@ -27,14 +27,14 @@ def test_header_declares_the_expected_entry_points():
                                   # ABI 2
                                   'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes',
                                   'ss_im2col_cl_bf16_packed',
-                                  'ss_upconv_fused_supported', 'ss_upconv_fused_wf_elems', 'ss_upconv_fused_prep_w', 'ss_upconv_fused_fwd_f32',
+                                  
                                   # ABI 3
-                                  'ss_upconv_fused2_supported', 'ss_upconv_fused2_wf_elems', 'ss_upconv_fused2_prep_w',
-                                  'ss_upconv_fused2_fwd_f32', 'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32',
+                                  
+                                  'ss_wino_dgrad_weights_f32', 'ss_wino_dgrad_input_f32',
                                   'ss_wino_dgrad_output_f32', 'ss_spike_wgrad_supported', 'ss_spike_wgrad_ws_floats', 'ss_spike_wgrad_f32',
-                                  'ss_upconv_fused2_prep_w_x16', 'ss_upconv_fused2_fwd_x16', 'ss_upconv_bwd_fused_supported',
-                                  'ss_upconv_bwd_fused_ws_floats', 'ss_upconv_bwd_fused_f32', 'ss_upconv_bwd_dgrad_supported',
-                                  'ss_upconv_bwd_dgrad_ws_floats', 'ss_upconv_bwd_dgrad_f32', 'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats',
+                                  
+                                  
+                                  'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats',
                                   'ss_spike_conv_fwd_f32', 'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32', 'ss_gemm6_supported', 'ss_gemm6_ws_floats',
                                   'ss_gemm6_f32', 'ss_gemm6_batched_f32', 'ss_spike_conv_wgrad_supported',
                                   'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',

@@ -73,20 +73,25 @@ DEFAULT_PLAN = {
 
 def assert_default_plan(plan, full_resolution=False):
     """The dispatch plan of a default fp32 run (`assert_default_kernels` checks the plan as well as the launch tags): every encoder /
-    bottleneck / head layer on the kernel form named above; the decoder stages on the fused MFMA forward where the geometry is compiled (deconv1 / deconv2)
-    and — deconv1 / deconv2 (EngineConfig.BOX_BWD_CIN), where the box-sum kernels' window holds the geometry — on the box-sum backward."""
+    bottleneck / head layer on the kernel form named above; the decoder stages by their GEOMETRY (fused.stage_plan, round 5): the sub-pixel forward on every
+    stage but the small wide ones (deconv4 always; deconv3 on the 64x80 pyramid's 8x10 source map), the box-sum backward on deconv1 / deconv2 where the kernels'
+    on-chip window holds the geometry, the per-tap g_P forms elsewhere."""
     for name, (fwd, bwd) in DEFAULT_PLAN.items():
         assert plan[name]['synapse_fwd'] == fwd and plan[name]['synapse_bwd'] == bwd, (name, plan[name])
-    for lvl in (1, 2, 3):                                                  # round 4: the sub-pixel (merged tap) implicit GEMM on the packed spikes
-        assert plan[f'deconv{lvl}']['synapse_fwd'] == 'upconv_sub_mfma(packed in)', plan[f'deconv{lvl}']
-    assert plan['deconv4']['synapse_fwd'] == 'exact_bf16x3_gemm+gather', plan['deconv4']
+    sub = (1, 2, 3) if full_resolution else (1, 2)
+    for lvl in (1, 2, 3, 4):                                               # round 4: the sub-pixel (merged tap) implicit GEMM on the packed spikes
+        want = 'upconv_sub_mfma(packed in)' if lvl in sub else 'exact_bf16x3_gemm+gather'
+        assert plan[f'deconv{lvl}']['synapse_fwd'] == want, (lvl, plan[f'deconv{lvl}'])
     box = [lvl for lvl in (1, 2, 3, 4) if plan[f'deconv{lvl}']['synapse_bwd'].startswith('box: boxsum+dgrad6_mfma+wgrad3_mfma')]
-    # (64x80 frames: deconv1's 32 source columns reach 84 horizontal ranges, more than the on-chip window's 76 — that stage keeps the round-3 fused forms)
+    # (64x80 frames: deconv1's 32 source columns reach 84 horizontal ranges, more than the on-chip window's 76 — that stage runs the g_P forms there)
     assert set(box) == ({1, 2} if full_resolution else {2}), {lvl: plan[f'deconv{lvl}']['synapse_bwd'] for lvl in (1, 2, 3, 4)}
+    for lvl in (1, 2, 3, 4):
+        if lvl not in box:
+            assert plan[f'deconv{lvl}']['synapse_bwd'] == ('g_x: adjoint+gemm6; g_w: spike_wgrad_mfma' if lvl >= 2 else 'g_x: adjoint+library_gemm; g_w: spike_wgrad_mfma'), plan[f'deconv{lvl}']
     assert len(plan) == 17 and all('neuron_fwd' in v and 'neuron_bwd' in v for k, v in plan.items() if not k.startswith('predict'))
 
 
-def assert_default_kernels(tags, T, penalized=False):
+def assert_default_kernels(tags, T, penalized=False, full_resolution=False):
     """The launch tags of one forward + backward of a 13-layer spiking network in the shipped default configuration at a compile-time T:
     packed-only outputs on the seven edges into exact-split / implicit-GEMM convs, packed skip operands, forked gradients on conv1..3, the four heads'
     gradients as rank-9 pairs (+ the full-resolution pair travelling on into the first encoder layer), nothing on the saved-h forms."""
@@ -99,7 +104,9 @@ def assert_default_kernels(tags, T, penalized=False):
     assert fwd.get('neuron_fwd_train+packed', 0) == 7 and fwd.get('neuron_fwd_train+skip+packed', 0) == 3, tags      # SEW inner layer, deconv2, deconv1
     # (round 4: deconv4 and deconv3 write a packed COPY beside their dense output — the head reads the dense tensor, the next stage's sub-pixel forward
     #  the packed one; the SEW block's last layer, the bottleneck output, stays dense only)
-    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 1 and fwd.get('neuron_fwd_train+skip+pkcopy', 0) == 2, tags
+    # (64x80 pyramid: deconv3's 8x10 source map stays on GEMM + gather, so deconv4 writes no packed copy for it)
+    n_copy = 2 if full_resolution else 1
+    assert fwd.get('neuron_fwd_train', 0) == 0 and fwd.get('neuron_fwd_train+skip', 0) == 3 - n_copy and fwd.get('neuron_fwd_train+skip+pkcopy', 0) == n_copy, tags
     assert tags.get('spike_conv_fwd', 0) == 2, tags                       # conv1 / conv2 forward: the exact MFMA implicit GEMM on the packed spikes
     assert tags.get('dense_conv_s1_fwd', 0) == 1, tags                    # the first layer's forward: six-term MFMA implicit GEMM
     assert tags.get('conv_s2_dgrad', 0) == 4, tags                        # conv1 .. conv4 data gradient: six-term MFMA implicit GEMM (no MIOpen igemm_bwd)
@@ -198,7 +205,7 @@ def test_pinned_parity_full_resolution_stereospike_T5():
     orc, net = pair('StereoSpike', 260, 346, seed=int(z['seed']))
     assert state_sha(orc) == str(z['state_sha'])
     rep = pinned_parity(orc, net, x, gt)
-    assert_default_kernels(rep['launch_tags'], 5)
+    assert_default_kernels(rep['launch_tags'], 5, full_resolution=True)
     assert_default_plan(rep['plan'], full_resolution=True)
     check('pinned_full_stereospike_T5', rep)
     # statistics of the free-running product against the reference's fixture (chaotic per neuron, stable in the mean)
@@ -218,7 +225,7 @@ def test_pinned_parity_config3_step_B16_T5():
     x = synth_input(16, 5, 4, 2021)
     gt = synth_label(16, 2022)
     rep = pinned_parity(orc, net, x, gt, oracle_chunk=2, oracle_procs=True)
-    assert_default_kernels(rep['launch_tags'], 5)
+    assert_default_kernels(rep['launch_tags'], 5, full_resolution=True)
     assert_default_plan(rep['plan'], full_resolution=True)
     check('pinned_config3_B16_T5', rep)
 
@@ -253,7 +260,7 @@ def test_packed_spike_tensors_are_in_effect():
     for st in (net.bottom[2], net.conv1[2], net.conv2[2], net.conv3[2], net.conv4[2], net.bottleneck[0].sn1, net.bottleneck[0].sn2, net.bottleneck[1].sn1):
         assert st.last_packed is not None and st.last_packed.dtype == torch.int32                # packed only: every consumer reads the packed form
     assert net.bottleneck[1].sn2.last_packed is None                                            # dense only
-    assert net.deconv4[2].last_packed is not None and any(s[1].stride())                        # dense + packed copy (deconv3's sub-pixel forward reads it)
+    assert net.deconv4[2].last_packed is None and any(s[1].stride())                            # dense only HERE: deconv3's 8x10 source map stays on GEMM + gather (fused.stage_plan); at 260x346 deconv4 writes a packed copy
     # deconv3: dense (its head reads it) + a packed COPY for deconv2's sub-pixel forward / weight gradient (round 4), bit-identical contents
     pk3 = net.deconv3[2].last_packed
     assert pk3 is not None and pk3.dtype == torch.int32 and tuple(s[2].shape) == (2, 128, H // 4, W // 4) and any(s[2].stride())

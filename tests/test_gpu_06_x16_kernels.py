@@ -303,8 +303,8 @@ def test_upconv_sub_forward_x16(dt, Cin, Cout, hw, HW, NB):
 @pytest.mark.parametrize('dt', DTS, ids=IDS)
 @pytest.mark.parametrize('Cin,Cout,hw,HW,NB', GEOS)
 def test_upconv_box_kernels_x16(dt, Cin, Cout, hw, HW, NB):
-    """Decoder stage backward on the box-sum image in the 16-bit modes (autograd of /root/reference/network/blocks.py:110-132): the box planes sum to the
-    fp32 box sum of the widened gradients within the planes' precision (bf16: hi + lo, 2^-16; fp16: one plane, 2^-11); data gradient and weight gradient are
+    """Decoder stage backward on the box-sum image in the 16-bit modes (autograd of /root/reference/network/blocks.py:110-132): the box plane is the fp32 box sum of the
+    widened gradients (the fp32 kernel's summation order) rounded once to the format; data gradient and weight gradient are
     held against float64 evaluated from the planes AS STORED and the weight rounded once."""
     from oracle import np_upconv_box as nbx
     from stereospike_amd import _lib, fused
@@ -322,12 +322,11 @@ def test_upconv_box_kernels_x16(dt, Cin, Cout, hw, HW, NB):
     g[:, : H // 5] = 0
     wt = up.up[1].weight.detach().contiguous()
     NP = _lib.upconv_box_planes_x16(dt)
-    assert NP == (2 if dt == torch.bfloat16 else 1)
+    assert NP == 1
     box = _lib.upconv_boxsum_x16(g, bt, NB, Cout, H, W)
     assert box.shape == (NB, Cout // 8, NP, len(vr), len(hr), 8)
     B32 = torch.tensor(nbx.boxsum(g.float().cpu().numpy(), vr, hr), device=DEV)                 # [NB, NVR, NHR, Cout] fp32, the fp32 kernel's summation order
     Beff = box.double().sum(2).permute(0, 2, 3, 1, 4).reshape(NB, len(vr), len(hr), Cout)        # the planes as stored
-    assert bool(((Beff - B32.double()).abs() <= B32.double().abs() * (2.0 ** -16 if NP == 2 else 2.0 ** -11) * (1 + 1e-6) + (2.0 ** -24 if dt == torch.float16 else 0)).all())
     assert torch.equal(box[:, :, 0], B32.view(NB, len(vr), len(hr), Cout // 8, 8).permute(0, 3, 1, 2, 4).to(dt))      # the first plane is the once-rounded fp32 box sum
     vm, hm = torch.tensor(vmap, device=DEV, dtype=torch.long), torch.tensor(hmap, device=DEV, dtype=torch.long)
     w64 = rt(wt, dt)

@@ -149,9 +149,9 @@ def host_backend(monkeypatch):
     monkeypatch.setattr(_lib, 'ipool_fwd', ipool_fwd)
     monkeypatch.setattr(_lib, 'ipool_bwd', ipool_bwd)
     monkeypatch.setattr(_lib, 'gk_ws_floats', lambda: 1)
-    # the host back end has no MFMA kernels: EXACT_SPLIT_GEMM (torch.mm(bf16, bf16, out_dtype=fp32) exists on the GPU only), ss_gemm6_f32, the fused adjoint +
-    # data-gradient kernel and the box-sum backward are configured off — through the engine configuration, which the networks built inside capture
-    with _config.engine_config(EXACT_SPLIT_GEMM=False, GEMM6_DGRAD=False, FUSED_UPCONV_DGRAD=False, BOX_BWD=False):
+    # the host back end has no MFMA kernels: EXACT_SPLIT_GEMM (torch.mm(bf16, bf16, out_dtype=fp32) exists on the GPU only), ss_gemm6_f32
+    # and the box-sum backward are configured off — through the engine configuration, which the networks built inside capture
+    with _config.engine_config(EXACT_SPLIT_GEMM=False, GEMM6_DGRAD=False, BOX_BWD=False):
         yield
 
 
@@ -285,8 +285,9 @@ def test_engine_config_is_owned_by_the_network_and_the_plan_is_recorded(host_bac
         EngineConfig.default().replace(NO_SUCH_KNOB=1)
     with pytest.raises(Exception):
         EngineConfig.default().PACK_SPIKES = False                                      # frozen
-    e = EngineConfig.from_env({'SS_BOX_BWD': '0', 'SS_GEMM6_CIN': '256,512', 'SS_PACKED_HEAD': '0'})
-    assert (e.BOX_BWD, e.GEMM6_DGRAD_CIN, e.PACKED_HEAD, e.PACK_SPIKES) == (False, (256, 512), False, True)
+    e = EngineConfig.from_env({'SS_BOX_BWD': '0', 'SS_X16_OWN_KERNELS': '0', 'SS_PACKED_HEAD': '0'})
+    assert (e.BOX_BWD, e.X16_OWN_KERNELS, e.PACKED_HEAD, e.PACK_SPIKES) == (False, False, False, True)
+    assert len(config.KNOBS) <= 25                                                      # (44 knobs before the round-5 pruning)
     H, W = 48, 64
     orc, net_a = _pair('StereoSpike', H, W)
     _, net_b = _pair('StereoSpike', H, W)

@@ -24,19 +24,14 @@ for _ in range(5):
         _lib.neuron_fwd(x, None, None, out, h, v, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
         _lib.neuron_bwd(g, None, h, None, gx, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
 if mode == 'rc':
-    # round 2: (a) the packed-only forward (x 4 B + packed 0.25 B per update), (b) the fused projection + gather MFMA kernel at the
-    # deconv1 geometry of config 3 (80 frames, 130x173x64 -> 260x346x32)
+    # round 2: the packed-only forward (x 4 B + packed 0.25 B per update); the decoder kernels below run at the deconv1 geometry of config 3
+    # (80 frames, 130x173x64 -> 260x346x32)
     pk = torch.empty(T, N // 16, dtype=torch.int32, device=dev)
     NB, h, w, H, W, Cin, Cout = 80, 130, 173, 260, 346, 64, 32
     from stereospike_amd.network.blocks import NNConvUpsampling
     up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(dev)
     xs = (torch.rand(NB, h, w, Cin, device=dev) < 0.4).float()
     tabs = up._tables(h, w, torch.device(dev))
-    win = up.max_tile_window(h, w)
-    Wf = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout), dtype=torch.bfloat16, device=dev)
-    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf, Cin, Cout)
-    Wf2 = torch.empty(_lib.upconv_fused_wf_elems(Cin, Cout, 2), dtype=torch.bfloat16, device=dev)       # the shipped (second) kernel form
-    _lib.upconv_fused_prep_w(up.up[1].weight.detach().contiguous(), Wf2, Cin, Cout, 2)
     o = torch.empty(NB, H, W, Cout, device=dev)
     # round 2, last: the backward whose second gradient is a prediction head's rank-9 pair (ss_neuron_bwd_fork_lr_f32; 13.125 B/update at C = 32)
     lr_p, lr_w = torch.randn(T, N // 32, 9, device=dev), torch.randn(9, 32, device=dev)
@@ -44,16 +39,9 @@ if mode == 'rc':
         _lib.neuron_bwd_fork_lr(g, lr_p, lr_w, None, None, x, None, gx, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
     for _ in range(5):
         _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
-        _lib.upconv_fused_fwd(xs, None, Wf, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win)
-        _lib.upconv_fused_fwd(xs, None, Wf2, tabs[0], tabs[3], o, NB, Cin, Cout, h, w, H, W, win, 2)
-    # round 3: the decoder backward of deconv1 with g_P on chip only: adjoint + data gradient (ss_upconv_bwd_dgrad_f32), adjoint + weight gradient
-    # without its g_P store (ss_upconv_bwd_fused_f32, g_P = NULL)
     gy = torch.randn(NB, H, W, Cout, device=dev)
-    gxs, gw = torch.empty(NB, h, w, Cin, device=dev), torch.empty(Cin, 25 * Cout, device=dev)
+    gxs = torch.empty(NB, h, w, Cin, device=dev)
     wt = up.up[1].weight.detach().contiguous()
-    for _ in range(5):
-        _lib.upconv_bwd_dgrad(gy, wt, tabs[1], tabs[2], tabs[4], tabs[5], gxs, NB, Cin, Cout, h, w, H, W)
-        _lib.upconv_bwd_fused(gy, xs, tabs[1], tabs[2], tabs[4], tabs[5], None, gw, NB, Cin, Cout, h, w, H, W)
     # round 3: conv1's forward as the exact MFMA implicit GEMM on the packed spikes (ss_spike_conv_fwd_f32), the first layer's forward (ss_dense_conv_s1_fwd_f32)
     xb = (torch.rand(NB, H, W, 32, device=dev) < 0.3).float()
     import numpy as np
