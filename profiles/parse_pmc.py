@@ -14,6 +14,10 @@ mode = sys.argv[2] if len(sys.argv) > 2 else 'rc'
 
 
 def key_of(name):
+    if 'neuron_fwd16_kernel' in name:
+        return 'neuron_fwd_x16_packed'
+    if 'neuron_bwd16_rc_kernel' in name:
+        return 'neuron_bwd_x16_lr'
     if 'neuron_fwd_kernel' in name:
         import re
         m = re.search(r'neuron_fwd_kernel<([^>]*)>', name)
@@ -78,6 +82,32 @@ def mean_counter(sub, counter):
 fetch, nf = mean_counter('fetch', 'FETCH_SIZE')
 write, nw = mean_counter('write', 'WRITE_SIZE')
 T, N = 5, 16 * 32 * 260 * 346
+if mode == 'x16':
+    # the 16-bit activation modes' own kernels (bf16), same shapes as the fp32 table below: algorithmic bytes with 2-byte activations, ONE weight term, one box plane
+    planes1 = 80 * 4 * 1 * 278 * 364 * 8 * 2
+    alg = {'neuron_fwd_x16_packed': int(2.25 * T * N), 'neuron_bwd_x16_lr': int((6 + 36 / 32) * T * N),
+           'dense_conv_s1_fwd': 4 * 80 * 260 * 346 * 4 + 2 * 80 * 260 * 346 * 32 + 4 * 25 * 4 * 32,
+           'dense_conv_s1_wgrad': 2 * 80 * 260 * 346 * 32 + 4 * 80 * 260 * 346 * 4 + 4 * 1024 * 4 * 32 * 128,
+           'spike_conv_fwd': 80 * 260 * 346 * 32 // 4 + 2 * 80 * 130 * 173 * 64 + 2 * 25 * 32 * 64,
+           'conv_s2_dgrad': 2 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 25 * 32 * 64,
+           'upconv_sub': 80 * 130 * 173 * 64 // 4 + 2 * 80 * 260 * 346 * 32 + 2 * 25 * 18 * 512 * 4,
+           'upconv_boxsum': 2 * 80 * 260 * 346 * 32 + planes1, 'upconv_box_dgrad': planes1 + 2 * 80 * 130 * 173 * 64 + 2 * 26 * 64 * 32,
+           'upconv_box_wgrad': planes1 + 2 * 80 * 130 * 176 * 64 + 4 * 128 * 25 * 32 * 64}
+    res = {'workload': 'config-3 shapes (80 frames), bf16 activations, tools/pmc_target.py x16', 'mode': mode, 'algorithmic_bytes_per_launch': alg,
+           'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported; separate --pmc passes'}
+    for k in alg:
+        if k in fetch and k in write:
+            hbm = (2 * fetch[k] + write[k]) * 1024
+            res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]], 'hbm_read_bytes': int(2 * fetch[k] * 1024),
+                      'hbm_write_bytes': int(write[k] * 1024), 'hbm_bytes_per_launch': int(hbm), 'ratio_to_algorithmic': round(hbm / alg[k], 4)}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from stereospike_amd import _lib
+        res['source'] = {'lib_source_hash': _lib.source_hash(), 'tree_source_hash': _lib.tree_source_hash(), 'git_head': os.environ.get('SS_GIT_HEAD', 'unknown')}
+    except Exception as e:                                                # noqa: BLE001
+        res['source'] = {'error': repr(e)}
+    print(json.dumps(res, indent=1))
+    sys.exit(0)
 per_update = {'neuron_fwd': 8 if mode == 'rc' else 12, 'neuron_bwd': 16 if mode == 'rc' else 12}
 res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, tools/pmc_target.py {mode}',
        'mode': mode, 'algorithmic_bytes_per_update': per_update,

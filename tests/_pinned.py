@@ -215,11 +215,12 @@ def launch_tags():
     return {k: v['launches'] for k, v in fused.TIMER.summary().items()}
 
 
-def narrowing_points(amp_dtype, own=True):
+def narrowing_points(amp_dtype, own=True, plan=None):
     """Where the product's 16-bit activation modes store 16-bit values / use 16-bit weights (module name -> (weight dtype, output dtype)).
     own=True — the shipped path since round 5 (EngineConfig.X16_OWN_KERNELS: every synapse on the engine's own single-term kernels, ABI 9):
-      encoder + bottleneck convs, decoder stages deconv1 .. deconv3 (sub-pixel forward): weight rounded ONCE to the mode's dtype inside the kernel's weight
-        preparation, output stored in the mode's dtype;
+      encoder + bottleneck convs, decoder stages on the sub-pixel forward (deconv1 .. deconv3 at 260x346; `plan` = the product run's net.plan() says which stages
+        took it on the geometry at hand — the 64x80 pyramid's deconv3 does not): weight rounded ONCE to the mode's dtype inside the kernel's weight preparation,
+        output stored in the mode's dtype;
       deconv4 (projection GEMM + gather, stereospike_amd/fused.py::_UpConvProjectedCL): output in the mode's dtype; weight rounded to bf16 in the bf16 mode,
         the EXACT fp32 weight in the fp16 mode (exact bf16x3 split);
       prediction heads (k = 3, fp32 output — they feed the fp32 I-pool): heads 1 / 2 read packed spikes with the exact fp32 weight; heads 3 / 4 as deconv4.
@@ -230,7 +231,9 @@ def narrowing_points(amp_dtype, own=True):
         if name.startswith('predict_depth'):
             return (None if (own and name[13] in '12') else dec_w), None
         if name.startswith('deconv'):
-            return (amp_dtype if (own and name[6] in '123') else dec_w), amp_dtype
+            stage = name.split('.')[0]
+            sub = (plan[stage].get('synapse_fwd', '').startswith('upconv_sub_mfma_x16') if (plan is not None and stage in plan) else stage[6] in '123')
+            return (amp_dtype if (own and sub) else dec_w), amp_dtype
         return amp_dtype, amp_dtype
     return policy
 
@@ -282,7 +285,7 @@ def pinned_parity(orc, net, x, gt, returns_spikes=True, is_ann=False, amp_dtype=
     orc.zero_grad()
     plif, stats = {}, {}
     B = x.shape[0]
-    narrow = narrowing_points(amp_dtype, x16_own) if amp_dtype is not None else None
+    narrow = narrowing_points(amp_dtype, x16_own, net.plan() if hasattr(net, 'plan') else None) if amp_dtype is not None else None
     if oracle_chunk is None or oracle_chunk >= B:
         res_o, _ = run_oracle_pinned(orc, x, z_by_node, float64=float64, stats=stats, plif=plif, narrow=narrow)
         d_o, s_o = res_o if returns_spikes else (res_o, [])

@@ -16,6 +16,52 @@ out, h, g, gx = torch.empty_like(x), torch.empty_like(x), torch.randn(T, N, devi
 v = torch.empty(N, device=dev)
 g2 = torch.randn(T, N, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'rc'
+if mode == 'x16':
+    # round 5: the 16-bit activation modes' own kernels (bf16) at the same config-3 shapes — packed-only neuron forward, low-rank forked backward, first layer,
+    # conv1 forward / data gradient, deconv1 sub-pixel forward and box-sum backward.  Counters of this mode: profiles/parse_pmc.py <dir> x16
+    import numpy as np
+    from oracle import np_pack
+    from stereospike_amd import fused
+    from stereospike_amd.network.blocks import NNConvUpsampling
+    dt = torch.bfloat16
+    x16, gx16, g16 = x.to(dt), torch.empty(T, N, dtype=dt, device=dev), g.to(dt)
+    pk = torch.empty(T, N // 16, dtype=torch.int32, device=dev)
+    lr_p, lr_w = torch.randn(T, N // 32, 9, device=dev), torch.randn(9, 32, device=dev)
+    NB, h, w, H, W, Cin, Cout = 80, 130, 173, 260, 346, 64, 32
+    up = NNConvUpsampling(Cin, Cout, 5, (H, W)).to(dev)
+    tabs = up._tables(h, w, torch.device(dev))
+    st, bt = fused.sub_tables(tabs, H, W), fused.box_tables(tabs, H, W)
+    wt = up.up[1].weight.detach().contiguous()
+    xs = (torch.rand(NB, h, w, Cin, device=dev) < 0.4).float()
+    xsp = torch.from_numpy(np_pack.pack(xs.cpu().numpy().reshape(-1)).view(np.int32)).to(dev)
+    o16 = torch.empty(NB, H, W, Cout, dtype=dt, device=dev)
+    gy16 = (torch.randn(NB, H, W, Cout, device=dev) * 1e-3).to(dt)
+    gxs16, gw = torch.empty(NB, h, w, Cin, dtype=dt, device=dev), torch.empty(Cout, Cin, 5, 5, device=dev)
+    xb = (torch.rand(NB, H, W, 32, device=dev) < 0.3).float()
+    xbp = torch.from_numpy(np_pack.pack(xb.cpu().numpy().reshape(-1)).view(np.int32)).to(dev)
+    w1 = torch.randn(64, 32, 5, 5, device=dev) * 0.05
+    y1 = torch.empty(NB, h, w, 64, dtype=dt, device=dev)
+    g1 = (torch.randn(NB, h, w, 64, device=dev) * 1e-3).to(dt)
+    gx1 = torch.empty(NB, H, W, 32, dtype=dt, device=dev)
+    xv = torch.poisson(torch.full((NB, H, W, 4), 0.05, device=dev))
+    w0 = torch.randn(32, 4, 5, 5, device=dev) * 0.1
+    y0 = torch.empty(NB, H, W, 32, dtype=dt, device=dev)
+    g0 = (torch.randn(NB, H, W, 32, device=dev) * 1e-3).to(dt)
+    gw0 = torch.empty(32, 4, 5, 5, device=dev)
+    for _ in range(5):
+        _lib.neuron_fwd_ex(x16, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.neuron_bwd_fork_lr_x16(g16, lr_p, lr_w, None, None, x16, None, gx16, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+        _lib.dense_conv_s1_fwd_x16(xv, w0, y0, NB, 4, 32, H, W)
+        _lib.dense_conv_s1_wgrad_x16(g0, xv, gw0, NB, 4, 32, H, W)
+        _lib.spike_conv_fwd_x16(None, xbp, w1, y1, NB, 32, 64, H, W)
+        _lib.conv_s2_dgrad_x16(g1, w1, gx1, NB, 32, 64, H, W)
+        wm = _lib.upconv_sub_prep_x16(wt, st, Cin, Cout, dt)
+        _lib.upconv_sub_fwd_x16(None, xsp, wm, st, o16, NB, Cin, Cout, h, w)
+        box = _lib.upconv_boxsum_x16(gy16, bt, NB, Cout, H, W)
+        _lib.upconv_box_dgrad_x16(box, wt, bt, gxs16, NB, Cin, Cout, h, w)
+        _lib.upconv_box_wgrad_x16(box, None, xsp, bt, gw, NB, Cin, Cout, h, w)
+    torch.cuda.synchronize()
+    sys.exit(0)
 for _ in range(5):
     if mode == 'rc':
         _lib.neuron_fwd(x, None, None, out, None, v, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)

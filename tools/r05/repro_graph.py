@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-VARIANTS = ['mono_fresh', 'bino_fresh', 'mono_after_eager_trainer', 'mono_after_plain_passes', 'mono_fresh_64x80', 'mono_fresh_fp32', 'mono_fresh_legacy']
+VARIANTS = ['mono_after_plain_passes_keepalive_emptycache', 'mono_after_plain_passes_del_only', 'mono_after_plain_passes_del_zerograd', 'mono_after_plain_passes_del_gc']
 
 if len(sys.argv) > 1:
     sys.path.insert(0, ROOT)
@@ -35,13 +35,41 @@ if len(sys.argv) > 1:
         functional.reset_net(net)
     if 'after_plain_passes' in v:
         from stereospike_amd.network.loss import Total_Loss
-        for _ in range(2):
+        if 'nolr' in v:
+            net.config = net.config.replace(LOWRANK_HEAD_GRAD=False)
+        for _ in range(1 if '_one' in v else 2):
             functional.reset_net(net)
             net.zero_grad(set_to_none=True)
             with torch.autocast('cuda', dtype=amp):
                 d = net.forward_sequence(x)
                 L = Total_Loss()(d, gt, None)
             L.backward()
+        if 'zerograd' in v:
+            net.zero_grad(set_to_none=True)
+        if 'detach' in v:
+            net.detach()
+        if 'keepalive_emptycache' in v:
+            net.zero_grad(set_to_none=True)
+            functional.reset_net(net)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        elif 'del_only' in v:
+            del d, L
+        elif 'del_zerograd' in v:
+            del d, L
+            net.zero_grad(set_to_none=True)
+        elif 'del_gc' in v:
+            del d, L
+            net.zero_grad(set_to_none=True)
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+        elif 'emptycache' in v:
+            del d, L
+            net.zero_grad(set_to_none=True)
+            functional.reset_net(net)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
         functional.reset_net(net)
     tr = GraphedTrainer(net, amp_dtype=amp, warmup=2)
     out = tr.step(x, gt)
