@@ -1,6 +1,7 @@
 """Training / evaluation steps of the hot path as the reference's scripts perform them
 (/root/reference/train.py:189-261, test.py:100-173), plus the synthetic MVSEC-shaped data of SURVEY.md §8(d)."""
 import torch
+from torch.nn.utils import stateless
 
 from .clock_driven import functional
 from .network.loss import Total_Loss
@@ -156,20 +157,32 @@ class GraphedTrainer:
         self.scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 16) if amp_dtype == torch.float16 else None   # see Trainer
         self.warmup = warmup
         self.graph = None
+        named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+        self._params = [p for _, p in named]
+        self._alias = {n: p.detach().requires_grad_() for n, p in named}     # same storage: Adam's in-place updates of p are what the next forward reads
 
     def _iteration(self):
         net = self.net
         functional.reset_net(net)
-        with torch.autocast(**self.amp):
-            out = net.forward_sequence(self.static_x)
-            pred, spks = out if isinstance(out, tuple) else (out, None)
-            loss = self.loss_module(pred, self.static_gt, spks)
+        # The forward runs on ALIASES of the parameters (detached views of the same storage that require grad), never on the Parameters themselves.  A
+        # Parameter's AccumulateGrad node is stream-stateful (it belongs to the stream that was current when it was created) and lives for as long as ANY
+        # autograd graph that reaches the parameter is alive — e.g. the caller still holds the loss / predictions of an eager iteration run on the default
+        # stream.  The autograd engine synchronises every gradient it routes to such a node with the node's stream, so a surviving default-stream node drags the
+        # default stream into the capture and hipStreamEndCapture crashed (the round-3 / round-4 "crash during capture" of config 2:
+        # tools/r05/repro_graph.py, profiles/r05/repro_graph_*.log; neither loss.backward() nor autograd.grad on the Parameters avoids it).  The aliases are
+        # leaves nothing outside this class can reach: their nodes are created inside this iteration, on this iteration's stream.
+        with stateless._reparametrize_module(net, self._alias):
+            with torch.autocast(**self.amp):
+                out = net.forward_sequence(self.static_x)
+                pred, spks = out if isinstance(out, tuple) else (out, None)
+                loss = self.loss_module(pred, self.static_gt, spks)
+        grads = torch.autograd.grad(self.scaler.scale(loss) if self.scaler is not None else loss, list(self._alias.values()), allow_unused=True)
+        for p, g in zip(self._params, grads):
+            p.grad = g                           # static tensors of the graph's pool in a capture: every replay overwrites them
         if self.scaler is not None:
-            self.scaler.scale(loss).backward()
             self.scaler.step(self.opt)
             self.scaler.update()
         else:
-            loss.backward()
             self.opt.step()
         return loss.detach(), pred[0].detach()
 

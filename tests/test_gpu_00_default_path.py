@@ -338,3 +338,35 @@ def test_low_rank_head_gradients_are_in_effect_and_equal_the_dense_form(name):
         assert float((g_on[n] - g_off[n]).norm()) <= bar * den + 1e-12, (n, float((g_on[n] - g_off[n]).norm()) / max(den, 1e-30))
 
 
+
+
+def test_stage_plan_follows_the_geometry():
+    """fused.stage_plan (round 5): which decoder stage takes the sub-pixel forward / the box-sum backward is decided ONCE per stage and
+    input geometry from what the geometry admits and the measured thresholds — no channel-count tuples.  BASELINE's 260x346 pyramid: deconv1 .. deconv3 on the
+    sub-pixel forward, deconv1 / deconv2 on the box-sum backward, deconv4 (17x22 source map, 512 channels) on GEMM + gather and the g_P forms; the parity suite's
+    64x80 pyramid: deconv3's 8x10 source map drops out of the sub-pixel forward, deconv1's 32 source columns reach more horizontal ranges than the box kernels'
+    on-chip window holds; a prediction head (k = 3) never takes either."""
+    from stereospike_amd import fused
+    from stereospike_amd.network import SNN_models as S
+    dev = torch.device(DEV)
+
+    def plans(size):
+        net = S.StereoSpike(multiply_factor=10., input_size=size).to(dev)
+        sz = S._pyramid(size)
+        out = {}
+        for lvl in (4, 3, 2, 1):
+            up = getattr(net, f'deconv{lvl}')[0]
+            h, w = sz[lvl]
+            conv = up.up[1]
+            out[lvl] = fused.stage_plan(up._tables(h, w, dev), conv.in_channels, conv.out_channels, 5, h, w, *sz[lvl - 1])
+            assert fused.stage_plan(up._tables(h, w, dev), conv.in_channels, conv.out_channels, 5, h, w, *sz[lvl - 1]) is out[lvl]        # decided once, cached
+            assert fused.stage_takes_packed_copy(up, h, w, dev) == out[lvl]['sub_fwd']
+        head = net.predict_depth1[0]
+        assert fused.stage_plan(head._tables(size[0], size[1], dev), 32, 1, 3, size[0], size[1], *size) == dict(sub_fwd=False, box_bwd=False)
+        return out
+    full = plans((260, 346))
+    assert {l: p['sub_fwd'] for l, p in full.items()} == {4: False, 3: True, 2: True, 1: True}, full
+    assert {l: p['box_bwd'] for l, p in full.items()} == {4: False, 3: False, 2: True, 1: True}, full
+    small = plans((64, 80))
+    assert {l: p['sub_fwd'] for l, p in small.items()} == {4: False, 3: False, 2: True, 1: True}, small
+    assert {l: p['box_bwd'] for l, p in small.items()} == {4: False, 3: False, 2: True, 1: False}, small

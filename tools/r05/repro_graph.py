@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-VARIANTS = ['mono_after_plain_passes_keepalive_emptycache', 'mono_after_plain_passes_del_only', 'mono_after_plain_passes_del_zerograd', 'mono_after_plain_passes_del_gc']
+VARIANTS = ['mono_fresh', 'mono_after_plain_passes', 'mono_after_plain_passes_fp32', 'mono_after_eager_trainer', 'mono_after_plain_passes_64x80']
 
 if len(sys.argv) > 1:
     sys.path.insert(0, ROOT)
