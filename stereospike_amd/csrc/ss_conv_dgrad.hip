@@ -43,7 +43,7 @@ __host__ __device__ constexpr int dg_cnt(int cls) { return cls == 0 ? 9 : (cls =
 
 // weight [C_out][C_in][5][5] fp32 -> Bf[chunk c of 32 co][tap][g][split][ci tile t][lane][8] bf16: element e of a lane = split term of
 // s * W[co = 32 c + 16 g + 8 (lane >> 5) + e][ci = 32 t + (lane & 31)][ky][kx], s = (-1)^n for the n-th tap of its class over all chunks
-// DT != 0 (16-bit activation modes): ONE term, the weight rounded once to the operand format (sign alternation kept: exact)
+// DT != 0 (16-bit activation modes): ONE term, the weight rounded once to the operand format, no sign alternation
 template <int DT = 0>
 __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Bf, unsigned* __restrict__ counters,
                                                                     int Cin, int Cout)
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void conv_s2_dgrad_prep_kernel(const float*
         for (int e = 0; e < 8; ++e) {
             const int co = 32 * c + 16 * g + 8 * (lane >> 5) + e;
             float v = W[(((long long)co * Cin + ci) * 5 + ky) * 5 + kx];
-            if (n & 1) v = -v;
+            if (DT == 0 && (n & 1)) v = -v;               // (16-bit modes accumulate on the class sums directly: no scratch sum, no sign)
             if constexpr (DT != 0) { o[e] = round_op<DT>(v); continue; }
             const unsigned short h1 = narrow<SS_DT_BF16>(v);
             const float r1 = v - widen<SS_DT_BF16>(h1);
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const type
     constexpr int CI = 32 * NTALL, KINDS = NTALL / NT, NCH = CO / 32;
     constexpr int RB = 32 / CB, TJR = 4 * RB * MB, WR = TJR + 2, WC = CB + 2, ROWB = WC * 64, PLANE = WR * ROWB;      // MB: M blocks (RB rows each) per wavefront
     static_assert(MB == 1 || (2 * RB) % 4 == 0, "the granule swizzle of a wavefront's M blocks must agree");
-    constexpr int STG = 2 * NSP * NT * 1024;                                    // bytes of one weight stage: one tap = 2 k-steps x 3 splits x NT tiles
+    constexpr int TAPB = 2 * NSP * NT * 1024;                                   // bytes of one tap's fragments: 2 k-steps x 3 splits x NT tiles
+    constexpr int TPS = DT ? 5 : 1;                                             // taps per weight stage and barrier: one tap with three splits; a whole kernel row (ky) in the 16-bit
+    constexpr int STG = TPS * TAPB;                                             // modes, whose taps are 2 NT MFMAs per wavefront — too little work to pay a barrier each
     constexpr int LPT = STG / 16 / kDgThreads, REM = STG / 16 - LPT * kDgThreads;
     constexpr int kItems = WR * WC * 4, kIter = (kItems + kDgThreads - 1) / kDgThreads;     // (window pixel, 8-channel granule)
     __shared__ __attribute__((aligned(16))) unsigned char wnd[NSP * PLANE];
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const type
         abase[d] = row * ROWB + col * 64 + ((half ^ (((col >> 2) + 2 * row) & 3)) << 4);
     }
     f4 st[LPT + 1];
-    auto stage_issue = [&](long long stage, int kind) {                         // stage = c * 25 + tap
+    auto stage_issue = [&](long long stage, int kind) {                         // stage = c * 25 + first tap of the stage
 #pragma unroll
         for (int u = 0; u <= LPT; ++u) {
             if (u == LPT && (REM == 0 || (int)threadIdx.x >= REM)) break;
@@ -236,13 +238,14 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const type
                     const int py = ky & 1, px = kx & 1, cls = py * 2 + px;
                     const int dy = (py + 2 - ky) / 2, dx = (px + 2 - kx) / 2;   // (py + 2 - ky) is even: exact, also for -2
                     const int idx = (ky >> 1) * (px ? 2 : 3) + (kx >> 1);       // index of the tap within its class
-                    const bool more = tap + 1 < 25;
-                    if (more && !(SS_DG_ABL & 16)) stage_issue((long long)c * 25 + tap + 1, kind);
+                    const int sidx = tap / TPS, sub = tap - sidx * TPS;         // weight stage of this tap, its place in it
+                    const bool more = (sidx + 1) * TPS < 25;
+                    if (sub == 0 && more && !(SS_DG_ABL & 16)) stage_issue((long long)c * 25 + (sidx + 1) * TPS, kind);
                     if (active) {
                         // The tap's 12 NT MFMAs run on a scratch accumulator that starts at zero; the class's running sum takes ONE fp32 addition
                         // per tap (25 C_out / 32 roundings of the large sum per element instead of 12 x as many: 3.5x closer to float64 at
                         // K = 4608, tests).  The tap's products carry the sign (-1)^n of its weight fragments; fma(+-1, tmp, acc) undoes it.
-                        const unsigned char* const bk = bst + (tap & 1) * STG + lane * 16;
+                        const unsigned char* const bk = bst + (sidx & 1) * STG + sub * TAPB + lane * 16;
                         f32x16 tmp[MB][NT];
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
@@ -268,7 +271,9 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const type
                                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                                     for (int t = 0; t < NT; ++t) {
-                                        if (g == 0 && q == 0) {
+                                        if constexpr (DT != 0) {                // 16-bit modes: straight onto the class sum (the drift is far below the store's rounding)
+                                            acc[i][cls][t] = mfma32<DT>(b[0][t], a[i][0], acc[i][cls][t]);
+                                        } else if (g == 0 && q == 0) {
                                             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                                             tmp[i][t] = mfma32<DT>(b[kTb[q]][t], a[i][kTa[q]], zero);      // D^T: rows = input channels, columns = pixels
                                         } else {
@@ -276,16 +281,20 @@ __global__ __launch_bounds__(kDgThreads, 2) void conv_s2_dgrad_kernel(const type
                                         }
                                     }
                         }
-                        const float sgn = (((c * dg_cnt(cls) + idx) & 1) && !(SS_DG_ABL & 2)) ? -1.f : 1.f;
+                        if constexpr (DT == 0) {
+                            const float sgn = (((c * dg_cnt(cls) + idx) & 1) && !(SS_DG_ABL & 2)) ? -1.f : 1.f;
 #pragma unroll
-                        for (int i = 0; i < MB; ++i)
+                            for (int i = 0; i < MB; ++i)
 #pragma unroll
-                            for (int t = 0; t < NT; ++t)
+                                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) acc[i][cls][t][r] = __builtin_fmaf(sgn, tmp[i][t][r], acc[i][cls][t][r]);
+                                    for (int r = 0; r < 16; ++r) acc[i][cls][t][r] = __builtin_fmaf(sgn, tmp[i][t][r], acc[i][cls][t][r]);
+                        }
                     }
-                    if (more && !(SS_DG_ABL & 16)) stage_commit(bst + ((tap + 1) & 1) * STG);
-                    if (!(SS_DG_ABL & 1)) __syncthreads();
+                    if (sub == TPS - 1) {
+                        if (more && !(SS_DG_ABL & 16)) stage_commit(bst + ((sidx + 1) & 1) * STG);
+                        if (!(SS_DG_ABL & 1)) __syncthreads();
+                    }
                 }
             }
         }
