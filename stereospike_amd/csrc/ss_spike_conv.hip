@@ -75,13 +75,10 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
 {
     constexpr int NTG = COUT / 32, NT = NTW, NCH = CIN / 32, NSL = NTG / NTW, NSP = DT ? 1 : 3;
     static_assert(NTG % NTW == 0, "slices");
-#ifdef SS_SC_KPS1
-    constexpr int KPS = 1;                                                      // A/B build (tools/): one k-step per stage everywhere
-#else
-    constexpr int KPS = NSP * NT <= 6 ? 2 : 1;
-#endif
-                                        // k-steps per weight stage and barrier: a whole tap where it fits beside the window
-                                                                                // at two workgroups per CU (C_out 64: 24 KB of stages; C_out 128 would need 48)
+    // k-steps per weight stage and barrier: as many as fit twice beside the 46 KB window at two workgroups per CU (10 | KPS: a tap row is 10 k-steps) —
+    // fp32 mode: a tap (2) at C_out 64, one k-step at C_out 128; 16-bit modes (one term): half a tap row (5) at C_out 64, a tap (2) at C_out 128
+    constexpr int KPS = NSP * NT <= 2 ? 5 : (NSP * NT <= 6 ? 2 : 1);
+    static_assert(10 % KPS == 0, "a stage never spans two tap rows");
     constexpr int KST = NSP * NT * 1024;                                        // bytes of one k-step's weight fragments (of this slice: the LDS stage)
     constexpr int KSTG = NSP * NTG * 1024;                                      // ... of all of C_out: the stride in Bf
     constexpr int STG = KPS * KST;                                              // bytes of one weight stage
@@ -117,6 +114,29 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
         for (int u = 0; u < LPT; ++u) *reinterpret_cast<f4*>(dst + (threadIdx.x + kScThreads * u) * 16) = st[u];
         if (REM && (int)threadIdx.x < REM) *reinterpret_cast<f4*>(dst + (threadIdx.x + kScThreads * LPT) * 16) = st[LPT];
     };
+    // PACKED input: the window of an item (tile, 32-channel chunk) is kPkItems 32-bit words (pixel, 16 codes) — few enough to fetch one item AHEAD into registers,
+    // so that no tile starts by waiting for HBM / L2 (the tile's MFMAs are 4 - 8 us; the exposed fetch was a quarter of that)
+    constexpr int kPkItems = kScWR * kScWC * 2, kPkIter = (kPkItems + kScThreads - 1) / kScThreads;
+    [[maybe_unused]] unsigned pkw[kPkIter];
+    [[maybe_unused]] auto pk_fetch = [&](long long tile, int chunk) {
+        const unsigned* xp = static_cast<const unsigned*>(xin);
+        const int cg_ = (int)(tile % CG);
+        const long long rr_ = tile / CG;
+        const int rg_ = (int)(rr_ % RG), nb_ = (int)(rr_ / RG);
+        const int iy0_ = 2 * kScTR * rg_ - 2, ix0_ = 2 * kScTC * cg_ - 2;
+#pragma unroll
+        for (int u = 0; u < kPkIter; ++u) {
+            const int i = threadIdx.x + kScThreads * u;
+            const int pix = i >> 1, j = i & 1;
+            const int wy = pix / kScWC, col = pix - wy * kScWC;
+            const int iy = iy0_ + wy, ix = ix0_ + col;
+            pkw[u] = 0u;
+            if (i < kPkItems && iy >= 0 && iy < h && ix >= 0 && ix < w)
+                pkw[u] = xp[((((long long)nb_ * h + iy) * w + ix) * CIN + 32 * chunk) / 16 + j];
+        }
+    };
+    if constexpr (PACKED) { if (t_begin < t_end) pk_fetch(t_begin, 0); }
+    if (t_begin < t_end) stage_issue(reinterpret_cast<const unsigned char*>(Bf));
 #pragma unroll 1
     for (long long tl = t_begin; tl < t_end; ++tl) {
         const int cg = (int)(tl % CG);
@@ -137,36 +157,26 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
             __syncthreads();                                                    // the previous chunk's / tile's readers of the window are done
             // ---- input window (32 channels of this chunk) -> LDS as bf16, zero outside the image
             if constexpr (PACKED) {
-                const unsigned* xp = static_cast<const unsigned*>(xin);
-                constexpr int kItems = kScWR * kScWC * 2, kIter = (kItems + kScThreads - 1) / kScThreads;   // (pixel, 16-channel word)
-                unsigned wv[kIter];
+                // the words of THIS item were fetched during the previous item's MFMAs (pk_fetch below): only the expansion is left
 #pragma unroll
-                for (int u = 0; u < kIter; ++u) {
+                for (int u = 0; u < kPkIter; ++u) {
                     const int i = threadIdx.x + kScThreads * u;
                     const int pix = i >> 1, j = i & 1;
                     const int wy = pix / kScWC, col = pix - wy * kScWC;
-                    const int iy = iy0 + wy, ix = ix0 + col;
-                    wv[u] = 0u;
-                    if (i < kItems && iy >= 0 && iy < h && ix >= 0 && ix < w)
-                        wv[u] = xp[((((long long)nb * h + iy) * w + ix) * CIN + 32 * c) / 16 + j];
-                }
-#pragma unroll
-                for (int u = 0; u < kIter; ++u) {
-                    const int i = threadIdx.x + kScThreads * u;
-                    const int pix = i >> 1, j = i & 1;
-                    const int wy = pix / kScWC, col = pix - wy * kScWC;
-                    if (i < kItems) {
+                    if (i < kPkItems) {
                         unsigned char* const pp = wnd + wy * kScRowB + col * kScPix;
                         const int swz = (col >> 2) & 3;
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {                             // granule 2 j + q = channels 16 j + 8 q .. + 7
                             u16x8 o;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = code_to_op<DT>((wv[u] >> (2 * (8 * q + e))) & 3u);
+                            for (int e = 0; e < 8; ++e) o[e] = code_to_op<DT>((pkw[u] >> (2 * (8 * q + e))) & 3u);
                             *reinterpret_cast<u16x8*>(pp + (((2 * j + q) ^ swz) << 4)) = o;
                         }
                     }
                 }
+                if (c + 1 < NCH) pk_fetch(tl, c + 1);
+                else if (tl + 1 < t_end) pk_fetch(tl + 1, 0);
             } else if constexpr (DT != 0) {
                 const unsigned short* x = static_cast<const unsigned short*>(xin);       // the 16-bit spike tensor: already the operand
                 constexpr int kItems = kScWR * kScWC * 4, kIter = (kItems + kScThreads - 1) / kScThreads;   // (pixel, 8-channel granule)
@@ -226,9 +236,9 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                     }
                 }
             }
-            // ---- weight stage 0 of this chunk
+            // ---- weight stage 0 of this chunk: in registers since the previous item's last stage (the very first one: since before the loop)
             const unsigned char* const bsrc = reinterpret_cast<const unsigned char*>(Bf) + (long long)c * 50 * KSTG;
-            stage_issue(bsrc);
+            const unsigned char* const bnext = reinterpret_cast<const unsigned char*>(Bf) + (long long)(c + 1 < NCH ? c + 1 : 0) * 50 * KSTG;
             stage_commit(bst);
             __syncthreads();
             // window byte offset of this lane's pixel at tap (0, 0): row 2 mb, column 2 tx
@@ -250,16 +260,16 @@ __global__ __launch_bounds__(kScThreads, 2) void spike_conv_fwd_kernel(const voi
                 for (int kx = 0; kx < 5; ++kx) {
 #pragma unroll
                     for (int gi = 0; gi < 2; ++gi) {
-                        const int s = (ky * 5 + kx) * 2 + gi;                   // k-step; stage = s / KPS (same MFMA order for either KPS: same result bits)
-                        const int sg = s / KPS;
-                        const bool first = s % KPS == 0, last = s % KPS == KPS - 1, more = sg + 1 < 50 / KPS;
-                        if (first && more) stage_issue(bsrc + (long long)(sg + 1) * KPS * KSTG);
+                        const int j = kx * 2 + gi;                              // k-step 10 ky + j; stage = k-step / KPS (same MFMA order for any KPS: same result bits)
+                        const int sub = j % KPS, sg = ky * (10 / KPS) + j / KPS;
+                        const bool first = sub == 0, last = sub == KPS - 1, more = sg + 1 < 50 / KPS;
+                        if (first) stage_issue(more ? bsrc + (long long)(sg + 1) * KPS * KSTG : bnext);      // (the last stage of an item fetches stage 0 of the next one)
                         if (active) {
                             const int col = 2 * tx + kx;
                             s16x8 a = *reinterpret_cast<const s16x8*>(lane_row + ky * kScRowB + col * kScPix + (((2 * gi + half) ^ ((col >> 2) & 3)) << 4));
 #pragma unroll
                             for (int e = 0; e < 8; ++e) a[e] = (short)(a[e] ^ sgn);          // -0 for a zero spike count: harmless
-                            const unsigned char* const bk = bst + (sg & 1) * STG + (s % KPS) * KST + lane * 16;
+                            const unsigned char* const bk = bst + (sg & 1) * STG + sub * KST + lane * 16;
                             s16x8 b[NSP * NT];                                  // [split][tile]
 #pragma unroll
                             for (int u = 0; u < NSP * NT; ++u) b[u] = *reinterpret_cast<const s16x8*>(bk + u * 1024);

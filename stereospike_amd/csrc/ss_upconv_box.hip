@@ -375,8 +375,10 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
     bx_win_load(wbuf, bl, win_src(cur), NHR, cur.nj, cur.ni);                   // the first window: the only one whose latency is exposed
     bx_win_store(wnd, wbuf, bl, cur.nj, cur.ni);
     int addr[kB2KS];
-    // KPS accumulator sets (one per k-step of a stage): with NT = 2 that makes 4 independent MFMA chains per wavefront instead of 2; added once per tile
-    f32x16 acc[KPS][NT];
+    // two accumulator sets (alternating k-steps of a stage) when a stage holds more than one k-step: with NT = 2 that makes 4 independent MFMA chains per wavefront
+    // instead of 2; added once per tile.  16-bit modes (one term: a k-step is NT MFMAs): stages of 6 | 3 k-steps — the fp32 mode's stage BYTES, a third of its barriers
+    constexpr int NACC = (KPS > 1 && NT <= 2) ? 2 : 1;                          // (k-step ks of a stage accumulates on set ks % NACC; NT = 4 has four chains already and no registers for eight)
+    f32x16 acc[NACC][NT];
     static_assert(kNS & 1, "the stage double buffer's parity flips per item");
     constexpr int kWR = (kB2WR + kNS - 3) / (kNS - 2);                          // window rows fetched per stage (3 | 2): done two stages before the item ends
     auto wsrc = [&](const Item& d) { return reinterpret_cast<const unsigned char*>(Wf) + ((long long)d.blk * NCH + d.c) * kB2KS * kKB; };
@@ -413,14 +415,14 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                 addr[s2] = (lane >> 5) ? a1 : a0;
             }
 #pragma unroll
-            for (int a2 = 0; a2 < KPS; ++a2)
+            for (int a2 = 0; a2 < NACC; ++a2)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[a2][t][r] = 0.f;
         } else {                                                                // sign of the running sum alternates per chunk (odd chunks' weights are negated)
 #pragma unroll
-            for (int a2 = 0; a2 < KPS; ++a2)
+            for (int a2 = 0; a2 < NACC; ++a2)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -475,13 +477,13 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
                     for (int q = 0; q < kNQ; ++q)
 #pragma unroll
                         for (int u = 0; u < NT; ++u) {
-                            if (SS_BX_ABLATE & 4) acc[ks][u][q] += (float)(fa[pa[q]][0] + fb[pb[q]][u][1]);
-                            else acc[ks][u] = mfma32<DT>(fb[pb[q]][u], fa[pa[q]], acc[ks][u]);      // D^T: rows = input channels, columns = pixels
+                            if (SS_BX_ABLATE & 4) acc[ks % NACC][u][q] += (float)(fa[pa[q]][0] + fb[pb[q]][u][1]);
+                            else acc[ks % NACC][u] = mfma32<DT>(fb[pb[q]][u], fa[pa[q]], acc[ks % NACC][u]);      // D^T: rows = input channels, columns = pixels
                         }
                 }
             }
 #if SS_BX_TRACE
-            if (sg == 0 || sg == kNS - 1) { if (acc[0][0][0] == 12345.f && acc[KPS - 1][NT - 1][3] == 3.f) bx_trace[63][15] = 1; BX_STAMP(sg == 0 ? 3 : 5); }
+            if (sg == 0 || sg == kNS - 1) { if (acc[0][0][0] == 12345.f && acc[NACC - 1][NT - 1][3] == 3.f) bx_trace[63][15] = 1; BX_STAMP(sg == 0 ? 3 : 5); }
 #endif
             if (more || has_next) {
                 unsigned char* const dst = bst + (((sg + 1) & 1) ^ par) * kStage;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = acc[0][t][4 * q + e];
-                            if constexpr (KPS > 1) x += acc[1][t][4 * q + e];
+                            if constexpr (NACC > 1) x += acc[1][t][4 * q + e];
                             v[e] = x * fin;
                         }
                         store_act4<DT>(op + 32 * t + 8 * q, v[0], v[1], v[2], v[3]);
@@ -975,9 +977,9 @@ int ss_upconv_box_dgrad_x16(const void* box, const float* weight, const int* vma
     const unsigned short* Bp = static_cast<const unsigned short*>(box);
     unsigned short* gx16 = static_cast<unsigned short*>(g_x);
 #define SS_BD16(DTT) do { \
-        if (NT == 4) hipLaunchKernelGGL((upconv_box_dgrad_kernel<4, 1, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
+        if (NT == 4) hipLaunchKernelGGL((upconv_box_dgrad_kernel<4, 3, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
                                         (int)NB, h, w, NVR, NHR, Cin, Cout / kBxCo, RG, CG); \
-        else hipLaunchKernelGGL((upconv_box_dgrad_kernel<2, 2, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
+        else hipLaunchKernelGGL((upconv_box_dgrad_kernel<2, 6, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
                                 (int)NB, h, w, NVR, NHR, Cin, Cout / kBxCo, RG, CG); } while (0)
     if (dtype == SS_DT_F16) SS_BD16(SS_DT_F16); else SS_BD16(SS_DT_BF16);
 #undef SS_BD16
