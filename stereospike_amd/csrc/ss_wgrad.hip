@@ -1,5 +1,6 @@
 // ss_wgrad.hip — exact bf16x3 MFMA contractions on spike operands (im2col / split operand preparation, weight gradients, fused decoder backward), the six-term dense GEMM, packed-spike readers + their C-ABI entry points (include/ss_neuron.h).
 #include "ss_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -497,6 +498,187 @@ __global__ __launch_bounds__(kBlock) void spike_conv_xprep_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same weight gradient straight from the 2-BIT PACKED spike tensor, second form (round 5): no operand-preparation passes at all
+// ---------------------------------------------------------------------------------------------------
+// spike_conv_wgrad_kernel reads every fragment from global memory: five column-decimated bf16 copies of x (spike_conv_xprep_kernel writes 1.15 GB for conv1 at
+// BASELINE config 3: 0.28 ms, HBM-bound) and a fragment-ordered copy of g (spike_conv_gprep_kernel), and it is bound by the vector-memory path (a 1 KB fragment
+// per MFMA in the 16-bit modes: the L1 rate).  Here a workgroup stages what a tile of 2 output rows x 32 output columns touches — the 7 x 67-pixel window of x
+// (32 input channels, expanded from the packed words to the operand format) and the 64 x 64 tile of g (16-bit modes: as stored; fp32 mode: split exactly into
+// three bf16 planes while staged) — ONCE in LDS, both pixel-major as they lie in HBM, and every MFMA fragment — 8 consecutive output pixels of one channel,
+// i.e. the arrays read against their grain, x with a pixel stride of 2 — is two ds_read_b64_tr_b16: the transposed LDS read hands lane i of a 16-lane group
+// column i of the 4 x 16 block whose rows the group's lanes address individually (out[i][r] = in[lane 4 r + i / 4][element i % 4], profiles/r04/tr16.log).
+//   * kind = (32 input channels, 64 output channels); wavefront w of 8 = output-channel tile w & 1 and the taps (w >> 1) + 4 j, j < 7: 7 | 6 accumulator tiles
+//     (D[co][ci], the first form's orientation and partial-sum layout: spike_conv_wgrad_reduce_kernel finishes) that stay in registers over the slice's tiles;
+//   * a k-step = 16 consecutive ox of one output row: 2 NSP transposed reads for g, 2 per tap for x, 7 NSP MFMAs;
+//   * LDS is double-buffered (one barrier per tile): the next tile's packed words and g granules are fetched into registers before this tile's MFMAs and
+//     expanded / stored after them;
+//   * bank conflicts of the transposed reads (4 pixels x 64 B of one pixel row per 32-lane pass): x pixels sit 128 B apart (stride 2), g pixels 128 B — pixel
+//     pairs would meet in the same banks; x swaps the two pixels of a column pair where bit 2 of the column is set, g swaps the 64-byte halves of pixels with
+//     bit 1 set: the four pixels of a pass cover the 64 banks once.
+constexpr int kTwThreads = 512;
+constexpr int kTwTR = 2, kTwTC = 32;                                             // output rows x columns of a tile
+constexpr int kTwWR = 2 * kTwTR + 3, kTwWC = 2 * kTwTC + 3;                      // 7 x 67 window pixels
+constexpr int kTwXRow = 68 * 64;                                                // bytes of a window row: 68 pixel slots x 32 channels x 2 B
+constexpr int kTwXBytes = kTwWR * kTwXRow;                                       // 30 464
+constexpr int kTwGPlane = kTwTR * kTwTC * 128;                                   // 8 192: 64 pixels x 64 output channels x 2 B
+constexpr int kTwXItems = kTwWR * kTwWC * 2, kTwXIter = (kTwXItems + kTwThreads - 1) / kTwThreads;      // (pixel, 16-code word) items per tile, per thread
+static_assert(kTwTR * kTwTC * 8 == kTwThreads, "one 8-channel granule of the g tile per thread");
+
+template <int DT>
+__global__ __launch_bounds__(kTwThreads, 1) void spike_conv_wgrad_tr_kernel(const typename ActT<DT>::type* __restrict__ g, const unsigned* __restrict__ xp,
+                                                                            float* __restrict__ ws, int NB, int h, int w, int ho, int wo, int CIN, int COUT, int slices)
+{
+    constexpr int NSP = DT ? 1 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned char xw[2][kTwXBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char gw[2][NSP * kTwGPlane];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int CIT = CIN / 32;
+    const int kind = (int)(blockIdx.x / slices), slice = (int)(blockIdx.x % slices);        // kinds of one slice: blockIdx apart by `slices` — the same XCD when 8 | slices
+    const int cit = kind % CIT, cp = kind / CIT;                                             // 32-input-channel tile, 64-output-channel pair
+    const int cot_l = wave & 1, tq = wave >> 1;
+    const int RG = (ho + kTwTR - 1) / kTwTR, CG = (wo + kTwTC - 1) / kTwTC;
+    const long long n_tiles = (long long)NB * RG * CG;
+    const long long t_begin = n_tiles * slice / slices, t_end = n_tiles * (slice + 1) / slices;
+    // this lane as a SOURCE lane of the transposed reads: pixel r_s of a 4-pixel block, channels 4 j_s .. + 3 of its 16-lane group's 16-channel half
+    const int r_s = (lane & 15) >> 2, j_s = lane & 3, hsel = (lane >> 4) & 1, khalf = lane >> 5;
+    int xoff[7];
+    bool own[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int tap = tq + 4 * j;
+        own[j] = tap < 25;                                                                   // wave-uniform
+        const int ky = own[j] ? tap / 5 : 0, kx = own[j] ? tap - 5 * (tap / 5) : 0;
+        const int cl = 2 * r_s + kx;                                                         // low part of the window column; + 16 khalf + 8 q + 32 half (no effect on bits 0..2)
+        xoff[j] = ky * kTwXRow + ((cl ^ ((cl >> 2) & 1)) + 16 * khalf) * 64 + (16 * hsel + 4 * j_s) * 2;
+    }
+    const int gbase = (8 * khalf + r_s) * 128 + (((32 * cot_l + 16 * hsel + 4 * j_s) * 2) ^ ((r_s >> 1) << 6));
+    f32x16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // ---- staging: registers of the NEXT tile
+    unsigned xr[kTwXIter];
+    u16x8 gr16;
+    f4 gra, grb;
+    auto fetch = [&](long long tl) {
+        const int cg = (int)(tl % CG);
+        const long long q = tl / CG;
+        const int rg = (int)(q % RG);
+        const long long nb = q / RG;
+        const int oy0 = kTwTR * rg, ox0 = kTwTC * cg;
+        const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;
+#pragma unroll
+        for (int u = 0; u < kTwXIter; ++u) {
+            const int i = threadIdx.x + kTwThreads * u;
+            const int pix = i >> 1, jw = i & 1;
+            const int wr = pix / kTwWC, wc = pix - wr * kTwWC;
+            const int iy = iy0 + wr, ix = ix0 + wc;
+            xr[u] = 0u;
+            if (i < kTwXItems && iy >= 0 && iy < h && ix >= 0 && ix < w) xr[u] = xp[(((nb * h + iy) * w + ix) * CIN + 32 * cit) / 16 + jw];
+        }
+        const int p = threadIdx.x >> 3, gran = threadIdx.x & 7;
+        const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+        const bool ok = oy < ho && ox < wo;
+        const long long el = ((nb * ho + oy) * wo + ox) * COUT + 64 * cp + 8 * gran;
+        if constexpr (DT != 0) {
+            gr16 = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) gr16 = *reinterpret_cast<const u16x8*>(g + el);
+        } else {
+            gra = (f4){0.f, 0.f, 0.f, 0.f}; grb = gra;
+            if (ok) { gra = *reinterpret_cast<const f4*>(g + el); grb = *reinterpret_cast<const f4*>(g + el + 4); }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < kTwXIter; ++u) {
+            const int i = threadIdx.x + kTwThreads * u;
+            const int pix = i >> 1, jw = i & 1;
+            const int wr = pix / kTwWC, wc = pix - wr * kTwWC;
+            if (i < kTwXItems) {
+                unsigned char* const pp = xw[buf] + wr * kTwXRow + (wc ^ ((wc >> 2) & 1)) * 64 + 32 * jw;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = code_to_op<DT>((xr[u] >> (2 * (8 * q + e))) & 3u);
+                    *reinterpret_cast<u16x8*>(pp + 16 * q) = o;
+                }
+            }
+        }
+        const int p = threadIdx.x >> 3, gran = threadIdx.x & 7;
+        unsigned char* const gp = gw[buf] + p * 128 + ((gran * 16) ^ (((p >> 1) & 1) << 6));
+        if constexpr (DT != 0) {
+            *reinterpret_cast<u16x8*>(gp) = gr16;
+        } else {
+            u16x8 o[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                                                    // truncation split: every residual is exactly representable, g = hi + mid + lo
+                const float v = e < 4 ? gra[e] : grb[e - 4];
+                const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
+                const float r1 = v - __uint_as_float(uh);
+                const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+                const float r2 = r1 - __uint_as_float(um);
+                o[0][e] = (unsigned short)(uh >> 16); o[1][e] = (unsigned short)(um >> 16); o[2][e] = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<u16x8*>(gp + sp * kTwGPlane) = o[sp];
+        }
+    };
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+    int cur = 0;
+    if (t_begin < t_end) { fetch(t_begin); commit(0); }
+#pragma unroll 1
+    for (long long tl = t_begin; tl < t_end; ++tl) {
+        __syncthreads();                                                                     // buffer `cur` is complete; every reader of the other one (the previous tile) is done
+        const bool has_next = tl + 1 < t_end;
+        if (has_next) fetch(tl + 1);
+        const unsigned char* const xb = xw[cur];
+        const unsigned char* const gb = gw[cur] + gbase;
+#pragma unroll
+        for (int ks = 0; ks < 2 * kTwTR; ++ks) {
+            const int rr = ks >> 1, hh = ks & 1;
+            s16x8 ga[NSP];
+#pragma unroll
+            for (int sp = 0; sp < NSP; ++sp) {
+                const unsigned char* const a = gb + sp * kTwGPlane + (32 * rr + 16 * hh) * 128;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(a + 4 * 128));
+                ga[sp] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (own[j]) {
+                    const unsigned char* const b = xb + xoff[j] + 2 * rr * kTwXRow + 32 * hh * 64;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(b));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(b + 8 * 64));
+                    const s16x8 xf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                    for (int sp = NSP - 1; sp >= 0; --sp) acc[j] = mfma32<DT>(ga[sp], xf, acc[j]);         // smallest term first
+                }
+            }
+        }
+        if (has_next) commit(cur ^ 1);
+        cur ^= 1;
+    }
+    // D[co][ci]: column (ci) = lane & 31, row (co) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);  ws[slice][virtual channel v * 32 + ci][co], v = tap * CIT + cit
+    float* const wsl = ws + (long long)slice * 25 * CIN * COUT;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if (own[j]) {
+            const int v = (tq + 4 * j) * CIT + cit;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 64 * cp + 32 * cot_l + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wsl[((long long)v * 32 + (lane & 31)) * COUT + co] = acc[j][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dense x dense fp32 GEMM on the bf16 matrix cores with SIX cross terms:  C[R][N] = A[R][K] @ B[K][N]   (decoder data gradient g_x = g_P @ W2)
 // ---------------------------------------------------------------------------------------------------
 // Both operands are dense fp32 (no spike operand), so the exact 3-term split of ONE operand is not enough.  a = ah + am + al and
@@ -842,6 +1024,13 @@ int ss_spike_conv_wgrad_supported(int Cin, int Cout, int k, int stride, int pad)
     return k == 5 && stride == 2 && pad == 2 && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128));
 }
 
+// A/B switch (tools/): SS_SPIKE_WGRAD_TR=0 keeps the first form (xprep + gprep + global-memory fragments) on packed input too — read once
+static bool spike_conv_wgrad_tr_on()
+{
+    static const char* const e = getenv("SS_SPIKE_WGRAD_TR");
+    return !(e && e[0] == '0');
+}
+
 static int spike_conv_wgrad_plan(int Cin, int* Q, int* slices)
 {
     int dev = 0, cus = 0;
@@ -876,6 +1065,14 @@ int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* 
     const long long part = (long long)slices * 25 * Cin * Cout, xk = ((5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + 3) & ~3LL;
     unsigned short* xK = reinterpret_cast<unsigned short*>(ws + part);
     unsigned short* gT = reinterpret_cast<unsigned short*>(ws + part + xk);
+    if (x_packed && spike_conv_wgrad_tr_on()) {                                  // packed input: the window / transposed-read form, no preparation passes
+        const int kinds = (Cin / 32) * (Cout / 64), sl = slices * Q / kinds > 0 ? slices * Q / kinds : 1;
+        if ((long long)sl * 25 * Cin * Cout > ss_spike_conv_wgrad_ws_floats(Cin, Cout, NB, h, w)) return SS_EINVAL;
+        hipLaunchKernelGGL(spike_conv_wgrad_tr_kernel<0>, dim3(kinds * sl), dim3(kTwThreads), 0, s, g, x_packed, ws, (int)NB, h, w, ho, wo, Cin, Cout, sl);
+        if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+        hipLaunchKernelGGL(spike_conv_wgrad_reduce_kernel, dim3(grid_for(25LL * Cin * Cout, 1024)), dim3(kBlock), 0, s, ws, g_w, sl, Cin, Cout, accumulate);
+        return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+    }
     if (x_packed) hipLaunchKernelGGL(spike_conv_xprep_kernel<true>, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
                                      static_cast<const void*>(x_packed), xK, (int)NB, h, w, Cin, wo);
     else hipLaunchKernelGGL(spike_conv_xprep_kernel<false>, dim3(grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd)), dim3(kBlock), 0, s,
@@ -906,6 +1103,16 @@ int ss_spike_conv_wgrad_x16(const void* g, const void* x, const unsigned int* x_
     const long long part = (long long)slices * 25 * Cin * Cout, xk = ((5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + 3) & ~3LL;
     unsigned short* xK = reinterpret_cast<unsigned short*>(ws + part);
     unsigned short* gT = reinterpret_cast<unsigned short*>(ws + part + xk);
+    if (x_packed && spike_conv_wgrad_tr_on()) {
+        const int kinds = (Cin / 32) * (Cout / 64), sl = slices * Q / kinds > 0 ? slices * Q / kinds : 1;
+        if ((long long)sl * 25 * Cin * Cout > ss_spike_conv_wgrad_ws_floats(Cin, Cout, NB, h, w)) return SS_EINVAL;
+        const unsigned short* gg16 = static_cast<const unsigned short*>(g);
+        if (dtype == SS_DT_F16) hipLaunchKernelGGL(spike_conv_wgrad_tr_kernel<SS_DT_F16>, dim3(kinds * sl), dim3(kTwThreads), 0, s, gg16, x_packed, ws, (int)NB, h, w, ho, wo, Cin, Cout, sl);
+        else hipLaunchKernelGGL(spike_conv_wgrad_tr_kernel<SS_DT_BF16>, dim3(kinds * sl), dim3(kTwThreads), 0, s, gg16, x_packed, ws, (int)NB, h, w, ho, wo, Cin, Cout, sl);
+        if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+        hipLaunchKernelGGL(spike_conv_wgrad_reduce_kernel, dim3(grid_for(25LL * Cin * Cout, 1024)), dim3(kBlock), 0, s, ws, g_w, sl, Cin, Cout, accumulate);
+        return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+    }
     const int xg = grid_for(NB * (h + 4) * (oxp / 8) * Cin, kMaxGridBwd), gg = grid_for(NB * ho * ksr * (Cout / 32) * 64, kMaxGridBwd);
     const unsigned grid = (unsigned)(Q * slices);
     const unsigned short* g16 = static_cast<const unsigned short*>(g);

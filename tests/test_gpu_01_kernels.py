@@ -1107,12 +1107,16 @@ def test_spike_conv_wgrad_mfma(NB, Cin, Cout, hw):
     gw2 = torch.empty_like(gw)
     _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w)
     assert torch.equal(gw, gw2)
-    if (NB * h * w * Cin) % 16 == 0:                         # packed spike input: the same operand copy, bit for bit
+    if (NB * h * w * Cin) % 16 == 0:                         # packed spike input: the window / transposed-read form (round 5) — same bound, every element written, deterministic
         from oracle import np_pack
         xp = torch.from_numpy(np_pack.pack(x.cpu().numpy().reshape(-1)).view(np.int32)).to(DEV)
-        gw3 = torch.empty_like(gw)
+        gw3 = torch.full_like(gw, float('nan'))
         _lib.spike_conv_wgrad(g, None, gw3, NB, Cin, Cout, h, w, x_packed=xp)
-        assert torch.equal(gw, gw3)
+        assert bool(((gw3.double() - ref).abs() <= mag * 2.0 ** -22 + 1e-30).all()), float(((gw3.double() - ref).abs() / (mag * 2.0 ** -22 + 1e-30)).max())
+        assert float((gw3.double() - ref).abs().max()) <= 2.0 * float((mi.double() - ref).abs().max()) + 1e-7 * float(ref.abs().max())
+        gw4 = torch.empty_like(gw)
+        _lib.spike_conv_wgrad(g, None, gw4, NB, Cin, Cout, h, w, x_packed=xp)
+        assert torch.equal(gw3, gw4)
     _lib.spike_conv_wgrad(g, x, gw2, NB, Cin, Cout, h, w, accumulate=True)
     assert torch.equal(gw2, gw + gw)
 
@@ -1352,7 +1356,8 @@ def test_spike_conv_stage_packed_only_input_matches_dense(monkeypatch):
         (y * g).sum().backward()
         outs.append((y.detach().clone(), st[0].weight.grad.clone(), xin.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and float(outs[0][0].mean()) > 0.01
-    assert torch.equal(outs[0][1], outs[1][1])
+    # weight gradient: the packed input runs the window / transposed-read kernel (round 5), the dense one the first form — exact products, another fp32 summation order
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-6 * float(outs[0][1].abs().max())
     assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-6 * float(outs[0][2].abs().max())       # MIOpen's data gradient (atomics: not bit-stable)
 
 

@@ -208,8 +208,11 @@ def test_spike_conv_x16(dt, NB, Cin, Cout, hw):
     assert_f32(gw, wgrad(g.double()), wgrad(g.double().abs()), 'spike_conv_wgrad_x16', scale=4.0)
     if packable:
         gw2 = torch.full_like(gw, float('nan'))
-        _lib.spike_conv_wgrad_x16(g, None, gw2, NB, Cin, Cout, h, w, x_packed=xp)
-        assert torch.equal(gw, gw2)
+        _lib.spike_conv_wgrad_x16(g, None, gw2, NB, Cin, Cout, h, w, x_packed=xp)        # packed input: the window / transposed-read form (another summation order)
+        assert_f32(gw2, wgrad(g.double()), wgrad(g.double().abs()), 'spike_conv_wgrad_x16(packed)', scale=4.0)
+        gw3 = torch.full_like(gw, float('nan'))
+        _lib.spike_conv_wgrad_x16(g, None, gw3, NB, Cin, Cout, h, w, x_packed=xp)
+        assert torch.equal(gw2, gw3)
     # ---- data gradient
     gx = torch.full((NB, h, w, Cin), float('nan'), device=DEV).to(dt)
     _lib.conv_s2_dgrad_x16(g, wt, gx, NB, Cin, Cout, h, w)
