@@ -200,10 +200,7 @@ __global__ __launch_bounds__(kBlock) void spike_wgrad_xprep_kernel(const float* 
     }
 }
 
-// XL (round 5): the spike fragments of a k-step are the same for all 8 wavefronts (each owns other COLUMNS of g) — 8 KB per wavefront and k-step through the
-// vector-memory path was what bounded the C_in 256 / 512 instance (52 B / clk / CU: the L1 rate).  With XL the workgroup copies a stage of PF k-steps of xT
-// (PF x 8 KB, one 16-byte piece per thread and k-step) into LDS, double-buffered, one LDS-only barrier per stage; the fragments are ds_read_b128.
-template <int CIT, int NTW, int PF, bool XL = false>
+template <int CIT, int NTW, int PF>
 __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __restrict__ g, const unsigned short* __restrict__ xT,
                                                                 float* __restrict__ ws, long long R, int N, int Q, int CIN)
 {
@@ -218,12 +215,10 @@ __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __
     // kind q owns the CONTIGUOUS column tiles [q tpk, (q + 1) tpk): a workgroup then reads one contiguous piece of every row of g
     const int tpk = (NT + Q - 1) / Q, kt = min(tpk, NT - q * tpk);
     const int tile0 = q * tpk + wave;                                            // this wavefront's column tiles: tile0 + 8 j, j < NTW
-    if (!XL && wave >= kt) return;                                              // (XL: every wavefront copies its share of the stages and meets the barriers)
+    if (wave >= kt) return;
     bool own[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) own[j] = wave + 8 * j < kt;
-    static_assert(!XL || (32 * CIT * 16 * 2 == kSwThreads * 16 && PF == 2), "XL: one 16-byte piece per thread and k-step, stages of two k-steps");
-    __shared__ __attribute__((aligned(16))) unsigned char xl[XL ? 2 * PF * 32 * CIT * 32 : 16];
     f32x16 acc[NTW][CIT];
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
@@ -241,10 +236,8 @@ __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __
     s16x8 xn[PF][CIT];
     auto load_step = [&](float (&gd)[NTW][8], s16x8 (&xd)[CIT], long long ks) {
         const unsigned short* xb = xT + (ks * CIN + ci0) * 16;
-        if constexpr (!XL) {
 #pragma unroll
-            for (int t = 0; t < CIT; ++t) xd[t] = *reinterpret_cast<const s16x8*>(xb + 32 * 16 * t + xoff);
-        }
+        for (int t = 0; t < CIT; ++t) xd[t] = *reinterpret_cast<const s16x8*>(xb + 32 * 16 * t + xoff);
         if (ks < KSF) {                                                          // all 16 rows exist: uniform bases
             const float* gb = g + ks * 16 * N + 32 * tile0;
 #pragma unroll
@@ -260,36 +253,15 @@ __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __
             }
         }
     };
-    constexpr int kXKS = 32 * CIT * 32;                                          // bytes of one k-step of xT for this workgroup's channels
-    [[maybe_unused]] f4 xr[PF];
-    [[maybe_unused]] auto x_fetch = [&](long long ks) {                          // stage starting at k-step ks -> registers (k-steps beyond the slice: not read by anyone)
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (ks + u < ks1) xr[u] = *reinterpret_cast<const f4*>(xT + ((ks + u) * CIN + ci0) * 16 + threadIdx.x * 8);
-    };
-    [[maybe_unused]] auto x_commit = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) *reinterpret_cast<f4*>(xl + (buf * PF + u) * kXKS + threadIdx.x * 16) = xr[u];
-    };
-    [[maybe_unused]] int xcur = 0;
-    if constexpr (XL) {
-        if (ks0 < ks1) { x_fetch(ks0); x_commit(0); }
-        __syncthreads();
-    }
 #pragma unroll
     for (int u = 0; u < PF - 1; ++u)
         if (ks0 + u < ks1) load_step(gv[u], xn[u], ks0 + u);
 #pragma unroll 1
     for (long long ks = ks0; ks < ks1; ks += PF) {
-        if constexpr (XL) { if (ks + PF < ks1) x_fetch(ks + PF); }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (ks + u < ks1) {
                 if (ks + u + PF - 1 < ks1) load_step(gv[(u + PF - 1) % PF], xn[(u + PF - 1) % PF], ks + u + PF - 1);
-                if constexpr (XL) {
-#pragma unroll
-                    for (int t = 0; t < CIT; ++t) xn[u][t] = *reinterpret_cast<const s16x8*>(xl + (xcur * PF + u) * kXKS + (32 * 16 * t + xoff) * 2);
-                }
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     if (own[j]) {
@@ -312,13 +284,7 @@ __global__ __launch_bounds__(kSwThreads) void spike_wgrad_kernel(const float* __
                 }
             }
         }
-        if constexpr (XL) {
-            if (ks + PF < ks1) x_commit(xcur ^ 1);
-            lds_barrier();                                                      // (LDS-only: the g prefetch stays in flight)
-            xcur ^= 1;
-        }
     }
-    if (XL && wave >= kt) return;
     // D[n][ci]: column (ci) = lane & 31, row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* const wsl = ws + (long long)slice * N * CIN;
 #pragma unroll
@@ -1015,7 +981,7 @@ int ss_spike_wgrad_f32(const float* g, const float* x, float* g_w, float* ws, lo
     const unsigned grid = (unsigned)(Q * slices * (Cin == 512 ? 2 : 1));
     if (Cin == 64) hipLaunchKernelGGL((spike_wgrad_kernel<2, 2, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
     else if (Cin == 128) hipLaunchKernelGGL((spike_wgrad_kernel<4, 1, 3>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
-    else hipLaunchKernelGGL((spike_wgrad_kernel<8, 1, 2, true>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
+    else hipLaunchKernelGGL((spike_wgrad_kernel<8, 1, 2>), dim3(grid), dim3(kSwThreads), 0, s, g, xT, ws, R, N, Q, Cin);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     hipLaunchKernelGGL(spike_wgrad_reduce_kernel, dim3(grid_for((long long)N * Cin, 1024)), dim3(kBlock), 0, s, ws, g_w, slices, N, Cin, accumulate);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
