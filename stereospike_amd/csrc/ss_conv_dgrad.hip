@@ -650,9 +650,212 @@ __global__ __launch_bounds__(kBlock) void dense_conv_s1_wgrad_finish_kernel(cons
     gW[i] = accumulate ? (float)((double)gW[i] + s) : (float)s;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same weight gradient for C_in = 4, second form (round 5): both tiles pixel-major in LDS, every fragment two transposed LDS reads
+// ---------------------------------------------------------------------------------------------------
+// dense_conv_s1_wgrad_kernel takes the same time in the fp32 mode (six MFMAs per product) and the 16-bit modes (one): it is bound by building its fragments — g
+// transposed into LDS with 4-byte stores, a B fragment = five dword reads + four funnel shifts per split plane.  Here (the scheme of spike_conv_wgrad_tr_kernel,
+// ss_wgrad.hip) the g tile (8 rows x 32 pixels x 32 channels) and the input window (12 x 36 pixels x 4 channels = 8 bytes per pixel) are staged as they lie in
+// HBM — split into three bf16 planes in the fp32 mode, the operand format as stored / rounded once in the 16-bit modes — and ds_read_b64_tr_b16 does both
+// transpositions: a source lane points at one pixel of ITS column's tap (an 8-byte window pixel is exactly the four channels of a tap), so the 25 taps x 4
+// channels of an N tile cost two reads per plane; taps beyond 24 read a zero pad.  Same tile order, sign alternation, partial-block layout and second pass as the
+// first form (which stays for C_in = 2).
+constexpr int kW2TR = 8, kW2TC = 32;                                             // pixel rows x columns of a tile: 16 k-steps, four per wavefront
+constexpr int kW2WR = kW2TR + 4, kW2WC = kW2TC + 4;                              // 12 x 36 window pixels
+constexpr int kW2XWin = kW2WR * kW2WC * 8;                                      // 3 456 bytes of window per plane
+constexpr int kW2XPlane = kW2XWin + 2304;                                       // + the zero pad a phantom tap's lanes read (the largest k-step offset is 2 176)
+constexpr int kW2GPlane = kW2TR * kW2TC * 64;                                   // 16 384: 256 pixels x 32 channels x 2 B
+
+template <int DT>
+__global__ __launch_bounds__(kW1Threads, 2) void dense_conv_s1_wgrad_tr_kernel(const typename ActT<DT>::type* __restrict__ G, const float* __restrict__ X,
+                                                                               float* __restrict__ part, int NB, int h, int w)
+{
+    constexpr int NSP = DT ? 1 : 3, NT = 4, CI = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char gl[NSP * kW2GPlane];
+    __shared__ __attribute__((aligned(16))) unsigned char xl[NSP * kW2XPlane];
+    static_assert(32 * NT * 32 * 4 <= kW2GPlane, "the reduction block fits one g plane");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int RG = (h + kW2TR - 1) / kW2TR, CG = (w + kW2TC - 1) / kW2TC;
+    const long long n_tiles = (long long)NB * RG * CG;
+    const long long t_begin = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    // this lane as a SOURCE lane of the transposed reads: pixel r_s of a 4-pixel block; channels 4 j_s .. + 3 of its 16-lane group's half of g / the tap
+    // 8 t + 4 hsel + j_s of N tile t
+    const int r_s = (lane & 15) >> 2, j_s = lane & 3, hsel = (lane >> 4) & 1, khalf = lane >> 5;
+    const int gbase = (8 * khalf + r_s) * 64 + (16 * hsel + 4 * j_s) * 2;
+    int boff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = 8 * t + 4 * hsel + j_s, ky = tap / 5, kx = tap - 5 * ky;
+        boff[t] = tap < 25 ? (ky * kW2WC + kx + 8 * khalf + r_s) * 8 : kW2XWin;
+    }
+    for (int i = threadIdx.x; i < NSP * 2304 / 16; i += kW1Threads)               // the zero pads (never written again)
+        *reinterpret_cast<f4*>(xl + (i / 144) * kW2XPlane + kW2XWin + (i % 144) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    bool neg = false;
+    constexpr int GU = kW2TR * kW2TC * 4 / kW1Threads;                            // (pixel, 8-channel granule) items of g per thread: 4
+    constexpr int XU = (kW2WR * kW2WC + kW1Threads - 1) / kW1Threads;              // window pixels per thread: 2
+    f4 ga[DT ? 1 : GU], gb[DT ? 1 : GU], xv[XU];
+    u16x8 g16[DT ? GU : 1];
+    auto load_tile = [&](long long tl) {
+        const int cg = (int)(tl % CG);
+        const long long rr = tl / CG;
+        const int rg = (int)(rr % RG), nb = (int)(rr / RG);
+        const int y0 = kW2TR * rg, x0 = kW2TC * cg;
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            const int pix = i >> 2, q = i & 3, py = pix >> 5, px = pix & 31;
+            const bool ok = y0 + py < h && x0 + px < w;
+            const long long el = (((long long)nb * h + y0 + py) * w + x0 + px) * 32 + 8 * q;
+            if constexpr (DT != 0) {
+                g16[u] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) g16[u] = load_stream(reinterpret_cast<const u16x8*>(G + el));
+            } else {
+                ga[u] = (f4){0.f, 0.f, 0.f, 0.f}; gb[u] = ga[u];
+                if (ok) { ga[u] = load_stream(reinterpret_cast<const f4*>(G + el)); gb[u] = load_stream(reinterpret_cast<const f4*>(G + el + 4)); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            const int wy = i / kW2WC, wx = i - wy * kW2WC;
+            const int iy = y0 - 2 + wy, ix = x0 - 2 + wx;
+            xv[u] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (i < kW2WR * kW2WC && iy >= 0 && iy < h && ix >= 0 && ix < w) xv[u] = *reinterpret_cast<const f4*>(X + (((long long)nb * h + iy) * w + ix) * CI);
+        }
+    };
+    auto store_tile = [&](bool negate) {
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            unsigned char* const d = gl + (i >> 2) * 64 + (i & 3) * 16;
+            if constexpr (DT != 0) {
+                u16x8 o = g16[u];
+                if (negate) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (unsigned short)(o[e] ^ 0x8000u);      // (-0 for a zero: harmless)
+                }
+                *reinterpret_cast<u16x8*>(d) = o;
+            } else {
+                u16x8 o[3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v0 = e < 4 ? ga[u][e] : gb[u][e - 4];
+                    const float v = negate ? -v0 : v0;
+                    const __bf16 h1 = (__bf16)v;
+                    const float r1 = v - (float)h1;
+                    const __bf16 h2 = (__bf16)r1;
+                    const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                    o[0][e] = __builtin_bit_cast(unsigned short, h1); o[1][e] = __builtin_bit_cast(unsigned short, h2); o[2][e] = __builtin_bit_cast(unsigned short, h3);
+                }
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<u16x8*>(d + sp * kW2GPlane) = o[sp];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = threadIdx.x + kW1Threads * u;
+            if (i < kW2WR * kW2WC) {
+                u16x4 o[NSP];
+#pragma unroll
+                for (int c = 0; c < CI; ++c) {
+                    const float v = xv[u][c];
+                    if constexpr (DT != 0) { o[0][c] = round_op<DT>(v); continue; }
+                    const __bf16 h1 = (__bf16)v;
+                    const float r1 = v - (float)h1;
+                    const __bf16 h2 = (__bf16)r1;
+                    const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                    o[0][c] = __builtin_bit_cast(unsigned short, h1);
+                    if constexpr (NSP == 3) { o[1][c] = __builtin_bit_cast(unsigned short, h2); o[2][c] = __builtin_bit_cast(unsigned short, h3); }
+                }
+#pragma unroll
+                for (int sp = 0; sp < NSP; ++sp) *reinterpret_cast<u16x4*>(xl + sp * kW2XPlane + i * 8) = o[sp];
+            }
+        }
+    };
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) * lds4_t;
+    auto frag = [&](const unsigned char* p0, int step) {                            // 8 consecutive pixels of one channel: two transposed reads, `step` bytes = 4 pixels
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + step));
+        return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+#pragma unroll 1
+    for (long long tl = t_begin; tl < t_end; ++tl) {
+        __syncthreads();                                                        // the previous tile's readers are done
+        store_tile(neg);
+        __syncthreads();
+        if (tl + 1 < t_end) load_tile(tl + 1);
+        const float sgn = neg ? -1.f : 1.f;
+        f32x16 tmp[NT];
+#pragma unroll
+        for (int j = 0; j < kW2TR / 2; ++j) {                                   // this wavefront's k-steps: ks = wv + 4 j -> tile row ks >> 1, column half ks & 1
+            const int ks = wv + 4 * j, py = ks >> 1, hh = ks & 1;
+            const int goff = (py * 32 + 16 * hh) * 64, xoff = (py * kW2WC + 16 * hh) * 8;
+            s16x8 a[NSP];
+#pragma unroll
+            for (int sp = 0; sp < NSP; ++sp) a[sp] = frag(gl + sp * kW2GPlane + gbase + goff, 4 * 64);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                s16x8 b[NSP];
+#pragma unroll
+                for (int sp = 0; sp < NSP; ++sp) b[sp] = frag(xl + sp * kW2XPlane + boff[t] + xoff, 4 * 8);
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (DT != 0) {
+                    tmp[t] = mfma32<DT>(a[0], b[0], j == 0 ? zero : tmp[t]);
+                } else {                                                        // six cross terms, smallest first: al bh, am bm, ah bl, am bh, ah bm, ah bh
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], j == 0 ? zero : tmp[t], 0, 0, 0);
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], tmp[t], 0, 0, 0);
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], tmp[t], 0, 0, 0);
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], tmp[t], 0, 0, 0);
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], tmp[t], 0, 0, 0);
+                    tmp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], tmp[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf(sgn, tmp[t][r], acc[t][r]);
+        neg = !neg;
+    }
+    // ---- the four wavefronts' sums meet in LDS, wavefront 0 first (fixed order): D[row = co = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = n] -> red[co][32 t + n]
+    float* const red = reinterpret_cast<float*>(gl);
+    const int mn = lane & 31, kq = lane >> 5;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+        if (wv == q) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* const d = red + ((r & 3) + 8 * (r >> 2) + 4 * kq) * (NT * 32) + 32 * t + mn;
+                    *d = q == 0 ? acc[t][r] : *d + acc[t][r];
+                }
+        }
+    }
+    __syncthreads();
+    float* const pp = part + (long long)blockIdx.x * 32 * NT * 32;
+    for (int i = threadIdx.x; i < 32 * NT * 32; i += kW1Threads) pp[i] = red[i];
+}
+
 constexpr int kW1Ranges = 16;
 
 }  // namespace
+
+// A/B switch (tools/): SS_S1_WGRAD_TR=0 keeps the first form for C_in = 4 too — read once
+static bool s1_wgrad_tr_on()
+{
+    static const char* const e = getenv("SS_S1_WGRAD_TR");
+    return !(e && e[0] == '0');
+}
 
 extern "C" {
 
@@ -675,7 +878,8 @@ int ss_dense_conv_s1_wgrad_f32(const float* g, const float* x, float* g_w, float
     const long long n_tiles = NB * ((h + kW1TR - 1) / kW1TR) * ((w + kW1TC - 1) / kW1TC);
     const unsigned grid = (unsigned)(n_tiles < kW1Groups ? n_tiles : kW1Groups);
     const int NTW = ((25 * Cin + 31) / 32) * 32;
-    if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<4>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
+    if (Cin == 4 && s1_wgrad_tr_on()) hipLaunchKernelGGL((dense_conv_s1_wgrad_tr_kernel<0>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
+    else if (Cin == 4) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<4>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
     else hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<2>), dim3(grid), dim3(kW1Threads), 0, s, g, x, ws, (int)NB, h, w);
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const int len = 32 * NTW, per_range = ((int)grid + kW1Ranges - 1) / kW1Ranges;
@@ -697,7 +901,10 @@ int ss_dense_conv_s1_wgrad_x16(const void* g, const float* x, float* g_w, float*
     const unsigned short* g16 = static_cast<const unsigned short*>(g);
 #define SS_W116(CI_) do { if (dtype == SS_DT_F16) hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<CI_, SS_DT_F16>), dim3(grid), dim3(kW1Threads), 0, s, g16, x, ws, (int)NB, h, w); \
                           else hipLaunchKernelGGL((dense_conv_s1_wgrad_kernel<CI_, SS_DT_BF16>), dim3(grid), dim3(kW1Threads), 0, s, g16, x, ws, (int)NB, h, w); } while (0)
-    if (Cin == 4) SS_W116(4); else SS_W116(2);
+    if (Cin == 4 && s1_wgrad_tr_on()) {
+        if (dtype == SS_DT_F16) hipLaunchKernelGGL((dense_conv_s1_wgrad_tr_kernel<SS_DT_F16>), dim3(grid), dim3(kW1Threads), 0, s, g16, x, ws, (int)NB, h, w);
+        else hipLaunchKernelGGL((dense_conv_s1_wgrad_tr_kernel<SS_DT_BF16>), dim3(grid), dim3(kW1Threads), 0, s, g16, x, ws, (int)NB, h, w);
+    } else if (Cin == 4) SS_W116(4); else SS_W116(2);
 #undef SS_W116
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const int len = 32 * NTW, per_range = ((int)grid + kW1Ranges - 1) / kW1Ranges;
