@@ -10,6 +10,6 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- python "$REPO/tools/pmc_target.py" $MODE > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- python "$REPO/tools/pmc_target.py" $MODE > "$OUT/write.log" 2>&1
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- python "$REPO/tools/pmc_target.py" $MODE > "$OUT/fetch.log" 2>&1
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- python "$REPO/tools/pmc_target.py" $MODE > "$OUT/write.log" 2>&1
 python "$REPO/profiles/parse_pmc.py" "$OUT" $MODE | tee "$OUT/pmc_traffic.json"
