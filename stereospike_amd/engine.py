@@ -143,7 +143,11 @@ class GraphedTrainer:
     are GPU-bound and gain nothing — use Trainer there.
 
     Same arithmetic as Trainer.step (the captured work IS that code): Adam with `capturable=True` and a tensor learning rate, so the
-    MultiStepLR schedule (train.py:127) keeps working without a re-capture.  Inputs must keep the shape / dtype of the first batch."""
+    MultiStepLR schedule (train.py:127) keeps working without a re-capture.  Inputs must keep the shape / dtype of the first batch.
+
+    The captured forward runs on detached ALIASES of the parameters (same storage: `load_state_dict` / in-place updates are seen; moving the network to another
+    device or replacing a Parameter object after construction is not) so that autograd graphs the caller still holds from earlier eager passes cannot drag the
+    default stream into the capture (see `_iteration`); gradients land in the Parameters' `.grad` as usual."""
 
     def __init__(self, net, lr=2e-4, weight_decay=0.0, loss_module=None, amp_dtype=None, warmup=3):
         dev = next(net.parameters()).device
