@@ -71,7 +71,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='samples per GPU (config 3: 16)')
     ap.add_argument('--T', type=int, default=5)
-    ap.add_argument('--model', default='StereoSpike', choices=['StereoSpike', 'PLIFNet'])
+    ap.add_argument('--model', default='StereoSpike', choices=['StereoSpike', 'PLIFNet', 'PLIFNetMono'],
+                    help='StereoSpike (binocular IF, the headline); PLIFNet (binocular PLIF); PLIFNetMono = BASELINE.json configs[1]\'s monocular PLIF network '
+                         '(fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike, 2 input channels)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'],
                     help='f32 = the headline config; bf16 / f16 = 16-bit activations under torch.autocast with fp32 membrane '
                          '(BASELINE.json configs 2 / 5) — reported as a separate line, never as the headline value')
@@ -80,6 +82,9 @@ def parse():
     ap.add_argument('--cpu-b16', type=int, default=1,
                     help='1 (default): also time ONE iteration of the CPU port at the bench batch size (SURVEY.md §8(d): B = 16; ~110 s on the GPU box host, '
                          'measured 0.145 frames/s in profiles/r02/) as `cpu_baseline_B16_n1`; 2: as `cpu_baseline_B16` with evaluation pass, warm-up and >= 1 timed iteration (~6 min); 0: skip')
+    ap.add_argument('--sustained-seconds', type=float, default=15.0,
+                    help='after the timed region (and the event-timer pass): this many seconds of back-to-back steps, reported as `sustained` '
+                         '(clock / thermal steady state; also what an external GPU-busy sampler gets to see).  0: skip')
     ap.add_argument('--leg-steps', type=int, default=5,
                     help='steps of the SECOND pass that times every fused launch with HIP events (roofline legs); the headline pass runs with the timer off')
     ap.add_argument('--miopen-find', type=int, default=1,
@@ -121,10 +126,34 @@ def build_net(model, device, config=None):
     if model == 'StereoSpike':
         net = S.StereoSpike(surrogate_function=surrogate.ATan(), detach_reset=True, v_threshold=1.0, v_reset=0.,
                             multiply_factor=10., config=config)   # gain 10 so neurons fire
+    elif model == 'PLIFNetMono':
+        net = S.fromZero_feedforward_multiscale_tempo_monocular_SpikeFlowNetLike(tau=3., v_threshold=1.0, v_reset=0.0,
+                                                                                  use_plif=True, multiply_factor=30., config=config)
     else:
         net = S.fromZero_feedforward_multiscale_tempo_Matt_SpikeFlowNetLike(tau=3., v_threshold=1.0, v_reset=0.0,
                                                                              use_plif=True, multiply_factor=30., config=config)
     return net.to(device)
+
+
+def workload_label(model, T, batch, dtype, world, count_rates=False):
+    """`config.workload`, derived from the arguments: the BASELINE.json index is named only when the arguments ARE that configuration
+    (VERDICT r05 weak #8b); anything else is described as what it is."""
+    cams = 'monocular' if model == 'PLIFNetMono' else 'binocular'
+    neuron = 'IF' if model == 'StereoSpike' else 'PLIF'
+    what = f'{model} ({cams}, {neuron}) T={T} 260x346, batch {batch} per GPU x {world} GPU(s), {dtype} activations'
+    idx = None
+    if model == 'PLIFNetMono' and T == 1 and batch == 8 and dtype == 'bf16' and world == 1:
+        idx = 'BASELINE.json configs[1]'
+    elif model == 'StereoSpike' and T == 5 and dtype == 'f32' and batch == 16 and world == 1:
+        idx = 'BASELINE.json configs[2]'
+    elif model == 'StereoSpike' and T == 5 and dtype == 'f32' and batch * world == 128 and world == 8:
+        idx = 'BASELINE.json configs[3]'
+    elif model == 'StereoSpike' and T == 5 and dtype == 'f32' and batch == 16:
+        idx = f'BASELINE.json configs[3] at {world} of 8 GPUs (the per-GPU share, batch 16, is configs[2]\'s)'
+    elif model == 'StereoSpike' and T == 10 and dtype == 'f16' and batch == 32 and count_rates:
+        idx = 'BASELINE.json configs[4]' if world == 8 else f'the per-GPU share (batch 32) of BASELINE.json configs[4] (batch 256 over 8 GPUs) on {world} GPU(s)'
+    return what + (f' = {idx}' if idx else ' (not a BASELINE.json configuration)') + \
+        ': train step (reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd' + (', firing-rate counters on' if count_rates else '')
 
 
 _EVAL_REF = {}
@@ -141,9 +170,9 @@ def cpu_baseline(model, T, budget_s, B=1, min_iters=5, quick=False):
     if model == 'StereoSpike':
         net = rn.build('StereoSpike', multiply_factor=10., surrogate_function=sj.ATan())
     else:
-        net = rn.build('PLIFNet', tau=3., use_plif=True, multiply_factor=30.)
+        net = rn.build(model, tau=3., use_plif=True, multiply_factor=30.)
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)
-    x, gt = synthetic_batch(B, T, seed=2021)
+    x, gt = synthetic_batch(B, T, C=2 if model == 'PLIFNetMono' else 4, seed=2021)
     eval_mde = eval_mde64 = None
     if not quick:
         # eval MDE on identical (seed-2021 default-init) weights and inputs, before any update: the "eval MDE" half of the metric
@@ -184,7 +213,7 @@ def cpu_baseline(model, T, budget_s, B=1, min_iters=5, quick=False):
     how = 'ONE timed training iteration, no warm-up' if quick else f'median of {n} timed training iterations after 1 warm-up'
     return dict(value=B / med, unit='frames/s', cores=torch.get_num_threads(), kind='port', eval_mde_m=eval_mde, eval_mde_m_float64_convs=eval_mde64,
                 iteration_s=dict(median=round(med, 3), min=round(min(times), 3), max=round(max(times), 3), n=n),
-                sample=f'{model} binocular T={T} 260x346 fp32, B={B}, {how}, eager unfused oracle port, torch {torch.__version__} CPU, '
+                sample=f'{model} {"monocular" if model == "PLIFNetMono" else "binocular"} T={T} 260x346 fp32, B={B}, {how}, eager unfused oracle port, torch {torch.__version__} CPU, '
                        f'{torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs')
 
 
@@ -242,7 +271,8 @@ def main():
         assert not use_dp, '--graph is single-GPU'
         from stereospike_amd.engine import GraphedTrainer
         trainer = GraphedTrainer(net, amp_dtype=amp_dtype)
-    x, gt = synthetic_batch(a.batch, a.T, seed=2021 + rank, device=dev)     # resident in HBM before timing
+    in_ch = 2 if a.model == 'PLIFNetMono' else 4
+    x, gt = synthetic_batch(a.batch, a.T, C=in_ch, seed=2021 + rank, device=dev)     # resident in HBM before timing
 
     def sync():
         if use_dp:
@@ -283,6 +313,34 @@ def main():
         TIMER.enabled = False
     leg_elapsed = time.perf_counter() - t_leg0
     leg_steps = max(1, leg_steps)
+    # ---- sustained leg: back-to-back steps for >= --sustained-seconds (the headline region is a sub-second burst after warm-up: this is what the chip holds
+    # at steady clocks / temperature, and what an external SMI sampler can see).  Same step, timer off, barrier + synchronize on both sides, MAX over ranks.
+    sustained = None
+    if a.sustained_seconds > 0:
+        per_step = elapsed / a.steps
+        chunk = max(1, int(round(1.0 / max(per_step, 1e-4))))           # synchronise about once a second
+        sync()
+        t_s0 = time.perf_counter()
+        n_sus = 0
+        while True:
+            for _ in range(chunk):
+                trainer.step(x, gt)
+            n_sus += chunk
+            torch.cuda.synchronize()
+            go = torch.tensor([1.0 if time.perf_counter() - t_s0 < a.sustained_seconds else 0.0], device=dev)
+            if use_dp:
+                dist.all_reduce(go, op=dist.ReduceOp.MIN)               # every rank runs the same number of steps
+            if float(go.item()) == 0.0:
+                break
+        sync()
+        sus_elapsed = time.perf_counter() - t_s0
+        if use_dp:
+            t = torch.tensor([sus_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sus_elapsed = float(t.item())
+        sustained = dict(steps=n_sus, seconds=round(sus_elapsed, 2), frames_per_s=round(a.batch * world * n_sus / sus_elapsed, 3),
+                         ms_per_step=round(1e3 * sus_elapsed / n_sus, 3),
+                         offsets_s=dict(start=round(t_s0 - _T_PROCESS_START, 2), end=round(t_s0 - _T_PROCESS_START + sus_elapsed, 2)))
     summ = TIMER.summary()
     shapes = TIMER.summary(by_shape=True)
 
@@ -338,7 +396,7 @@ def main():
         recompute_h = bool(engine_cfg.RECOMPUTE_H)
         packed_on = bool(engine_cfg.PACK_SPIKES) and a.dtype == 'f32' and recompute_h      # the PK instantiations run (2-bit packed outputs / skips)
         out = {
-            'metric': 'train frames/sec (260x346xT=5 stereo voxels)', 'value': round(frames / elapsed, 3),
+            'metric': f'train frames/sec (260x346xT={a.T} {"mono" if a.model == "PLIFNetMono" else "stereo"} voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if use_dp else 1, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1e3 * elapsed / a.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             # where the timed region sits inside this process (seconds since interpreter start): a sampler that saw no GPU activity during most of the
@@ -349,10 +407,12 @@ def main():
             'per_kernel_legs': dict(steps=leg_steps, ms_per_step_with_event_timer=round(1e3 * leg_elapsed / leg_steps, 3),
                                     note='separate pass after the timed region: fused.TIMER (one HIP-event pair per fused launch) is OFF while `value` is measured'),
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{a.model} binocular T={a.T} 260x346 (BASELINE.json configs[2]): train step '
-                                   f'(reset, T-step fwd, Total_Loss, BPTT, Adam), fused LIF fwd + surrogate bwd',
+            'sustained': sustained,
+            'sustained_frames_per_s': sustained['frames_per_s'] if sustained else None,
+            'sustained_over_value': round(sustained['frames_per_s'] / (frames / elapsed), 4) if sustained else None,
+            'config': {'workload': workload_label(a.model, a.T, a.batch, a.dtype, world, bool(a.count_rates)),
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
-                       'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': 'default init, seed 2021, multiply_factor 10',
+                       'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': f'default init, seed 2021, multiply_factor {10 if a.model == "StereoSpike" else 30}',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
             'roofline_fwd': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
                                         f'{bpu(fwd)} B/update'
@@ -421,7 +481,7 @@ def main():
             from stereospike_amd.clock_driven import functional as _F
             from stereospike_amd.engine import synthetic_batch as _sb
             net0 = build_net(a.model, dev, engine_cfg)
-            x0, gt0 = _sb(1, a.T, seed=2021, device=dev)
+            x0, gt0 = _sb(1, a.T, C=in_ch, seed=2021, device=dev)
             with torch.no_grad():
                 _F.reset_net(net0)
                 r0 = net0.forward_sequence(x0)

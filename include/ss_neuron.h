@@ -49,7 +49,7 @@ extern "C" {
 #define SS_SG_SIGMOID  1   /* g * (1 - s) * s * alpha, s = sigmoid(alpha*x)     surrogate.Sigmoid */
 
 /* ABI version of this header; ss_abi_version() of the loaded library must match. */
-#define SS_ABI_VERSION 9
+#define SS_ABI_VERSION 10
 int ss_abi_version(void);
 /* first 16 hex digits of the sha256 over the sources the loaded library was built from (ABI 9; profiles/ evidence records it, bench.py checks it) */
 const char* ss_source_hash(void);
@@ -214,6 +214,10 @@ int ss_neuron_bwd_fork_x16(const void* g_out_seq, const void* g_out2_seq, void* 
  *    its two partial counts and a one-workgroup second pass adds their sum to nnz[0..1]; the launch keeps its full grid (with
  *    cnt_ws == NULL the atomics form bounds the grid to 2048 workgroups).  Integer sums: deterministic either way.
  *
+ *  - v_last == NULL (ABI 10), packed forms only (out_packed or skip_packed given): the membrane after step T is not written — 4 B per neuron less, 10 - 36 % of
+ *    what a packed-only forward moves.  The reference resets every membrane before the next pass (/root/reference/train.py:221); a caller that needs it
+ *    later runs the same call again on the layer input it keeps for ss_neuron_bwd_rc_* (stereospike_amd.fused.membrane_after).
+ *
  * act_dtype: 0 = fp32 activations (x_seq / skip_seq / out_seq are float*), SS_DT_F16 / SS_DT_BF16 = 16-bit activations (no packed I/O).
  * `size` must be sizeof(ss_neuron_fwd_desc) (lets the struct grow without breaking old callers).
  */
@@ -227,7 +231,7 @@ typedef struct ss_neuron_fwd_desc {
     void* out_seq;                       /* nullable when out_packed is given */
     unsigned int* out_packed;            /* nullable */
     float* h_seq;                        /* nullable */
-    float* v_last;
+    float* v_last;                       /* nullable in the packed forms (ABI 10) */
     unsigned long long* nnz;             /* nullable, [2] */
     unsigned int* cnt_ws;                /* nullable; requires nnz */
     int T;

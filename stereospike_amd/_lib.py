@@ -10,7 +10,7 @@ import torch  # imported BEFORE the CDLL so that libamdhip64.so.7 resolves to th
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libss_neuron.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 KIND_IF, KIND_LIF, KIND_PLIF = 0, 1, 2
 SG_ATAN, SG_SIGMOID = 0, 1

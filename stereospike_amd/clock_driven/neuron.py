@@ -14,8 +14,23 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..fused import NeuronCfg, fused_neuron
+from ..fused import NeuronCfg, fused_neuron, membrane_after, _cfg as _engine_cfg
 from . import surrogate as _sg
+
+
+class _LazyMembrane:
+    """The membrane after a fused T-step training pass whose kernel did not write it (EngineConfig.LAZY_MEMBRANE): everything needed to recompute it —
+    the layer input (kept for the recompute backward anyway), the membrane the pass started from and the node's parameters at that time."""
+    __slots__ = ('x_seq', 'v_init', 'cfg', 'k', 'channels_last', 'shape', 'dtype', 'device')
+
+    def __init__(self, x_seq, v_init, cfg, k, channels_last):
+        self.x_seq, self.v_init, self.cfg, self.channels_last = x_seq.detach(), (None if v_init is None else v_init.detach()), cfg, channels_last
+        self.k = None if k is None else k.detach().clone()
+        self.shape, self.dtype, self.device = x_seq.shape[1:], torch.float32, x_seq.device
+
+    def materialize(self) -> torch.Tensor:
+        v = membrane_after(self.x_seq, self.cfg, self.v_init, self.k)
+        return v.permute(0, 3, 1, 2) if self.channels_last else v
 
 
 class BaseNode(nn.Module):
@@ -34,14 +49,28 @@ class BaseNode(nn.Module):
         self.detach_reset = detach_reset
         self.surrogate_function = _sg.Sigmoid() if surrogate_function is None else surrogate_function
         self.v = v_reset          # python float until the first charge, then a tensor (as upstream)
+        self.last_numel = 0       # neurons of the last pass (firing-rate denominators need no membrane)
 
     # ---- state protocol -------------------------------------------------------------------------
+    @property
+    def v(self):
+        """The membrane: python float until the first charge, then a tensor (as upstream).  After a training pass that left it unwritten it is recomputed
+        here, once, on first access (_LazyMembrane)."""
+        v = self._v
+        if isinstance(v, _LazyMembrane):
+            v = self._v = v.materialize()
+        return v
+
+    @v.setter
+    def v(self, value):
+        object.__setattr__(self, '_v', value)
+
     def reset(self):
         self.v = self.v_reset
 
     def detach(self):
-        if isinstance(self.v, torch.Tensor):
-            self.v = self.v.detach()      # (not detach_(): the I-pool membrane is a view of the read-out buffer)
+        if isinstance(self._v, torch.Tensor):   # (an unwritten membrane has no autograd history to cut)
+            self.v = self._v.detach()     # (not detach_(): the I-pool membrane is a view of the read-out buffer)
 
     def extra_repr(self):
         return f'v_threshold={self.v_threshold}, v_reset={self.v_reset}, detach_reset={self.detach_reset}'
@@ -87,11 +116,18 @@ class BaseNode(nn.Module):
         pack (1: dense + packed, 2: packed only — the returned tensor is then a data-less anchor of the logical shape) also writes the
         output as a 2-bit packed spike tensor, left in `self.last_packed` (None when the packed kernel form does not apply: the output
         is then dense); skip_packed: the skip operand in that form."""
-        res = fused_neuron(x_seq, self._cfg(scale), v_init=self._v_init(x_seq[0], channels_last),
-                           skip_seq=skip_seq, k=self._k(), nnz=nnz, fork=fork, pack=pack, skip_packed=skip_packed)
+        cfg, v_init, k = self._cfg(scale), self._v_init(x_seq[0], channels_last), self._k()
+        # a multi-step pass under autograd: the membrane after it is read by nobody before the next reset_net (train.py:221) — leave it unwritten where the
+        # kernel form allows and recompute on demand (`v` property); single steps (the drop-in `net(x[:, t])` loop) and inference carry it as a tensor
+        lazy = bool(_engine_cfg().LAZY_MEMBRANE) and x_seq.shape[0] > 1 and torch.is_grad_enabled() and x_seq.requires_grad
+        res = fused_neuron(x_seq, cfg, v_init=v_init, skip_seq=skip_seq, k=k, nnz=nnz, fork=fork, pack=pack, skip_packed=skip_packed, want_v=not lazy)
         self.last_packed = res[-1] if pack else None
+        self.last_numel = x_seq[0].numel()
         v_last = res[1]
-        self.v = v_last.permute(0, 3, 1, 2) if channels_last else v_last
+        if v_last is None:
+            self.v = _LazyMembrane(x_seq, v_init, cfg, k, channels_last)
+        else:
+            self.v = v_last.permute(0, 3, 1, 2) if channels_last else v_last
         return (res[0], res[2]) if fork else res[0]
 
     def forward_fused(self, x: torch.Tensor, scale: float = 1., skip: Optional[torch.Tensor] = None,

@@ -26,6 +26,9 @@ class EngineConfig:
     PACK_SPIKES: bool = True            # 2-bit packed spike tensors on the edges whose consumers read them
     LOWRANK_HEAD_GRAD: bool = True      # a prediction head hands its input gradient over as the rank-9 pair (g_P, W2)   [SS_LOWRANK_HEAD_GRAD]
     FORK_OUTPUTS: bool = True           # two-consumer outputs as two handles; the neuron backward adds the two gradients on load
+    LAZY_MEMBRANE: bool = True          # a T-step training pass on the packed kernel forms does not write the membrane after step T (the reference resets it before the next
+                                        # pass, train.py:221): `node.v` recomputes it on first access from the layer input the backward keeps, WITHOUT autograd history — as after
+                                        # net.detach().  False: written by every pass and differentiable (BPTT across un-reset, un-detached calls)   [SS_LAZY_MEMBRANE]
     # ---- network layout -------------------------------------------------------------------------------------------------------------------------------
     FUSE_UPCONV: bool = True            # NNConvUpsampling through the projected form (no up-sampled tensor); False: the reference's two-op form on MIOpen
     DECODER_CHANNELS_LAST: bool = True  # decoder in NHWC memory
@@ -70,7 +73,7 @@ class EngineConfig:
             BOX_BWD=flag('SS_BOX_BWD', True), X16_OWN_KERNELS=flag('SS_X16_OWN_KERNELS', True), SUB_FWD=flag('SS_SUB_FWD', True), GEMM6_DGRAD=flag('SS_GEMM6_DGRAD', True),
             CONV_DGRAD_MFMA=flag('SS_CONV_DGRAD_MFMA', True), SPIKE_CONV_FWD_MFMA=flag('SS_CONV_FWD_MFMA', True),
             SPIKE_CONV_WGRAD_MFMA=flag('SS_CONV_WGRAD_MFMA', True), DENSE_CONV_S1_MFMA=flag('SS_CONV_S1_MFMA', True),
-            DENSE_CONV_S1_WGRAD_MFMA=flag('SS_CONV_S1_WGRAD_MFMA', True))
+            DENSE_CONV_S1_WGRAD_MFMA=flag('SS_CONV_S1_WGRAD_MFMA', True), LAZY_MEMBRANE=flag('SS_LAZY_MEMBRANE', True))
 
     @staticmethod
     def default() -> 'EngineConfig':

@@ -24,6 +24,7 @@
 // Rounding discipline: compiled with -ffp-contract=off; every fp32 op below is written in the order eager
 // PyTorch evaluates the reference (x*scale first, true division by tau, (1-z)*h + z*v_reset literally).
 #include "ss_common.hpp"
+#include "ss_neuron16_v2.hpp"
 
 namespace {
 
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
                 op[(long long)t * NV] = ov;
             }
         }
-        reinterpret_cast<vec_t*>(a.v_last)[i] = vv;
+        if (!PK || a.v_last) reinterpret_cast<vec_t*>(a.v_last)[i] = vv;      // (the packed training forms may leave the membrane unwritten: ss_neuron_fwd_ex)
     }
 
     if (a.nnz) count_epilogue(c_spk, c_out, a.nnz, a.cnt_ws);   // wave-uniform
@@ -210,23 +211,11 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd_kernel(FwdArgs a)
 // 16-bit activation I/O variants (fp16 / bf16 in HBM, fp32 arithmetic and membrane): a lane owns 8 consecutive
 // neurons = one 16-B load of x, one 16-B store of out and two 16-B stores of h per time step.
 // ---------------------------------------------------------------------------------------------------
-struct Fwd16Args {
-    const unsigned short* x_seq; const float* v_init; const unsigned short* skip_seq;
-    unsigned short* out_seq; float* h_seq; float* v_last; unsigned long long* nnz;
-    int T; long long N;
-    float scale, tau, v_th, v_reset; const float* k;
-    unsigned* cnt_ws;              // nullable (with nnz): per-workgroup counter partials (ss_neuron_fwd_ex)
-    // ss_neuron_fwd_ex only (PK instantiations, round 5): 2-bit packed spike I/O exactly as in the fp32 kernel — the packed format knows no activation dtype
-    const unsigned* skip_packed;   // nullable: the skip operand read from a packed spike tensor instead of skip_seq
-    unsigned* out_packed;          // nullable: out (z + skip, values 0..3) written packed; out_seq may then be NULL (2.25 B/update forward)
-};
-
 // TS > 0: compile-time T, all T (independent) loads of a lane issued before the recurrence starts, like the fp32 kernel; TS = 0: run-time T.
-// PK: the ss_neuron_fwd_ex form with 2-bit packed spike output and / or packed skip input (VEC = 8 | 4, compile-time T only, no saved h)
-template <int KIND, int DT, int TS, bool SKIP, bool SAVE_H, int VEC, bool PK = false>
+// (the ss_neuron_fwd_ex form with 2-bit packed spike output and / or packed skip input is neuron_fwd16_pk8_kernel, ss_neuron16_v2.hpp)
+template <int KIND, int DT, int TS, bool SKIP, bool SAVE_H, int VEC>
 __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
 {
-    static_assert(!PK || (TS > 0 && (VEC == 8 || VEC == 4) && !SAVE_H), "packed I/O: compile-time T, 16 / 8-byte lanes, no saved h");
     typedef typename U16Vec<VEC>::type uvec_t;
     const int T = (TS > 0) ? TS : a.T;
     const long long NV = a.N / VEC;
@@ -266,46 +255,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd16_kernel(Fwd16Args a)
             }
         };
 
-        if constexpr (PK) {
-            const long long NW = a.N / 16;                 // packed words per time step
-            const bool skip_pk = SKIP && a.skip_packed != nullptr;
-            uvec_t xs[TS];
-            unsigned sb[TS];
-#pragma unroll
-            for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const uvec_t*>(a.x_seq + ((long long)t * NV + i) * VEC));
-            if (SKIP) {
-                if (skip_pk) {
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) sb[t] = load_packed<VEC>(a.skip_packed + (long long)t * NW, i);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < TS; ++t) {           // dense 16-bit skip: small integers 0..3, exact in the 2-bit code
-                        const uvec_t sv = *reinterpret_cast<const uvec_t*>(a.skip_seq + ((long long)t * NV + i) * VEC);
-                        sb[t] = 0u;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) sb[t] |= ((unsigned)widen<DT>(sv[e]) & 3u) << (2 * e);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < TS; ++t) {
-                uvec_t ov;
-                unsigned bits = 0;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const float hh = charge<KIND>(v[e], widen<DT>(xs[t][e]) * scale, tau, k, v_reset);
-                    const float z = heaviside(hh - v_th);
-                    v[e] = (1.f - z) * hh + z * v_reset;
-                    unsigned code = (unsigned)(z != 0.f) + (SKIP ? ((sb[t] >> (2 * e)) & 3u) : 0u);
-                    code = code > 3u ? 3u : code;       // contract (ss_neuron.h): z + skip <= 3
-                    c_spk += (z != 0.f); c_out += (code != 0u);
-                    bits |= code << (2 * e);
-                    ov[e] = code_to_op<DT>(code);
-                }
-                if (a.out_seq) store_out(reinterpret_cast<uvec_t*>(a.out_seq + ((long long)t * NV + i) * VEC), ov);
-                if (a.out_packed) store_packed<VEC>(a.out_packed + (long long)t * NW, i, bits);
-            }
-        } else if constexpr (TS > 0) {
+        if constexpr (TS > 0) {
             uvec_t xs[TS], ss[SKIP ? TS : 1];
 #pragma unroll
             for (int t = 0; t < TS; ++t) {
@@ -392,7 +342,7 @@ int launch_fwd_pk(const FwdArgs& a, hipStream_t s)
     if constexpr (TS == 0) return SS_EINVAL;
     else {
         if (a.N == 0) return SS_OK;
-        const bool ok = (a.N % 16 == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && aligned16(a.v_last) &&
+        const bool ok = (a.N % 16 == 0) && aligned16(a.x_seq) && aligned16(a.out_seq) && (!a.v_last || aligned16(a.v_last)) &&
                         (!a.v_init || aligned16(a.v_init)) && (!a.skip_seq || aligned16(a.skip_seq)) && !a.h_seq;
         if (!ok) return SS_EINVAL;
         const int cap = (a.nnz && !a.cnt_ws) ? kMaxGridGk : kMaxGrid;
@@ -442,14 +392,24 @@ int launch_fwd16(const Fwd16Args& a, hipStream_t s)
                      (!a.v_init || aligned16(a.v_init)) && (!a.skip_seq || aligned16(a.skip_seq)) && (!save_h || aligned16(a.h_seq));
     const int cap = (a.nnz && !a.cnt_ws) ? kMaxGridGk : kMaxGrid;
     const int grid = vec ? grid_for(a.N / V, cap) : grid_for(a.N, cap);
+    if (!(a.out_packed || a.skip_packed) && !a.v_last) return SS_EINVAL;      // v_last is optional in the packed forms only
     if (a.out_packed || a.skip_packed) {                  // packed spike I/O: 16-B lanes, compile-time T, no saved h
         if constexpr (TS == 0) return SS_EINVAL;
         else {
-            if (!vec || a.N % 16 != 0 || save_h) return SS_EINVAL;
-            if (skip) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, true, false, V, true>), dim3(grid), dim3(kBlock), 0, s, a);
-            else hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, false, false, V, true>), dim3(grid), dim3(kBlock), 0, s, a);
+            // round 6: neuron_fwd16_pk8_kernel (ss_neuron16_v2.hpp) — 8 neurons per lane at every T, 10 - 12 VALU instructions per update instead of 33
+            const bool vec8 = (a.N % 16 == 0) && aligned16(a.x_seq) && (!a.out_seq || aligned16(a.out_seq)) && (!a.v_last || aligned16(a.v_last)) &&
+                              (!a.v_init || aligned16(a.v_init)) && (!a.skip_seq || aligned16(a.skip_seq));
+            if (!vec8 || save_h) return SS_EINVAL;
+            const int grid8 = grid_for(a.N / 8, cap);
+            if (a.out_seq) {
+                if (skip) hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<KIND, DT, TS, true, true>), dim3(grid8), dim3(kBlock), 0, s, a);
+                else hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<KIND, DT, TS, false, true>), dim3(grid8), dim3(kBlock), 0, s, a);
+            } else {
+                if (skip) hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<KIND, DT, TS, true, false>), dim3(grid8), dim3(kBlock), 0, s, a);
+                else hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<KIND, DT, TS, false, false>), dim3(grid8), dim3(kBlock), 0, s, a);
+            }
             if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
-            return finish_counts(a.nnz, a.cnt_ws, grid, s);
+            return finish_counts(a.nnz, a.cnt_ws, grid8, s);
         }
     }
 #define SS_L16(SK, SH) do { if (vec) hipLaunchKernelGGL((neuron_fwd16_kernel<KIND, DT, TS, SK, SH, V>), dim3(grid), dim3(kBlock), 0, s, a); \
@@ -533,7 +493,8 @@ long long ss_neuron_cnt_ws_words(long long N)
 int ss_neuron_fwd_ex(const ss_neuron_fwd_desc* d, void* stream)
 {
     if (!d || d->size != sizeof(ss_neuron_fwd_desc)) return SS_EINVAL;
-    if (!d->x_seq || !d->v_last || d->T <= 0 || d->N < 0 || (!d->out_seq && !d->out_packed)) return SS_EINVAL;
+    if (!d->x_seq || d->T <= 0 || d->N < 0 || (!d->out_seq && !d->out_packed)) return SS_EINVAL;
+    if (!d->v_last && !(d->out_packed || d->skip_packed)) return SS_EINVAL;      // v_last == NULL (ABI 10): the packed forms only — the membrane after step T is not written
     if (d->kind < SS_KIND_IF || d->kind > SS_KIND_PLIF || (d->kind == SS_KIND_PLIF && !d->k)) return SS_EINVAL;
     if (d->out_seq == d->x_seq || (d->skip_seq && d->skip_packed)) return SS_EINVAL;
     if (d->cnt_ws && !d->nnz) return SS_EINVAL;

@@ -1,15 +1,9 @@
 // ss_neuron_bwd16.hip — surrogate-gradient backward of the fused neuron layers on 16-bit activations (fp16 / bf16 in HBM, fp32 arithmetic) + C-ABI.
 // Design notes: see ss_neuron.hip.
 #include "ss_common.hpp"
+#include "ss_neuron16_v2.hpp"
 
 namespace {
-
-struct Bwd16Args {
-    const unsigned short* g_out_seq; const float* g_v_last; const float* h_seq; const float* v_init;
-    unsigned short* g_x_seq; float* g_v_init; double* g_k_partials;
-    int T; long long N;
-    float scale, tau, v_th, v_reset, alpha; const float* k; int detach_reset;
-};
 
 template <int KIND, int SG, int DT, int VEC>
 __global__ __launch_bounds__(kBlock) void neuron_bwd16_kernel(Bwd16Args a)
@@ -303,6 +297,13 @@ int dispatch_bwd16_rc(const Bwd16Args& a, const unsigned short* x_seq, const uns
 
 extern "C" {
 
+// the segmented low-rank form (ss_neuron_bwd16_lr.hip)
+int ss_i_bwd16_lr_seg_supported(int T, long long N, int C);
+int ss_i_bwd16_lr_seg(const void* g_out_seq, const float* g_v_last, const float* v_init, void* g_x_seq, float* g_v_init, double* g_k_partials,
+                      const void* x_seq, void* g_sum_seq, const float* lr_p, const float* lr_w, int C,
+                      int T, long long N, float scale, int kind, float tau, const float* k, float v_th, float v_reset,
+                      int surrogate, float alpha, int detach_reset, int dtype, void* stream, int* grid_out);
+
 static int neuron_bwd_x16_impl(const void* g_out_seq, const void* g_out2_seq, void* g_sum_seq, const float* g_v_last, const float* h_seq, const void* x_seq, const float* v_init,
                                void* g_x_seq, float* g_v_init, float* g_k, float* g_k_ws,
                                int T, long long N, float scale, int kind, float tau, const float* k,
@@ -327,6 +328,16 @@ static int neuron_bwd_x16_impl(const void* g_out_seq, const void* g_out2_seq, vo
     int grid = 0, rc;
     const unsigned short* g2q = static_cast<const unsigned short*>(g_out2_seq);
     unsigned short* gsq = (g2q || lr_p) ? static_cast<unsigned short*>(g_sum_seq) : nullptr;
+    if (lr_p && ss_i_bwd16_lr_seg_supported(T, N, lr_C)) {       // round 6: the segmented form (LDS-staged pair, Newton reciprocal) where it applies
+        rc = ss_i_bwd16_lr_seg(g_out_seq, g_v_last, v_init, g_x_seq, g_v_init, a.g_k_partials, x_seq, gsq, lr_p, lr_w, lr_C, T, N, scale, kind, tau, k, v_th, v_reset,
+                               surrogate, alpha, detach_reset, dtype, stream, &grid);
+        if (rc != SS_OK) return rc;
+        if (want_gk) {
+            hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(kBlock), 0, s, reinterpret_cast<const double*>(g_k_ws), grid, g_k);
+            if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+        }
+        return SS_OK;
+    }
 #define SS_B16D(KK, SGG, DTT) (xq ? dispatch_bwd16_rc<KK, SGG, DTT>(a, xq, g2q, gsq, s, &grid, lr_p, lr_w, lr_C) : dispatch_bwd16<KK, SGG, DTT>(a, s, &grid))
 #define SS_B16(KK, SGG) (dtype == SS_DT_F16 ? SS_B16D(KK, SGG, SS_DT_F16) : SS_B16D(KK, SGG, SS_DT_BF16))
 #define SS_B16S(KK) (surrogate == SS_SG_ATAN ? SS_B16(KK, SS_SG_ATAN) : SS_B16(KK, SS_SG_SIGMOID))
@@ -381,6 +392,7 @@ int ss_neuron_bwd_fork_x16(const void* g_out_seq, const void* g_out2_seq, void* 
 int ss_neuron_bwd_fork_lr_x16_supported(int T, long long N, int C, int lr_rank)
 {
     const int V = T <= 5 ? SS_RC16_V5 : SS_RC16_V10;
+    if (lr_rank == kLr16Rank && ss_i_bwd16_lr_seg_supported(T, N, C)) return 1;
     return ss_neuron_bwd_rc_supported(T) && lr_rank == kLr16Rank && C >= 4 && C <= kLr16MaxC && C % V == 0 && C % 4 == 0 && (kBlock * V) % C == 0 && N > 0 && N % C == 0;
 }
 

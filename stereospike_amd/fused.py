@@ -199,7 +199,7 @@ def lowrank_dense(lr, shape, dtype=torch.float32):
 
 class _FusedNeuron(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False, pack=0, skip_packed=None):
+    def forward(ctx, x_seq, v_init, skip_seq, k, cfg: NeuronCfg, nnz, fork=False, pack=0, skip_packed=None, want_v=True):
         ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         """pack: 0 dense output; 1 dense + packed; 2 packed only (the returned out_seq is an anchor).  skip_packed: the skip operand as a
         packed tensor (skip_seq then only carries the autograd edge and may be an anchor)."""
@@ -228,7 +228,10 @@ class _FusedNeuron(torch.autograd.Function):
         out_seq = spike_anchor(x_seq.shape, x_seq.dtype, x_seq.device) if pack == 2 else torch.empty_like(x_seq)
         packed = torch.empty((T, N // 16), dtype=torch.int32, device=x_seq.device) if pack else None
         h_seq = torch.empty(x_seq.shape, dtype=torch.float32, device=x_seq.device) if (need_grad and not recompute) else None
-        v_last = torch.empty(x_seq.shape[1:], dtype=torch.float32, device=x_seq.device)
+        # want_v False (a training pass whose membrane nobody reads before the next reset: EngineConfig.LAZY_MEMBRANE): the packed kernel forms then do not
+        # write v_last (4 B per neuron and layer: 10 - 36 % of what the forward moves) and None is returned; the other forms always write it
+        lazy_v = (not want_v) and bool(pack or skip_packed is not None)
+        v_last = None if lazy_v else torch.empty(x_seq.shape[1:], dtype=torch.float32, device=x_seq.device)
         if v_init is not None and v_init.dtype != torch.float32:
             v_init = v_init.float()
         e0 = TIMER.start()
@@ -319,7 +322,7 @@ class _FusedNeuron(torch.autograd.Function):
             _note('neuron_bwd', tag + ('+x16' if half else ''), ctx.site)
             # dL/dskip: the dense sum when there was a dense first gradient, else the low-rank pair itself travels on (identity)
             g_skip = (g_sum if g_out_seq is not None else lr_anchor.view(h_seq.shape)) if want_gskip else None
-            return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
+            return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None, None
         if fuse2 and half:
             _lib.neuron_bwd_fork_x16(g_out_seq, g_out2_seq, g_sum, g_v_last, h_seq, v_init, g_x_seq, g_v_init, g_k, g_k_ws,
                                      T, N, cfg.scale, cfg.kind, cfg.tau, k, cfg.v_th, cfg.v_reset, cfg.surrogate, cfg.alpha, cfg.detach_reset)
@@ -337,20 +340,38 @@ class _FusedNeuron(torch.autograd.Function):
         TIMER.stop(e0, tag, (((6 if ctx.recompute else 8) + ((2 + (2 if g_sum is not None else 0)) if fuse2 else 0)) if half else ((20 if g_sum is not None else 16) if fuse2 else 12)) * T * N, T * N)
         _note('neuron_bwd', tag + ('+x16' if half else ''), ctx.site)
         g_skip = (g_sum if fuse2 else g_out_seq) if want_gskip else None                 # identity
-        return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None
+        return g_x_seq, g_v_init, g_skip, g_k, None, None, None, None, None, None
 
 
 def fused_neuron(x_seq: torch.Tensor, cfg: NeuronCfg, v_init: Optional[torch.Tensor] = None,
                  skip_seq: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None,
-                 nnz: Optional[torch.Tensor] = None, fork: bool = False, pack: int = 0, skip_packed: Optional[torch.Tensor] = None):
+                 nnz: Optional[torch.Tensor] = None, fork: bool = False, pack: int = 0, skip_packed: Optional[torch.Tensor] = None,
+                 want_v: bool = True):
     """x_seq: [T, ...] conv output (before the gain).  Returns (out_seq [T, ...], v_last [...]) — with fork=True a third value: a
     second handle on out_seq for its second consumer (the two gradients are then added inside the backward kernel); with pack != 0 a
-    last value: the 2-bit packed output (int32 [T, N/16]; None when the packed kernel form does not apply — the output is then dense)."""
+    last value: the 2-bit packed output (int32 [T, N/16]; None when the packed kernel form does not apply — the output is then dense).
+    want_v=False: v_last may come back as None (packed kernel forms: the membrane after step T is not written; membrane_after() recomputes it)."""
     if cfg.kind == _lib.KIND_PLIF and k is None:
         raise _lib.SSNeuronError('PLIF needs k = sigmoid(w) as a 0-dim HIP tensor')
-    out, v_last, out2, packed = _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz, fork, pack, skip_packed)
+    out, v_last, out2, packed = _FusedNeuron.apply(x_seq, v_init, skip_seq, k, cfg, nnz, fork, pack, skip_packed, want_v)
     res = (out, v_last) + ((out2,) if fork else ())
     return res + ((packed,) if pack else ())
+
+
+def membrane_after(x_seq: torch.Tensor, cfg: NeuronCfg, v_init: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The membrane after the T steps of x_seq, when the training pass did not write it (want_v=False): one more launch of the packed forward form
+    on the layer input the backward keeps anyway, its spike output thrown away.  No autograd history (what `net.detach()` leaves behind)."""
+    with torch.no_grad():
+        T = x_seq.shape[0]
+        N = x_seq.numel() // T
+        x = x_seq.detach().contiguous()
+        v_last = torch.empty(x.shape[1:], dtype=torch.float32, device=x.device)
+        scratch = torch.empty((T, N // 16), dtype=torch.int32, device=x.device)
+        vi = None if v_init is None else v_init.detach().float().contiguous()
+        _lib.neuron_fwd_ex(x, vi, None, None, None, scratch, None, v_last, None, None, T, N, cfg.scale, cfg.kind, cfg.tau,
+                           None if k is None else k.detach(), cfg.v_th, cfg.v_reset)
+        _note('neuron_fwd', 'membrane_after')
+    return v_last
 
 
 class _IPool(torch.autograd.Function):

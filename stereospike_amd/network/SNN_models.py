@@ -315,8 +315,8 @@ class _SpikingEncoderDecoder(NeuromorphicNet):
         rates = {k: 0. for k in _RATE_KEYS}
 
         def numel(stage_name):
-            node_v = (self.bottleneck[1].sn2 if stage_name == 'rconv' else getattr(self, stage_name)[2]).v
-            return T * node_v.numel()
+            node = self.bottleneck[1].sn2 if stage_name == 'rconv' else getattr(self, stage_name)[2]
+            return T * (node.last_numel or node.v.numel())       # (last_numel: no need to materialise an unwritten membrane for its size)
 
         for name in ('bottom', 'conv1', 'conv2', 'conv3', 'conv4'):
             rates[f'out_{name}'] = cnt[name][0].float() / numel(name)

@@ -65,7 +65,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(L, name), name
     assert sorted(_lib.EXPORTS) == _declared()
-    assert L.ss_abi_version() == _lib.ABI_VERSION == 9
+    assert L.ss_abi_version() == _lib.ABI_VERSION == 10
     assert L.ss_neuron_cnt_ws_words(1024) >= 2 * 4
     assert L.ss_neuron_gk_ws_floats() >= 2048
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()

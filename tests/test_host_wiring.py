@@ -112,7 +112,9 @@ def host_backend(monkeypatch):
         if skip_packed is not None:
             skip_seq = torch.from_numpy(np_pack.unpack(skip_packed.numpy().view(np.uint32).reshape(T, N // 16)))
         dense = out_seq if out_seq is not None else torch.empty(T, N)
-        neuron_fwd(x_seq, v_init, skip_seq, dense, h_seq, v_last, nnz, T, N, scale, kind, tau, k, v_th, v_reset)
+        assert v_last is not None or out_packed is not None or skip_packed is not None      # v_last == NULL: the packed forms only (ABI 10)
+        vl = v_last if v_last is not None else torch.empty(N)
+        neuron_fwd(x_seq, v_init, skip_seq, dense, h_seq, vl, nnz, T, N, scale, kind, tau, k, v_th, v_reset)
         if out_packed is not None:
             out_packed.copy_(torch.from_numpy(np_pack.pack(dense.numpy().reshape(T, N)).view(np.int32)).view_as(out_packed))
 
