@@ -378,11 +378,11 @@ def main():
 
         def roof(d, which='neuron_fwd', pmc_key=None):
             ach = (d['bytes'] / 1e9) / (d['ms'] / 1e3) if d['ms'] > 0 else 0.0
-            traffic = _pmc_traffic(pmc_key or which)
+            traffic = _pmc_traffic(pmc_key or which, a.dtype, a.T, a.batch)
             avg_us = 1e3 * d['ms'] / max(1, d['launches'])
             return dict(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
-                        traffic_source=_pmc_source() if traffic else None,
+                        traffic_source=_pmc_source(a.dtype) if traffic else None,
                         launches=d['launches'], avg_launch_us=round(avg_us, 2),
                         bytes_per_launch=int(d['bytes'] / max(1, d['launches'])),
                         # counter-measured HBM bytes (incl. the O(N) v_last write the per-update figure leaves out) over the same time
@@ -394,7 +394,26 @@ def main():
         def bpu(d):
             return round(d['bytes'] / d['updates'], 1) if d['updates'] else 0
         recompute_h = bool(engine_cfg.RECOMPUTE_H)
-        packed_on = bool(engine_cfg.PACK_SPIKES) and a.dtype == 'f32' and recompute_h      # the PK instantiations run (2-bit packed outputs / skips)
+        packed_on = bool(engine_cfg.PACK_SPIKES) and recompute_h and (a.dtype == 'f32' or bool(engine_cfg.X16_OWN_KERNELS))   # the packed forms run (2-bit packed outputs / skips)
+        half = a.dtype != 'f32'
+        dtc = {'f16': 1, 'bf16': 2}.get(a.dtype, 0)              # SS_DT_F16 / SS_DT_BF16: the DT template argument rocprof prints
+        tf = lambda b: 'true' if b else 'false'                  # noqa: E731
+
+        def fwd_name(skip):
+            if half:       # ss_neuron16_v2.hpp (round 6): <KIND, DT, T, SKIP, DENSE copy>
+                return f'neuron_fwd16_pk8_kernel<0, {dtc}, {a.T}, {tf(skip)}, false>'
+            return (f'neuron_fwd_kernel<0, {a.T}, {tf(skip)}, false, 4, true>' if packed_on
+                    else f'neuron_fwd_kernel<0, {a.T}, {tf(skip)}, {tf(not recompute_h)}, 4, false>')
+
+        def bwd_name(tag):
+            if half:
+                if '+lr' in tag:   # <KIND, SG, DT, T, VEC, NSEG, G2, LR, WAVES, HAS_G1, SUM>
+                    return f'neuron_bwd16_seg_kernel<0, 0, {dtc}, {a.T}, 4, {2 if a.T > 5 else 1}, true, true, {3 if a.T > 5 else 4}, true, false>'
+                v = 4 if a.T <= 5 else 2
+                return f'neuron_bwd16_rc_kernel<0, 0, {dtc}, {a.T}, {v}, {tf("fork" in tag)}, false>'
+            return (f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, true>' if '+lr' in tag else
+                    f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, false>' if 'fork' in tag
+                    else f'neuron_bwd_kernel<*, *, {a.T}, 4, {tf(recompute_h)}, false, false>')
         out = {
             'metric': f'train frames/sec (260x346xT={a.T} {"mono" if a.model == "PLIFNetMono" else "stereo"} voxels)', 'value': round(frames / elapsed, 3),
             'unit': 'frames/s', 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if use_dp else 1, 'steps': a.steps, 'warmup': a.warmup,
@@ -414,7 +433,7 @@ def main():
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
                        'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': f'default init, seed 2021, multiply_factor {10 if a.model == "StereoSpike" else 30}',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
-            'roofline_fwd': dict(kernel=f'neuron_fwd_kernel<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
+            'roofline_fwd': dict(kernel=f'{"neuron_fwd16_pk8_kernel" if half else "neuron_fwd_kernel"}<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
                                         f'{bpu(fwd)} B/update'
                                         f'{", + skip add (2-bit packed skip operand)" if "+skip" in fwd_tag and packed_on else ", + skip add" if "+skip" in fwd_tag else ""}'
                                         f'{", 2-bit packed output only" if "+packed" in fwd_tag else ""}) on its dominant launch shape: '
@@ -422,9 +441,8 @@ def main():
                                  **roof(fwd, 'neuron_fwd', fwd_pmc),
                                  all_launches_of_this_instantiation=inst(
                                      ['neuron_fwd_train+skip', 'neuron_fwd_train+skip+packed'] if '+skip' in fwd_tag else ['neuron_fwd_train', 'neuron_fwd_train+packed'],
-                                     f'neuron_fwd_kernel<0, {a.T}, {"true" if "+skip" in fwd_tag else "false"}, false, 4, true>' if packed_on
-                                     else f'neuron_fwd_kernel<0, {a.T}, {"true" if "+skip" in fwd_tag else "false"}, {"false" if recompute_h else "true"}, 4, false>')),
-            'roofline_bwd': dict(kernel=f'neuron_bwd_kernel (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
+                                     fwd_name('+skip' in fwd_tag))),
+            'roofline_bwd': dict(kernel=f'{bwd_name(bwd_tag).split("<")[0]} (fused surrogate backward over T, {a.dtype} I/O, {bpu(bwd)} B/update'
                                         f'{", h recomputed from the layer input" if recompute_h else ""}'
                                         f'{", second consumer gradient added on load" if "fork" in bwd_tag else ""}'
                                         f'{", second consumer (prediction head) gradient formed in registers from its rank-9 pair and added on load" if "+lr" in bwd_tag else ""}), largest launch shape',
@@ -432,9 +450,7 @@ def main():
                                  all_launches_of_this_instantiation=inst(
                                      ['neuron_bwd+lr', 'neuron_bwd+lr+sum', 'neuron_bwd+lronly'] if '+lr' in bwd_tag else
                                      ['neuron_bwd+fork', 'neuron_bwd+fork+sum'] if 'fork' in bwd_tag else ['neuron_bwd'],
-                                     f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, true>' if '+lr' in bwd_tag else
-                                     f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, false>' if 'fork' in bwd_tag
-                                     else f'neuron_bwd_kernel<*, *, {a.T}, 4, {"true" if recompute_h else "false"}, false, false>')),
+                                     bwd_name(bwd_tag))),
             'neuron_kernels_all_layers': dict(
                 launches=sum(v['launches'] for k, v in summ.items() if k.startswith('neuron_')),
                 ms_per_step=round(all_ms / leg_steps, 3), algorithmic_GB_per_step=round(all_bytes / leg_steps / 1e9, 3),
@@ -446,9 +462,9 @@ def main():
                 name: (round(1e3 * sum(summ[t]['ms'] for t in tags if t in summ) / max(1, sum(summ[t]['launches'] for t in tags if t in summ)), 1)
                        if any(t in summ for t in tags) else None)
                 for name, tags in (
-                    (f'neuron_fwd_kernel<0, {a.T}, false, false, 4, {"true" if packed_on else "false"}>', ['neuron_fwd_train', 'neuron_fwd_train+packed']),
-                    (f'neuron_fwd_kernel<0, {a.T}, true, false, 4, {"true" if packed_on else "false"}>', ['neuron_fwd_train+skip', 'neuron_fwd_train+skip+packed']),
-                    ('neuron_bwd_kernel<*>', [k for k in summ if k.startswith('neuron_bwd')]))},
+                    (fwd_name(False), ['neuron_fwd_train', 'neuron_fwd_train+packed']),
+                    (fwd_name(True), ['neuron_fwd_train+skip', 'neuron_fwd_train+skip+packed']),
+                    ('neuron_bwd*_kernel<*>', [k for k in summ if k.startswith('neuron_bwd')]))},
             'other_fused_kernels_ms_per_step': {k: round(v['ms'] / leg_steps, 3) for k, v in summ.items()
                                                 if not k.startswith('neuron_')},
             # the up-conv stages one by one (projection GEMM + gather, resp. adjoint + dgrad / wgrad GEMMs), keyed by output elements
@@ -601,29 +617,38 @@ def us_of(d):
     return 1e3 * d['ms'] / d['launches']
 
 
-def _pmc_source():
+def _pmc_file(dtype='f32'):
+    # the counter passes are per mode: fp32 kernels -> profiles/pmc_traffic.json, 16-bit kernels -> profiles/pmc_traffic_x16.json (tools/pmc_target.py x16)
+    return 'pmc_traffic.json' if dtype == 'f32' else 'pmc_traffic_x16.json'
+
+
+def _pmc_source(dtype='f32'):
     """Where `traffic` comes from and whether it belongs to the kernels this process runs: profiles/pmc_traffic.json records the source hash compiled into the
     library the counter passes loaded; it is compared with the library loaded HERE (VERDICT r04 #6)."""
     from stereospike_amd import _lib
     src = {}
     try:
-        src = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('source', {})
+        src = json.load(open(os.path.join(ROOT, 'profiles', _pmc_file(dtype)))).get('source', {})
     except Exception:
         pass
     here = _lib.source_hash()
-    return dict(file='profiles/pmc_traffic.json', how='separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_target.py, committed; not measured in this run',
+    return dict(file='profiles/' + _pmc_file(dtype), how='separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_target.py, committed; not measured in this run',
                 measured_on_lib_source_hash=src.get('lib_source_hash'), measured_at_git_head=src.get('git_head'), loaded_lib_source_hash=here,
                 tree_source_hash=_lib.tree_source_hash(), matches_loaded_library=(src.get('lib_source_hash') == here) if src.get('lib_source_hash') else None)
 
 
-def _pmc_traffic(which='neuron_fwd'):
+def _pmc_traffic(which='neuron_fwd', dtype='f32', T=5, batch=16):
     """HBM bytes per launch of the fused kernel at the dominant launch shape, from the rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, written by profiles/collect_pmc.sh with the guide's gfx950 correction: FETCH_SIZE doubled);
-    None if not collected."""
-    p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    (profiles/pmc_traffic.json resp. pmc_traffic_x16.json, written by profiles/collect_pmc.sh with the guide's gfx950 correction: FETCH_SIZE doubled);
+    None if not collected for this mode, or collected at another launch shape (the file records the T and batch of its target)."""
+    p = os.path.join(ROOT, 'profiles', _pmc_file(dtype))
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get(which, {}).get('hbm_bytes_per_launch')
+            j = json.load(open(p))
+            shape = j.get('shape')
+            if shape and (shape.get('T'), shape.get('batch'), shape.get('dtype', dtype)) != (T, batch, dtype):
+                return None
+            return j.get(which, {}).get('hbm_bytes_per_launch')
         except Exception:
             return None
     return None

@@ -14,6 +14,16 @@ mode = sys.argv[2] if len(sys.argv) > 2 else 'rc'
 
 
 def key_of(name):
+    if 'neuron_fwd16_pk8_kernel' in name:                           # round 6: <KIND, DT, T, SKIP, DENSE>
+        import re
+        m = re.search(r'neuron_fwd16_pk8_kernel<([^>]*)>', name)
+        args = [a.strip() for a in m.group(1).split(',')] if m else []
+        skip = len(args) >= 4 and args[3] == 'true'
+        if mode == 'x16c5':
+            return 'neuron_fwd_skip_packed' if skip else 'neuron_fwd_packed'
+        return 'neuron_fwd_x16_packed'
+    if 'neuron_bwd16_seg_kernel' in name:                           # round 6: the low-rank form
+        return 'neuron_bwd_lr' if mode == 'x16c5' else 'neuron_bwd_x16_lr'
     if 'neuron_fwd16_kernel' in name:
         return 'neuron_fwd_x16_packed'
     if 'neuron_bwd16_rc_kernel' in name:
@@ -82,6 +92,28 @@ def mean_counter(sub, counter):
 fetch, nf = mean_counter('fetch', 'FETCH_SIZE')
 write, nw = mean_counter('write', 'WRITE_SIZE')
 T, N = 5, 16 * 32 * 260 * 346
+if mode == 'x16c5':
+    T, N = 10, 32 * 32 * 260 * 346
+    alg = {'neuron_fwd_packed': int(2.25 * T * N), 'neuron_fwd_skip_packed': int(2.5 * T * N), 'neuron_bwd_lr': int((6 + 36 / 32) * T * N)}
+    res = {'workload': 'BASELINE config 5 per-GPU layer shape: fp16 activations, T = 10, batch 32, 32 x 260 x 346 (9.2e8 updates), tools/pmc_target.py x16c5',
+           'mode': mode, 'shape': {'T': 10, 'batch': 32, 'dtype': 'f16'},
+           'algorithmic_bytes_per_update': {'neuron_fwd_packed': 2.25, 'neuron_fwd_skip_packed': 2.5, 'neuron_bwd_lr': 6 + 36 / 32},
+           'algorithmic_bytes_per_launch': alg,
+           'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported; separate --pmc passes; the forward leaves the '
+                   'membrane unwritten (v_last == NULL, ABI 10), as the training step runs it'}
+    for k in alg:
+        if k in fetch and k in write:
+            hbm = (2 * fetch[k] + write[k]) * 1024
+            res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]], 'hbm_read_bytes': int(2 * fetch[k] * 1024),
+                      'hbm_write_bytes': int(write[k] * 1024), 'hbm_bytes_per_launch': int(hbm), 'ratio_to_algorithmic': round(hbm / alg[k], 4)}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from stereospike_amd import _lib
+        res['source'] = {'lib_source_hash': _lib.source_hash(), 'tree_source_hash': _lib.tree_source_hash(), 'git_head': os.environ.get('SS_GIT_HEAD', 'unknown')}
+    except Exception as e:                                                # noqa: BLE001
+        res['source'] = {'error': repr(e)}
+    print(json.dumps(res, indent=1))
+    sys.exit(0)
 if mode == 'x16':
     # the 16-bit activation modes' own kernels (bf16), same shapes as the fp32 table below: algorithmic bytes with 2-byte activations, ONE weight term, one box plane
     planes1 = 80 * 4 * 1 * 278 * 364 * 8 * 2
@@ -110,7 +142,7 @@ if mode == 'x16':
     sys.exit(0)
 per_update = {'neuron_fwd': 8 if mode == 'rc' else 12, 'neuron_bwd': 16 if mode == 'rc' else 12}
 res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, tools/pmc_target.py {mode}',
-       'mode': mode, 'algorithmic_bytes_per_update': per_update,
+       'mode': mode, 'shape': {'T': 5, 'batch': 16, 'dtype': 'f32'}, 'algorithmic_bytes_per_update': per_update,
        'algorithmic_bytes_per_launch': {k: v * T * N for k, v in per_update.items()},
        'o_n_terms_bytes': {'neuron_fwd': 4 * N, 'neuron_bwd': 0},
        'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported; '

@@ -114,6 +114,9 @@ __device__ __forceinline__ void sweep_step(f2v (&v)[VEC / 2], const typename U32
 //   G2   a second consumer's gradient is added on load (dense 16-bit g_out2_seq, or with LR the prediction head's rank-9 pair)
 // ---------------------------------------------------------------------------------------------------
 constexpr int kLr2Rank = 9;
+#ifndef SS_LR_PIPE
+#define SS_LR_PIPE 0
+#endif
 // dynamic LDS bytes of the low-rank form: 9 x C weights + per wavefront T x 9 x (64 * VEC / C) pair values
 inline size_t bwd16_seg_lds_bytes(int T, int VEC, int C) { return sizeof(float) * ((size_t)kLr2Rank * C + (size_t)(kBlock / 64) * T * kLr2Rank * ((64 * VEC) / C)); }
 
@@ -258,25 +261,38 @@ __global__ __launch_bounds__(kBlock, WAVES) void neuron_bwd16_seg_kernel(Bwd16Ar
                     __builtin_amdgcn_wave_barrier();
                     const float* pl = lr_pw + lr_pl * kLr2Rank;
                     const float* wl = &lr_ws[lr_c0];
-#pragma unroll
-                    for (int j = 0; j < kLr2Rank; j += 2) {
-                        __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads of a tap pair next to their use: hoisted, they cost 2 * 9 * NP + 10 * SEG registers
-                        f2v wa[NP], wb[NP];
+                    // software pipeline over the tap pairs: the LDS reads of pair jj + 1 (its weights, its T-segment of pair values) are issued before the
+                    // multiply-adds of pair jj, into the other half of a double buffer (SS_LR_PIPE 2; 1: all reads of a pair up front, one wait; 0: read at use)
+                    f2v wa[2][NP], wb[2][NP], pq[2][SEGMAX];
+                    auto lr_load = [&](int j, int buf) {
 #pragma unroll
                         for (int q = 0; q < NP; ++q) {
-                            wa[q] = *reinterpret_cast<const f2v*>(wl + j * lr_C + 2 * q);
-                            if (j + 1 < kLr2Rank) wb[q] = *reinterpret_cast<const f2v*>(wl + (j + 1) * lr_C + 2 * q);
+                            wa[buf][q] = *reinterpret_cast<const f2v*>(wl + j * lr_C + 2 * q);
+                            if (j + 1 < kLr2Rank) wb[buf][q] = *reinterpret_cast<const f2v*>(wl + (j + 1) * lr_C + 2 * q);
                         }
 #pragma unroll
                         for (int t = t1 - 1; t >= t0; --t) {
-                            f2v pp;
-                            pp[0] = pl[t * lr_per + j];
-                            pp[1] = (j + 1 < kLr2Rank) ? pl[t * lr_per + j + 1] : 0.f;
+                            pq[buf][t - t0][0] = pl[t * lr_per + j];
+                            pq[buf][t - t0][1] = (j + 1 < kLr2Rank) ? pl[t * lr_per + j + 1] : 0.f;
+                        }
+                    };
+                    if constexpr (SS_LR_PIPE == 2) lr_load(0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < (kLr2Rank + 1) / 2; ++jj) {
+                        const int j = 2 * jj;
+                        const int buf = SS_LR_PIPE == 2 ? (jj & 1) : 0;
+                        __builtin_amdgcn_sched_barrier(0);           // (hoisted to the top, all reads together would cost 2 * 9 * NP + 10 * SEG registers)
+                        if constexpr (SS_LR_PIPE == 2) { if (j + 2 < kLr2Rank) lr_load(j + 2, (jj + 1) & 1); }
+                        else lr_load(j, 0);
+                        if constexpr (SS_LR_PIPE >= 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = t1 - 1; t >= t0; --t) {
+                            const f2v pp = pq[buf][t - t0];
 #pragma unroll
                             for (int q = 0; q < NP; ++q) {
-                                const f2v m0 = pk_mul_lo(pp, wa[q]);
+                                const f2v m0 = pk_mul_lo(pp, wa[buf][q]);
                                 lracc[t - t0][q] = (j == 0) ? m0 : lracc[t - t0][q] + m0;
-                                if (j + 1 < kLr2Rank) { const f2v m1 = pk_mul_hi(pp, wb[q]); lracc[t - t0][q] = lracc[t - t0][q] + m1; }
+                                if (j + 1 < kLr2Rank) { const f2v m1 = pk_mul_hi(pp, wb[buf][q]); lracc[t - t0][q] = lracc[t - t0][q] + m1; }
                             }
                         }
                     }

@@ -16,6 +16,24 @@ out, h, g, gx = torch.empty_like(x), torch.empty_like(x), torch.randn(T, N, devi
 v = torch.empty(N, device=dev)
 g2 = torch.randn(T, N, device=dev)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'rc'
+if mode == 'x16c5':
+    # round 6: the fused neuron kernels at BASELINE config 5's per-GPU layer shape — fp16 activations, T = 10, batch 32, the 32 x 260 x 346 layer (9.2e8 updates):
+    # packed-only forward without / with a packed skip (membrane unwritten, as the training step runs it: EngineConfig.LAZY_MEMBRANE) and the low-rank backward.
+    # Counters of this mode: profiles/parse_pmc.py <dir> x16c5 -> profiles/pmc_traffic_x16.json
+    del x, out, h, g, gx, v, g2
+    T, N = 10, 32 * 32 * 260 * 346
+    dt = torch.float16
+    x16 = (torch.randn(T, N, device=dev) * 0.06).to(dt)
+    g16 = (torch.randn(T, N, device=dev) * 1e-3).to(dt)
+    gx16 = torch.empty(T, N, dtype=dt, device=dev)
+    pk, skp = torch.empty(T, N // 16, dtype=torch.int32, device=dev), torch.randint(0, 2 ** 31 - 1, (T, N // 16), dtype=torch.int32, device=dev) & 0x55555555
+    lr_p, lr_w = torch.randn(T, N // 32, 9, device=dev) * 1e-3, torch.randn(9, 32, device=dev) * 0.3
+    for _ in range(5):
+        _lib.neuron_fwd_ex(x16, None, None, None, None, pk, None, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.neuron_fwd_ex(x16, None, None, skp, None, pk, None, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.neuron_bwd_fork_lr_x16(g16, lr_p, lr_w, None, None, x16, None, gx16, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
+    torch.cuda.synchronize()
+    sys.exit(0)
 if mode == 'x16':
     # round 5: the 16-bit activation modes' own kernels (bf16) at the same config-3 shapes — packed-only neuron forward, low-rank forked backward, first layer,
     # conv1 forward / data gradient, deconv1 sub-pixel forward and box-sum backward.  Counters of this mode: profiles/parse_pmc.py <dir> x16
@@ -49,7 +67,7 @@ if mode == 'x16':
     g0 = (torch.randn(NB, H, W, 32, device=dev) * 1e-3).to(dt)
     gw0 = torch.empty(32, 4, 5, 5, device=dev)
     for _ in range(5):
-        _lib.neuron_fwd_ex(x16, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.neuron_fwd_ex(x16, None, None, None, None, pk, None, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)      # (round 6: membrane unwritten, as the step runs it)
         _lib.neuron_bwd_fork_lr_x16(g16, lr_p, lr_w, None, None, x16, None, gx16, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
         _lib.dense_conv_s1_fwd_x16(xv, w0, y0, NB, 4, 32, H, W)
         _lib.dense_conv_s1_wgrad_x16(g0, xv, gw0, NB, 4, 32, H, W)
