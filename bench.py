@@ -570,7 +570,7 @@ def _roof_upconv(shapes, a, cfg):
                     mfma=dict(achieved_TFLOPs=round(flops / us_of(d) / 1e6, 1), peak_TFLOPs=2500.0, frac=round(flops / us_of(d) / 1e6 / 2500.0, 4),
                               issued_frac=round(issued / us_of(d) / 1e6 / 2500.0, 4),
                               note='frac: useful FLOPs of the minimal projection x 3 exact bf16 terms; issued_frac: what the kernel issues (9 merged taps per output pixel)'),
-                    note='latency / issue bound at 3 workgroups per CU (profiles/r04/sub_fwd_ablations.log); replaces upconv_fused2_fwd_kernel (1.9 x halo MFMAs, gather wavefronts)',
+                    note='latency / issue bound at 3 workgroups per CU (profiles/r04/sub_fwd_ablations.log)',
                     fused=True)
     return None            # projection GEMM + gather (--sub-fwd 0): a library GEMM and an HBM-bound gather, no single kernel to price
 

@@ -333,6 +333,8 @@ int ss_gemm6_batched_f32(const float* A, const float* B, float* C, float* ws, in
  */
 int ss_spike_conv_wgrad_supported(int Cin, int Cout, int k, int stride, int pad);
 long long ss_spike_conv_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w);
+/* ABI 10: the workspace the packed-input form (x_packed given) needs — its partial sums only; 0 when that form does not apply (then the figure above) */
+long long ss_spike_conv_wgrad_tr_ws_floats(int Cin, int Cout);
 int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* x_packed, float* g_w, float* ws, long long NB, int Cin, int Cout, int h,
                             int w, int accumulate, void* stream);     /* x_packed != NULL: the input as a 2-bit packed spike tensor (x may be NULL) */
 

@@ -43,10 +43,6 @@ def key_of(name):
         return 'head_proj_packed'
     if 'head_wgrad_packed_kernel' in name:
         return 'head_wgrad_packed'
-    if 'upconv_fused2_fwd_kernel' in name:
-        return 'upconv_fused2'
-    if 'upconv_fused_fwd_kernel' in name:
-        return 'upconv_fused'
     if 'spike_conv_fwd_kernel' in name:
         return 'spike_conv_fwd'
     if 'dense_conv_s1_fwd_kernel' in name:
@@ -59,10 +55,6 @@ def key_of(name):
         return 'upconv_box_dgrad'
     if 'upconv_box_wgrad_kernel' in name:
         return 'upconv_box_wgrad'
-    if 'upconv_bwd_dgrad_kernel' in name:
-        return 'upconv_bwd_dgrad'
-    if 'upconv_bwd_fused_kernel' in name:
-        return 'upconv_bwd_wgrad_nogp'
     if 'neuron_bwd_kernel' in name:
         import re
         m = re.search(r'neuron_bwd_kernel<([^>]*)>', name)
@@ -150,10 +142,6 @@ res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, to
 alg = {k: v * T * N for k, v in per_update.items()}
 alg['neuron_fwd_packed'] = int(4.25 * T * N)                        # x 4 B + 2-bit packed output 0.25 B per update (no dense output)
 alg['neuron_bwd_lr'] = int((12 + 36 / 32) * T * N)                   # g_out, x, g_x + the head's rank-9 pair: 9 floats per 32-channel pixel
-alg['upconv_fused'] = 4 * (80 * 130 * 173 * 64 + 80 * 260 * 346 * 32) + 2 * 3 * 25 * 64 * 32      # deconv1: spikes in + out + split weights
-alg['upconv_fused2'] = alg['upconv_fused']                          # the shipped form: wavefront-specialised persistent workgroups
-alg['upconv_bwd_dgrad'] = 4 * (80 * 260 * 346 * 32 + 80 * 130 * 173 * 64) + 2 * 3 * 25 * 64 * 32   # deconv1: g_y in + g_x out + split weights (g_P: none)
-alg['upconv_bwd_wgrad_nogp'] = 4 * 80 * 260 * 346 * 32 + 2 * 80 * 130 * 176 * 64 + 4 * 25 * 32 * 64      # deconv1: g_y in + bf16 transposed spikes in + g_W partials
 alg['spike_conv_fwd'] = 80 * 260 * 346 * 32 // 4 + 4 * 80 * 130 * 173 * 64 + 2 * 3 * 25 * 32 * 64        # conv1: packed spikes in + fp32 out + split weights
 alg['dense_conv_s1_fwd'] = 4 * 80 * 260 * 346 * (4 + 32) + 4 * 25 * 4 * 32                                # bottom: voxel input + fp32 out + weights
 alg['neuron_fwd_skip_packed'] = int(4.5 * T * N)                    # x 4 B + packed skip 0.25 B + packed output 0.25 B per update (deconv1 since the packed head)
@@ -168,7 +156,7 @@ alg['upconv_box_dgrad'] = planes + 4 * 80 * 130 * 173 * 64 + 2 * 3 * 26 * 64 * 3
 alg['upconv_box_wgrad'] = planes + 2 * 80 * 130 * 176 * 64 + 4 * 128 * 25 * 32 * 64                   # planes + bf16 transposed spikes in, 128 slices of partials out
 alg['upconv_sub'] = 80 * 130 * 173 * 64 // 4 + 4 * 80 * 260 * 346 * 32 + 2 * 25 * 27 * 512 * 4            # deconv1 forward: packed spikes in, fp32 out, merged weights
 res['algorithmic_bytes_per_launch'] = alg
-for k in ('upconv_sub', 'upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad', 'conv_s2_dgrad', 'dense_conv_s1_wgrad', 'head_proj_packed', 'head_wgrad_packed', 'neuron_fwd_skip_packed', 'spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed', 'upconv_fused', 'upconv_fused2', 'upconv_bwd_dgrad', 'upconv_bwd_wgrad_nogp'):
+for k in ('upconv_sub', 'upconv_boxsum', 'upconv_box_dgrad', 'upconv_box_wgrad', 'conv_s2_dgrad', 'dense_conv_s1_wgrad', 'head_proj_packed', 'head_wgrad_packed', 'neuron_fwd_skip_packed', 'spike_conv_fwd', 'dense_conv_s1_fwd', 'neuron_fwd', 'neuron_bwd', 'neuron_bwd_lr', 'neuron_fwd_packed'):
     if k in fetch and k in write:
         hbm = (2 * fetch[k] + write[k]) * 1024
         res[k] = {'FETCH_SIZE_KiB_raw': fetch[k], 'WRITE_SIZE_KiB_raw': write[k], 'dispatches': [nf[k], nw[k]],

@@ -204,6 +204,8 @@ def lib():
     L.ss_spike_conv_wgrad_supported.restype = i32
     L.ss_spike_conv_wgrad_ws_floats.argtypes = [i32, i32, i64, i32, i32]
     L.ss_spike_conv_wgrad_ws_floats.restype = i64
+    L.ss_spike_conv_wgrad_tr_ws_floats.argtypes = [i32, i32]
+    L.ss_spike_conv_wgrad_tr_ws_floats.restype = i64
     L.ss_spike_conv_wgrad_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     L.ss_spike_conv_wgrad_f32.restype = i32
     L.ss_spike_wgrad_supported.argtypes = [i32, i32]
@@ -246,7 +248,7 @@ EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_
            'ss_upconv_box_elems', 'ss_upconv_boxsum_f32', 'ss_upconv_box_window', 'ss_upconv_box_dgrad_supported', 'ss_upconv_box_tiles_supported', 'ss_upconv_box_dgrad_ws_floats', 'ss_upconv_box_dgrad_f32',
            'ss_upconv_box_wgrad_supported', 'ss_upconv_box_wgrad_ws_floats', 'ss_upconv_box_wgrad_f32',
            'ss_gemm6_supported', 'ss_gemm6_ws_floats', 'ss_gemm6_f32', 'ss_gemm6_batched_f32',
-           'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
+           'ss_spike_conv_wgrad_supported', 'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_tr_ws_floats', 'ss_spike_conv_wgrad_f32',
            'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32',
            # ABI 9
            'ss_neuron_bwd_fork_lr_x16_supported', 'ss_neuron_bwd_fork_lr_x16', 'ss_dense_conv_s1_fwd_x16', 'ss_dense_conv_s1_wgrad_x16', 'ss_spike_conv_fwd_x16',
@@ -793,11 +795,17 @@ def spike_conv_wgrad_supported(Cin, Cout, k, stride, pad):
     return bool(lib().ss_spike_conv_wgrad_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
 
 
+def _spike_conv_wgrad_ws(Cin, Cout, NB, h, w, packed):
+    """workspace floats of ss_spike_conv_wgrad_*: the packed-input form needs its partial sums only (ABI 10), not the first form's operand copies"""
+    n = int(lib().ss_spike_conv_wgrad_tr_ws_floats(int(Cin), int(Cout))) if packed else 0
+    return n if n > 0 else int(lib().ss_spike_conv_wgrad_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w)))
+
+
 def spike_conv_wgrad(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False, x_packed=None):
     """g_w [Cout, Cin, 5, 5] (+)= weight gradient of conv2d(x, ., stride 2, pad 2): g [NB, ho, wo, Cout] fp32 NHWC, x [NB, h, w, Cin] fp32 spikes."""
     _require_hip(g, 'g')
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    ws = torch.empty(int(lib().ss_spike_conv_wgrad_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g.device)
+    ws = torch.empty(_spike_conv_wgrad_ws(Cin, Cout, NB, h, w, x_packed is not None), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
         rc = lib().ss_spike_conv_wgrad_f32(_f32(g, 'g', NB * ho * wo * Cout), None if x_packed is not None else _f32(x, 'x', NB * h * w * Cin),
                                            _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),
@@ -1017,7 +1025,7 @@ def spike_conv_wgrad_x16(g, x, g_w, NB, Cin, Cout, h, w, accumulate=False, x_pac
     _require_hip(g, 'g')
     dt = _dt_of(g, 'g')
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    ws = torch.empty(int(lib().ss_spike_conv_wgrad_ws_floats(int(Cin), int(Cout), int(NB), int(h), int(w))), dtype=torch.float32, device=g.device)
+    ws = torch.empty(_spike_conv_wgrad_ws(Cin, Cout, NB, h, w, x_packed is not None), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
         rc = lib().ss_spike_conv_wgrad_x16(_x16(g, 'g', NB * ho * wo * Cout, dt), None if x_packed is not None else _x16(x, 'x', NB * h * w * Cin, dt),
                                            _ptr(x_packed, 'x_packed', None if x_packed is None else NB * h * w * Cin // 16),

@@ -44,6 +44,11 @@ class EngineConfig:
     PACKED_DECONV2: bool = True         # deconv2's output packed-only   [SS_PACKED_DECONV2]
     SUB_FWD: bool = True                # decoder stages, spike input: sub-pixel (merged tap) implicit GEMM forward, ss_upconv_sub.hip [SS_SUB_FWD]
     BOX_BWD: bool = True                # decoder stages: the backward on the box-sum image (ss_upconv_box.hip), no g_P anywhere   [SS_BOX_BWD]
+                                        # 16-bit modes: the box-sum image is ONE plane of the activation format — sums of up to 5 x 5 neighbouring g_out values rounded to
+                                        # 8 (bf16) / 11 (fp16) significand bits before both contractions (the g_P forms kept them in fp32): the weight-gradient parity bar of
+                                        # these modes is 1e-2 for that reason, and in fp16 a box sum can exceed 65504 under a large loss scale although every g_out element is
+                                        # finite — GradScaler then sees inf gradients and skips the step (it halves the scale and recovers; fp16 + a FIXED large scale does
+                                        # not).  BOX_BWD=False keeps the fp32-accumulating g_P forms.
     EXACT_WGRAD_MFMA: bool = True       # g_P forms: weight gradient on spike inputs as the exact bf16x3 MFMA contraction (ss_spike_wgrad_f32)
     GEMM6_DGRAD: bool = True            # g_P forms: data gradient of the wide stages on ss_gemm6_f32   [SS_GEMM6_DGRAD]
     # ---- encoder / bottleneck convolutions ----------------------------------------------------------------------------------------------------------------

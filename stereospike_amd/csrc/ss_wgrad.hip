@@ -1051,6 +1051,17 @@ long long ss_spike_conv_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, 
     return (long long)slices * 25 * Cin * Cout + (5LL * NB * (h + 4) * Cin * oxp + 1) / 2 + NB * ho * ksr * (Cout / 32) * 768 + 8;
 }
 
+/* workspace of the packed-input (window / transposed-read) form alone: its per-slice partial sums — 0 when that form is off (SS_SPIKE_WGRAD_TR=0) or the shape is
+   not supported; then ss_spike_conv_wgrad_ws_floats applies.  (ABI 10; ADVICE r05: the full figure also covers the first form's five decimated copies of x and
+   the fragment-ordered g — 1.9 GB at conv1 / config 3 — which the packed form never touches.) */
+long long ss_spike_conv_wgrad_tr_ws_floats(int Cin, int Cout)
+{
+    int Q = 0, slices = 0;
+    if (!spike_conv_wgrad_tr_on() || !ss_spike_conv_wgrad_supported(Cin, Cout, 5, 2, 2) || !spike_conv_wgrad_plan(Cin, &Q, &slices)) return 0;
+    const int kinds = (Cin / 32) * (Cout / 64), sl = slices * Q / kinds > 0 ? slices * Q / kinds : 1;
+    return (long long)sl * 25 * Cin * Cout + 8;
+}
+
 int ss_spike_conv_wgrad_f32(const float* g, const float* x, const unsigned int* x_packed, float* g_w, float* ws, long long NB, int Cin, int Cout, int h,
                             int w, int accumulate, void* stream)
 {

@@ -1,7 +1,7 @@
 """Training / evaluation steps of the hot path as the reference's scripts perform them
 (/root/reference/train.py:189-261, test.py:100-173), plus the synthetic MVSEC-shaped data of SURVEY.md §8(d)."""
 import torch
-from torch.nn.utils import stateless
+import contextlib
 
 from .clock_driven import functional
 from .network.loss import Total_Loss
@@ -136,6 +136,29 @@ class GraphedInference:
         return self.static_out
 
 
+@contextlib.contextmanager
+def _parameters_replaced(net, tensors):
+    """Inside the block, the named Parameters of `net` are plain tensor attributes `tensors[name]`; restored on exit (public nn.Module API only —
+    what torch's private stateless._reparametrize_module does)."""
+    swapped, order = [], {}
+    try:
+        for name, t in tensors.items():
+            mod_name, _, attr = name.rpartition('.')
+            mod = net.get_submodule(mod_name) if mod_name else net
+            order.setdefault(mod, list(mod._parameters.keys()))
+            swapped.append((mod, attr, mod._parameters.pop(attr)))
+            setattr(mod, attr, t)
+        yield
+    finally:
+        for mod, attr, p in swapped:
+            if attr in mod.__dict__:
+                delattr(mod, attr)
+            mod._parameters[attr] = p
+        for mod, keys in order.items():          # the registration order (state_dict key order) as it was
+            for k in keys:
+                mod._parameters[k] = mod._parameters.pop(k)
+
+
 class GraphedTrainer:
     """One whole training iteration — reset -> T-step forward -> Total_Loss -> backward -> Adam — captured ONCE into a HIP graph and
     replayed per batch (single GPU).  For small steps (e.g. BASELINE.json config 2: T = 1, B = 8) the ~900 launches of an iteration
@@ -175,7 +198,7 @@ class GraphedTrainer:
         # default stream into the capture and hipStreamEndCapture crashed (the round-3 / round-4 "crash during capture" of config 2:
         # tools/r05/repro_graph.py, profiles/r05/repro_graph_*.log; neither loss.backward() nor autograd.grad on the Parameters avoids it).  The aliases are
         # leaves nothing outside this class can reach: their nodes are created inside this iteration, on this iteration's stream.
-        with stateless._reparametrize_module(net, self._alias):
+        with _parameters_replaced(net, self._alias):
             with torch.autocast(**self.amp):
                 out = net.forward_sequence(self.static_x)
                 pred, spks = out if isinstance(out, tuple) else (out, None)
@@ -230,6 +253,10 @@ class GraphedTrainer:
         Returns (loss, final depth map) as STATIC tensors (overwritten by the next call)."""
         if self.graph is None:
             self._capture(x, label)
+        # the aliases are views of the storage the Parameters had at construction: a Parameter moved / replaced since then would train against stale memory
+        for (n, a), p in zip(self._alias.items(), self._params):
+            if p.data_ptr() != a.data_ptr():
+                raise RuntimeError(f'GraphedTrainer: the storage of parameter {n} changed after construction (net.to / net.half / p.data = ...): build a new GraphedTrainer')
         self.static_x.copy_(x, non_blocking=True)
         self.static_gt.copy_(label, non_blocking=True)
         self.graph.replay()

@@ -37,7 +37,7 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_spike_conv_fwd_supported', 'ss_spike_conv_fwd_ws_floats',
                                   'ss_spike_conv_fwd_f32', 'ss_dense_conv_s1_fwd_supported', 'ss_dense_conv_s1_fwd_f32', 'ss_gemm6_supported', 'ss_gemm6_ws_floats',
                                   'ss_gemm6_f32', 'ss_gemm6_batched_f32', 'ss_spike_conv_wgrad_supported',
-                                  'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_f32',
+                                  'ss_spike_conv_wgrad_ws_floats', 'ss_spike_conv_wgrad_tr_ws_floats', 'ss_spike_conv_wgrad_f32',
                                   # ABI 4
                                   'ss_neuron_bwd_fork_lr_supported', 'ss_neuron_bwd_fork_lr_f32',
                                   # ABI 6

@@ -17,12 +17,12 @@ layers = [('deconv4', 512, 256, 5, (17, 22), (33, 44)), ('deconv3', 256, 128, 5,
 which = os.environ.get('WHICH', 'projected,miopen').split(',')
 from stereospike_amd import fused
 from stereospike_amd import config as _config
-_cm = _config.engine_config(PROJECTION_IMPL=os.environ.get('PROJ', 'auto'), P_CHUNK_BYTES=int(os.environ.get('CHUNK_MB', fused.P_CHUNK_BYTES >> 20)) << 20)
+_cm = _config.engine_config()   # (the PROJECTION_IMPL / P_CHUNK_BYTES knobs of rounds 2 - 4 left EngineConfig in round 5: the chunk size is the private fused._P_CHUNK_BYTES)
 _cm.__enter__()                # a one-off diagnostic script: the ambient configuration for the rest of the process
 only = os.environ.get('LAYERS')
 if only:
     layers = [l for l in layers if l[0] in only.split(',')]
-print('PROJECTION_IMPL', fused.PROJECTION_IMPL, 'chunk MB', fused.P_CHUNK_BYTES >> 20)
+print('projection chunk MB', fused._P_CHUNK_BYTES >> 20)
 for name, ci, co, k, insz, up in layers:
     m = NNConvUpsampling(ci, co, k, up, bias=(co == 1)).to(dev)
     x = (torch.rand(NB, ci, *insz, device=dev) < 0.3).float().requires_grad_()

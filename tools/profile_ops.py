@@ -15,24 +15,29 @@ from stereospike_amd import gemm_tuning
 gemm_tuning.enable(0)
 dev = torch.device('cuda:0')
 from stereospike_amd.engine import Trainer, synthetic_batch
+# round 6: DTYPE=f16|bf16|f32, T, B, RATES=1 select the configuration (default: the headline); STACK=1 groups by the Python call site instead of input shapes
+DT = {'f16': torch.float16, 'bf16': torch.bfloat16}.get(os.environ.get('DTYPE', 'f32'))
+Tn, Bn = int(os.environ.get('T', 5)), int(os.environ.get('B', 16))
 net = bench.build_net('StereoSpike', dev)
-tr = Trainer(net)
-x, gt = synthetic_batch(16, 5, seed=2021, device=dev)
+tr = Trainer(net, amp_dtype=DT, count_rates=bool(int(os.environ.get('RATES', 0))))
+x, gt = synthetic_batch(Bn, Tn, seed=2021, device=dev)
 for _ in range(3):
     tr.step(x, gt)
 torch.cuda.synchronize()
 STEPS = 2
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as prof:
+STACK = bool(int(os.environ.get('STACK', 0)))
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True, with_stack=STACK) as prof:
     for _ in range(STEPS):
         tr.step(x, gt)
     torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages(group_by_input_shape=True):
+for e in (prof.key_averages(group_by_stack_n=8) if STACK else prof.key_averages(group_by_input_shape=True)):
     t = getattr(e, 'self_device_time_total', None)
     if t is None:
         t = getattr(e, 'self_cuda_time_total', 0)
     if t and t / STEPS >= float(os.environ.get('MIN_US', 30)):
-        rows.append((t / STEPS, e.count / STEPS, e.key, str(e.input_shapes)[:150]))
+        where = ' <- '.join(f.split('/')[-1] for f in (e.stack or []) if 'stereospike_amd' in f or 'bench' in f)[:260] if STACK else str(e.input_shapes)[:150]
+        rows.append((t / STEPS, e.count / STEPS, e.key, where))
 rows.sort(key=lambda r: -r[0])
 skip = ('mm', 'bmm', 'convolution', 'miopen', '_FusedNeuron', 'UpConv', 'SpikeConv', 'IPool', 'ScaleLoss')
 tot = 0
