@@ -1064,7 +1064,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             # a stage built with bias=True (NNConvUpsampling accepts it; the shipped decoder stages have none): its gradient as in every other form
             g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
-        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank) else None
+        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank and not (lowp and n >= NB)) else None
         g_Wt = torch.zeros_like(Wt) if need_w else None
         W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
         if lowp:
@@ -1076,8 +1076,13 @@ class _UpConvProjectedCL(torch.autograd.Function):
             rows = (c1 - c0) * h * w
             if x_packed is not None and k == 5 and need_w:
                 # a stage whose input arrived as packed spikes and whose geometry the box-sum kernels do not take: the g_P forms read the dense tensor
-                # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one)
-                x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None
+                # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one).  16-bit modes whose
+                # dense copy is not in the GEMMs' bf16 operand format (fp16 mode): unpack straight to bf16 — 0.25 B read per element instead of an fp16 -> bf16
+                # conversion pass over the dense copy (round 6: 0.3 - 0.4 ms per stage at config 5's share)
+                if lowp and x_cl.dtype != torch.bfloat16:
+                    x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, torch.bfloat16), None
+                else:
+                    x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None
             if lowp and k == 5:
                 # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
@@ -1098,6 +1103,10 @@ class _UpConvProjectedCL(torch.autograd.Function):
                 g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
             elif gemm6:
                 _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
+            elif need_x and lowp and c0 == 0 and c1 == NB:
+                # one chunk (the usual case): the GEMM's own output IS the gradient — in the bf16 mode written in the activation format by its epilogue (fp32
+                # accumulation, one rounding: what fp32-then-narrow gives), in the fp16 mode fp32 and narrowed once below; no copy into a preallocated buffer
+                g_x = (torch.mm(g_P, W2) if ctx.x_dtype == torch.bfloat16 else torch.mm(g_P, W2, **f32)).view(x_cl.shape)
             elif need_x:
                 g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                     torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
