@@ -849,18 +849,261 @@ def stage_plan(tables, Cin: int, Cout: int, k: int, h: int, w: int, H: int, W: i
     return plan
 
 
+@dataclass(frozen=True)
+class StageOpts:
+    """What upconv_projected_cl derives from the call and the autocast state for one stage / head pass (one object instead of nine positional arguments)."""
+    k: int
+    H: int
+    W: int
+    lowp: bool = False                          # bf16 autocast: GEMM operands in bf16 (fp32 accumulation / output)
+    spikes_in: bool = False                     # the input holds spike counts (exact in bf16): exact-split forms apply
+    lowp_bwd: Optional[bool] = None             # backward operand precision under ANY 16-bit autocast (None: as lowp)
+    act_dtype: Optional[torch.dtype] = None     # decoder stages under 16-bit autocast write 16-bit activations
+    lowrank_grad: bool = False                  # a one-channel 3 x 3 head may hand its input gradient on as the rank-9 pair
+    own16: Optional[torch.dtype] = None         # the 16-bit mode's dtype when it runs on the engine's own single-term kernels
+
+
+# ---- the forms of a decoder stage / prediction head (dispatch: _UpConvProjectedCL below); each reads what the dispatcher derived and sets the ctx fields the
+#      backward forms need
+def _stage_fwd_packed_head(ctx, *, H, W, act_dtype, bias, k, lowp, lowrank_grad, tables, weight, x_cl, x_packed):
+    """One-channel 3 x 3 prediction head on a 2-bit packed input: MFMA projection to the 9 taps (ss_head_proj_packed_f32) + gather."""
+    NB, h, w, Cin = x_cl.shape
+    Cout, kk = weight.shape[0], k * k
+    if not (k == 3 and Cout == 1 and not lowp and act_dtype is None and _lib.head_packed_supported(Cin, Cout, k)):
+        raise _lib.SSNeuronError('packed-only spike tensor handed to an up-conv that reads dense activations')
+    ctx.lowrank_grad = bool(lowrank_grad)
+    ctx.x_dtype = x_cl.dtype
+    weight = weight.float()
+    Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()
+    src_y, _, _, src_x, _, _ = tables
+    out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=x_cl.device)
+    rows = NB * h * w
+    P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
+    e0 = TIMER.start()
+    _lib.head_proj_packed(x_packed, Wt, P, rows, Cin)
+    _lib.upconv_cl_fwd(P, src_y, src_x, None if bias is None else bias.float(), out, NB, k, Cout, h, w, H, W)
+    TIMER.stop(e0, 'upconv_cl_fwd', x_cl.numel() // 4 + 4 * out.numel(), out.numel())
+    _note('synapse_fwd', 'head_proj_packed_mfma+gather')
+    ctx.save_for_backward(x_cl, Wt, x_packed, weight)
+    ctx.lowp, ctx.exact = False, False
+    ctx.tables, ctx.k, ctx.n = tables, k, NB
+    ctx.wshape = weight.shape
+    ctx.has_bias = bias is not None
+    return out
+
+def _stage_fwd_sub_x16(ctx, *, Cin, Cout, H, NB, W, Wt, h, k, lowp, lowp_bwd, n, out, own16, tables, w, weight, x_cl, x_packed):
+    """Decoder stage forward, 16-bit mode on own kernels: the sub-pixel (merged tap) implicit GEMM with two terms of the mode\'s format."""
+    st16 = sub_tables(tables, H, W)
+    e0 = TIMER.start()
+    wm = _lib.upconv_sub_prep_x16(weight.contiguous(), st16, Cin, Cout, own16)
+    _lib.upconv_sub_fwd_x16(None if x_packed is not None else x_cl, x_packed, wm, st16, out, NB, Cin, Cout, h, w)
+    TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()) + 2 * out.numel(), out.numel())
+    _note('synapse_fwd', 'upconv_sub_mfma_x16' + ('(packed in)' if x_packed is not None else ''))
+    ctx.save_for_backward(x_cl, Wt, x_packed, weight)
+    ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+    ctx.exact = False
+    ctx.tables, ctx.k, ctx.n = tables, k, n
+    ctx.wshape = weight.shape
+    ctx.has_bias = False
+    return out
+
+def _stage_fwd_sub_f32(ctx, *, Cin, Cout, NB, Wt, h, k, lowp, lowp_bwd, n, out, st, tables, w, weight, x_cl, x_packed):
+    """Decoder stage forward, fp32 mode: the sub-pixel (merged tap) implicit GEMM on exact bf16x3 products."""
+    if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
+        assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
+    e0 = TIMER.start()
+    wm = _lib.upconv_sub_prep(weight.contiguous(), st, Cin, Cout)
+    _lib.upconv_sub_fwd(None if x_packed is not None else x_cl, x_packed, wm, st, out, NB, Cin, Cout, h, w)
+    TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
+    _note('synapse_fwd', 'upconv_sub_mfma' + ('(packed in)' if x_packed is not None else ''))
+    ctx.save_for_backward(x_cl, Wt, x_packed, weight)
+    ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+    ctx.exact = True
+    ctx.tables, ctx.k, ctx.n = tables, k, n
+    ctx.wshape = weight.shape
+    ctx.has_bias = False
+    return out
+
+def _stage_fwd_projected(ctx, *, Cin, Cout, H, NB, W, Wt, act_dtype, bias, exact, h, half_in, k, lowp, lowp_bwd, n, out, src_x, src_y, tables, w, weight, x_cl):
+    """Projection GEMM (exact bf16x3 / bf16 / fp32 on the library) + the channels-last gather kernel: geometries the sub-pixel kernel does not take, heads on dense inputs."""
+    if lowp:
+        xg = x_cl if x_cl.dtype == torch.bfloat16 else x_cl.to(torch.bfloat16)
+    elif exact or not half_in:
+        xg = x_cl                                   # exact: any dtype feeds the bf16 triple copy; plain fp32 path: fp32
+    else:
+        xg = x_cl.float()                           # 16-bit input on the plain fp32 GEMM path (narrow stages, heads)
+    Wg = Wt.to(torch.bfloat16) if lowp else Wt
+    if exact:
+        if _cfg().ASSERT_EXACT_SPLIT:
+            assert bool((x_cl.to(torch.bfloat16).float() == x_cl.float()).all()), 'spikes_in=True but the input is not exact in bf16'
+        W3 = _split3_bf16(Wt)
+    e0 = TIMER.start()
+    for c0 in range(0, NB, n):
+        c1 = min(NB, c0 + n)
+        xs = xg[c0:c1].view((c1 - c0) * h * w, Cin)
+        if exact:
+            x3 = torch.empty((xs.shape[0], 3, Cin), dtype=torch.bfloat16, device=xs.device)
+            x3.copy_(xs.unsqueeze(1))                                                  # one cast kernel writing the 3 copies
+            P = torch.mm(x3.view(-1, 3 * Cin), W3, out_dtype=torch.float32)
+            del x3
+        else:
+            P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
+        (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
+    TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
+    _note('synapse_fwd', ('exact_bf16x3_gemm' if exact else ('bf16_gemm' if lowp else 'fp32_gemm')) + '+gather' + ('_x16' if act_dtype else ''))
+    ctx.save_for_backward(xg, Wt, None, weight)
+    # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
+    # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
+    ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
+    ctx.exact = exact
+    ctx.tables, ctx.k, ctx.n = tables, k, n
+    ctx.wshape = weight.shape
+    ctx.has_bias = bias is not None
+    return out
+
+def _stage_bwd_box_x16(ctx, *, Cin, Cout, H, NB, W, bt, g_out, h, need_w, need_x, own16, w, weight, x_cl, x_packed):
+    """Stage backward on the box-sum image, 16-bit I/O (one plane of the mode\'s format, one weight term)."""
+    e0 = TIMER.start()
+    e1 = TIMER.start()
+    box = _lib.upconv_boxsum_x16(g_out, bt, NB, Cout, H, W)
+    TIMER.stop(e1, 'box_boxsum', 2 * g_out.numel() + 2 * box.numel(), g_out.numel())
+    g_x = g_w = None
+    wc = weight.detach().contiguous()
+    if need_x:
+        g_x = torch.empty(x_cl.shape, dtype=own16, device=g_out.device)
+        e1 = TIMER.start()
+        _lib.upconv_box_dgrad_x16(box, wc, bt, g_x, NB, Cin, Cout, h, w)
+        TIMER.stop(e1, 'box_dgrad', 2 * box.numel() + 2 * g_x.numel(), g_x.numel())
+    if need_w:
+        g_w = torch.empty(wc.shape, dtype=torch.float32, device=g_out.device)
+        e1 = TIMER.start()
+        _lib.upconv_box_wgrad_x16(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
+        TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()), g_out.numel())
+    TIMER.stop(e0, 'upconv_cl_bwd', 2 * (x_cl.numel() + g_out.numel()), g_out.numel())
+    _note('synapse_bwd', 'box_x16: boxsum' + ('+dgrad1_mfma' if need_x else '') + ('+wgrad1_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
+    if g_x is not None and g_x.dtype != ctx.x_dtype:
+        g_x = g_x.to(ctx.x_dtype)
+    g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+    return g_x, g_w, g_b, None, None, None
+
+def _stage_bwd_box_f32(ctx, *, Cin, Cout, H, NB, W, bt, g_out, h, need_w, need_x, w, weight, x_cl, x_packed):
+    """Stage backward on the box-sum image, fp32 mode: box-sum launch, then both contractions over its three bf16 planes; no g_P."""
+    e0 = TIMER.start()                                                   # the stage's whole backward ('upconv_cl_bwd', as every other form) ...
+    e1 = TIMER.start()                                                   # ... and its three launches one by one ('box_*': inside the former, not additional)
+    box = _lib.upconv_boxsum(g_out, bt, NB, Cout, H, W)
+    TIMER.stop(e1, 'box_boxsum', 4 * g_out.numel() + 2 * box.numel(), g_out.numel())
+    g_x = g_w = None
+    wc = weight.detach().contiguous()
+    if need_x:
+        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=g_out.device)
+        e1 = TIMER.start()
+        _lib.upconv_box_dgrad(box, wc, bt, g_x, NB, Cin, Cout, h, w)
+        TIMER.stop(e1, 'box_dgrad', 2 * box.numel() + 4 * g_x.numel(), g_x.numel())
+    if need_w:
+        g_w = torch.empty(wc.shape, dtype=torch.float32, device=g_out.device)
+        e1 = TIMER.start()
+        _lib.upconv_box_wgrad(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
+        TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()), g_out.numel())
+    TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
+    _note('synapse_bwd', 'box: boxsum' + ('+dgrad6_mfma' if need_x else '') + ('+wgrad3_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
+    if g_x is not None and g_x.dtype != ctx.x_dtype:
+        g_x = g_x.to(ctx.x_dtype)
+    # a stage built with bias=True (NNConvUpsampling accepts it; the shipped decoder stages have none): its gradient as in every other form (ADVICE r04)
+    g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+    return g_x, g_w, g_b, None, None, None
+
+def _stage_bwd_gp(ctx, *, Cin, Cout, H, NB, W, Wt, g16, g_out, h, k, kk, lowp, lowrank, n, need_w, need_x, w, x_cl, x_hi, x_lo, x_packed, y_hi, y_lo):
+    """Stage backward through the per-tap tensor g_P: gather adjoint, then data / weight gradient GEMMs (ss_gemm6_f32, ss_spike_wgrad_f32, ss_head_wgrad_packed_f32 or the library); a head may hand its input gradient on as the rank-9 pair."""
+    g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank and not (lowp and n >= NB)) else None
+    g_Wt = torch.zeros_like(Wt) if need_w else None
+    W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
+    if lowp:
+        W2 = W2.to(torch.bfloat16)
+    f32 = dict(out_dtype=torch.float32) if lowp else {}
+    e0 = TIMER.start()
+    for c0 in range(0, NB, n):
+        c1 = min(NB, c0 + n)
+        rows = (c1 - c0) * h * w
+        if x_packed is not None and k == 5 and need_w:
+            # a stage whose input arrived as packed spikes and whose geometry the box-sum kernels do not take: the g_P forms read the dense tensor
+            # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one; ADVICE r04).  16-bit modes whose
+            # dense copy is not in the GEMMs' bf16 operand format (fp16 mode): unpack straight to bf16 — 0.25 B read per element instead of an fp16 -> bf16
+            # conversion pass over the dense copy (round 6: 0.3 - 0.4 ms per stage at config 5's share)
+            if lowp and x_cl.dtype != torch.bfloat16:
+                x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, torch.bfloat16), None
+            else:
+                x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None
+        if lowp and k == 5:
+            # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
+            g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
+            _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+        else:
+            if lowrank:      # the adjoint writes g_P straight into the pair buffer the consumer's neuron backward will read
+                lr_anchor, g_P, lr_w = lowrank_buffer(x_cl.shape, x_cl.device, kk * Cout, ctx.x_dtype)
+                lr_w.copy_(W2)
+            else:
+                g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
+            (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
+            if lowp:
+                g_P = g_P.to(torch.bfloat16)
+        # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy) where the fp32 library GEMM is compute-bound: wide stages
+        # (measured: C_in 64 — deconv1 — is faster on the library's fp32 GEMM, 1.63 vs 2.48 ms, profiles/r04/bench_box_bwd_v5.log)
+        gemm6 = bool(need_x and not lowrank and not lowp and ctx.ecfg.GEMM6_DGRAD and Cin >= 128 and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin))
+        if lowrank:
+            g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
+        elif gemm6:
+            _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
+        elif need_x and lowp and c0 == 0 and c1 == NB:
+            # one chunk (the usual case): the GEMM's own output IS the gradient — in the bf16 mode written in the activation format by its epilogue (fp32
+            # accumulation, one rounding: what fp32-then-narrow gives), in the fp16 mode fp32 and narrowed once below; no copy into a preallocated buffer
+            g_x = (torch.mm(g_P, W2) if ctx.x_dtype == torch.bfloat16 else torch.mm(g_P, W2, **f32)).view(x_cl.shape)
+        elif need_x:
+            g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
+                torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
+        spike_wgrad = bool(need_w and ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32 and _lib.spike_wgrad_supported(Cin, kk * Cout))
+        if need_w and x_packed is not None and k == 3:
+            _lib.head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=True)     # reads the 2-bit packed spikes (1/16 of the dense tensor)
+        elif spike_wgrad:
+            # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
+            _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)
+        elif need_w:
+            xs = x_cl[c0:c1].view(rows, Cin)
+            if lowp and xs.dtype != torch.bfloat16:
+                xs = xs.to(torch.bfloat16)                                    # spikes: exact
+            elif not lowp and xs.dtype != torch.float32:
+                xs = xs.float()
+            S = max(1, rows // _WGRAD_SPLIT_ROWS)
+            L = rows // S
+            if S > 1:
+                g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout), **f32).sum(0)
+                if S * L < rows:
+                    g_Wt += torch.mm(xs[S * L:].t(), g_P[S * L:], **f32)
+            else:
+                g_Wt += torch.mm(xs.t(), g_P, **f32)
+    TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
+    how_x = 'none' if not need_x else ('lowrank_pair' if lowrank else ('adjoint+gemm6' if gemm6 else 'adjoint+library_gemm'))
+    how_w = 'none' if not need_w else ('head_wgrad_packed_mfma' if (x_packed is not None and k == 3) else ('spike_wgrad_mfma' if spike_wgrad else 'library_gemm'))
+    _note('synapse_bwd', f'g_x: {how_x}; g_w: {how_w}' + ('; 16-bit' if (lowp or g16) else ''), ctx.site)
+    g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
+    g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+    if g_x is not None and g_x.dtype != ctx.x_dtype:
+        g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
+    return g_x, g_w, g_b, None, None, None
+
+
 class _UpConvProjectedCL(torch.autograd.Function):
-    """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory.
-    forward : P = x_cl[NB*h*w, C_in] @ W[C_in, k*k*C_out]   — ONE row-major GEMM, no per-image batching, no transposes —
-              then the channels-last gather kernel (ss_upconv_cl_fwd_f32);
-    backward: g_P = gather adjoint (ss_upconv_cl_bwd_f32); dgrad g_x = g_P @ W^T (one GEMM); wgrad g_W = x^T @ g_P as a
-              split-K batched GEMM (the contraction runs over all NB*h*w rows) summed over the splits.
-    The whole batch goes through in one pass (P in HBM); frames are chunked only when P would exceed P_MAX_BYTES_CL."""
+    """x_cl [NB, h, w, C_in] -> out_cl [NB, H, W, C_out], everything in NHWC memory: the autograd node of a decoder stage / prediction head.
+    Since round 6 a DISPATCHER: it derives what the forms share (stage plan, dtypes, re-laid-out weight, output buffer) and hands the pass to
+    ONE form, each a module-level function above —
+      forward : _stage_fwd_packed_head | _stage_fwd_sub_x16 | _stage_fwd_sub_f32 | _stage_fwd_projected   (P = x @ W as ONE row-major GEMM + the gather kernel)
+      backward: _stage_bwd_box_x16 | _stage_bwd_box_f32 | _stage_bwd_gp   (gather adjoint -> g_P -> data / weight gradient contractions)
+    chosen from fused.stage_plan (geometry), StageOpts (call + autocast state) and the operand dtypes; net.plan() records the choice."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda')          # called with autocast disabled (upconv_projected_cl): dtypes are explicit
-    def forward(ctx, x_cl, weight, bias, tables, k, H, W, lowp=False, spikes_in=False, lowp_bwd=None, act_dtype=None,
-                lowrank_grad=False, x_packed=None, own16=None):
+    def forward(ctx, x_cl, weight, bias, tables, opts: 'StageOpts', x_packed=None):
+        k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, lowrank_grad, own16 = (opts.k, opts.H, opts.W, opts.lowp, opts.spikes_in, opts.lowp_bwd, opts.act_dtype,
+                                                                               opts.lowrank_grad, opts.own16)
         ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         # own16 (round 5): the 16-bit activation mode's dtype when the mode runs on the engine's own single-term kernels (x16_mode()) — decoder stages then take
         # the sub-pixel forward / box-sum backward on 16-bit I/O, and a packed head keeps its exact fp32 weights
@@ -877,29 +1120,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
             if not (sub16_ok or sub32_ok):
                 x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None     # (a dense copy came along: use it)
         if x_packed is not None and k == 3:
-            NB, h, w, Cin = x_cl.shape
-            Cout, kk = weight.shape[0], k * k
-            if not (k == 3 and Cout == 1 and not lowp and act_dtype is None and _lib.head_packed_supported(Cin, Cout, k)):
-                raise _lib.SSNeuronError('packed-only spike tensor handed to an up-conv that reads dense activations')
-            ctx.lowrank_grad = bool(lowrank_grad)
-            ctx.x_dtype = x_cl.dtype
-            weight = weight.float()
-            Wt = weight.permute(1, 2, 3, 0).reshape(Cin, kk * Cout).contiguous()
-            src_y, _, _, src_x, _, _ = tables
-            out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=x_cl.device)
-            rows = NB * h * w
-            P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
-            e0 = TIMER.start()
-            _lib.head_proj_packed(x_packed, Wt, P, rows, Cin)
-            _lib.upconv_cl_fwd(P, src_y, src_x, None if bias is None else bias.float(), out, NB, k, Cout, h, w, H, W)
-            TIMER.stop(e0, 'upconv_cl_fwd', x_cl.numel() // 4 + 4 * out.numel(), out.numel())
-            _note('synapse_fwd', 'head_proj_packed_mfma+gather')
-            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
-            ctx.lowp, ctx.exact = False, False
-            ctx.tables, ctx.k, ctx.n = tables, k, NB
-            ctx.wshape = weight.shape
-            ctx.has_bias = bias is not None
-            return out
+            return _stage_fwd_packed_head(ctx, H=H, W=W, act_dtype=act_dtype, bias=bias, k=k, lowp=lowp, lowrank_grad=lowrank_grad, tables=tables, weight=weight, x_cl=x_cl, x_packed=x_packed)
         # lowrank_grad: the caller guarantees x_cl is consumed by nothing else and produced by a fused neuron layer (a forked handle), so
         # the input gradient of a one-channel 3 x 3 head may be handed over as the pair (g_P, W2) instead of their product (lowrank_anchor)
         ctx.lowrank_grad = bool(lowrank_grad)
@@ -924,71 +1145,13 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
         n = max(1, min(NB, _P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
         exact = spikes_in and not lowp and _cfg().EXACT_SPLIT_GEMM and Cin >= _EXACT_SPLIT_MIN_K
-        if sub16_ok:                                  # decoder stage, 16-bit mode on own kernels: merged-tap implicit GEMM, two terms of the mode's format
-            st16 = sub_tables(tables, H, W)
-            e0 = TIMER.start()
-            wm = _lib.upconv_sub_prep_x16(weight.contiguous(), st16, Cin, Cout, own16)
-            _lib.upconv_sub_fwd_x16(None if x_packed is not None else x_cl, x_packed, wm, st16, out, NB, Cin, Cout, h, w)
-            TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()) + 2 * out.numel(), out.numel())
-            _note('synapse_fwd', 'upconv_sub_mfma_x16' + ('(packed in)' if x_packed is not None else ''))
-            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
-            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
-            ctx.exact = False
-            ctx.tables, ctx.k, ctx.n = tables, k, n
-            ctx.wshape = weight.shape
-            ctx.has_bias = False
-            return out
+        if sub16_ok:
+            return _stage_fwd_sub_x16(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, Wt=Wt, h=h, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, own16=own16, tables=tables, w=w, weight=weight, x_cl=x_cl, x_packed=x_packed)
         # round 4: the sub-pixel (merged tap) implicit GEMM — 9 instead of 25 multiply-adds per output element and channel, no P, no gather, no halo
         st = sub_tables(tables, H, W) if sub32_ok else None
         if st is not None:
-            if _cfg().ASSERT_EXACT_SPLIT and x_packed is None:
-                assert bool((x_cl.to(torch.bfloat16).float() == x_cl).all()), 'spikes_in=True but the input is not exact in bf16'
-            e0 = TIMER.start()
-            wm = _lib.upconv_sub_prep(weight.contiguous(), st, Cin, Cout)
-            _lib.upconv_sub_fwd(None if x_packed is not None else x_cl, x_packed, wm, st, out, NB, Cin, Cout, h, w)
-            TIMER.stop(e0, 'upconv_cl_fwd', (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()) + 4 * out.numel(), out.numel())
-            _note('synapse_fwd', 'upconv_sub_mfma' + ('(packed in)' if x_packed is not None else ''))
-            ctx.save_for_backward(x_cl, Wt, x_packed, weight)
-            ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
-            ctx.exact = True
-            ctx.tables, ctx.k, ctx.n = tables, k, n
-            ctx.wshape = weight.shape
-            ctx.has_bias = False
-            return out
-        if lowp:
-            xg = x_cl if x_cl.dtype == torch.bfloat16 else x_cl.to(torch.bfloat16)
-        elif exact or not half_in:
-            xg = x_cl                                   # exact: any dtype feeds the bf16 triple copy; plain fp32 path: fp32
-        else:
-            xg = x_cl.float()                           # 16-bit input on the plain fp32 GEMM path (narrow stages, heads)
-        Wg = Wt.to(torch.bfloat16) if lowp else Wt
-        if exact:
-            if _cfg().ASSERT_EXACT_SPLIT:
-                assert bool((x_cl.to(torch.bfloat16).float() == x_cl.float()).all()), 'spikes_in=True but the input is not exact in bf16'
-            W3 = _split3_bf16(Wt)
-        e0 = TIMER.start()
-        for c0 in range(0, NB, n):
-            c1 = min(NB, c0 + n)
-            xs = xg[c0:c1].view((c1 - c0) * h * w, Cin)
-            if exact:
-                x3 = torch.empty((xs.shape[0], 3, Cin), dtype=torch.bfloat16, device=xs.device)
-                x3.copy_(xs.unsqueeze(1))                                                  # one cast kernel writing the 3 copies
-                P = torch.mm(x3.view(-1, 3 * Cin), W3, out_dtype=torch.float32)
-                del x3
-            else:
-                P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
-            (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
-        TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-        _note('synapse_fwd', ('exact_bf16x3_gemm' if exact else ('bf16_gemm' if lowp else 'fp32_gemm')) + '+gather' + ('_x16' if act_dtype else ''))
-        ctx.save_for_backward(xg, Wt, None, weight)
-        # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
-        # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
-        ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
-        ctx.exact = exact
-        ctx.tables, ctx.k, ctx.n = tables, k, n
-        ctx.wshape = weight.shape
-        ctx.has_bias = bias is not None
-        return out
+            return _stage_fwd_sub_f32(ctx, Cin=Cin, Cout=Cout, NB=NB, Wt=Wt, h=h, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, st=st, tables=tables, w=w, weight=weight, x_cl=x_cl, x_packed=x_packed)
+        return _stage_fwd_projected(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, Wt=Wt, act_dtype=act_dtype, bias=bias, exact=exact, h=h, half_in=half_in, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, src_x=src_x, src_y=src_y, tables=tables, w=w, weight=weight, x_cl=x_cl)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
@@ -1015,130 +1178,13 @@ class _UpConvProjectedCL(torch.autograd.Function):
             box_geo = _lib.upconv_box_dgrad_supported(Cin, Cout, k, bt, NB, h, w) and _lib.upconv_box_wgrad_supported(Cin, Cout, k, bt, NB, h, w)     # (+ the launch limits at this NB)
         box16_ok = bool(box_geo and own16 is not None and g16 and g_out.dtype == own16 and (x_packed is not None or x_cl.dtype == own16))
         if box16_ok:
-            e0 = TIMER.start()
-            e1 = TIMER.start()
-            box = _lib.upconv_boxsum_x16(g_out, bt, NB, Cout, H, W)
-            TIMER.stop(e1, 'box_boxsum', 2 * g_out.numel() + 2 * box.numel(), g_out.numel())
-            g_x = g_w = None
-            wc = weight.detach().contiguous()
-            if need_x:
-                g_x = torch.empty(x_cl.shape, dtype=own16, device=g_out.device)
-                e1 = TIMER.start()
-                _lib.upconv_box_dgrad_x16(box, wc, bt, g_x, NB, Cin, Cout, h, w)
-                TIMER.stop(e1, 'box_dgrad', 2 * box.numel() + 2 * g_x.numel(), g_x.numel())
-            if need_w:
-                g_w = torch.empty(wc.shape, dtype=torch.float32, device=g_out.device)
-                e1 = TIMER.start()
-                _lib.upconv_box_wgrad_x16(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
-                TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 2 * x_cl.numel()), g_out.numel())
-            TIMER.stop(e0, 'upconv_cl_bwd', 2 * (x_cl.numel() + g_out.numel()), g_out.numel())
-            _note('synapse_bwd', 'box_x16: boxsum' + ('+dgrad1_mfma' if need_x else '') + ('+wgrad1_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
-            if g_x is not None and g_x.dtype != ctx.x_dtype:
-                g_x = g_x.to(ctx.x_dtype)
-            g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
+            return _stage_bwd_box_x16(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, bt=bt, g_out=g_out, h=h, need_w=need_w, need_x=need_x, own16=own16, w=w, weight=weight, x_cl=x_cl, x_packed=x_packed)
         # ---- round 4: the whole stage backward on the box-sum image (ss_upconv_box.hip): one HBM-bound box-sum launch, then both contractions as implicit
         #      GEMMs over its three bf16 planes — no per-tap tensor g_P in HBM or on chip, no per-fragment operand arithmetic
         box_ok = bool(box_geo and not lowp and not g16 and ctx.exact and g_out.dtype == torch.float32 and not lowrank and (x_packed is not None or x_cl.dtype == torch.float32))
         if box_ok:
-            e0 = TIMER.start()                                                   # the stage's whole backward ('upconv_cl_bwd', as every other form) ...
-            e1 = TIMER.start()                                                   # ... and its three launches one by one ('box_*': inside the former, not additional)
-            box = _lib.upconv_boxsum(g_out, bt, NB, Cout, H, W)
-            TIMER.stop(e1, 'box_boxsum', 4 * g_out.numel() + 2 * box.numel(), g_out.numel())
-            g_x = g_w = None
-            wc = weight.detach().contiguous()
-            if need_x:
-                g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=g_out.device)
-                e1 = TIMER.start()
-                _lib.upconv_box_dgrad(box, wc, bt, g_x, NB, Cin, Cout, h, w)
-                TIMER.stop(e1, 'box_dgrad', 2 * box.numel() + 4 * g_x.numel(), g_x.numel())
-            if need_w:
-                g_w = torch.empty(wc.shape, dtype=torch.float32, device=g_out.device)
-                e1 = TIMER.start()
-                _lib.upconv_box_wgrad(box, None if x_packed is not None else x_cl, x_packed, bt, g_w, NB, Cin, Cout, h, w)
-                TIMER.stop(e1, 'box_wgrad', 2 * box.numel() + (x_cl.numel() // 4 if x_packed is not None else 4 * x_cl.numel()), g_out.numel())
-            TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
-            _note('synapse_bwd', 'box: boxsum' + ('+dgrad6_mfma' if need_x else '') + ('+wgrad3_mfma' if need_w else '') + ('(packed x)' if (need_w and x_packed is not None) else ''), ctx.site)
-            if g_x is not None and g_x.dtype != ctx.x_dtype:
-                g_x = g_x.to(ctx.x_dtype)
-            # a stage built with bias=True (NNConvUpsampling accepts it; the shipped decoder stages have none): its gradient as in every other form
-            g_b = g_out.sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
-        g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank and not (lowp and n >= NB)) else None
-        g_Wt = torch.zeros_like(Wt) if need_w else None
-        W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
-        if lowp:
-            W2 = W2.to(torch.bfloat16)
-        f32 = dict(out_dtype=torch.float32) if lowp else {}
-        e0 = TIMER.start()
-        for c0 in range(0, NB, n):
-            c1 = min(NB, c0 + n)
-            rows = (c1 - c0) * h * w
-            if x_packed is not None and k == 5 and need_w:
-                # a stage whose input arrived as packed spikes and whose geometry the box-sum kernels do not take: the g_P forms read the dense tensor
-                # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one).  16-bit modes whose
-                # dense copy is not in the GEMMs' bf16 operand format (fp16 mode): unpack straight to bf16 — 0.25 B read per element instead of an fp16 -> bf16
-                # conversion pass over the dense copy (round 6: 0.3 - 0.4 ms per stage at config 5's share)
-                if lowp and x_cl.dtype != torch.bfloat16:
-                    x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, torch.bfloat16), None
-                else:
-                    x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None
-            if lowp and k == 5:
-                # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
-                g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
-                _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
-            else:
-                if lowrank:      # the adjoint writes g_P straight into the pair buffer the consumer's neuron backward will read
-                    lr_anchor, g_P, lr_w = lowrank_buffer(x_cl.shape, x_cl.device, kk * Cout, ctx.x_dtype)
-                    lr_w.copy_(W2)
-                else:
-                    g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
-                (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
-                if lowp:
-                    g_P = g_P.to(torch.bfloat16)
-            # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy) where the fp32 library GEMM is compute-bound: wide stages
-            # (measured: C_in 64 — deconv1 — is faster on the library's fp32 GEMM, 1.63 vs 2.48 ms, profiles/r04/bench_box_bwd_v5.log)
-            gemm6 = bool(need_x and not lowrank and not lowp and ctx.ecfg.GEMM6_DGRAD and Cin >= 128 and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin))
-            if lowrank:
-                g_x = lr_anchor                                                   # the pair was written in place (lowrank_buffer)
-            elif gemm6:
-                _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
-            elif need_x and lowp and c0 == 0 and c1 == NB:
-                # one chunk (the usual case): the GEMM's own output IS the gradient — in the bf16 mode written in the activation format by its epilogue (fp32
-                # accumulation, one rounding: what fp32-then-narrow gives), in the fp16 mode fp32 and narrowed once below; no copy into a preallocated buffer
-                g_x = (torch.mm(g_P, W2) if ctx.x_dtype == torch.bfloat16 else torch.mm(g_P, W2, **f32)).view(x_cl.shape)
-            elif need_x:
-                g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
-                    torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
-            spike_wgrad = bool(need_w and ctx.exact and not lowp and ctx.ecfg.EXACT_WGRAD_MFMA and x_cl.dtype == torch.float32 and _lib.spike_wgrad_supported(Cin, kk * Cout))
-            if need_w and x_packed is not None and k == 3:
-                _lib.head_wgrad_packed(x_packed, g_P, g_Wt, rows, Cin, accumulate=True)     # reads the 2-bit packed spikes (1/16 of the dense tensor)
-            elif spike_wgrad:
-                # x is a spike tensor: hand-written exact bf16x3 MFMA contraction over the rows, g_P split in registers (read once from HBM)
-                _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)
-            elif need_w:
-                xs = x_cl[c0:c1].view(rows, Cin)
-                if lowp and xs.dtype != torch.bfloat16:
-                    xs = xs.to(torch.bfloat16)                                    # spikes: exact
-                elif not lowp and xs.dtype != torch.float32:
-                    xs = xs.float()
-                S = max(1, rows // _WGRAD_SPLIT_ROWS)
-                L = rows // S
-                if S > 1:
-                    g_Wt += torch.bmm(xs[:S * L].view(S, L, Cin).transpose(1, 2), g_P[:S * L].view(S, L, kk * Cout), **f32).sum(0)
-                    if S * L < rows:
-                        g_Wt += torch.mm(xs[S * L:].t(), g_P[S * L:], **f32)
-                else:
-                    g_Wt += torch.mm(xs.t(), g_P, **f32)
-        TIMER.stop(e0, 'upconv_cl_bwd', 4 * (x_cl.numel() + g_out.numel()), g_out.numel())
-        how_x = 'none' if not need_x else ('lowrank_pair' if lowrank else ('adjoint+gemm6' if gemm6 else 'adjoint+library_gemm'))
-        how_w = 'none' if not need_w else ('head_wgrad_packed_mfma' if (x_packed is not None and k == 3) else ('spike_wgrad_mfma' if spike_wgrad else 'library_gemm'))
-        _note('synapse_bwd', f'g_x: {how_x}; g_w: {how_w}' + ('; 16-bit' if (lowp or g16) else ''), ctx.site)
-        g_w = g_Wt.view(Cin, k, k, Cout).permute(3, 0, 1, 2).contiguous() if need_w else None
-        g_b = g_out.float().sum((0, 1, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        if g_x is not None and g_x.dtype != ctx.x_dtype:
-            g_x = g_x.to(ctx.x_dtype)                    # the gradient of a 16-bit activation input is a 16-bit activation gradient
-        return g_x, g_w, g_b, None, None, None, None, None, None, None, None, None, None, None
+            return _stage_bwd_box_f32(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, bt=bt, g_out=g_out, h=h, need_w=need_w, need_x=need_x, w=w, weight=weight, x_cl=x_cl, x_packed=x_packed)
+        return _stage_bwd_gp(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, Wt=Wt, g16=g16, g_out=g_out, h=h, k=k, kk=kk, lowp=lowp, lowrank=lowrank, n=n, need_w=need_w, need_x=need_x, w=w, x_cl=x_cl, x_hi=x_hi, x_lo=x_lo, x_packed=x_packed, y_hi=y_hi, y_lo=y_lo)
 
 
 class _SpikeConvCL(torch.autograd.Function):
@@ -1665,7 +1711,8 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
         # a prediction head on packed spikes in a 16-bit mode: the packed kernels with the exact fp32 weight, fp32 P and output (the head feeds the fp32 I-pool)
         lowp = lowp_bwd = False
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
-        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, lowrank_grad, x_packed, own16)
+        return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, StageOpts(k=k, H=H, W=W, lowp=lowp, spikes_in=spikes_in, lowp_bwd=lowp_bwd, act_dtype=act_dtype,
+                                                                             lowrank_grad=lowrank_grad, own16=own16), x_packed)
 
 
 _guard_module(__name__, 'fused')
