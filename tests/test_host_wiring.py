@@ -231,6 +231,43 @@ def test_sequence_path_equals_stepwise_oracle(host_backend):
     assert all(not m.v.requires_grad for m in net.modules() if hasattr(m, 'v') and torch.is_tensor(m.v))
 
 
+def test_lazy_membrane_host_logic(host_backend):
+    """EngineConfig.LAZY_MEMBRANE (round 6), node level (the network packs its spikes on the GPU only): after a multi-step pass under autograd on a packed
+    kernel form the node holds an unwritten membrane; `node.v` recomputes it once, equal to what the writing pass produces, without autograd history;
+    reset() / detach() / a second pass without reset behave as before; single steps, no_grad passes and dense forms write it."""
+    from stereospike_amd import config as _config
+    from stereospike_amd.clock_driven import neuron, surrogate
+    torch.manual_seed(4)
+    T, shape = 4, (2, 3, 4, 16)
+    x = (torch.randn((T,) + shape) * 0.3)
+    res = {}
+    for lazy in (True, False):
+        with _config.engine_config(LAZY_MEMBRANE=lazy):
+            node = neuron.ParametricLIFNode(init_tau=3.0, surrogate_function=surrogate.ATan(), detach_reset=True)
+            xs = x.clone().requires_grad_()
+            out = node.forward_sequence(xs, scale=5.0, pack=2)
+            assert node.last_packed is not None and isinstance(node._v, neuron._LazyMembrane) == lazy
+            v1 = node.v
+            assert torch.is_tensor(node._v) and (not lazy or not v1.requires_grad) and node.v is v1       # materialised once, kept
+            pk1 = node.last_packed.clone()
+            node.detach()
+            out2 = node.forward_sequence(xs, scale=5.0, pack=2)                                            # no reset: continues from v1
+            v2 = node.v.detach().clone()
+            with torch.no_grad():
+                node.reset()
+                node.forward_sequence(x, scale=5.0, pack=2)
+                assert torch.is_tensor(node._v)                                                             # no_grad: written by the pass
+            node.reset()
+            assert node.v == node.v_reset and not torch.is_tensor(node._v)
+            node.forward_sequence(xs, scale=5.0)                                                           # dense form: always written
+            assert torch.is_tensor(node._v)
+            node.reset()
+            node(xs[0])                                                                                    # single step: written (and differentiable)
+            assert torch.is_tensor(node._v) and node._v.requires_grad
+            res[lazy] = (v1.detach().clone(), pk1, v2, node.last_numel)
+    assert all(torch.equal(a, b) for a, b in zip(res[True][:3], res[False][:3])) and res[True][3] == x[0].numel()
+
+
 @pytest.mark.parametrize('name', ['StereoSpike', 'PLIFNet'])
 def test_pinned_oracle_machinery_on_the_host_backend(host_backend, name):
     """tests/_pinned.py (the end-to-end parity protocol of the GPU suite) exercised on CPU: product python layer over the C-oracle
