@@ -22,7 +22,12 @@ def key_of(name):
         if mode == 'x16c5':
             return 'neuron_fwd_skip_packed' if skip else 'neuron_fwd_packed'
         return 'neuron_fwd_x16_packed'
-    if 'neuron_bwd16_seg_kernel' in name:                           # round 6: the low-rank form
+    if 'neuron_bwd16_seg_kernel' in name:                           # round 6: the low-rank form <KIND, SG, DT, T, VEC, NSEG, G2, LR, WAVES, HAS_G1, SUM, PASS>
+        import re
+        m = re.search(r'neuron_bwd16_seg_kernel<([^>]*)>', name)
+        args = [a.strip() for a in m.group(1).split(',')] if m else []
+        if len(args) >= 12 and args[11] == '1':                    # the exact pass behind the fast one: returns at once unless asked for (no traffic)
+            return None
         return 'neuron_bwd_lr' if mode == 'x16c5' else 'neuron_bwd_x16_lr'
     if 'neuron_fwd16_kernel' in name:
         return 'neuron_fwd_x16_packed'
@@ -138,7 +143,7 @@ res = {'workload': f'B16 x T5 x 32x260x346 layer (config-3 bottom), IF, fp32, to
        'algorithmic_bytes_per_launch': {k: v * T * N for k, v in per_update.items()},
        'o_n_terms_bytes': {'neuron_fwd': 4 * N, 'neuron_bwd': 0},
        'note': 'FETCH_SIZE (KiB) doubled per the gfx950 note in MI355X_MICROARCH.md; WRITE_SIZE (KiB) as reported; '
-               'separate --pmc passes; the forward also writes v_last (4 B x N, an O(N) term outside the per-update figure)'}
+               'separate --pmc passes; the dense forward also writes v_last (4 B x N, an O(N) term outside the per-update figure); the packed forwards leave it unwritten (ABI 10), as the training step runs them'}
 alg = {k: v * T * N for k, v in per_update.items()}
 alg['neuron_fwd_packed'] = int(4.25 * T * N)                        # x 4 B + 2-bit packed output 0.25 B per update (no dense output)
 alg['neuron_bwd_lr'] = int((12 + 36 / 32) * T * N)                   # g_out, x, g_x + the head's rank-9 pair: 9 floats per 32-channel pixel

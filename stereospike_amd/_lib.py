@@ -266,9 +266,13 @@ def tree_source_hash() -> str:
     import hashlib
     import re
     csrc = os.path.join(_PKG, 'csrc')
-    units = re.search(r'^UNITS\s*:=\s*(.*)$', open(os.path.join(csrc, 'Makefile')).read(), re.M).group(1).split()
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    units = re.search(r'^UNITS\s*:=\s*(.*)$', mk, re.M).group(1).split()
+    # HDRS of the Makefile, in its order (headers next to the units, then $(ROOT)/include/...)
+    hdrs = [os.path.join(os.path.dirname(_PKG), h[len('$(ROOT)/'):]) if h.startswith('$(ROOT)/') else os.path.join(csrc, h)
+            for h in re.search(r'^HDRS\s*:=\s*(.*)$', mk, re.M).group(1).split()]
     hsh = hashlib.sha256()
-    for f in [os.path.join(csrc, u + '.hip') for u in units] + [os.path.join(csrc, 'ss_common.hpp'), os.path.join(os.path.dirname(_PKG), 'include', 'ss_neuron.h')]:
+    for f in [os.path.join(csrc, u + '.hip') for u in units] + hdrs:
         hsh.update(open(f, 'rb').read())
     return hsh.hexdigest()[:16]
 

@@ -120,11 +120,18 @@ constexpr int kLr2Rank = 9;
 // dynamic LDS bytes of the low-rank form: 9 x C weights + per wavefront T x 9 x (64 * VEC / C) pair values
 inline size_t bwd16_seg_lds_bytes(int T, int VEC, int C) { return sizeof(float) * ((size_t)kLr2Rank * C + (size_t)(kBlock / 64) * T * kLr2Rank * ((64 * VEC) / C)); }
 
-template <int KIND, int SG, int DT, int TS, int VEC, int NSEG, bool G2, bool LR, int WAVES = 1, bool HAS_G1 = true, bool SUM = false>
+// PASS (ATan surrogate): 0 = the fast pass — rcp_newton reciprocals; a wavefront that saw a denominator >= 2^126 raises *redo_flag; 1 = the exact pass, a second
+// launch behind the first that returns at once unless *redo_flag is set and otherwise redoes the whole layer with the IEEE division (same loads, same stores);
+// 2 = one launch with the IEEE division (Sigmoid surrogate; A/B).  Two launches instead of a redo branch inside one kernel: the branch cost 24 registers of the
+// fast pass (shared allocation) — spills to scratch at 3 wavefronts per SIMD, 1.19 x the algorithmic HBM bytes instead of 1.07 x (profiles/r06/).
+template <int KIND, int SG, int DT, int TS, int VEC, int NSEG, bool G2, bool LR, int WAVES = 1, bool HAS_G1 = true, bool SUM = false, int PASS = 2>
 __global__ __launch_bounds__(kBlock, WAVES) void neuron_bwd16_seg_kernel(Bwd16Args a, const unsigned short* __restrict__ x_seq,
                                                                   const unsigned short* __restrict__ g_out2_seq, unsigned short* __restrict__ g_sum_seq,
-                                                                  const float* __restrict__ lr_p, const float* __restrict__ lr_w, int lr_C, int pair_x4)
+                                                                  const float* __restrict__ lr_p, const float* __restrict__ lr_w, int lr_C, int pair_x4,
+                                                                  unsigned* __restrict__ redo_flag = nullptr)
 {
+    constexpr bool EXACT = !(SG == SS_SG_ATAN && PASS == 0);
+    if constexpr (PASS == 1) { if (*redo_flag == 0u) return; }              // (uniform; written by the previous launch on this stream)
     static_assert(VEC == 8 || VEC == 4 || VEC == 2, "vector lanes");
     static_assert(NSEG >= 1 && NSEG <= TS, "segments");
     static_assert(!LR || G2, "the low-rank pair is a second gradient");
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void neuron_bwd16_seg_kernel(Bwd16Ar
     const bool want_gk = (KIND == SS_KIND_PLIF) && a.g_k_partials != nullptr;
     constexpr bool has_g1 = HAS_G1;
     double acc_k = 0.0;
+    [[maybe_unused]] unsigned dmax = 0u;                          // largest ATan denominator seen (as an integer: NaN > inf > finite)
     const int lr_log2C = LR ? __builtin_ctz((unsigned)lr_C) : 0;                              // C divides 64 * VEC: a power of two (host)
     // wave-uniform trip count: the wavefront's lanes stage the low-rank pair together
     for (long long i0 = (long long)blockIdx.x * kBlock + wave * 64; i0 < NV; i0 += (long long)gridDim.x * kBlock) {
@@ -195,19 +203,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void neuron_bwd16_seg_kernel(Bwd16Ar
             }
         }
 
-        // the iteration after its loads of x: with EXACT false the ATan reciprocal is rcp_newton and the return value tells whether a denominator left its range
-        double dk = 0.0;
-        auto body = [&](auto exact_tag) -> bool {
-            constexpr bool EXACT = decltype(exact_tag)::value;
-            unsigned dmax = 0u;
-            dk = 0.0;
-            // ---- the lane's x of all steps (read twice: membrane sweep, then segment by segment).  The redo loads them again through a laundered pointer:
-            // it shares nothing with the first pass (otherwise the compiler keeps x and the first pass's h alive for it: +35 registers)
-            const unsigned short* xbl = xb;
-            if constexpr (EXACT && SG == SS_SG_ATAN) asm volatile("" : "+s"(xbl));
+        {
+            // ---- the lane's x of all steps (read twice: membrane sweep, then segment by segment)
             wvec_t xs[TS];
 #pragma unroll
-            for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const wvec_t*>(xbl + (long long)t * N + lo));
+            for (int t = 0; t < TS; ++t) xs[t] = load_stream(reinterpret_cast<const wvec_t*>(xb + (long long)t * N + lo));
             f2v v0[NP], gv[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void neuron_bwd16_seg_kernel(Bwd16Ar
                                 if (t == t0) v_prev = vchk[s][q];
                                 else { const f2v hp = h[t > t0 ? t - t0 - 1 : 0][q]; v_prev = reset_if_fired(hp, hp - v_th, v_reset, c0); }
                                 // element order of the round-5 kernel: ascending within the lane; idle lanes add nothing
-                                dk += active ? (double)g_h[0] * (double)((he[0] - v_prev[0]) / k) : 0.0;
-                                dk += active ? (double)g_h[1] * (double)((he[1] - v_prev[1]) / k) : 0.0;
+                                acc_k += active ? (double)g_h[0] * (double)((he[0] - v_prev[0]) / k) : 0.0;
+                                acc_k += active ? (double)g_h[1] * (double)((he[1] - v_prev[1]) / k) : 0.0;
                             }
                         }
                         xv[q] = narrow2<DT>(g_x * scale);
@@ -349,12 +349,10 @@ __global__ __launch_bounds__(kBlock, WAVES) void neuron_bwd16_seg_kernel(Bwd16Ar
 #pragma unroll
                 for (int q = 0; q < NP; ++q) *reinterpret_cast<f2v*>(a.g_v_init + i0 * VEC + lo + 2 * q) = gv[q];
             }
-            return dmax >= kRcpNewtonLimit;
-        };
-        if constexpr (SG == SS_SG_ATAN) {
-            if (__builtin_expect(__any((int)body(std::false_type{})), 0)) body(std::true_type{});      // wave-uniform redo: same loads, same stores, the true division
-        } else body(std::true_type{});
-        acc_k += dk;
+        }
+    }
+    if constexpr (!EXACT) {                             // a denominator left rcp_newton's range somewhere in this wavefront: ask for the exact pass
+        if (__any((int)(dmax >= kRcpNewtonLimit)) && lane == 0) atomicOr(redo_flag, 1u);
     }
     if (want_gk) gk_epilogue(acc_k, a.g_k_partials);   // wave-uniform
 }

@@ -3,28 +3,56 @@
 // ss_neuron_bwd16.hip; shapes it does not take stay on neuron_bwd16_rc_kernel there.
 #include "ss_common.hpp"
 #include "ss_neuron16_v2.hpp"
+#include <atomic>
 
 namespace {
+
+// The exact pass's request flags (ss_neuron16_v2.hpp, PASS): one word per launch in flight, taken round-robin.  The only state of the library that outlives a call
+// — 4 KB of device memory: a launch clears its word, the fast pass may set it, the exact pass behind it on the same stream reads it.  1024 launches would have to be
+// in flight at once for two of them to share a word, and then the worst case is an exact pass that was not needed.
+constexpr int kRedoSlots = 1024;
+__device__ unsigned ss_lr_redo_flags[kRedoSlots];
+
+inline unsigned* redo_slot()
+{
+    static unsigned* base = [] { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(ss_lr_redo_flags)) == hipSuccess ? static_cast<unsigned*>(p) : nullptr; }();
+    static std::atomic<unsigned> next{0};
+    return base ? base + (next.fetch_add(1, std::memory_order_relaxed) % kRedoSlots) : nullptr;
+}
 
 // lane width / segments / wavefronts per SIMD the compiler is held to, measured on the MI355X at BASELINE config 5's and config 3's layer shapes
 // (tools/ubench/neuron16_ab.hip, profiles/r06/neuron16_ab_*.log): T <= 5: 4 neurons per lane, one segment, 4 waves (128 registers) — 0.63 - 0.67 of 8 TB/s
 // (round 5: 0.45 - 0.47); T > 5: 4 per lane, two segments, 3 waves (168 registers) — 0.51 - 0.55 (round 5: 0.39 - 0.41).  8 per lane (16-byte accesses) spills.
+template <int KIND, int SG, int DT, int TS, bool HAS_G1, bool SUM>
+int launch_lr_form(const Bwd16Args& a, const unsigned short* x_seq, unsigned short* g_sum, const float* lr_p, const float* lr_w, int C, hipStream_t s, int grid, int pair_x4)
+{
+    constexpr int V = 4, NSEG = TS > 5 ? 2 : 1, W = TS > 5 ? 3 : 4;
+    const size_t lds = bwd16_seg_lds_bytes(TS, V, C);
+    if constexpr (SG == SS_SG_ATAN) {
+        unsigned* const flag = redo_slot();
+        if (!flag || hipMemsetAsync(flag, 0, sizeof(unsigned), s) != hipSuccess) return SS_ELAUNCH;
+        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<KIND, SG, DT, TS, V, NSEG, true, true, W, HAS_G1, SUM, 0>), dim3(grid), dim3(kBlock), lds, s, a, x_seq, nullptr, g_sum, lr_p, lr_w, C, pair_x4, flag);
+        if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
+        // the exact pass: returns at once unless the fast pass asked for it.  Its grid is bounded (it loops) — except with dL/dk partials, which are per workgroup
+        const int grid1 = a.g_k_partials ? grid : (grid < 2048 ? grid : 2048);
+        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<KIND, SG, DT, TS, V, NSEG, true, true, 2, HAS_G1, SUM, 1>), dim3(grid1), dim3(kBlock), lds, s, a, x_seq, nullptr, g_sum, lr_p, lr_w, C, pair_x4, flag);
+    } else {
+        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<KIND, SG, DT, TS, V, NSEG, true, true, W, HAS_G1, SUM, 2>), dim3(grid), dim3(kBlock), lds, s, a, x_seq, nullptr, g_sum, lr_p, lr_w, C, pair_x4, nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+}
+
 template <int KIND, int SG, int DT, int TS>
 int launch_lr(const Bwd16Args& a, const unsigned short* x_seq, unsigned short* g_sum, const float* lr_p, const float* lr_w, int C, hipStream_t s, int* grid_out)
 {
-    constexpr int V = 4, NSEG = TS > 5 ? 2 : 1, W = TS > 5 ? 3 : 4;
+    constexpr int V = 4;
     int grid = grid_for(a.N / V, kMaxGridBwd);
     if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
     *grid_out = grid;
     const int pair_x4 = ((a.N / C) % 4 == 0) && (((64 * V) / C) % 4 == 0) && aligned16(lr_p);
-    const size_t lds = bwd16_seg_lds_bytes(TS, V, C);
-    if (!a.g_out_seq)
-        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<KIND, SG, DT, TS, V, NSEG, true, true, W, false, false>), dim3(grid), dim3(kBlock), lds, s, a, x_seq, nullptr, nullptr, lr_p, lr_w, C, pair_x4);
-    else if (g_sum)
-        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<KIND, SG, DT, TS, V, NSEG, true, true, W, true, true>), dim3(grid), dim3(kBlock), lds, s, a, x_seq, nullptr, g_sum, lr_p, lr_w, C, pair_x4);
-    else
-        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<KIND, SG, DT, TS, V, NSEG, true, true, W, true, false>), dim3(grid), dim3(kBlock), lds, s, a, x_seq, nullptr, nullptr, lr_p, lr_w, C, pair_x4);
-    return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
+    if (!a.g_out_seq) return launch_lr_form<KIND, SG, DT, TS, false, false>(a, x_seq, nullptr, lr_p, lr_w, C, s, grid, pair_x4);
+    if (g_sum) return launch_lr_form<KIND, SG, DT, TS, true, true>(a, x_seq, g_sum, lr_p, lr_w, C, s, grid, pair_x4);
+    return launch_lr_form<KIND, SG, DT, TS, true, false>(a, x_seq, nullptr, lr_p, lr_w, C, s, grid, pair_x4);
 }
 
 template <int KIND, int SG, int DT>

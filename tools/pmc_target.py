@@ -102,7 +102,7 @@ if mode == 'rc':
     for _ in range(5):
         _lib.neuron_bwd_fork_lr(g, lr_p, lr_w, None, None, x, None, gx, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0, 0, 2.0, True)
     for _ in range(5):
-        _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.neuron_fwd_ex(x, None, None, None, None, pk, None, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)      # (round 6: membrane unwritten, as the training step runs it)
     gy = torch.randn(NB, H, W, Cout, device=dev)
     gxs = torch.empty(NB, h, w, Cin, device=dev)
     wt = up.up[1].weight.detach().contiguous()
@@ -133,7 +133,7 @@ if mode == 'rc':
         _lib.dense_conv_s1_wgrad(g0, xv, gw0, NB, 4, 32, H, W)
         _lib.head_proj_packed(xbp, Wh, Ph, rows, 32)
         _lib.head_wgrad_packed(xbp, gPh, gWh, rows, 32)
-        _lib.neuron_fwd_ex(x, None, None, xbp.view(T, -1), None, pk, None, v, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
+        _lib.neuron_fwd_ex(x, None, None, xbp.view(T, -1), None, pk, None, None, None, None, T, N, 10.0, 0, 2.0, None, 1.0, 0.0)
 if mode == 'rc':
     # round 4: the decoder backward of deconv1 on the box-sum image (ss_upconv_boxsum_f32 -> ss_upconv_box_dgrad_f32 + ss_upconv_box_wgrad_f32), what the default path runs
     from stereospike_amd import fused

@@ -108,6 +108,7 @@ template <int DT, int TS> int run(int B, int C, int H, int W, void* lib)
     CHK(hipMalloc(&lrp, (long long)TS * rows * 9 * 4)); CHK(hipMalloc(&lrw, 9 * C * 4));
     CHK(hipMalloc(&vl0, N * 4)); CHK(hipMalloc(&vl1, N * 4)); CHK(hipMalloc(&nnz, 64)); CHK(hipMalloc(&cws, (2 * (N / 256 + 2)) * 4));
     CHK(hipMalloc(&g_cnt, 8));
+    unsigned* redo_flag; CHK(hipMalloc(&redo_flag, 4));
     fill16<DT><<<8192, 256>>>(x, TN, 0.06f, 1); fill16<DT><<<8192, 256>>>(g, TN, 1e-3f, 2); fill16<DT><<<8192, 256>>>(g2, TN, 1e-3f, 3);
     fill32<<<4096, 256>>>(lrp, (long long)TS * rows * 9, 1e-3f, 4); fill32<<<1, 256>>>(lrw, 9 * C, 0.3f, 5);
     fill_codes<<<4096, 256>>>(skp, TN / 16, 6);
@@ -149,8 +150,11 @@ template <int DT, int TS> int run(int B, int C, int H, int W, void* lib)
 #define NEW_BWDW(VEC, NSEG, G2, LR, GS, G2P, LRP, WV) NEW_BWDS(VEC, NSEG, G2, LR, GS, G2P, LRP, WV, false)
 #define NEW_BWDS(VEC, NSEG, G2, LR, GS, G2P, LRP, WV, SUMF) do { \
         const int grid_ = grid_for(N / VEC, kMaxGridBwd); \
-        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<SS_KIND_IF, SS_SG_ATAN, DT, TS, VEC, NSEG, G2, LR, WV, true, SUMF>), dim3(grid_), dim3(kBlock), LR ? bwd16_seg_lds_bytes(TS, VEC, C) : 0, 0, ba, x, G2P, GS, LRP, lrw, C, \
-                           (pair_x4 && ((64 * VEC / C) % 4 == 0)) ? 1 : 0); } while (0)
+        (void)hipMemsetAsync(redo_flag, 0, 4, 0); \
+        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<SS_KIND_IF, SS_SG_ATAN, DT, TS, VEC, NSEG, G2, LR, WV, true, SUMF, 0>), dim3(grid_), dim3(kBlock), LR ? bwd16_seg_lds_bytes(TS, VEC, C) : 0, 0, ba, x, G2P, GS, LRP, lrw, C, \
+                           (pair_x4 && ((64 * VEC / C) % 4 == 0)) ? 1 : 0, redo_flag); \
+        hipLaunchKernelGGL((neuron_bwd16_seg_kernel<SS_KIND_IF, SS_SG_ATAN, DT, TS, VEC, NSEG, G2, LR, 2, true, SUMF, 1>), dim3(grid_ < 2048 ? grid_ : 2048), dim3(kBlock), LR ? bwd16_seg_lds_bytes(TS, VEC, C) : 0, 0, ba, x, G2P, GS, LRP, lrw, C, \
+                           (pair_x4 && ((64 * VEC / C) % 4 == 0)) ? 1 : 0, redo_flag); } while (0)
 #define AB(NAME, BASECALL, BYTES, HAS_SUM, ...) do { \
         CHK(hipMemset(gx0, 0xff, TN * 2)); CHK(hipMemset(gs0, 0xff, TN * 2)); \
         if ((BASECALL) != 0) { printf("base call failed\n"); return 1; } \
