@@ -407,8 +407,8 @@ def main():
 
         def bwd_name(tag):
             if half:
-                if '+lr' in tag:   # <KIND, SG, DT, T, VEC, NSEG, G2, LR, WAVES, HAS_G1, SUM>
-                    return f'neuron_bwd16_seg_kernel<0, 0, {dtc}, {a.T}, 4, {2 if a.T > 5 else 1}, true, true, {3 if a.T > 5 else 4}, true, false>'
+                if '+lr' in tag:   # <KIND, SG, DT, T, VEC, NSEG, G2, LR, WAVES, HAS_G1, SUM, PASS>: the fast pass (PASS 0); the exact pass behind it (PASS 1) returns at once
+                    return f'neuron_bwd16_seg_kernel<0, 0, {dtc}, {a.T}, 4, {2 if a.T > 5 else 1}, true, true, {3 if a.T > 5 else 4}, true, false, 0>'
                 v = 4 if a.T <= 5 else 2
                 return f'neuron_bwd16_rc_kernel<0, 0, {dtc}, {a.T}, {v}, {tf("fork" in tag)}, false>'
             return (f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, true>' if '+lr' in tag else

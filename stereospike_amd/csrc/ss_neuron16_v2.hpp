@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void neuron_fwd16_pk8_kernel(Fwd16Args a)
                 }
             }
             if (a.out_packed) {
-                const unsigned hi = (unsigned)__shfl_down((int)cf, 1, 64);
+                const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)cf, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]: the odd neighbour's codes, on the VALU (a shuffle would go through the LDS pipe)
                 if ((threadIdx.x & 1) == 0) a.out_packed[(long long)t * NW + (i >> 1)] = cf | (hi << 16);
             }
         }
