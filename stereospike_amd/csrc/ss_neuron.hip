@@ -376,6 +376,7 @@ int dispatch_fwd_T(const FwdArgs& a, hipStream_t s)
     }
 }
 
+constexpr int kFwd16Pk8Grid = 4096;
 #ifndef SS_F16_V5
 #define SS_F16_V5 8
 #endif
@@ -400,7 +401,9 @@ int launch_fwd16(const Fwd16Args& a, hipStream_t s)
             const bool vec8 = (a.N % 16 == 0) && aligned16(a.x_seq) && (!a.out_seq || aligned16(a.out_seq)) && (!a.v_last || aligned16(a.v_last)) &&
                               (!a.v_init || aligned16(a.v_init)) && (!a.skip_seq || aligned16(a.skip_seq));
             if (!vec8 || save_h) return SS_EINVAL;
-            const int grid8 = grid_for(a.N / 8, cap);
+            // a bounded grid with a grid-stride loop: at 10 instructions per update a wavefront's start-up is no longer hidden — 4096 workgroups (2 - 3 rounds of
+            // resident ones) instead of one vector per lane: 0.68 -> 0.74 of 8 TB/s at T = 10, 0.54 -> 0.65 at T = 5 (profiles/r06/neuron16_fwd_grid_ab.log)
+            const int grid8 = grid_for(a.N / 8, cap < kFwd16Pk8Grid ? cap : kFwd16Pk8Grid);
             if (a.out_seq) {
                 if (skip) hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<KIND, DT, TS, true, true>), dim3(grid8), dim3(kBlock), 0, s, a);
                 else hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<KIND, DT, TS, false, true>), dim3(grid8), dim3(kBlock), 0, s, a);

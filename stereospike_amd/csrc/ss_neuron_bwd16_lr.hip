@@ -10,6 +10,7 @@ namespace {
 // The exact pass's request flags (ss_neuron16_v2.hpp, PASS): one word per launch in flight, taken round-robin.  The only state of the library that outlives a call
 // — 4 KB of device memory: a launch clears its word, the fast pass may set it, the exact pass behind it on the same stream reads it.  1024 launches would have to be
 // in flight at once for two of them to share a word, and then the worst case is an exact pass that was not needed.
+constexpr int kLrGridCap = 8192;
 constexpr int kRedoSlots = 1024;
 __device__ unsigned ss_lr_redo_flags[kRedoSlots];
 
@@ -50,8 +51,11 @@ int launch_lr(const Bwd16Args& a, const unsigned short* x_seq, unsigned short* g
     if (a.g_k_partials && grid > kMaxGridGk) grid = kMaxGridGk;
     *grid_out = grid;
     const int pair_x4 = ((a.N / C) % 4 == 0) && (((64 * V) / C) % 4 == 0) && aligned16(lr_p);
+    if (g_sum && a.g_out_seq) return launch_lr_form<KIND, SG, DT, TS, true, true>(a, x_seq, g_sum, lr_p, lr_w, C, s, grid, pair_x4);
+    // without the g_sum store: a bounded grid with the grid-stride loop (the wavefronts' start-up amortised over several vectors): 0.565 -> 0.593 of 8 TB/s at
+    // T = 10, 0.59 -> 0.66 at T = 5; the form that also writes g_sum (and the forms without a pair) lose with it (profiles/r06/neuron16_bwd_grid_ab.log)
+    if (grid > kLrGridCap) { grid = kLrGridCap; *grid_out = grid; }
     if (!a.g_out_seq) return launch_lr_form<KIND, SG, DT, TS, false, false>(a, x_seq, nullptr, lr_p, lr_w, C, s, grid, pair_x4);
-    if (g_sum) return launch_lr_form<KIND, SG, DT, TS, true, true>(a, x_seq, g_sum, lr_p, lr_w, C, s, grid, pair_x4);
     return launch_lr_form<KIND, SG, DT, TS, true, false>(a, x_seq, nullptr, lr_p, lr_w, C, s, grid, pair_x4);
 }
 

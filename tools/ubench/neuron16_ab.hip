@@ -126,7 +126,8 @@ template <int DT, int TS> int run(int B, int C, int H, int W, void* lib)
         unsigned long long n0[2]; CHK(hipMemcpy(n0, nnz, 16, hipMemcpyDeviceToHost));
         const float t_base = time_us([&] { fwd_ex(&d, nullptr); });
         Fwd16Args a{x, nullptr, nullptr, nullptr, nullptr, vl1, nnz, TS, N, scale, tau, v_th, v_reset, nullptr, cws, skip ? skp : nullptr, op1};
-        const int grid = grid_for(N / 8, kMaxGrid);
+        const int grid_cap = getenv("SS_AB_FWD_GRID") ? atoi(getenv("SS_AB_FWD_GRID")) : kMaxGrid;      // A/B: a bounded grid with a grid-stride loop
+        const int grid = grid_for(N / 8, grid_cap);
         auto launch_new = [&](bool with_v) {
             Fwd16Args b = a; if (!with_v) b.v_last = nullptr;
             if (skip) hipLaunchKernelGGL((neuron_fwd16_pk8_kernel<SS_KIND_IF, DT, TS, true, false>), dim3(grid), dim3(kBlock), 0, 0, b);
@@ -149,7 +150,7 @@ template <int DT, int TS> int run(int B, int C, int H, int W, void* lib)
 #define NEW_BWD(VEC, NSEG, G2, LR, GS, G2P, LRP) NEW_BWDW(VEC, NSEG, G2, LR, GS, G2P, LRP, 1)
 #define NEW_BWDW(VEC, NSEG, G2, LR, GS, G2P, LRP, WV) NEW_BWDS(VEC, NSEG, G2, LR, GS, G2P, LRP, WV, false)
 #define NEW_BWDS(VEC, NSEG, G2, LR, GS, G2P, LRP, WV, SUMF) do { \
-        const int grid_ = grid_for(N / VEC, kMaxGridBwd); \
+        const int grid_ = grid_for(N / VEC, getenv("SS_AB_BWD_GRID") ? atoi(getenv("SS_AB_BWD_GRID")) : kMaxGridBwd); \
         (void)hipMemsetAsync(redo_flag, 0, 4, 0); \
         hipLaunchKernelGGL((neuron_bwd16_seg_kernel<SS_KIND_IF, SS_SG_ATAN, DT, TS, VEC, NSEG, G2, LR, WV, true, SUMF, 0>), dim3(grid_), dim3(kBlock), LR ? bwd16_seg_lds_bytes(TS, VEC, C) : 0, 0, ba, x, G2P, GS, LRP, lrw, C, \
                            (pair_x4 && ((64 * VEC / C) % 4 == 0)) ? 1 : 0, redo_flag); \
