@@ -861,6 +861,7 @@ class StageOpts:
     act_dtype: Optional[torch.dtype] = None     # decoder stages under 16-bit autocast write 16-bit activations
     lowrank_grad: bool = False                  # a one-channel 3 x 3 head may hand its input gradient on as the rank-9 pair
     own16: Optional[torch.dtype] = None         # the 16-bit mode's dtype when it runs on the engine's own single-term kernels
+    fwd16: bool = False                         # fp16 mode on own kernels: the projection GEMM takes ONE fp16 weight term (as every other synapse of the mode) instead of bf16x3
 
 
 # ---- the forms of a decoder stage / prediction head (dispatch: _UpConvProjectedCL below); each reads what the dispatcher derived and sets the ctx fields the
@@ -924,15 +925,16 @@ def _stage_fwd_sub_f32(ctx, *, Cin, Cout, NB, Wt, h, k, lowp, lowp_bwd, n, out, 
     ctx.has_bias = False
     return out
 
-def _stage_fwd_projected(ctx, *, Cin, Cout, H, NB, W, Wt, act_dtype, bias, exact, h, half_in, k, lowp, lowp_bwd, n, out, src_x, src_y, tables, w, weight, x_cl):
+def _stage_fwd_projected(ctx, *, fwd16, Cin, Cout, H, NB, W, Wt, act_dtype, bias, exact, h, half_in, k, lowp, lowp_bwd, n, out, src_x, src_y, tables, w, weight, x_cl):
     """Projection GEMM (exact bf16x3 / bf16 / fp32 on the library) + the channels-last gather kernel: geometries the sub-pixel kernel does not take, heads on dense inputs."""
-    if lowp:
-        xg = x_cl if x_cl.dtype == torch.bfloat16 else x_cl.to(torch.bfloat16)
+    gdt = torch.bfloat16 if lowp else (torch.float16 if fwd16 else None)      # single-term GEMM: operands in the mode's format, fp32 accumulation / output
+    if gdt is not None:
+        xg = x_cl if x_cl.dtype == gdt else x_cl.to(gdt)
     elif exact or not half_in:
         xg = x_cl                                   # exact: any dtype feeds the bf16 triple copy; plain fp32 path: fp32
     else:
         xg = x_cl.float()                           # 16-bit input on the plain fp32 GEMM path (narrow stages, heads)
-    Wg = Wt.to(torch.bfloat16) if lowp else Wt
+    Wg = Wt.to(gdt) if gdt is not None else Wt
     if exact:
         if _cfg().ASSERT_EXACT_SPLIT:
             assert bool((x_cl.to(torch.bfloat16).float() == x_cl.float()).all()), 'spikes_in=True but the input is not exact in bf16'
@@ -947,13 +949,14 @@ def _stage_fwd_projected(ctx, *, Cin, Cout, H, NB, W, Wt, act_dtype, bias, exact
             P = torch.mm(x3.view(-1, 3 * Cin), W3, out_dtype=torch.float32)
             del x3
         else:
-            P = torch.mm(xs, Wg, out_dtype=torch.float32) if lowp else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
+            P = torch.mm(xs, Wg, out_dtype=torch.float32) if gdt is not None else torch.mm(xs, Wg)   # [(n*h*w), kk*Cout]
         (_lib.upconv_cl_fwd_x16 if act_dtype else _lib.upconv_cl_fwd)(P, src_y, src_x, bias, out[c0:c1], c1 - c0, k, Cout, h, w, H, W)
     TIMER.stop(e0, 'upconv_cl_fwd', 4 * (x_cl.numel() + out.numel()), out.numel())
-    _note('synapse_fwd', ('exact_bf16x3_gemm' if exact else ('bf16_gemm' if lowp else 'fp32_gemm')) + '+gather' + ('_x16' if act_dtype else ''))
+    _note('synapse_fwd', ('exact_bf16x3_gemm' if exact else ('bf16_gemm' if lowp else ('fp16_gemm' if fwd16 else 'fp32_gemm'))) + '+gather' + ('_x16' if act_dtype else ''))
     ctx.save_for_backward(xg, Wt, None, weight)
     # backward operand precision: bf16 operands (fp32 accumulate / output) under ANY 16-bit autocast — bf16 has the fp32 exponent
-    # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode stays the exact bf16x3 form
+    # range, so the fp16 mode needs no loss scaling for it; the forward of the fp16 mode: ONE fp16 term on the engine's own kernel path (round 6: as every other
+    # synapse of the mode), the exact bf16x3 form on the round-2 .. 4 path (X16_OWN_KERNELS off)
     ctx.lowp = lowp if lowp_bwd is None else lowp_bwd
     ctx.exact = exact
     ctx.tables, ctx.k, ctx.n = tables, k, n
@@ -1104,6 +1107,7 @@ class _UpConvProjectedCL(torch.autograd.Function):
     def forward(ctx, x_cl, weight, bias, tables, opts: 'StageOpts', x_packed=None):
         k, H, W, lowp, spikes_in, lowp_bwd, act_dtype, lowrank_grad, own16 = (opts.k, opts.H, opts.W, opts.lowp, opts.spikes_in, opts.lowp_bwd, opts.act_dtype,
                                                                                opts.lowrank_grad, opts.own16)
+        fwd16 = bool(opts.fwd16)
         ctx.ecfg, ctx.site = _cfg(), _site()          # the engine configuration and plan site of THIS forward: the backward dispatches from them
         # own16 (round 5): the 16-bit activation mode's dtype when the mode runs on the engine's own single-term kernels (x16_mode()) — decoder stages then take
         # the sub-pixel forward / box-sum backward on 16-bit I/O, and a packed head keeps its exact fp32 weights
@@ -1144,14 +1148,14 @@ class _UpConvProjectedCL(torch.autograd.Function):
         # one pass: measured on the MI355X (profiles/r01/chunk_sweep*.log) cache-sized chunks lose more in GEMM efficiency (M = n*h*w
         # rows) than they save in HBM traffic of P — 71.7 -> 69.9 ms/step for config 3; chunks only bound the memory of very large batches
         n = max(1, min(NB, _P_MAX_BYTES_CL // (Cout * kk * h * w * 4)))
-        exact = spikes_in and not lowp and _cfg().EXACT_SPLIT_GEMM and Cin >= _EXACT_SPLIT_MIN_K
+        exact = spikes_in and not lowp and not fwd16 and _cfg().EXACT_SPLIT_GEMM and Cin >= _EXACT_SPLIT_MIN_K
         if sub16_ok:
             return _stage_fwd_sub_x16(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, Wt=Wt, h=h, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, own16=own16, tables=tables, w=w, weight=weight, x_cl=x_cl, x_packed=x_packed)
         # round 4: the sub-pixel (merged tap) implicit GEMM — 9 instead of 25 multiply-adds per output element and channel, no P, no gather, no halo
         st = sub_tables(tables, H, W) if sub32_ok else None
         if st is not None:
             return _stage_fwd_sub_f32(ctx, Cin=Cin, Cout=Cout, NB=NB, Wt=Wt, h=h, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, st=st, tables=tables, w=w, weight=weight, x_cl=x_cl, x_packed=x_packed)
-        return _stage_fwd_projected(ctx, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, Wt=Wt, act_dtype=act_dtype, bias=bias, exact=exact, h=h, half_in=half_in, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, src_x=src_x, src_y=src_y, tables=tables, w=w, weight=weight, x_cl=x_cl)
+        return _stage_fwd_projected(ctx, fwd16=fwd16, Cin=Cin, Cout=Cout, H=H, NB=NB, W=W, Wt=Wt, act_dtype=act_dtype, bias=bias, exact=exact, h=h, half_in=half_in, k=k, lowp=lowp, lowp_bwd=lowp_bwd, n=n, out=out, src_x=src_x, src_y=src_y, tables=tables, w=w, weight=weight, x_cl=x_cl)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
@@ -1711,8 +1715,11 @@ def upconv_projected_cl(x_cl: torch.Tensor, weight: torch.Tensor, bias, tables, 
         # a prediction head on packed spikes in a 16-bit mode: the packed kernels with the exact fp32 weight, fp32 P and output (the head feeds the fp32 I-pool)
         lowp = lowp_bwd = False
     with torch.autocast('cuda', enabled=False):      # dtypes are handled explicitly inside (no blanket casts in either direction)
+        # fp16 mode on the engine's own kernels: the library projection (deconv4, heads 3 / 4) on ONE fp16 weight term — the mode's definition everywhere else —
+        # instead of the exact bf16x3 form (a [X X X] copy + three times the products); the packed heads keep the exact fp32 weight
+        fwd16 = bool(own16 == torch.float16 and adt == torch.float16 and not (k == 3 and x_packed is not None))
         return _UpConvProjectedCL.apply(x_cl, weight, bias, tables, StageOpts(k=k, H=H, W=W, lowp=lowp, spikes_in=spikes_in, lowp_bwd=lowp_bwd, act_dtype=act_dtype,
-                                                                             lowrank_grad=lowrank_grad, own16=own16), x_packed)
+                                                                             lowrank_grad=lowrank_grad, own16=own16, fwd16=fwd16), x_packed)
 
 
 _guard_module(__name__, 'fused')

@@ -221,13 +221,13 @@ def narrowing_points(amp_dtype, own=True, plan=None):
       encoder + bottleneck convs, decoder stages on the sub-pixel forward (deconv1 .. deconv3 at 260x346; `plan` = the product run's net.plan() says which stages
         took it on the geometry at hand — the 64x80 pyramid's deconv3 does not): weight rounded ONCE to the mode's dtype inside the kernel's weight preparation,
         output stored in the mode's dtype;
-      deconv4 (projection GEMM + gather, stereospike_amd/fused.py::_UpConvProjectedCL): output in the mode's dtype; weight rounded to bf16 in the bf16 mode,
-        the EXACT fp32 weight in the fp16 mode (exact bf16x3 split);
+      deconv4 (projection GEMM + gather, stereospike_amd/fused.py::_UpConvProjectedCL): output in the mode's dtype; weight rounded ONCE to the mode's dtype
+        (round 6: the fp16 mode too — one fp16 term, as every other synapse of the mode; it was the exact bf16x3 split);
       prediction heads (k = 3, fp32 output — they feed the fp32 I-pool): heads 1 / 2 read packed spikes with the exact fp32 weight; heads 3 / 4 as deconv4.
     own=False — the round-2 .. 4 path (X16_OWN_KERNELS off: encoder / bottleneck synapses = MIOpen convolutions under autocast): encoder + bottleneck
       weight and output in the autocast dtype; every decoder stage and head as deconv4 / heads 3, 4 above."""
     def policy(name):
-        dec_w = torch.bfloat16 if amp_dtype == torch.bfloat16 else None
+        dec_w = torch.bfloat16 if amp_dtype == torch.bfloat16 else (torch.float16 if (own and amp_dtype == torch.float16) else None)
         if name.startswith('predict_depth'):
             return (None if (own and name[13] in '12') else dec_w), None
         if name.startswith('deconv'):
