@@ -1172,7 +1172,9 @@ class _UpConvProjectedCL(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         # one-channel 3 x 3 head on a forked neuron output: g_x = g_P [rows, 9] @ W2 [9, C_in] is left to the consumer's backward kernel
         # (anomaly detection scans every backward output for NaNs and would trip over the anchor: it gets the dense form)
-        lowrank = (need_x and ctx.lowrank_grad and ctx.ecfg.LOWRANK_HEAD_GRAD and not lowp and not g16 and kk * Cout == 9 and n >= NB
+        # (round 6: also the dense-input heads of the 16-bit modes on own kernels — `lowp`: their weight-gradient GEMM keeps its bf16 operands, the pair is fp32 —
+        #  instead of a [rows, 9] x [9, C] GEMM, an fp32 -> 16-bit conversion of its C-channel result and the dense second gradient in the stage's neuron backward)
+        lowrank = (need_x and ctx.lowrank_grad and ctx.ecfg.LOWRANK_HEAD_GRAD and (not lowp or ctx.own16 is not None) and not g16 and kk * Cout == 9 and n >= NB
                    and (ctx.x_dtype == torch.float32 or ctx.own16 is not None) and Cin % 4 == 0 and 1024 % Cin == 0 and not torch.is_anomaly_enabled())
         # ---- round 5: the 16-bit activation modes on own kernels — the same box-sum backward on 16-bit I/O (box planes in the mode's format, ONE weight term)
         own16 = ctx.own16
