@@ -302,17 +302,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # ---- second, short pass for the roofline legs: the same step with a HIP-event pair around every fused launch (on the launch stream) ----
-    leg_steps = max(1, min(a.leg_steps, a.steps)) if not a.graph else 0
-    t_leg0 = time.perf_counter()
-    if leg_steps:
+    # (under --graph the replayed launches cannot carry event pairs: the legs then run the SAME launches uncaptured, through an eager Trainer on the same
+    # network, after the sustained leg — it steps the parameters outside the graph, so nothing of the graph is timed after it)
+    leg_steps = max(1, min(a.leg_steps, a.steps))
+
+    def legs_pass(tr):
+        t_leg0 = time.perf_counter()
         TIMER.enabled = True
         TIMER.clear()
         for _ in range(leg_steps):
-            trainer.step(x, gt)
+            tr.step(x, gt)
         sync()
         TIMER.enabled = False
-    leg_elapsed = time.perf_counter() - t_leg0
-    leg_steps = max(1, leg_steps)
+        return time.perf_counter() - t_leg0
+    leg_elapsed = legs_pass(trainer) if not a.graph else 0.0
     # ---- sustained leg: back-to-back steps for >= --sustained-seconds (the headline region is a sub-second burst after warm-up: this is what the chip holds
     # at steady clocks / temperature, and what an external SMI sampler can see).  Same step, timer off, barrier + synchronize on both sides, MAX over ranks.
     sustained = None
@@ -341,6 +344,12 @@ def main():
         sustained = dict(steps=n_sus, seconds=round(sus_elapsed, 2), frames_per_s=round(a.batch * world * n_sus / sus_elapsed, 3),
                          ms_per_step=round(1e3 * sus_elapsed / n_sus, 3),
                          offsets_s=dict(start=round(t_s0 - _T_PROCESS_START, 2), end=round(t_s0 - _T_PROCESS_START + sus_elapsed, 2)))
+    if a.graph:
+        eager = Trainer(net, amp_dtype=amp_dtype, count_rates=bool(a.count_rates))
+        for _ in range(2):
+            eager.step(x, gt)
+        sync()
+        leg_elapsed = legs_pass(eager)
     summ = TIMER.summary()
     shapes = TIMER.summary(by_shape=True)
 
@@ -399,20 +408,25 @@ def main():
         dtc = {'f16': 1, 'bf16': 2}.get(a.dtype, 0)              # SS_DT_F16 / SS_DT_BF16: the DT template argument rocprof prints
         tf = lambda b: 'true' if b else 'false'                  # noqa: E731
 
+        kd = 0 if a.model == 'StereoSpike' else 2                # SS_KIND_IF / SS_KIND_PLIF: the KIND template argument rocprof prints
+        seg_T = a.T in (4, 5, 8, 10)                             # ss_neuron_bwd16_lr.hip: the step counts the segmented low-rank form is instantiated for
+
         def fwd_name(skip):
             if half:       # ss_neuron16_v2.hpp (round 6): <KIND, DT, T, SKIP, DENSE copy>
-                return f'neuron_fwd16_pk8_kernel<0, {dtc}, {a.T}, {tf(skip)}, false>'
-            return (f'neuron_fwd_kernel<0, {a.T}, {tf(skip)}, false, 4, true>' if packed_on
-                    else f'neuron_fwd_kernel<0, {a.T}, {tf(skip)}, {tf(not recompute_h)}, 4, false>')
+                return f'neuron_fwd16_pk8_kernel<{kd}, {dtc}, {a.T}, {tf(skip)}, false>'
+            return (f'neuron_fwd_kernel<{kd}, {a.T}, {tf(skip)}, false, 4, true>' if packed_on
+                    else f'neuron_fwd_kernel<{kd}, {a.T}, {tf(skip)}, {tf(not recompute_h)}, 4, false>')
 
         def bwd_name(tag):
             if half:
-                if '+lr' in tag:   # <KIND, SG, DT, T, VEC, NSEG, G2, LR, WAVES, HAS_G1, SUM, PASS>: the fast pass (PASS 0); the exact pass behind it (PASS 1) returns at once
-                    return f'neuron_bwd16_seg_kernel<0, 0, {dtc}, {a.T}, 4, {2 if a.T > 5 else 1}, true, true, {3 if a.T > 5 else 4}, true, false, 0>'
                 v = 4 if a.T <= 5 else 2
-                return f'neuron_bwd16_rc_kernel<0, 0, {dtc}, {a.T}, {v}, {tf("fork" in tag)}, false>'
-            return (f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, true>' if '+lr' in tag else
-                    f'neuron_bwd_kernel<0, 0, {a.T}, 4, true, true, false>' if 'fork' in tag
+                if '+lr' in tag and seg_T:   # <KIND, SG, DT, T, VEC, NSEG, G2, LR, WAVES, HAS_G1, SUM, PASS>: the fast pass (PASS 0); the exact pass behind it (PASS 1) returns at once
+                    return f'neuron_bwd16_seg_kernel<{kd}, 0, {dtc}, {a.T}, 4, {2 if a.T > 5 else 1}, true, true, {3 if a.T > 5 else 4}, true, false, 0>'
+                if '+lr' in tag:             # other step counts: the round-5 form <KIND, SG, DT, T, VEC, G2, LR>
+                    return f'neuron_bwd16_rc_kernel<{kd}, 0, {dtc}, {a.T}, {v}, true, true>'
+                return f'neuron_bwd16_rc_kernel<{kd}, 0, {dtc}, {a.T}, {v}, {tf("fork" in tag)}, false>'
+            return (f'neuron_bwd_kernel<{kd}, 0, {a.T}, 4, true, true, true>' if '+lr' in tag else
+                    f'neuron_bwd_kernel<{kd}, 0, {a.T}, 4, true, true, false>' if 'fork' in tag
                     else f'neuron_bwd_kernel<*, *, {a.T}, 4, {tf(recompute_h)}, false, false>')
         out = {
             'metric': f'train frames/sec (260x346xT={a.T} {"mono" if a.model == "PLIFNetMono" else "stereo"} voxels)', 'value': round(frames / elapsed, 3),
@@ -424,7 +438,8 @@ def main():
             'timed_region_offsets_s': dict(start=round(t_region_start - _T_PROCESS_START, 2), end=round(t_region_end - _T_PROCESS_START, 2),
                                            legs_pass_end=round(t_region_end - _T_PROCESS_START + leg_elapsed, 2)),
             'per_kernel_legs': dict(steps=leg_steps, ms_per_step_with_event_timer=round(1e3 * leg_elapsed / leg_steps, 3),
-                                    note='separate pass after the timed region: fused.TIMER (one HIP-event pair per fused launch) is OFF while `value` is measured'),
+                                    note='separate pass after the timed region: fused.TIMER (one HIP-event pair per fused launch) is OFF while `value` is measured'
+                                         + ('; --graph: the same launches uncaptured (eager Trainer on the same network), after the sustained leg' if a.graph else '')),
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'sustained': sustained,
             'sustained_frames_per_s': sustained['frames_per_s'] if sustained else None,
@@ -433,7 +448,7 @@ def main():
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'T': a.T,
                        'parallelism': f'dp{world}', 'fuse_upconv': bool(a.fuse_upconv), 'decoder_nhwc': bool(a.decoder_nhwc), 'encoder_nhwc': bool(a.encoder_nhwc), 'weights': f'default init, seed 2021, multiply_factor {10 if a.model == "StereoSpike" else 30}',
                        'input': 'Poisson(0.05) voxels, label 0.5+9.5U with 25% NaN'},
-            'roofline_fwd': dict(kernel=f'{"neuron_fwd16_pk8_kernel" if half else "neuron_fwd_kernel"}<IF,T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
+            'roofline_fwd': dict(kernel=f'{"neuron_fwd16_pk8_kernel" if half else "neuron_fwd_kernel"}<{"IF" if kd == 0 else "PLIF"},T={a.T},train> (fused gain+charge+fire+reset over T, {a.dtype} I/O, '
                                         f'{bpu(fwd)} B/update'
                                         f'{", + skip add (2-bit packed skip operand)" if "+skip" in fwd_tag and packed_on else ", + skip add" if "+skip" in fwd_tag else ""}'
                                         f'{", 2-bit packed output only" if "+packed" in fwd_tag else ""}) on its dominant launch shape: '

@@ -45,6 +45,11 @@ constexpr int kBxCo = 8;                       // output channels per chunk of t
 // first build; 2 MFMAs per k-step and twice the plane traffic for a rounding the g_P path does not spare either.)
 // The weight is ONE term (rounded once to the format), so a k-step costs NP MFMAs instead of six (data gradient) / three (weight gradient).
 template <int DT> struct BxT { static constexpr int NP = DT == 0 ? 3 : 1, NW = DT == 0 ? 3 : 1; };
+// Round 6: with ONE plane and ONE weight term an item of the contraction kernels (a tile x an 8-channel chunk) holds a third / a sixth of the fp32 mode's MFMAs
+// behind the same staging, barriers and address work — the 16-bit kernels ran at 0.12 - 0.2 of the MFMA peak on overhead.  The chunks of a frame are adjacent
+// in HBM exactly as the planes of a chunk are ([nb][chunk][plane][NVR][NHR][8] with one plane), so in these modes the window's planes are NG CONSECUTIVE CHUNKS
+// (template argument NG: 2 where C_out % 16 == 0, else 1): the data gradient adds their products into the same accumulators (a k-step = NG x NT MFMAs), the weight
+// gradient keeps one accumulator set per chunk and shares the spike fragments and the addresses between them.
 
 template <int DT> __device__ __forceinline__ void bx_split(const float (&v)[8], u16x8 (&pl)[BxT<DT>::NP])
 {
@@ -287,11 +292,12 @@ __device__ __forceinline__ void bx_win_store(unsigned char* wnd, const f4 (&buf)
 // ss_gemm6_f32's order; the running sum's sign alternates per chunk (the bf16 MFMA's fp32 accumulation drifts down by ~2^-28 of the magnitude sum).
 // weight [C_out][C_in][5][5] fp32 -> Wf[ci block of 32 NT][chunk][k-step 13][plane 3][tile NT][lane 64][8] bf16: element e of a lane = split term of
 // (+ / -) W[co = 8 chunk + e][ci = 32 NT blk + 32 tile + (lane & 31)][tap = 2 s + (lane >> 5)]  (tap 25: zero; odd chunks negated)
-template <int DT = 0>
+template <int DT = 0, int NG = 1>           // NG > 1 (16-bit modes): "plane" sp of chunk GROUP c is chunk NG c + sp; the sign alternates per group
 __global__ __launch_bounds__(kBlock) void upconv_box_dgrad_prep_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wf, int Cin, int Cout, int NT)
 {
-    constexpr int NW = BxT<DT>::NW;
-    const int NCH = Cout / kBxCo;
+    static_assert(DT != 0 || NG == 1, "chunk groups: 16-bit modes only");
+    constexpr int NW = DT == 0 ? BxT<DT>::NW : NG;
+    const int NCH = Cout / (kBxCo * NG);
     const long long total = (long long)(Cin / (32 * NT)) * NCH * kB2KS * NW * NT * 64;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock) {
         const int lane = (int)(i & 63);
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void upconv_box_dgrad_prep_kernel(const flo
         u16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int co = kBxCo * c + e;
+            const int co = DT == 0 ? kBxCo * c + e : kBxCo * (NG * c + sp) + e;
             float v = tap < 25 ? W[((long long)co * Cin + ci) * 25 + tap] : 0.f;
             if (c & 1) v = -v;
             if constexpr (DT != 0) { o[e] = round_op<DT>(v); continue; }
@@ -319,13 +325,14 @@ __global__ __launch_bounds__(kBlock) void upconv_box_dgrad_prep_kernel(const flo
     }
 }
 
-template <int NT, int KPS, int DT = 0>
+template <int NT, int KPS, int DT = 0, int NG = 1>      // NCH: chunk GROUPS (C_out / (8 NG))
 __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const unsigned short* __restrict__ Bp, const unsigned short* __restrict__ Wf,
                                                                          const int* __restrict__ vmap, const int* __restrict__ hmap,
                                                                          const int* __restrict__ tr, const int* __restrict__ tc,
                                                                          typename ActT<DT>::type* __restrict__ gx, int NB, int h, int w, int NVR, int NHR, int CIN, int NCH, int RG, int CG)
 {
-    constexpr int NP = BxT<DT>::NP, NW = BxT<DT>::NW;
+    static_assert(DT != 0 || NG == 1, "chunk groups: 16-bit modes only");
+    constexpr int NP = DT == 0 ? BxT<DT>::NP : NG, NW = DT == 0 ? BxT<DT>::NW : NG;     // window planes / weight planes of a k-step (16-bit modes: the NG chunks of the group)
     constexpr int kKB = NW * NT * 1024;                                         // bytes of one k-step of weights
     constexpr int kStage = KPS * kKB;                                           // 12 KB
     constexpr int kNS = (kB2KS + KPS - 1) / KPS;                                // stages per chunk (7 | 13)
@@ -471,8 +478,9 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_dgrad_kernel(const u
 #pragma unroll
                         for (int u = 0; u < NT; ++u) fb[p2][u] = *reinterpret_cast<const s16x8*>(bk + (p2 * NT + u) * 1024);
                     // fp32 mode: the six cross terms, smallest first: (h, l) (m, m) (l, h) (h, m) (m, h) (h, h); 16-bit modes: the planes of B against the ONE weight term, lo first
+                    // (round 6: the planes are the group's chunks, each against ITS weight plane)
                     constexpr int kNQ = DT ? NP : 6;
-                    constexpr int pa[6] = {DT ? NP - 1 : 0, DT ? 0 : 1, 2, 0, 1, 0}, pb[6] = {DT ? 0 : 2, DT ? 0 : 1, 0, 1, 0, 0};
+                    constexpr int pa[6] = {0, 1, 2, 0, 1, 0}, pb[6] = {DT ? 0 : 2, 1, DT ? 2 : 0, DT ? 0 : 1, DT ? 1 : 0, 0};
 #pragma unroll
                     for (int q = 0; q < kNQ; ++q)
 #pragma unroll
@@ -564,23 +572,27 @@ __device__ __forceinline__ void bx3_store_rows(unsigned char* wnd, const f4 (&bu
 // the group's lanes address INDIVIDUALLY (measured: out[i][r] = in[lane 4 r + i / 4][element i % 4], profiles/r04/tr16.log), so each source lane points at
 // "its" pixel through the two index maps and the gather along k costs nothing.  The main loop is branch-free: rows / columns beyond the tile meet a zeroed
 // spike fragment, phantom taps and quads read the window's zero row.  Partials -> ws[slice][co][tap][ci] -> upconv_box_wgrad_reduce_kernel (fixed order).
-template <int NT, bool PF, int DT = 0>         // NT: input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of
+template <int NT, bool PF, int DT = 0, int NG = 1>      // NT: input-channel tiles per kind = per WAVEFRONT (1 | 2 | 4): a wavefront owns the tap quads wv and wv + 4 for all of
                                                // them, so every transposed A fragment feeds NT MFMAs.  PF: the next tile's window is fetched into registers while this
                                                // tile multiplies (14 x 16 B per thread: NT <= 2 only — NT = 4 holds 128 accumulator registers)
+                                               // NG (16-bit modes, BxT comment): the window's planes are NG consecutive chunks, one accumulator set each — a transposed
+                                               // A fragment still feeds NT MFMAs, a spike fragment NG x 2 of them; NT x NG <= 4 (128 accumulator registers)
 __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const unsigned short* __restrict__ Bp, const unsigned short* __restrict__ xT,
                                                                          const int* __restrict__ vmap, const int* __restrict__ hmap,
                                                                          const int* __restrict__ tr, const int* __restrict__ tc,
                                                                          float* __restrict__ ws, int NB, int h, int w, int NVR, int NHR, int CIN, int COUT, int KINDS,
                                                                          int RG, int CG)
 {
+    static_assert(DT != 0 || NG == 1, "chunk groups: 16-bit modes only");
     constexpr int NQ = 2;                                                       // tap quads per wavefront: wv, wv + 4 (the 8th is a phantom: zero row)
-    constexpr int NP = BxT<DT>::NP;
+    constexpr int NP = DT == 0 ? BxT<DT>::NP : NG;                              // window planes: the three terms of a chunk | the NG chunks of a group
+    constexpr int NA = DT == 0 ? 1 : NG;                                        // accumulator sets
     __shared__ __attribute__((aligned(16))) unsigned char wnd[NP * kB3Plane];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NCH = COUT / kBxCo, CIB = CIN / (32 * NT);
+    const int NCH = COUT / (kBxCo * NG), CIB = CIN / (32 * NT);                 // NCH: chunk groups
     const int kind = (int)(blockIdx.x % KINDS), slice = (int)(blockIdx.x / KINDS), slices = (int)(gridDim.x / KINDS);
-    const int c = kind / CIB, cib = kind - c * CIB;                              // chunk of C_out, block of input channels
+    const int c = kind / CIB, cib = kind - c * CIB;                              // chunk (group) of C_out, block of input channels
     const int KSR = (w + 15) / 16;
     const long long n_tiles = (long long)NB * RG * CG;
     const long long t_begin = n_tiles * slice / slices, t_end = n_tiles * (slice + 1) / slices;
@@ -598,13 +610,15 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
         kyq[u] = real[u] ? t / 5 : 0;
         kxq[u] = real[u] ? t - 5 * (t / 5) : 0;
     }
-    f32x16 acc[NQ][NT];
+    f32x16 acc[NA][NQ][NT];
 #pragma unroll
-    for (int u = 0; u < NQ; ++u)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int u = 0; u < NQ; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][t][r] = 0.f;
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][u][t][r] = 0.f;
     const unsigned xoffT = (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * 8u;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     const unsigned short* const xbase = xT + (long long)(cib * NT) * (32 * 16) + xoffT;
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
                 for (int u = 0; u < NQ; ++u) {
                     const s16x8 af = {lo[u][p][0], lo[u][p][1], lo[u][p][2], lo[u][p][3], hi[u][p][0], hi[u][p][1], hi[u][p][2], hi[u][p][3]};
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[u][t] = mfma32<DT>(af, xf[t], acc[u][t]);
+                    for (int t = 0; t < NT; ++t) acc[DT ? p : 0][u][t] = mfma32<DT>(af, xf[t], acc[DT ? p : 0][u][t]);
                 }
         };
         s16x4 la[NQ][NP], ha[NQ][NP], lb[NQ][NP], hb[NQ][NP];
@@ -762,15 +776,17 @@ __global__ __launch_bounds__(kB2Threads, 2) void upconv_box_wgrad_kernel(const u
     // ---- partials: D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][ci = lane & 31], m = 8 (tap - 4 quad) + channel  ->  ws[slice][co][tap][ci]
     float* const wsl = ws + (long long)slice * COUT * 25 * CIN;
 #pragma unroll
-    for (int u = 0; u < NQ; ++u)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int u = 0; u < NQ; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int tap = 4 * (wv + 4 * u) + (mm >> 3), co = kBxCo * c + (mm & 7);
-                if (tap < 25) wsl[((long long)co * 25 + tap) * CIN + 32 * (cib * NT + t) + (lane & 31)] = acc[u][t][r];
-            }
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int tap = 4 * (wv + 4 * u) + (mm >> 3), co = kBxCo * (NA * c + a) + (mm & 7);
+                    if (tap < 25) wsl[((long long)co * 25 + tap) * CIN + 32 * (cib * NT + t) + (lane & 31)] = acc[a][u][t][r];
+                }
 }
 
 // g_W [C_out][C_in][25] (+)= sum over slices of ws[slice][co][tap][ci], slices in ascending order
@@ -874,13 +890,17 @@ int ss_upconv_box_dgrad_f32(const void* box, const float* weight, const int* vma
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
-static int box_wgrad_plan(int Cin, int Cout, int* NT, int* kinds, int* slices)
+// x16: the 16-bit modes' plan (chunk groups of NG = 2 where C_out allows, then NT <= 2: BxT comment); *NG is written only then
+static int box_wgrad_plan(int Cin, int Cout, int* NT, int* kinds, int* slices, bool x16 = false, int* NG = nullptr)
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
     static const int force_nt2 = getenv("SS_BOX_WGRAD_NT2") ? atoi(getenv("SS_BOX_WGRAD_NT2")) : 0;          // A/B only (profiles/r04/box_nt_ab.log)
-    *NT = (Cin % 128 == 0 && !force_nt2) ? 4 : (Cin % 64 == 0 ? 2 : 1);        // input-channel tiles per kind (= per wavefront)
-    *kinds = (Cout / kBxCo) * (Cin / (32 * *NT));
+    static const int force_ng1 = getenv("SS_BOX_X16_NG1") ? atoi(getenv("SS_BOX_X16_NG1")) : 0;              // A/B only (profiles/r06/box_x16_ng_ab.log)
+    const int ng = (x16 && Cout % (2 * kBxCo) == 0 && !force_ng1) ? 2 : 1;
+    if (NG) *NG = ng;
+    *NT = (Cin % 128 == 0 && !force_nt2 && ng == 1) ? 4 : (Cin % 64 == 0 ? 2 : 1);        // input-channel tiles per kind (= per wavefront)
+    *kinds = (Cout / (kBxCo * ng)) * (Cin / (32 * *NT));
     int sl = (2 * cus) / *kinds;                                                // two workgroups per CU
     if (sl < 1) sl = 1;
     *slices = sl;
@@ -895,8 +915,10 @@ int ss_upconv_box_wgrad_supported(int Cin, int Cout, int k, int max_tile_rows, i
 
 long long ss_upconv_box_wgrad_ws_floats(int Cin, int Cout, long long NB, int h, int w)
 {
-    int NT = 0, kinds = 0, slices = 0;
+    int NT = 0, kinds = 0, slices = 0, nt16 = 0, kinds16 = 0, slices16 = 0, ng16 = 0;
     if (!ss_upconv_box_wgrad_supported(Cin, Cout, 5, 1, 1) || NB <= 0 || h <= 0 || w <= 0 || !box_wgrad_plan(Cin, Cout, &NT, &kinds, &slices)) return 0;
+    if (!box_wgrad_plan(Cin, Cout, &nt16, &kinds16, &slices16, true, &ng16)) return 0;
+    if (slices16 > slices) slices = slices16;                                   // one size for both entry points (the 16-bit plan has fewer kinds, hence more slices)
     return (long long)slices * Cout * 25 * Cin + (NB * h * ((w + 15) / 16) * Cin * 16 + 1) / 2 + 8;      // slice partials + the spike operand in fragment order (bf16)
 }
 
@@ -967,22 +989,28 @@ int ss_upconv_box_dgrad_x16(const void* box, const float* weight, const int* vma
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned short* Wf = reinterpret_cast<unsigned short*>(ws);
     const int NT = Cin % 128 == 0 ? 4 : 2;
+    static const int force_ng1 = getenv("SS_BOX_X16_NG1") ? atoi(getenv("SS_BOX_X16_NG1")) : 0;                // A/B only (profiles/r06/box_x16_ng_ab.log)
+    const int NG = (Cout % (2 * kBxCo) == 0 && !force_ng1) ? 2 : 1;           // chunks per window (BxT comment)
     const long long frag16 = (long long)(Cin / 32) * (Cout / kBxCo) * kB2KS * 64;
-    if (dtype == SS_DT_F16) hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel<SS_DT_F16>, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
-    else hipLaunchKernelGGL(upconv_box_dgrad_prep_kernel<SS_DT_BF16>, dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT);
+#define SS_BP16(DTT, NGG) hipLaunchKernelGGL((upconv_box_dgrad_prep_kernel<DTT, NGG>), dim3(grid_for(frag16, 4096)), dim3(kBlock), 0, s, weight, Wf, Cin, Cout, NT)
+    if (dtype == SS_DT_F16) { if (NG == 2) SS_BP16(SS_DT_F16, 2); else SS_BP16(SS_DT_F16, 1); }
+    else { if (NG == 2) SS_BP16(SS_DT_BF16, 2); else SS_BP16(SS_DT_BF16, 1); }
+#undef SS_BP16
     if (hipGetLastError() != hipSuccess) return SS_ELAUNCH;
     const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
     const long long n_tiles = NB * RG * CG * (Cin / (32 * NT));
     const unsigned grid = (unsigned)(n_tiles < 2 * cus ? n_tiles : 2 * cus);
     const unsigned short* Bp = static_cast<const unsigned short*>(box);
     unsigned short* gx16 = static_cast<unsigned short*>(g_x);
+#define SS_BD16K(NT_, KPS_, DTT, NGG) hipLaunchKernelGGL((upconv_box_dgrad_kernel<NT_, KPS_, DTT, NGG>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, \
+                                                        tile_cols, gx16, (int)NB, h, w, NVR, NHR, Cin, Cout / (kBxCo * NGG), RG, CG)
+    // stage sizes: the fp32 mode's 12 KB where NT = 2 (NG x 3 | 6 k-steps), 16 | 12 KB at NT = 4
 #define SS_BD16(DTT) do { \
-        if (NT == 4) hipLaunchKernelGGL((upconv_box_dgrad_kernel<4, 3, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
-                                        (int)NB, h, w, NVR, NHR, Cin, Cout / kBxCo, RG, CG); \
-        else hipLaunchKernelGGL((upconv_box_dgrad_kernel<2, 6, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, Wf, vmap, hmap, tile_rows, tile_cols, gx16, \
-                                (int)NB, h, w, NVR, NHR, Cin, Cout / kBxCo, RG, CG); } while (0)
+        if (NG == 2) { if (NT == 4) SS_BD16K(4, 2, DTT, 2); else SS_BD16K(2, 3, DTT, 2); } \
+        else { if (NT == 4) SS_BD16K(4, 3, DTT, 1); else SS_BD16K(2, 6, DTT, 1); } } while (0)
     if (dtype == SS_DT_F16) SS_BD16(SS_DT_F16); else SS_BD16(SS_DT_BF16);
 #undef SS_BD16
+#undef SS_BD16K
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -994,8 +1022,8 @@ int ss_upconv_box_wgrad_x16(const void* box, const void* x, const unsigned int* 
     if (!box || (!x && !x_packed) || !vmap || !hmap || !tile_rows || !tile_cols || !g_w || !ws || NB <= 0 || h <= 0 || w <= 0 || NVR <= 0 || NHR <= 0 || n_row_tiles <= 0) return SS_EINVAL;
     if (!ss_upconv_box_wgrad_supported(Cin, Cout, 5, 1, 1) || !aligned16(box) || !aligned16(ws) || (dtype != SS_DT_F16 && dtype != SS_DT_BF16)) return SS_EINVAL;
     if (!ss_upconv_box_tiles_supported(n_row_tiles, w, NB * h * (long long)w)) return SS_EINVAL;
-    int NT = 0, kinds = 0, slices = 0;
-    if (!box_wgrad_plan(Cin, Cout, &NT, &kinds, &slices)) return SS_ELAUNCH;
+    int NT = 0, kinds = 0, slices = 0, NG = 1;
+    if (!box_wgrad_plan(Cin, Cout, &NT, &kinds, &slices, true, &NG)) return SS_ELAUNCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     long long part = (long long)slices * Cout * 25 * Cin;
     part = (part + 3) / 4 * 4;
@@ -1004,12 +1032,13 @@ int ss_upconv_box_wgrad_x16(const void* box, const void* x, const unsigned int* 
     const unsigned grid = (unsigned)(kinds * slices);
     const unsigned short* Bp = static_cast<const unsigned short*>(box);
     const int RG = n_row_tiles, CG = (w + kB2TC - 1) / kB2TC;
-#define SS_BW16K(NT_, PF_, DTT) hipLaunchKernelGGL((upconv_box_wgrad_kernel<NT_, PF_, DTT>), dim3(grid), dim3(kB2Threads), 0, s, Bp, xT, vmap, hmap, tile_rows, tile_cols, ws, \
-                                                  (int)NB, h, w, NVR, NHR, Cin, Cout, kinds, RG, CG)
+#define SS_BW16K(NT_, PF_, DTT, NGG) hipLaunchKernelGGL((upconv_box_wgrad_kernel<NT_, PF_, DTT, NGG>), dim3(grid), dim3(kB2Threads), 0, s, Bp, xT, vmap, hmap, tile_rows, \
+                                                       tile_cols, ws, (int)NB, h, w, NVR, NHR, Cin, Cout, kinds, RG, CG)
 #define SS_BW16(DTT) do { \
         if (x_packed) hipLaunchKernelGGL((upconv_bwd_xprep_kernel<true, DTT>), dim3(xg), dim3(kBlock), 0, s, static_cast<const void*>(x_packed), xT, NB * h, w, Cin); \
         else hipLaunchKernelGGL((upconv_bwd_xprep_kernel<false, DTT>), dim3(xg), dim3(kBlock), 0, s, x, xT, NB * h, w, Cin); \
-        if (NT == 4) SS_BW16K(4, false, DTT); else if (NT == 2) SS_BW16K(2, true, DTT); else SS_BW16K(1, true, DTT); } while (0)
+        if (NG == 2) { if (NT == 2) SS_BW16K(2, false, DTT, 2); else SS_BW16K(1, true, DTT, 2); } \
+        else if (NT == 4) SS_BW16K(4, false, DTT, 1); else if (NT == 2) SS_BW16K(2, true, DTT, 1); else SS_BW16K(1, true, DTT, 1); } while (0)
     if (dtype == SS_DT_F16) SS_BW16(SS_DT_F16); else SS_BW16(SS_DT_BF16);
 #undef SS_BW16
 #undef SS_BW16K
