@@ -119,49 +119,59 @@ __global__ __launch_bounds__(kBlock) void unpack_spikes_kernel(const unsigned* _
     }
 }
 
-// im2col_cl_bf16_kernel reading its NHWC input from a packed spike tensor: 8 channels = 16 bits of one word (C % 8 == 0)
-// DT: the operand format of the patch matrix (0 / SS_DT_BF16: bf16; SS_DT_F16: fp16 — the 16-bit activation modes' single-term GEMMs)
-template <int DT = 0>
-__global__ __launch_bounds__(kBlock) void im2col_cl_bf16_packed_kernel(const unsigned* __restrict__ xp, unsigned short* __restrict__ A,
-                                                                       int h, int w, int C, int k, int stride, int pad, int ho, int wo)
+// im2col_cl_bf16_kernel reading its NHWC input from a packed spike tensor (8 channels = 16 bits of one word, C % 8 == 0), or from a DENSE 16-bit NHWC array
+// (any values: an activation gradient — a plain gather of 16-byte granules; the data gradient of a 3 x 3 / stride 1 / padding 1 convolution is the same
+// convolution of g with the flipped, channel-transposed kernel: the caller flips the weight matrix, the patch matrix is the plain one).
+// DT: the operand format of the patch matrix built from spikes (0 / SS_DT_BF16: bf16; SS_DT_F16: fp16 — the 16-bit activation modes' single-term GEMMs).
+// Round 6: a workgroup owns kI2cRows consecutive patch rows and its threads walk the row's granules — 24 .. 32 granules per thread instead of ONE (the
+// one-granule form launched 3.6e5 workgroups of four short-lived wavefronts for a bottleneck patch matrix at config 5's share and wrote at 2.6 TB/s); the
+// rows' (frame, oy, ox) are wave-uniform scalars, a granule's (tap, channel group) is computed once per thread and granule column; four loads in flight.
+constexpr int kI2cRows = 8;
+template <int DT, bool PACKED>
+__global__ __launch_bounds__(kBlock) void im2col_rows_kernel(const void* __restrict__ xin, unsigned short* __restrict__ A,
+                                                             int h, int w, int C, int k, int stride, int pad, int ho, int wo, unsigned rows)
 {
-    const unsigned row = blockIdx.x;
-    const unsigned C8 = (unsigned)C / 8;
-    const unsigned r = blockIdx.y * kBlock + threadIdx.x;
-    if (r >= (unsigned)(k * k) * C8) return;
-    const unsigned ox = row % (unsigned)wo, t = row / (unsigned)wo;
-    const unsigned oy = t % (unsigned)ho, nb = t / (unsigned)ho;
-    const unsigned tap = r / C8, c8 = r - tap * C8;
-    const unsigned ky = tap / (unsigned)k, kx = tap - ky * (unsigned)k;
-    const int iy = (int)(oy * stride + ky) - pad, ix = (int)(ox * stride + kx) - pad;
-    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
-        const long long e = (((long long)nb * h + iy) * w + ix) * C + c8 * 8;
-        const unsigned bits = (xp[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu;
+    const unsigned C8 = (unsigned)C / 8, per_row = (unsigned)(k * k) * C8;
+    const unsigned row0 = blockIdx.x * kI2cRows;
+    int nbq[kI2cRows], iy0[kI2cRows], ix0[kI2cRows];                              // wave-uniform: frame, top-left input pixel of the row's patch
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = code_to_op<DT>((bits >> (2 * q)) & 3u);
+    for (int j = 0; j < kI2cRows; ++j) {
+        const unsigned row = min(row0 + j, rows - 1);
+        const unsigned ox = row % (unsigned)wo, t = row / (unsigned)wo;
+        nbq[j] = (int)(t / (unsigned)ho);
+        iy0[j] = (int)((t % (unsigned)ho) * stride) - pad;
+        ix0[j] = (int)(ox * stride) - pad;
     }
-    *reinterpret_cast<u16x8*>(A + ((long long)row * (k * k) + tap) * C + c8 * 8) = o;
-}
-
-// im2col of a DENSE 16-bit NHWC array (any values: an activation gradient) into a patch matrix of the same format: a plain gather of 16-byte granules.
-// (The data gradient of a 3 x 3 / stride 1 / padding 1 convolution is the same convolution of g with the flipped, channel-transposed kernel: the caller
-// flips the weight matrix, the patch matrix is the plain one.)
-__global__ __launch_bounds__(kBlock) void im2col_cl_x16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ A,
-                                                               int h, int w, int C, int k, int stride, int pad, int ho, int wo)
-{
-    const unsigned row = blockIdx.x;
-    const unsigned C8 = (unsigned)C / 8;
-    const unsigned r = blockIdx.y * kBlock + threadIdx.x;
-    if (r >= (unsigned)(k * k) * C8) return;
-    const unsigned ox = row % (unsigned)wo, t = row / (unsigned)wo;
-    const unsigned oy = t % (unsigned)ho, nb = t / (unsigned)ho;
-    const unsigned tap = r / C8, c8 = r - tap * C8;
-    const unsigned ky = tap / (unsigned)k, kx = tap - ky * (unsigned)k;
-    const int iy = (int)(oy * stride + ky) - pad, ix = (int)(ox * stride + kx) - pad;
-    u16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (iy >= 0 && iy < h && ix >= 0 && ix < w) o = *reinterpret_cast<const u16x8*>(x + (((long long)nb * h + iy) * w + ix) * C + c8 * 8);
-    *reinterpret_cast<u16x8*>(A + ((long long)row * (k * k) + tap) * C + c8 * 8) = o;
+    for (unsigned r = threadIdx.x; r < per_row; r += kBlock) {
+        const unsigned tap = r / C8, c8 = r - tap * C8;
+        const int ky = (int)(tap / (unsigned)k), kx = (int)tap - ky * k;
+        unsigned short* const dst = A + ((long long)row0 * (k * k) + tap) * C + c8 * 8;
+#pragma unroll
+        for (int j0 = 0; j0 < kI2cRows; j0 += 4) {
+            u16x8 o[4];
+            [[maybe_unused]] unsigned bits[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j0 + j] + ky, ix = ix0[j0 + j] + kx;
+                const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                const long long e = (((long long)nbq[j0 + j] * h + (ok ? iy : 0)) * w + (ok ? ix : 0)) * C + c8 * 8;
+                if constexpr (PACKED) {
+                    bits[j] = ok ? (static_cast<const unsigned*>(xin)[e >> 4] >> (2 * (int)(e & 15))) & 0xFFFFu : 0u;       // code 0 -> 0.0
+                } else {
+                    o[j] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) o[j] = *reinterpret_cast<const u16x8*>(static_cast<const unsigned short*>(xin) + e);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (PACKED) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) o[j][q] = code_to_op<DT>((bits[j] >> (2 * q)) & 3u);
+                }
+                if (row0 + j0 + j < rows) *reinterpret_cast<u16x8*>(dst + (long long)(j0 + j) * (k * k) * C) = o[j];
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -878,8 +888,8 @@ int ss_im2col_cl_bf16_packed(const unsigned int* x_packed, void* A, long long NB
     const long long rows = NB * ho * wo;
     const long long per_row = (long long)k * k * (C / 8);
     if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
-    hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel<0>, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), x_packed, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    hipLaunchKernelGGL((im2col_rows_kernel<0, true>), dim3((unsigned)((rows + kI2cRows - 1) / kI2cRows)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const void*>(x_packed), static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo, (unsigned)rows);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -894,8 +904,8 @@ int ss_im2col_cl_packed_x16(const unsigned int* x_packed, void* A, long long NB,
     const long long rows = NB * ho * wo;
     const long long per_row = (long long)k * k * (C / 8);
     if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
-    hipLaunchKernelGGL(im2col_cl_bf16_packed_kernel<SS_DT_F16>, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), x_packed, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    hipLaunchKernelGGL((im2col_rows_kernel<SS_DT_F16, true>), dim3((unsigned)((rows + kI2cRows - 1) / kI2cRows)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const void*>(x_packed), static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo, (unsigned)rows);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 
@@ -908,8 +918,8 @@ int ss_im2col_cl_x16(const void* x, void* A, long long NB, int h, int w, int C, 
     const long long rows = NB * ho * wo;
     const long long per_row = (long long)k * k * (C / 8);
     if (rows > 0x7fffffffLL || per_row > 65535LL * kBlock) return SS_EINVAL;
-    hipLaunchKernelGGL(im2col_cl_x16_kernel, dim3((unsigned)rows, (unsigned)((per_row + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       static_cast<hipStream_t>(stream), static_cast<const unsigned short*>(x), static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo);
+    hipLaunchKernelGGL((im2col_rows_kernel<0, false>), dim3((unsigned)((rows + kI2cRows - 1) / kI2cRows)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), x, static_cast<unsigned short*>(A), h, w, C, k, stride, pad, ho, wo, (unsigned)rows);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;
 }
 

@@ -303,8 +303,9 @@ def test_upconv_sub_forward_x16(dt, Cin, Cout, hw, HW, NB):
         assert torch.equal(y, y2)
 
 
+# (64, 24, ..) / (32, 8, ..): C_out % 16 != 0 — the one-chunk-per-window forms (ss_upconv_box.hip: NG = 1); every other geometry runs two chunks per window (round 6)
 @pytest.mark.parametrize('dt', DTS, ids=IDS)
-@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', GEOS)
+@pytest.mark.parametrize('Cin,Cout,hw,HW,NB', GEOS + [(64, 24, (13, 18), (25, 35), 2), (128, 8, (16, 20), (32, 40), 2)])
 def test_upconv_box_kernels_x16(dt, Cin, Cout, hw, HW, NB):
     """Decoder stage backward on the box-sum image in the 16-bit modes (autograd of /root/reference/network/blocks.py:110-132): the box plane is the fp32 box sum of the
     widened gradients (the fp32 kernel's summation order) rounded once to the format; data gradient and weight gradient are
