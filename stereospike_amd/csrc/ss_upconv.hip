@@ -1,5 +1,6 @@
 // ss_upconv.hip — NNConvUpsampling kernels (gather forms, fused projection + gather on the bf16 matrix cores) + their C-ABI entry points (include/ss_neuron.h).
 #include "ss_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -317,6 +318,38 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
                 for (int kx = 0; kx < K; ++kx) store_act<GP, VEC>(g_P, gpo + (ky * K + kx) * C, acc[kx]);
             }
 #endif
+        } else if constexpr (K == 3 && VEC == 1) {
+            // Prediction heads at large up-sampling ratios (x4 .. x15: a source pixel collects up to 16 x 16 output pixels per tap).  The nine rectangles are ONE
+            // rectangle shifted by (ky, kx): a single scan of their union — rows ylo-2 .. yhi-1, columns xlo-2 .. xhi-1 — feeds all nine sums, every element loaded
+            // once instead of up to nine times (round 6: 2 304 -> 324 loads per lane for predict_depth4; the per-tap loops below took 0.72 ms there at config 5's
+            // share).  Same summation order as the per-tap form — within a row x ascending from zero, rows ascending — hence the same bits.
+            vec_t acc[K][K];
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[ky][kx] = zero;
+            const int ya = max(ylo - (K - 1), 0), yb = min(yhi, H), xa = max(xlo - (K - 1), 0), xb = min(xhi, W);
+            for (int y = ya; y < yb; ++y) {
+                vec_t cs[K];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) cs[kx] = zero;
+                for (int x = xa; x < xb; ++x) {
+                    const vec_t v = load_act<ACT, VEC>(g_out, gbase + (long long)(y * W + x) * C);
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx)
+                        if (x >= xlo - kx && x < xhi - kx) cs[kx] += v;
+                }
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+                    if (y >= ylo - ky && y < yhi - ky) {
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) acc[ky][kx] += cs[kx];
+                    }
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) store_act<GP, VEC>(g_P, gpo + (ky * K + kx) * C, acc[ky][kx]);
         } else {
             for (int ky = 0; ky < K; ++ky) {
                 const int y0 = max(ylo - ky, 0), y1 = min(yhi - ky, H);
@@ -342,7 +375,14 @@ int launch_cl_fwd(const float* P, const int* sy, const int* sx, const float* bia
 {
     const bool vec = (C % 4 == 0) && aligned16(P) && aligned16(out) && (!bias || aligned16(bias));
     const long long per_img = (long long)H * W * (vec ? C / 4 : C);
-    const dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
+    dim3 grid((unsigned)((per_img + kBlock - 1) / kBlock), (unsigned)(NB < 65535 ? NB : 65535));
+    if (C == 1) {
+        // prediction heads (one channel): a thread's work per frame is nine loads and a store — let it walk several frames, its index arithmetic and table
+        // look-ups paid once (round 6; A/B profiles/r06/heads_ab.log)
+        static const int per_frame = getenv("SS_HEAD_GATHER_OLD") ? atoi(getenv("SS_HEAD_GATHER_OLD")) : 0;
+        const long long gy = 16384 / (long long)grid.x;
+        if (!per_frame) grid.y = (unsigned)(gy < 1 ? 1 : (gy > NB ? NB : gy));
+    }
     if (vec) hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 4, ACT>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
     else     hipLaunchKernelGGL((upconv_cl_fwd_kernel<K, 1, ACT>), grid, dim3(kBlock), 0, s, P, sy, sx, bias, out, NB, C, h, w, H, W);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ELAUNCH;

@@ -281,7 +281,10 @@ def test_upconv_channels_last_vs_oracle_and_torch():
     from stereospike_amd.fused import nearest_tables, upconv_projected_cl
     torch.manual_seed(2)
     for (Cin, Cout, h, w, H, W, k, B) in [(512, 256, 17, 22, 33, 44, 5, 3), (64, 32, 130, 173, 260, 346, 5, 2),
-                                           (8, 4, 9, 11, 20, 25, 5, 2), (32, 1, 65, 87, 260, 346, 3, 2), (6, 3, 5, 7, 40, 50, 3, 2)]:
+                                           (8, 4, 9, 11, 20, 25, 5, 2), (32, 1, 65, 87, 260, 346, 3, 2), (6, 3, 5, 7, 40, 50, 3, 2),
+                                           # prediction heads (3 x 3, ONE channel; round 6): the LDS-staged gather — more frames than workgroup rows (23 > 8192 / 390 tiles),
+                                           # tiles ragged in both directions — and the union-scan adjoint at x15 / x4 up-sampling; then the x2 row-scan path
+                                           (8, 1, 17, 22, 260, 346, 3, 23), (8, 1, 9, 11, 37, 90, 3, 3), (8, 1, 33, 44, 66, 88, 3, 2)]:
         up = nn.Sequential(nn.UpsamplingNearest2d(size=(H + k - 1, W + k - 1)), nn.Conv2d(Cin, Cout, k, bias=(Cout == 1)))
         x = (torch.rand(B, Cin, h, w) < 0.4).float().requires_grad_()
         y = up(x)
@@ -297,8 +300,8 @@ def test_upconv_channels_last_vs_oracle_and_torch():
         assert rel_err(y_cl.permute(0, 3, 1, 2), y) < 3e-6, (Cin, Cout)
         assert rel_err(x_cl.grad.permute(0, 3, 1, 2), x.grad) < 2e-5, (Cin, Cout)
         assert rel_err(wd.grad, up[1].weight.grad) < 2e-5, (Cin, Cout)
-        if bd is not None:
-            assert rel_err(bd.grad, up[1].bias.grad) < 2e-5
+        if bd is not None:       # a plain sum over every output element: cancelling — held against its magnitude sum (both sides are fp32 sums in different orders)
+            assert float((bd.grad.cpu() - up[1].bias.grad).abs().max()) <= 1e-6 * float(g.abs().sum()), (Cin, Cout)
         # kernels vs the C oracle on identical P / g_out: same summation order => bit-exact
         Wt = up[1].weight.detach().permute(1, 2, 3, 0).reshape(Cin, k * k * Cout)
         P = (x.detach().permute(0, 2, 3, 1).reshape(-1, Cin) @ Wt).view(B, h, w, k * k * Cout).contiguous()
