@@ -318,7 +318,8 @@ def test_upconv_box_kernels_x16(dt, Cin, Cout, hw, HW, NB):
     tables = up._tables(h, w, torch.device(DEV))
     bt = fused.box_tables(tables, H, W)
     if not _lib.upconv_box_dgrad_supported(Cin, Cout, 5, bt, NB, h, w):
-        return
+        assert bt['max_cols32'] > 76, bt          # deconv3's geometry: 32 source columns reach 78 horizontal ranges, the window holds 76 (the stage runs the g_P forms)
+        pytest.skip('geometry exceeds the box window')
     vr, vmap = nbx.range_tables(tables[1].cpu().numpy(), tables[2].cpu().numpy(), H)
     hr, hmap = nbx.range_tables(tables[4].cpu().numpy(), tables[5].cpu().numpy(), W)
     gen = torch.Generator(device=DEV).manual_seed(23 + Cin + h)
