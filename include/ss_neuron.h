@@ -485,6 +485,11 @@ int ss_upconv_cl_bwd_x16(const void* g_out, const int* y_lo, const int* y_hi, co
  * take bf16 operands: no fp32 g_P round trip and no separate cast pass.  g_dtype: 0 = fp32 g_out, SS_DT_F16 / SS_DT_BF16 = 16-bit. */
 int ss_upconv_cl_bwd_lowp(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
                           void* g_P_bf16, long long NB, int k, int C, int h, int w, int H, int W, void* stream);
+/* ABI 10 (round 6): the same with g_P in `gp_dtype` — SS_DT_BF16 (== ss_upconv_cl_bwd_lowp) or, for an fp16 g_out, SS_DT_F16: the fp16 activation mode's g_P forms
+ * (deconv3 / deconv4 backward) then run their two GEMMs on fp16 operands — the mode's own weight rounding, the data gradient written in fp16 by the GEMM's
+ * epilogue — instead of bf16 operands and an fp32 -> fp16 conversion pass over the result. */
+int ss_upconv_cl_bwd_lowp_dt(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                             void* g_P, int gp_dtype, long long NB, int k, int C, int h, int w, int H, int W, void* stream);
 
 /*
  * Voxeliser — the step BEFORE the path: events -> per-pixel two-polarity count frames,
@@ -598,6 +603,8 @@ int ss_upconv_sub_fwd_f32(const float* x, const unsigned int* x_packed, const vo
  *   ss_im2col_cl_packed_x16         ss_im2col_cl_bf16_packed with the patch matrix in `dtype`;  ss_im2col_cl_x16: patch matrix of a DENSE 16-bit array
  *   ss_upconv_sub_{prep,fwd}_x16    decoder stage forward: taps rounded once to `dtype`, their merged sums carried as TWO `dtype` terms (16 / 22 bits)
  *   ss_upconv_box{sum,_dgrad,_wgrad}_x16  decoder stage backward on the box-sum image: ss_upconv_box_planes_x16(dtype) planes of `dtype` (one: the box sum rounded once, as the g_P path rounds g_P)
+ *                                         (round 6: the two contraction kernels stage TWO consecutive 8-channel chunks per window where C_out % 16 == 0 — same layout, same entry points;
+ *                                         ss_upconv_box_wgrad_ws_floats returns one size that serves the f32 and the x16 entry point)
  */
 int ss_neuron_bwd_fork_lr_x16_supported(int T, long long N, int C, int lr_rank);
 int ss_neuron_bwd_fork_lr_x16(const void* g_out_seq, const float* lr_p, const float* lr_w, int lr_rank, int C, void* g_sum_seq,

@@ -85,6 +85,8 @@ def lib():
     L.ss_upconv_cl_bwd_x16.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_cl_bwd_lowp.argtypes = [p, i32, p, p, p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.ss_upconv_cl_bwd_lowp.restype = i32
+    L.ss_upconv_cl_bwd_lowp_dt.argtypes = [p, i32, p, p, p, p, p, i32, i64, i32, i32, i32, i32, i32, i32, p]
+    L.ss_upconv_cl_bwd_lowp_dt.restype = i32
     L.ss_upconv_cl_fwd_x16.restype = i32
     L.ss_upconv_cl_bwd_x16.restype = i32
     L.ss_neuron_bwd_fork_x16.argtypes = [p, p, p, p, p, p, p, p, p, p, i32, i64, f32, i32, f32, p, f32, f32, i32, f32, i32, i32, p]
@@ -230,7 +232,7 @@ def lib():
 EXPORTS = ('ss_abi_version', 'ss_neuron_gk_ws_floats', 'ss_neuron_fwd_f32', 'ss_neuron_bwd_f32',
            'ss_ipool_fwd_f32', 'ss_ipool_bwd_f32', 'ss_upconv1_fwd_f32', 'ss_upconv1_bwd_f32',
            'ss_upconv_cl_fwd_f32', 'ss_upconv_cl_bwd_f32', 'ss_neuron_fwd_x16', 'ss_neuron_bwd_x16', 'ss_voxelize_f64',
-           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_wgrad_reduce3_f32', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
+           'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32', 'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16', 'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_wgrad_reduce3_f32', 'ss_neuron_bwd_fork_f32', 'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp', 'ss_upconv_cl_bwd_lowp_dt',
            'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes', 'ss_im2col_cl_bf16_packed',
            
            
@@ -532,16 +534,18 @@ def upconv_cl_bwd_x16(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, C, h, w, H, W):
 
 
 def upconv_cl_bwd_lowp(g_out, y_lo, y_hi, x_lo, x_hi, g_P, NB, k, C, h, w, H, W):
-    """Adjoint gather with g_P written as bf16; g_out fp32 / fp16 / bf16."""
+    """Adjoint gather with g_P written in g_P's dtype: bf16 (g_out fp32 / fp16 / bf16) or fp16 (g_out fp16: the fp16 activation mode's own format, ABI 10)."""
     _require_hip(g_out, 'g_out')
     code = 0 if g_out.dtype == torch.float32 else DT_CODE.get(g_out.dtype)
     if code is None:
         raise SSNeuronError(f'g_out: expected float32, float16 or bfloat16, got {g_out.dtype}')
+    if g_P.dtype not in DT_CODE:
+        raise SSNeuronError(f'g_P: expected bfloat16 or float16, got {g_P.dtype}')
     with torch.cuda.device(g_out.device):
-        rc = lib().ss_upconv_cl_bwd_lowp(_ptr(g_out, 'g_out', NB * H * W * C), code, _i32(y_lo, 'y_lo', h), _i32(y_hi, 'y_hi', h),
-                                         _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
-                                         _x16(g_P, 'g_P', NB * k * k * C * h * w, torch.bfloat16), NB, k, C, h, w, H, W, _stream(g_out))
-    _check(rc, 'ss_upconv_cl_bwd_lowp')
+        rc = lib().ss_upconv_cl_bwd_lowp_dt(_ptr(g_out, 'g_out', NB * H * W * C), code, _i32(y_lo, 'y_lo', h), _i32(y_hi, 'y_hi', h),
+                                            _i32(x_lo, 'x_lo', w), _i32(x_hi, 'x_hi', w),
+                                            _x16(g_P, 'g_P', NB * k * k * C * h * w, g_P.dtype), DT_CODE[g_P.dtype], NB, k, C, h, w, H, W, _stream(g_out))
+    _check(rc, 'ss_upconv_cl_bwd_lowp_dt')
 
 
 def voxelize(events, start, end, counts, H, W):

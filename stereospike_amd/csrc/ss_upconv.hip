@@ -4,6 +4,10 @@
 
 namespace {
 
+#ifndef SS_CL_BWD_PREFETCH
+#define SS_CL_BWD_PREFETCH 1                  // A/B: make variant VARIANT=nopf DEFS=-DSS_CL_BWD_PREFETCH=0 (profiles/r06/adjoint_prefetch_ab.log)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // predict_depth head: nearest-upsample + valid kxk conv to one channel, as a gather over per-tap projections
 // ---------------------------------------------------------------------------------------------------
@@ -182,6 +186,21 @@ store_act(void* base, long long e, typename std::conditional<VEC == 4, f4, float
     }
 }
 
+// a window row of the adjoint as it sits in HBM (16-bit activations: the 8-byte pattern, widened at use — half the registers of the widened form while a
+// prefetched row waits for its turn)
+template <int ACT, int VEC> struct ClRaw { typedef typename std::conditional<ACT == 0, typename std::conditional<VEC == 4, f4, float>::type, typename U16Vec<VEC>::type>::type type; };
+template <int ACT, int VEC> __device__ __forceinline__ typename ClRaw<ACT, VEC>::type load_raw(const void* base, long long e)
+{
+    if constexpr (ACT == 0) return load_act<0, VEC>(base, e);
+    else return *reinterpret_cast<const typename U16Vec<VEC>::type*>(static_cast<const unsigned short*>(base) + e);
+}
+template <int ACT, int VEC> __device__ __forceinline__ typename std::conditional<VEC == 4, f4, float>::type widen_raw(typename ClRaw<ACT, VEC>::type v)
+{
+    if constexpr (ACT == 0) return v;
+    else if constexpr (VEC == 4) return (f4){widen<ACT>(v[0]), widen<ACT>(v[1]), widen<ACT>(v[2]), widen<ACT>(v[3])};
+    else return widen<ACT>(v);
+}
+
 template <int K, int VEC, int ACT = 0>
 __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __restrict__ P, const int* __restrict__ src_y,
                                                                const int* __restrict__ src_x, const float* __restrict__ bias,
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_fwd_kernel(const float* __re
     }
 }
 
-// GP = 0: g_P written as fp32; SS_DT_BF16: g_P written as bf16 (the 16-bit modes' backward GEMMs take bf16 operands: no separate cast pass)
+// GP = 0: g_P written as fp32; SS_DT_BF16 / SS_DT_F16: g_P written in that format (the 16-bit modes' backward GEMMs take 16-bit operands: no separate cast pass)
 template <int K, int VEC, int ACT = 0, int GP = 0>
 __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __restrict__ g_out, const int* __restrict__ y_lo,
                                                                const int* __restrict__ y_hi, const int* __restrict__ x_lo,
@@ -247,6 +266,54 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
             vec_t p1[K], p2[K];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) { p1[kx] = zero; p2[kx] = zero; }
+            if constexpr (SS_CL_BWD_PREFETCH && ACT != 0) {
+            // the NEXT row's loads are issued before this row is reduced and stored (round 6: with one row in flight per lane every row paid a full memory
+            // latency — the 16-bit form wrote g_P at 2 - 2.6 TB/s: 1.52 -> 1.25 ms for deconv3 at config 5's share.
+            // fp32 input: the 28 extra registers cost a wavefront per SIMD and the kernel LOSES 10 % — the one-row form stays there; profiles/r06/adjoint_prefetch_ab.log)
+            typedef typename ClRaw<ACT, VEC>::type raw_t;
+            raw_t nxt[K + 2];
+            auto fetch_row = [&](int j) {
+                const int y = ylo - (K - 1) + j;
+                const bool yok = y >= 0 && y < H;
+#pragma unroll
+                for (int c = 0; c < K + 2; ++c) {
+                    const int x = xlo - (K - 1) + c;
+                    const bool ok = yok && x >= 0 && x < W && c < K - 1 + rx;
+                    nxt[c] = raw_t{};
+                    if (ok) nxt[c] = load_raw<ACT, VEC>(g_out, gbase + (long long)(y * W + x) * C);
+                }
+            };
+            fetch_row(0);
+#pragma unroll 1
+            for (int j = 0; j < ry + K - 1; ++j) {
+                vec_t row[K + 2];
+#pragma unroll
+                for (int c = 0; c < K + 2; ++c) row[c] = widen_raw<ACT, VEC>(nxt[c]);          // (a zero pattern widens to +0: rows / columns outside the image)
+                if (j + 1 < ry + K - 1) fetch_row(j + 1);
+                vec_t cs[K];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int b0 = K - 1 - kx;
+                    cs[kx] = zero;
+                    if (rx > 0) cs[kx] += row[b0];
+                    if (rx > 1) cs[kx] += row[b0 + 1];
+                    if (rx > 2) cs[kx] += row[b0 + 2];
+                }
+                const int ky = (K - 2) + ry - j;                      // the vertical tap whose last row this is
+                if (j >= ry - 1 && ky >= 0) {
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        vec_t acc = zero;
+                        if (ry > 2) acc += p2[kx];
+                        if (ry > 1) acc += p1[kx];
+                        acc += cs[kx];
+                        store_act<GP, VEC>(g_P, gpo + (ky * K + kx) * C, acc);
+                    }
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) { p2[kx] = p1[kx]; p1[kx] = cs[kx]; }
+            }
+            } else {
 #pragma unroll 1
             for (int j = 0; j < ry + K - 1; ++j) {
                 const int y = ylo - (K - 1) + j;
@@ -282,6 +349,7 @@ __global__ __launch_bounds__(kBlock) void upconv_cl_bwd_kernel(const void* __res
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) { p2[kx] = p1[kx]; p1[kx] = cs[kx]; }
+            }
             }
 #else
         if (ry <= 3 && rx <= 3) {
@@ -488,17 +556,25 @@ int ss_upconv_cl_bwd_x16(const void* g_out, const int* y_lo, const int* y_hi, co
                               : launch_cl_bwd<5, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
 }
 
-int ss_upconv_cl_bwd_lowp(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
-                          void* g_P_bf16, long long NB, int k, int C, int h, int w, int H, int W, void* stream)
+int ss_upconv_cl_bwd_lowp_dt(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                             void* g_P, int gp_dtype, long long NB, int k, int C, int h, int w, int H, int W, void* stream)
 {
-    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P_bf16 || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
+    if (!g_out || !y_lo || !y_hi || !x_lo || !x_hi || !g_P || NB < 0 || C <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SS_EINVAL;
     if (k != 5 || (g_dtype != 0 && g_dtype != SS_DT_F16 && g_dtype != SS_DT_BF16)) return SS_EINVAL;
+    if (gp_dtype != SS_DT_BF16 && !(gp_dtype == SS_DT_F16 && g_dtype == SS_DT_F16)) return SS_EINVAL;     // fp16 g_P: the fp16 mode's own gradients only
     if (NB > 0x7fffffffLL || (long long)H * W * C > 0x7fffffffLL || (long long)k * k * C * h * w > 0x7fffffffLL) return SS_EINVAL;
     if (NB == 0) return SS_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g_dtype == 0) return launch_cl_bwd<5, 0, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P_bf16, (int)NB, C, h, w, H, W, s);
-    if (g_dtype == SS_DT_F16) return launch_cl_bwd<5, SS_DT_F16, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P_bf16, (int)NB, C, h, w, H, W, s);
-    return launch_cl_bwd<5, SS_DT_BF16, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P_bf16, (int)NB, C, h, w, H, W, s);
+    if (gp_dtype == SS_DT_F16) return launch_cl_bwd<5, SS_DT_F16, SS_DT_F16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+    if (g_dtype == 0) return launch_cl_bwd<5, 0, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+    if (g_dtype == SS_DT_F16) return launch_cl_bwd<5, SS_DT_F16, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+    return launch_cl_bwd<5, SS_DT_BF16, SS_DT_BF16>(g_out, y_lo, y_hi, x_lo, x_hi, g_P, (int)NB, C, h, w, H, W, s);
+}
+
+int ss_upconv_cl_bwd_lowp(const void* g_out, int g_dtype, const int* y_lo, const int* y_hi, const int* x_lo, const int* x_hi,
+                          void* g_P_bf16, long long NB, int k, int C, int h, int w, int H, int W, void* stream)
+{
+    return ss_upconv_cl_bwd_lowp_dt(g_out, g_dtype, y_lo, y_hi, x_lo, x_hi, g_P_bf16, SS_DT_BF16, NB, k, C, h, w, H, W, stream);
 }
 
 }  // extern "C"

@@ -1020,8 +1020,12 @@ def _stage_bwd_gp(ctx, *, Cin, Cout, H, NB, W, Wt, g16, g_out, h, k, kk, lowp, l
     g_x = torch.empty(x_cl.shape, dtype=torch.float32, device=x_cl.device) if (need_x and not lowrank and not (lowp and n >= NB)) else None
     g_Wt = torch.zeros_like(Wt) if need_w else None
     W2 = Wt.t().contiguous()                                                   # [kk*Cout, Cin]
+    # operand format of the two backward GEMMs under a 16-bit mode: bf16 — except the fp16 mode on own kernels, whose fp16 gradients make fp16 g_P, fp16 weights
+    # (the mode's own rounding, what its forward multiplies with) and an fp16 data gradient straight from the GEMM's epilogue (round 6; it was bf16 operands,
+    # an fp32 result and a conversion pass over it: ~1 ms at config 5's share)
+    gdt = torch.float16 if (lowp and k == 5 and ctx.own16 == torch.float16 and g_out.dtype == torch.float16) else torch.bfloat16
     if lowp:
-        W2 = W2.to(torch.bfloat16)
+        W2 = W2.to(gdt)
     f32 = dict(out_dtype=torch.float32) if lowp else {}
     e0 = TIMER.start()
     for c0 in range(0, NB, n):
@@ -1032,13 +1036,13 @@ def _stage_bwd_gp(ctx, *, Cin, Cout, H, NB, W, Wt, g16, g_out, h, k, kk, lowp, l
             # (a dense copy came along with the packed one — pack = 1 producers: use it instead of unpacking a second one).  16-bit modes whose
             # dense copy is not in the GEMMs' bf16 operand format (fp16 mode): unpack straight to bf16 — 0.25 B read per element instead of an fp16 -> bf16
             # conversion pass over the dense copy (round 6: 0.3 - 0.4 ms per stage at config 5's share)
-            if lowp and x_cl.dtype != torch.bfloat16:
-                x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, torch.bfloat16), None
+            if lowp and x_cl.dtype != gdt:
+                x_cl, x_packed = unpack_dense(x_packed, x_cl.shape, gdt), None
             else:
                 x_cl, x_packed = (unpack_dense(x_packed, x_cl.shape, x_cl.dtype) if x_cl.stride(-1) == 0 else x_cl), None
         if lowp and k == 5:
-            # 16-bit modes: the adjoint writes g_P as bf16, the operand format of both backward GEMMs (no fp32 round trip, no cast)
-            g_P = torch.empty((rows, kk * Cout), dtype=torch.bfloat16, device=x_cl.device)
+            # 16-bit modes: the adjoint writes g_P in the operand format of both backward GEMMs (no fp32 round trip, no cast)
+            g_P = torch.empty((rows, kk * Cout), dtype=gdt, device=x_cl.device)
             _lib.upconv_cl_bwd_lowp(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
         else:
             if lowrank:      # the adjoint writes g_P straight into the pair buffer the consumer's neuron backward will read
@@ -1048,7 +1052,7 @@ def _stage_bwd_gp(ctx, *, Cin, Cout, H, NB, W, Wt, g16, g_out, h, k, kk, lowp, l
                 g_P = torch.empty((rows, kk * Cout), dtype=torch.float32, device=x_cl.device)
             (_lib.upconv_cl_bwd_x16 if g16 else _lib.upconv_cl_bwd)(g_out[c0:c1], y_lo, y_hi, x_lo, x_hi, g_P, c1 - c0, k, Cout, h, w, H, W)
             if lowp:
-                g_P = g_P.to(torch.bfloat16)
+                g_P = g_P.to(gdt)
         # dense x dense on the bf16 matrix cores with six cross terms (fp32-product accuracy) where the fp32 library GEMM is compute-bound: wide stages
         # (measured: C_in 64 — deconv1 — is faster on the library's fp32 GEMM, 1.63 vs 2.48 ms, profiles/r04/bench_box_bwd_v5.log)
         gemm6 = bool(need_x and not lowrank and not lowp and ctx.ecfg.GEMM6_DGRAD and Cin >= 128 and g_P.dtype == torch.float32 and _lib.gemm6_supported(kk * Cout, Cin))
@@ -1057,9 +1061,9 @@ def _stage_bwd_gp(ctx, *, Cin, Cout, H, NB, W, Wt, g16, g_out, h, k, kk, lowp, l
         elif gemm6:
             _lib.gemm6(g_P, W2, g_x[c0:c1].view(rows, Cin), rows, kk * Cout, Cin)
         elif need_x and lowp and c0 == 0 and c1 == NB:
-            # one chunk (the usual case): the GEMM's own output IS the gradient — in the bf16 mode written in the activation format by its epilogue (fp32
+            # one chunk (the usual case): the GEMM's own output IS the gradient — when the operand format IS the activation format (bf16 mode; fp16 mode on own kernels) written in it by the GEMM's epilogue (fp32
             # accumulation, one rounding: what fp32-then-narrow gives), in the fp16 mode fp32 and narrowed once below; no copy into a preallocated buffer
-            g_x = (torch.mm(g_P, W2) if ctx.x_dtype == torch.bfloat16 else torch.mm(g_P, W2, **f32)).view(x_cl.shape)
+            g_x = (torch.mm(g_P, W2) if ctx.x_dtype == gdt else torch.mm(g_P, W2, **f32)).view(x_cl.shape)
         elif need_x:
             g_x[c0:c1].view(rows, Cin).copy_(torch.mm(g_P, W2, **f32)) if lowp else \
                 torch.mm(g_P, W2, out=g_x[c0:c1].view(rows, Cin))             # dgrad
@@ -1071,8 +1075,8 @@ def _stage_bwd_gp(ctx, *, Cin, Cout, H, NB, W, Wt, g16, g_out, h, k, kk, lowp, l
             _lib.spike_wgrad(g_P, x_cl[c0:c1].view(rows, Cin), g_Wt, rows, Cin, kk * Cout, accumulate=True)
         elif need_w:
             xs = x_cl[c0:c1].view(rows, Cin)
-            if lowp and xs.dtype != torch.bfloat16:
-                xs = xs.to(torch.bfloat16)                                    # spikes: exact
+            if lowp and xs.dtype != gdt:
+                xs = xs.to(gdt)                                               # spikes: exact
             elif not lowp and xs.dtype != torch.float32:
                 xs = xs.float()
             S = max(1, rows // _WGRAD_SPLIT_ROWS)

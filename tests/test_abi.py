@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
                                   'ss_loss_ws_doubles', 'ss_loss_stats_f32', 'ss_loss_grad_f32',
                                   'ss_neuron_bwd_rc_supported', 'ss_neuron_bwd_rc_f32', 'ss_neuron_bwd_rc_x16',
                                   'ss_im2col_cl_bf16', 'ss_split3_bf16', 'ss_neuron_bwd_fork_f32',
-                                  'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp',
+                                  'ss_upconv_cl_fwd_x16', 'ss_upconv_cl_bwd_x16', 'ss_upconv_cl_bwd_lowp', 'ss_upconv_cl_bwd_lowp_dt',
                                   # ABI 2
                                   'ss_neuron_bwd_fork_x16', 'ss_neuron_fwd_ex', 'ss_neuron_cnt_ws_words', 'ss_unpack_spikes',
                                   'ss_im2col_cl_bf16_packed',

@@ -731,6 +731,13 @@ def test_upconv_cl_x16_equals_fp32_gather_with_narrowed_io(dt):
     gp_c = torch.empty(P.shape, dtype=torch.bfloat16, device=DEV)
     _lib.upconv_cl_bwd_lowp(g16, ylo, yhi, xlo, xhi, gp_c, NB, k, C, h, w, H, W)
     assert torch.equal(gp_c, gp_a.to(torch.bfloat16))
+    if dt == torch.float16:     # ABI 10: g_P in fp16 for an fp16 gradient (the fp16 mode's g_P forms); any other pairing is refused
+        gp_h = torch.empty(P.shape, dtype=torch.float16, device=DEV)
+        _lib.upconv_cl_bwd_lowp(g16, ylo, yhi, xlo, xhi, gp_h, NB, k, C, h, w, H, W)
+        assert torch.equal(gp_h, gp_a.to(torch.float16))
+    else:
+        with pytest.raises(_lib.SSNeuronError):
+            _lib.upconv_cl_bwd_lowp(g16, ylo, yhi, xlo, xhi, torch.empty(P.shape, dtype=torch.float16, device=DEV), NB, k, C, h, w, H, W)
     g32 = torch.randn(NB, H, W, C, device=DEV)
     _lib.upconv_cl_bwd(g32, ylo, yhi, xlo, xhi, gp_a, NB, k, C, h, w, H, W)
     _lib.upconv_cl_bwd_lowp(g32, ylo, yhi, xlo, xhi, gp_c, NB, k, C, h, w, H, W)
